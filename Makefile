@@ -1,0 +1,38 @@
+# Build the gfx950 kernel library (product) and, for the CPU test tier only, the same
+# kernel sources against the host-side SIMT simulator.
+HIPCC   ?= /opt/rocm/bin/hipcc
+HOSTCXX ?= /opt/rocm/lib/llvm/bin/clang++
+ARCH    ?= gfx950
+CSRC    := dpc_amd/csrc
+SRCS    := $(wildcard $(CSRC)/*.hip)
+HDRS    := $(wildcard $(CSRC)/*.h) include/dpc_hip.h
+OBJS    := $(patsubst $(CSRC)/%.hip,build/hip/%.o,$(SRCS))
+EOBJS   := $(patsubst $(CSRC)/%.hip,build/emu/%.o,$(SRCS))
+EMU     := tests/simt_emu
+
+all: dpc_amd/libdpc_hip.so
+
+dpc_amd/libdpc_hip.so: $(OBJS)
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(OBJS)
+
+build/hip/%.o: $(CSRC)/%.hip $(HDRS)
+	@mkdir -p build/hip
+	$(HIPCC) --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -Iinclude -c $< -o $@
+
+emu: $(EMU)/libdpc_emu.so
+
+$(EMU)/libdpc_emu.so: $(EOBJS) build/emu/simt_emu.o
+	$(HOSTCXX) -shared -fPIC -o $@ $(EOBJS) build/emu/simt_emu.o
+
+build/emu/%.o: $(CSRC)/%.hip $(HDRS) $(EMU)/simt_emu.h
+	@mkdir -p build/emu
+	$(HOSTCXX) -x c++ -DDPC_SIMT_EMU -O2 -g -std=c++17 -fPIC -Wno-unused-value -I$(EMU) -Iinclude -c $< -o $@
+
+build/emu/simt_emu.o: $(EMU)/simt_emu.cpp $(EMU)/simt_emu.h
+	@mkdir -p build/emu
+	$(HOSTCXX) -O2 -g -std=c++17 -fPIC -I$(EMU) -c $< -o $@
+
+clean:
+	rm -rf build dpc_amd/libdpc_hip.so $(EMU)/libdpc_emu.so
+
+.PHONY: all emu clean

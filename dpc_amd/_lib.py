@@ -1,0 +1,150 @@
+"""ctypes binding of the C ABI in include/dpc_hip.h.
+
+The product path loads ``dpc_amd/libdpc_hip.so`` (gfx950 code objects, built by
+``make`` / ``__graft_entry__.build()``) and raises if it is missing -- there is no
+CPU or eager-PyTorch fallback.  ``load_emulator()`` exists for the CPU test tier
+only (``tests/``): it loads the same kernel sources compiled against the host-side
+SIMT simulator in ``tests/simt_emu`` and is never used by the engine on its own.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+HIP_LIB_PATH = os.path.join(_HERE, "libdpc_hip.so")
+EMU_LIB_PATH = os.path.join(os.path.dirname(_HERE), "tests", "simt_emu", "libdpc_emu.so")
+
+F32, BF16 = 0, 1
+ABI_VERSION = 1
+
+
+def dtype_code(dt: torch.dtype) -> int:
+    if dt == torch.float32:
+        return F32
+    if dt == torch.bfloat16:
+        return BF16
+    raise TypeError(f"unsupported dtype {dt}")
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        "dtype_in", "dtype_out", "mode", "N", "RT", "RH", "RW", "ST", "SH", "SW", "Ci", "src_ld",
+        "Co", "ldw", "ldo", "KT", "KH", "KW", "st", "sh", "sw", "pt", "ph", "pw")]
+
+
+class DpcError(RuntimeError):
+    pass
+
+
+def _p(t) -> C.c_void_p:
+    if t is None:
+        return C.c_void_p(0)
+    return C.c_void_p(t.data_ptr())
+
+
+_vp, _i32, _i64, _f32, _f64 = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_double
+_SIGS = {
+    "dpc_abi_version": [],
+    "dpc_conv_stats_rows": [C.POINTER(ConvDesc)],
+    "dpc_conv_igemm": [C.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _vp],
+    "dpc_conv_wgrad": [C.POINTER(ConvDesc), _vp, _vp, _i32, _vp, C.POINTER(_i32), _vp],
+    "dpc_pack3d": [_vp, _vp, _i32, _i32, _i32, _i32, _i64, _i64, _i64, _vp],
+    "dpc_reduce_unpack": [_vp, _i32, _vp, _i32, _i32, _i32, _i64, _i64, _i64, _i32, _vp],
+    "dpc_transpose2d": [_vp, _i32, _i32, _vp, _i32, _i32, _i32, _i32, _vp],
+    "dpc_pack_input_s2d": [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp],
+    "dpc_pack_stem_weight": [_vp, _vp, _i32, _i32, _vp],
+    "dpc_unpack_stem_wgrad": [_vp, _i32, _vp, _i32, _vp],
+    "dpc_bn_finalize": [_vp, _i32, _i32, _f64, _vp, _vp, _f32, _vp, _vp, _vp, _vp, _vp],
+    "dpc_bn_apply": [_vp, _vp, _i32, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _vp],
+    "dpc_bn_bwd_reduce": [_vp, _vp, _vp, _i32, _i64, _i32, _vp, _vp, _i32, _vp, C.POINTER(_i32), _vp],
+    "dpc_bn_bwd_finalize": [_vp, _i32, _i32, _f64, _vp, _vp, _vp, _vp],
+    "dpc_bn_bwd_apply": [_vp, _vp, _vp, _i32, _i64, _i32, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp],
+    "dpc_bn_relu_maxpool_fwd": [_vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp],
+    "dpc_maxpool_bwd": [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp],
+    "dpc_tpool_split_fwd": [_vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp],
+    "dpc_tpool_split_bwd": [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp],
+    "dpc_gru_gates1": [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp],
+    "dpc_gru_gates2": [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp],
+    "dpc_gru_bwd1": [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp],
+    "dpc_gru_bwd2": [_vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp],
+    "dpc_bias_act": [_vp, _vp, _i32, _i32, _i32, _vp, _i32, _i32, _i32, _i32, _vp, _i32, _vp],
+    "dpc_relu_bwd": [_vp, _vp, _i32, _vp, _i64, _vp, _i32, _vp],
+    "dpc_colsum": [_vp, _i32, _i32, _i32, _i32, _vp, _i32, _vp],
+    "dpc_gather_rows": [_vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp],
+    "dpc_convert": [_vp, _i32, _vp, _i32, _i64, _vp],
+    "dpc_axpy_f32": [_vp, _vp, _i64, _vp],
+    "dpc_mask_gen": [_vp, _i32, _i32, _i32, _vp],
+    "dpc_ce_topk": [_vp, _i32, _i32, _i32, _vp, _vp, _vp, _i32, _i32, _vp],
+    "dpc_adam": [_vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _f32, _f32, _f32, _f32, _vp],
+}
+
+
+class Lib:
+    """Loaded kernel library + thin checked wrappers (return codes -> DpcError)."""
+
+    def __init__(self, path: str, kind: str):
+        if not os.path.exists(path):
+            raise DpcError(
+                f"{path} not found: build it with `make` (or __graft_entry__.build()); "
+                "dpc_amd has no CPU/eager fallback")
+        self.kind = kind
+        self.path = path
+        self.c = C.CDLL(path)
+        self._bound = {}
+        if self.call("dpc_abi_version") != ABI_VERSION:
+            raise DpcError("ABI version mismatch")
+
+    def _fn(self, name: str):
+        fn = self._bound.get(name)
+        if fn is None:
+            fn = getattr(self.c, name)  # AttributeError => ABI mismatch, loud by design
+            fn.argtypes = _SIGS[name]
+            fn.restype = C.c_int
+            self._bound[name] = fn
+        return fn
+
+    def missing_symbols(self):
+        return [n for n in _SIGS if not hasattr(self.c, n)]
+
+    # -- stream handle for the device the tensors live on
+    def stream(self) -> C.c_void_p:
+        if self.kind == "hip":
+            return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        return C.c_void_p(0)
+
+    def call(self, name: str, *args) -> int:
+        rc = self._fn(name)(*args)
+        if rc < 0:
+            raise DpcError(f"{name} failed with code {rc}")
+        return rc
+
+
+_HIP: Optional[Lib] = None
+_EMU: Optional[Lib] = None
+
+
+def load_hip() -> Lib:
+    global _HIP
+    if _HIP is None:
+        _HIP = Lib(HIP_LIB_PATH, "hip")
+    return _HIP
+
+
+def load_emulator() -> Lib:
+    """CPU functional simulator of the kernels -- tests only."""
+    global _EMU
+    if _EMU is None:
+        _EMU = Lib(EMU_LIB_PATH, "emu")
+    return _EMU
+
+
+def lib_for(device: torch.device, emu: Optional[Lib] = None) -> Lib:
+    if device.type == "cuda":
+        return load_hip()
+    if emu is not None and emu.kind == "emu":
+        return emu
+    raise DpcError("dpc_amd runs on MI355X only: tensors must live on a cuda (HIP) device")

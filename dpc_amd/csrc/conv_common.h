@@ -1,0 +1,127 @@
+// conv_common.h -- geometry shared by the implicit-GEMM forward/dgrad kernel and the
+// weight-gradient kernel: how GEMM row m and GEMM k' map onto the channels-last source.
+#pragma once
+#include "dpc_rt.h"
+#include "../../include/dpc_hip.h"
+
+struct GatherGeom {
+    int M;                 // rows = N*RT*RH*RW
+    int Kp;                // taps*Ci
+    int mode;              // 0 forward gather, 1 input-gradient gather
+    int RT, RH, RW;
+    int ST, SH, SW;
+    int Ci, src_ld, log2C, taps;
+    int KT, KH, KW;
+    int st, sh, sw, lst, lsh, lsw;  // strides and their log2
+    int pt, ph, pw;
+    FastDiv dRW, dRH, dRT, dKW, dKH;
+};
+
+struct RowPos {  // decoded GEMM row: source-batch base and the tap-independent coordinates
+    int nbase, t0, h0, w0;
+};
+
+static inline int ilog2_exact(int v) {
+    int l = 0;
+    while ((1 << l) < v) ++l;
+    return ((1 << l) == v) ? l : -1;
+}
+
+static inline int make_gather_geom(const dpc_conv_desc* d, GatherGeom* g) {
+    if (!d || d->N <= 0 || d->Ci <= 0 || d->Co <= 0) return DPC_ERR_ARG;
+    const int per16 = d->dtype_in == DPC_BF16 ? 8 : 4;
+    if (d->dtype_in != DPC_F32 && d->dtype_in != DPC_BF16) return DPC_ERR_ARG;
+    g->taps = d->KT * d->KH * d->KW;
+    if (g->taps <= 0) return DPC_ERR_ARG;
+    if (d->Ci % per16 || d->src_ld % per16) return DPC_ERR_UNSUPPORTED;
+    g->log2C = ilog2_exact(d->Ci);
+    if (g->taps > 1 && g->log2C < 0) return DPC_ERR_UNSUPPORTED;
+    g->lst = ilog2_exact(d->st);
+    g->lsh = ilog2_exact(d->sh);
+    g->lsw = ilog2_exact(d->sw);
+    if (g->lst < 0 || g->lsh < 0 || g->lsw < 0) return DPC_ERR_UNSUPPORTED;
+    long long M = (long long)d->N * d->RT * d->RH * d->RW;
+    if (M <= 0 || M >= (1ll << 31)) return DPC_ERR_ARG;
+    if ((long long)d->N * d->ST * d->SH * d->SW >= (1ll << 31)) return DPC_ERR_ARG;
+    g->M = (int)M;
+    g->Kp = g->taps * d->Ci;
+    g->mode = d->mode;
+    g->RT = d->RT; g->RH = d->RH; g->RW = d->RW;
+    g->ST = d->ST; g->SH = d->SH; g->SW = d->SW;
+    g->Ci = d->Ci; g->src_ld = d->src_ld;
+    g->KT = d->KT; g->KH = d->KH; g->KW = d->KW;
+    g->st = d->st; g->sh = d->sh; g->sw = d->sw;
+    g->pt = d->pt; g->ph = d->ph; g->pw = d->pw;
+    g->dRW = make_fastdiv(d->RW);
+    g->dRH = make_fastdiv(d->RH);
+    g->dRT = make_fastdiv(d->RT);
+    g->dKW = make_fastdiv(d->KW);
+    g->dKH = make_fastdiv(d->KH);
+    return DPC_OK;
+}
+
+__device__ __forceinline__ RowPos decode_row(const GatherGeom& g, int m) {
+    RowPos r;
+    if (m >= g.M) {
+        r.nbase = 0; r.t0 = -(1 << 28); r.h0 = 0; r.w0 = 0;
+        return r;
+    }
+    unsigned q1 = fdiv((unsigned)m, g.dRW);
+    int rw = m - (int)q1 * g.RW;
+    unsigned q2 = fdiv(q1, g.dRH);
+    int rh = (int)q1 - (int)q2 * g.RH;
+    unsigned n = fdiv(q2, g.dRT);
+    int rt = (int)q2 - (int)n * g.RT;
+    r.nbase = (int)n * g.ST;
+    if (g.mode == 0) {
+        r.t0 = rt * g.st - g.pt; r.h0 = rh * g.sh - g.ph; r.w0 = rw * g.sw - g.pw;
+    } else {
+        r.t0 = rt + g.pt; r.h0 = rh + g.ph; r.w0 = rw + g.pw;
+    }
+    return r;
+}
+
+struct TapPos {
+    int kt, kh, kw, ci;
+    bool ok;  // k' inside the reduction extent
+};
+__device__ __forceinline__ TapPos decode_k(const GatherGeom& g, int k) {
+    TapPos t;
+    t.ok = k < g.Kp;
+    if (g.taps == 1) {
+        t.kt = t.kh = t.kw = 0; t.ci = k;
+        return t;
+    }
+    int tap = k >> g.log2C;
+    t.ci = k - (tap << g.log2C);
+    unsigned q = fdiv((unsigned)tap, g.dKW);
+    t.kw = tap - (int)q * g.KW;
+    unsigned kt = fdiv(q, g.dKH);
+    t.kh = (int)q - (int)kt * g.KH;
+    t.kt = (int)kt;
+    return t;
+}
+
+// element offset of (row, tap, ci) in the source, or -1 when the tap falls into padding
+__device__ __forceinline__ long long gather_off(const GatherGeom& g, const RowPos& r, const TapPos& t) {
+    int ti, hi, wi;
+    bool ok = t.ok;
+    if (g.mode == 0) {
+        ti = r.t0 + t.kt; hi = r.h0 + t.kh; wi = r.w0 + t.kw;
+        ok = ok && ti >= 0 && ti < g.ST && hi >= 0 && hi < g.SH && wi >= 0 && wi < g.SW;
+    } else {
+        int a = r.t0 - t.kt, b = r.h0 - t.kh, c = r.w0 - t.kw;
+        ok = ok && a >= 0 && b >= 0 && c >= 0 && ((a & (g.st - 1)) | (b & (g.sh - 1)) | (c & (g.sw - 1))) == 0;
+        ti = a >> g.lst; hi = b >> g.lsh; wi = c >> g.lsw;
+        ok = ok && ti < g.ST && hi < g.SH && wi < g.SW;
+    }
+    if (!ok) return -1;
+    long long pos = ((long long)(r.nbase + ti) * g.SH + hi) * g.SW + wi;
+    return pos * g.src_ld + t.ci;
+}
+
+__device__ __forceinline__ u32x4 load_unit(const void* base, long long elem_off, int esize) {
+    u32x4 z = {0u, 0u, 0u, 0u};
+    if (elem_off < 0) return z;
+    return *(const u32x4*)((const char*)base + elem_off * esize);
+}

@@ -1,0 +1,146 @@
+// dpc_rt.h -- the one place that knows which toolchain is compiling the kernels.
+//
+// Product build: hipcc --offload-arch=gfx950 (real CDNA4 code, MFMA builtins).
+// Test build   : host clang++ with -DDPC_SIMT_EMU (tests/simt_emu, CPU functional
+//                simulator used only by the `-m "not gpu"` test tier).
+// Kernel sources are written once, for gfx950; nothing below is a CUDA shim.
+#pragma once
+#include <stdint.h>
+
+#ifdef DPC_SIMT_EMU
+#include "simt_emu.h"
+#define DPC_LAUNCH(kernel, grid, block, stream, ...) \
+    simt::launch((grid), (block), [=]() { (kernel)(__VA_ARGS__); })
+#define DPC_UNROLL
+#else
+#include <hip/hip_runtime.h>
+#define DPC_LAUNCH(kernel, grid, block, stream, ...) \
+    hipLaunchKernelGGL(kernel, (grid), (block), 0, (stream), __VA_ARGS__)
+#define DPC_UNROLL _Pragma("unroll")
+#endif
+
+#define DPC_OK 0
+#define DPC_ERR_ARG (-1)
+#define DPC_ERR_LAUNCH (-2)
+#define DPC_ERR_UNSUPPORTED (-3)
+
+static inline int dpc_launch_status() {
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? DPC_OK : DPC_ERR_LAUNCH;
+}
+
+// ---------------------------------------------------------------- element types
+// Activations/operands are either f32 (parity mode) or bf16 (throughput mode); bf16
+// is carried as its raw 16-bit pattern.
+typedef uint16_t bf16_t;
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __host__ __forceinline__ float bf16_to_f32(bf16_t h) {
+    union { uint32_t u; float f; } c;
+    c.u = (uint32_t)h << 16;
+    return c.f;
+}
+// round-to-nearest-even (NaN kept quiet); matches torch's float->bfloat16
+__device__ __host__ __forceinline__ bf16_t f32_to_bf16(float f) {
+    union { uint32_t u; float f; } c;
+    c.f = f;
+    uint32_t u = c.u;
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40u);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (bf16_t)(u >> 16);
+}
+
+template <class T> struct Elt;
+template <> struct Elt<float> {
+    static constexpr int PER16 = 4;  // elements per 16-byte unit
+    __device__ __host__ static __forceinline__ float to_f32(float v) { return v; }
+    __device__ __host__ static __forceinline__ float from_f32(float v) { return v; }
+};
+template <> struct Elt<bf16_t> {
+    static constexpr int PER16 = 8;
+    __device__ __host__ static __forceinline__ float to_f32(bf16_t v) { return bf16_to_f32(v); }
+    __device__ __host__ static __forceinline__ bf16_t from_f32(float v) { return f32_to_bf16(v); }
+};
+
+// unpack element e of a 16-byte unit
+template <class T> __device__ __forceinline__ float unit_get(const u32x4& u, int e);
+template <> __device__ __forceinline__ float unit_get<float>(const u32x4& u, int e) {
+    union { uint32_t u; float f; } c;
+    c.u = u[e];
+    return c.f;
+}
+template <> __device__ __forceinline__ float unit_get<bf16_t>(const u32x4& u, int e) {
+    uint32_t w = u[e >> 1];
+    return bf16_to_f32((bf16_t)((e & 1) ? (w >> 16) : (w & 0xffffu)));
+}
+template <class T> __device__ __forceinline__ void unit_set(u32x4& u, int e, float v);
+template <> __device__ __forceinline__ void unit_set<float>(u32x4& u, int e, float v) {
+    union { uint32_t u; float f; } c;
+    c.f = v;
+    u[e] = c.u;
+}
+template <> __device__ __forceinline__ void unit_set<bf16_t>(u32x4& u, int e, float v) {
+    uint32_t h = f32_to_bf16(v);
+    uint32_t w = u[e >> 1];
+    u[e >> 1] = (e & 1) ? ((w & 0x0000ffffu) | (h << 16)) : ((w & 0xffff0000u) | h);
+}
+
+// ---------------------------------------------------------------- exact division by a runtime constant
+// q = x / d for 0 <= x < 2^31 (Granlund-Montgomery, p = 31 + ceil(log2 d)); built on the host.
+struct FastDiv {
+    uint32_t mul, shift, d, pad;
+};
+static inline FastDiv make_fastdiv(uint32_t d) {
+    FastDiv f;
+    uint32_t l = 0;
+    while ((1ull << l) < d) ++l;
+    f.shift = 31 + l;
+    f.mul = (uint32_t)(((1ull << f.shift) + d - 1) / d);
+    f.d = d;
+    f.pad = 0;
+    return f;
+}
+__device__ __host__ __forceinline__ uint32_t fdiv(uint32_t x, const FastDiv& f) {
+    return (uint32_t)(((unsigned long long)x * f.mul) >> f.shift);
+}
+
+// ---------------------------------------------------------------- MFMA wrappers (gfx950)
+// 32x32 tiles; lane l supplies A[i=l&31][k-group=l>>5] and B[k-group][j=l&31];
+// C/D: col=l&31, row=(r&3)+8*(r>>2)+4*(l>>5).
+__device__ __forceinline__ f32x16 mfma_32x32x2_f32(float a, float b, f32x16 c) {
+#ifdef DPC_SIMT_EMU
+    return simt_mfma_f32_32x32x2f32(a, b, c);
+#else
+    return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+#endif
+}
+// a,b: 16 bytes = 8 bf16 (k = (l>>5)*8 + j)
+__device__ __forceinline__ f32x16 mfma_32x32x16_bf16(const u32x4& a, const u32x4& b, f32x16 c) {
+#ifdef DPC_SIMT_EMU
+    simt_bf16x8 av, bv;
+    std::memcpy(&av, &a, 16);
+    std::memcpy(&bv, &b, 16);
+    return simt_mfma_f32_32x32x16_bf16(av, bv, c);
+#else
+    typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+#endif
+}
+
+// one 16-byte unit of operands -> the MFMA k-steps it feeds (f32: 4 steps of K=2; bf16: 1 step of K=16)
+template <class T> __device__ __forceinline__ f32x16 mfma_unit(const u32x4& a, const u32x4& b, f32x16 c);
+template <> __device__ __forceinline__ f32x16 mfma_unit<float>(const u32x4& a, const u32x4& b, f32x16 c) {
+    DPC_UNROLL
+    for (int s = 0; s < 4; ++s) c = mfma_32x32x2_f32(unit_get<float>(a, s), unit_get<float>(b, s), c);
+    return c;
+}
+template <> __device__ __forceinline__ f32x16 mfma_unit<bf16_t>(const u32x4& a, const u32x4& b, f32x16 c) {
+    return mfma_32x32x16_bf16(a, b, c);
+}
+
+// LDS tile rows are 128 bytes = 8 units of 16 B; unit u of row r lives at slot u ^ ((r>>1)&7):
+// a ds_read_b128 lane group (16 distinct rows, same logical unit) then touches all 64 banks once.
+__device__ __forceinline__ int lds_unit_off(int row, int unit) { return row * 128 + (((unit ^ (row >> 1)) & 7) << 4); }

@@ -1,0 +1,229 @@
+// pack.hip -- layout/precision repacking around the matrix-core kernels.  All HBM-bound,
+// all tiny next to the conv stack except dpc_pack_input_s2d (one pass over the video).
+#include "dpc_rt.h"
+#include "../../include/dpc_hip.h"
+
+template <class TO>
+__global__ void pack3d_kernel(const float* in, TO* out, int d0, int d1, int d2, long long s0, long long s1, long long s2) {
+    const long long n = (long long)d0 * d1 * d2;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const int i2 = (int)(i % d2);
+        const long long q = i / d2;
+        const int i1 = (int)(q % d1);
+        const int i0 = (int)(q / d1);
+        out[i] = Elt<TO>::from_f32(in[i0 * s0 + i1 * s1 + i2 * s2]);
+    }
+}
+
+static inline unsigned grid_for(long long n, int block = 256, int cap = 4096) {
+    long long g = (n + block - 1) / block;
+    if (g < 1) g = 1;
+    if (g > cap) g = cap;
+    return (unsigned)g;
+}
+
+extern "C" int dpc_pack3d(const float* in, void* out, int32_t dtype_out, int32_t d0, int32_t d1, int32_t d2,
+                          int64_t s0, int64_t s1, int64_t s2, dpc_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!in || !out || d0 <= 0 || d1 <= 0 || d2 <= 0) return DPC_ERR_ARG;
+    const long long n = (long long)d0 * d1 * d2;
+    if (dtype_out == DPC_F32) {
+        DPC_LAUNCH((pack3d_kernel<float>), dim3(grid_for(n)), dim3(256), stream, in, (float*)out, d0, d1, d2, (long long)s0, (long long)s1, (long long)s2);
+    } else if (dtype_out == DPC_BF16) {
+        DPC_LAUNCH((pack3d_kernel<bf16_t>), dim3(grid_for(n)), dim3(256), stream, in, (bf16_t*)out, d0, d1, d2, (long long)s0, (long long)s1, (long long)s2);
+    } else {
+        return DPC_ERR_ARG;
+    }
+    return dpc_launch_status();
+}
+
+__global__ void reduce_unpack_kernel(const float* part, int nsplit, float* out, int d0, int d1, int d2, long long s0,
+                                     long long s1, long long s2, int accumulate) {
+    const long long n = (long long)d0 * d1 * d2;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        float s = 0.f;
+        for (int k = 0; k < nsplit; ++k) s += part[(long long)k * n + i];
+        const int i2 = (int)(i % d2);
+        const long long q = i / d2;
+        const int i1 = (int)(q % d1);
+        const int i0 = (int)(q / d1);
+        float* o = out + i0 * s0 + i1 * s1 + i2 * s2;
+        *o = accumulate ? (*o + s) : s;
+    }
+}
+
+extern "C" int dpc_reduce_unpack(const float* part, int32_t nsplit, float* out, int32_t d0, int32_t d1, int32_t d2,
+                                 int64_t s0, int64_t s1, int64_t s2, int32_t accumulate, dpc_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!part || !out || nsplit <= 0 || d0 <= 0 || d1 <= 0 || d2 <= 0) return DPC_ERR_ARG;
+    const long long n = (long long)d0 * d1 * d2;
+    DPC_LAUNCH(reduce_unpack_kernel, dim3(grid_for(n)), dim3(256), stream, part, nsplit, out, d0, d1, d2, (long long)s0, (long long)s1, (long long)s2, accumulate);
+    return dpc_launch_status();
+}
+
+template <class TI, class TO>
+__global__ void transpose2d_kernel(const TI* in, int ld_in, TO* out, int ld_out, int rows, int cols) {
+    __shared__ float tile[32][33];
+    const int bx = blockIdx.x * 32, by = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 256 threads: 8 row groups
+    for (int r = ty; r < 32; r += 8) {
+        const int row = by + r, col = bx + tx;
+        tile[r][tx] = (row < rows && col < cols) ? Elt<TI>::to_f32(in[(long long)row * ld_in + col]) : 0.f;
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        const int orow = bx + r, ocol = by + tx;  // out[col][row]
+        if (orow < cols && ocol < rows) out[(long long)orow * ld_out + ocol] = Elt<TO>::from_f32(tile[tx][r]);
+    }
+}
+
+extern "C" int dpc_transpose2d(const void* in, int32_t dtype_in, int32_t ld_in, void* out, int32_t dtype_out,
+                               int32_t ld_out, int32_t rows, int32_t cols, dpc_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!in || !out || rows <= 0 || cols <= 0) return DPC_ERR_ARG;
+    dim3 grid((cols + 31) / 32, (rows + 31) / 32), block(256);
+    if (dtype_in == DPC_F32 && dtype_out == DPC_F32) {
+        DPC_LAUNCH((transpose2d_kernel<float, float>), grid, block, stream, (const float*)in, ld_in, (float*)out, ld_out, rows, cols);
+    } else if (dtype_in == DPC_F32 && dtype_out == DPC_BF16) {
+        DPC_LAUNCH((transpose2d_kernel<float, bf16_t>), grid, block, stream, (const float*)in, ld_in, (bf16_t*)out, ld_out, rows, cols);
+    } else if (dtype_in == DPC_BF16 && dtype_out == DPC_BF16) {
+        DPC_LAUNCH((transpose2d_kernel<bf16_t, bf16_t>), grid, block, stream, (const bf16_t*)in, ld_in, (bf16_t*)out, ld_out, rows, cols);
+    } else if (dtype_in == DPC_BF16 && dtype_out == DPC_F32) {
+        DPC_LAUNCH((transpose2d_kernel<bf16_t, float>), grid, block, stream, (const bf16_t*)in, ld_in, (float*)out, ld_out, rows, cols);
+    } else {
+        return DPC_ERR_ARG;
+    }
+    return dpc_launch_status();
+}
+
+// ---- stem: NCDHW f32 video -> 2x2 space-to-depth channels-last, 16 channels (12 live)
+// thread = one (n,t,hb,wb) cell; reads are float2 along W (coalesced NCDHW rows),
+// the write is one contiguous 16-channel cell.
+template <class TO>
+__global__ void pack_input_s2d_kernel(const float* in, TO* out, int BN, int T, int H, int W) {
+    const int Hb = H / 2, Wb = W / 2;
+    const long long cells = (long long)BN * T * Hb * Wb;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < cells; i += (long long)gridDim.x * blockDim.x) {
+        const int wb = (int)(i % Wb);
+        long long q = i / Wb;
+        const int hb = (int)(q % Hb);
+        q /= Hb;
+        const int t = (int)(q % T);
+        const int n = (int)(q / T);
+        float v[16];
+        DPC_UNROLL
+        for (int k = 12; k < 16; ++k) v[k] = 0.f;
+        DPC_UNROLL
+        for (int c = 0; c < 3; ++c)
+            DPC_UNROLL
+            for (int sy = 0; sy < 2; ++sy) {
+                const float* p = in + ((((long long)n * 3 + c) * T + t) * H + (2 * hb + sy)) * W + 2 * wb;
+                const float2 x = *(const float2*)p;
+                v[(sy * 2 + 0) * 3 + c] = x.x;
+                v[(sy * 2 + 1) * 3 + c] = x.y;
+            }
+        TO* o = out + i * 16;
+        DPC_UNROLL
+        for (int k = 0; k < 16; ++k) o[k] = Elt<TO>::from_f32(v[k]);
+    }
+}
+
+extern "C" int dpc_pack_input_s2d(const float* block, void* out, int32_t dtype_out, int32_t BN, int32_t T, int32_t H,
+                                  int32_t W, dpc_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!block || !out || BN <= 0 || T <= 0 || H <= 0 || W <= 0) return DPC_ERR_ARG;
+    if ((H & 1) || (W & 1)) return DPC_ERR_UNSUPPORTED;
+    const long long cells = (long long)BN * T * (H / 2) * (W / 2);
+    if (dtype_out == DPC_F32) {
+        DPC_LAUNCH((pack_input_s2d_kernel<float>), dim3(grid_for(cells, 256, 16384)), dim3(256), stream, block, (float*)out, BN, T, H, W);
+    } else if (dtype_out == DPC_BF16) {
+        DPC_LAUNCH((pack_input_s2d_kernel<bf16_t>), dim3(grid_for(cells, 256, 16384)), dim3(256), stream, block, (bf16_t*)out, BN, T, H, W);
+    } else {
+        return DPC_ERR_ARG;
+    }
+    return dpc_launch_status();
+}
+
+// stem weight [Co][3][1][7][7] -> [Co][th*4+tw][(sy*2+sx)*3+c], ky = 2*th+sy-1, kx = 2*tw+sx-1
+template <class TO>
+__global__ void pack_stem_weight_kernel(const float* w, TO* out, int Co) {
+    const int n = Co * 256;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const int c16 = i & 15, tap = (i >> 4) & 15, co = i >> 8;
+        const int th = tap >> 2, tw = tap & 3;
+        float v = 0.f;
+        if (c16 < 12) {
+            const int c = c16 % 3, s = c16 / 3, sy = s >> 1, sx = s & 1;
+            const int ky = 2 * th + sy - 1, kx = 2 * tw + sx - 1;
+            if (ky >= 0 && ky < 7 && kx >= 0 && kx < 7) v = w[((co * 3 + c) * 7 + ky) * 7 + kx];
+        }
+        out[i] = Elt<TO>::from_f32(v);
+    }
+}
+
+extern "C" int dpc_pack_stem_weight(const float* w, void* out, int32_t dtype_out, int32_t Co, dpc_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!w || !out || Co <= 0) return DPC_ERR_ARG;
+    if (dtype_out == DPC_F32) {
+        DPC_LAUNCH((pack_stem_weight_kernel<float>), dim3(grid_for(Co * 256)), dim3(256), stream, w, (float*)out, Co);
+    } else if (dtype_out == DPC_BF16) {
+        DPC_LAUNCH((pack_stem_weight_kernel<bf16_t>), dim3(grid_for(Co * 256)), dim3(256), stream, w, (bf16_t*)out, Co);
+    } else {
+        return DPC_ERR_ARG;
+    }
+    return dpc_launch_status();
+}
+
+__global__ void unpack_stem_wgrad_kernel(const float* part, int nsplit, float* dw, int Co) {
+    const int n = Co * 147;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const int kx = i % 7, ky = (i / 7) % 7, c = (i / 49) % 3, co = i / 147;
+        const int th = (ky + 1) >> 1, sy = (ky + 1) & 1, tw = (kx + 1) >> 1, sx = (kx + 1) & 1;
+        const int src = (co * 16 + th * 4 + tw) * 16 + (sy * 2 + sx) * 3 + c;
+        float s = 0.f;
+        for (int k = 0; k < nsplit; ++k) s += part[(long long)k * Co * 256 + src];
+        dw[i] = s;
+    }
+}
+
+extern "C" int dpc_unpack_stem_wgrad(const float* part, int32_t nsplit, float* dw, int32_t Co, dpc_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!part || !dw || nsplit <= 0 || Co <= 0) return DPC_ERR_ARG;
+    DPC_LAUNCH(unpack_stem_wgrad_kernel, dim3(grid_for(Co * 147)), dim3(256), stream, part, nsplit, dw, Co);
+    return dpc_launch_status();
+}
+
+template <class TI, class TO>
+__global__ void convert_kernel(const TI* in, TO* out, long long n) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+        out[i] = Elt<TO>::from_f32(Elt<TI>::to_f32(in[i]));
+}
+
+extern "C" int dpc_convert(const void* in, int32_t dtype_in, void* out, int32_t dtype_out, int64_t n, dpc_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!in || !out || n <= 0) return DPC_ERR_ARG;
+    dim3 grid(grid_for(n)), block(256);
+    if (dtype_in == DPC_F32 && dtype_out == DPC_BF16) {
+        DPC_LAUNCH((convert_kernel<float, bf16_t>), grid, block, stream, (const float*)in, (bf16_t*)out, (long long)n);
+    } else if (dtype_in == DPC_BF16 && dtype_out == DPC_F32) {
+        DPC_LAUNCH((convert_kernel<bf16_t, float>), grid, block, stream, (const bf16_t*)in, (float*)out, (long long)n);
+    } else if (dtype_in == DPC_F32 && dtype_out == DPC_F32) {
+        DPC_LAUNCH((convert_kernel<float, float>), grid, block, stream, (const float*)in, (float*)out, (long long)n);
+    } else if (dtype_in == DPC_BF16 && dtype_out == DPC_BF16) {
+        DPC_LAUNCH((convert_kernel<bf16_t, bf16_t>), grid, block, stream, (const bf16_t*)in, (bf16_t*)out, (long long)n);
+    } else {
+        return DPC_ERR_ARG;
+    }
+    return dpc_launch_status();
+}
+
+__global__ void axpy_kernel(const float* x, float* y, long long n) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) y[i] += x[i];
+}
+
+extern "C" int dpc_axpy_f32(const float* x, float* y, int64_t n, dpc_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!x || !y || n <= 0) return DPC_ERR_ARG;
+    DPC_LAUNCH(axpy_kernel, dim3(grid_for(n)), dim3(256), stream, x, y, (long long)n);
+    return dpc_launch_status();
+}

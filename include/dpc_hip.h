@@ -1,0 +1,183 @@
+/* dpc_hip.h -- C ABI of libdpc_hip.so, the MI355X (gfx950) kernels of the DPC-RNN
+ * training step.
+ *
+ * The reference (TengdaHan/DPC) has NO native/FFI layer: every op on its hot path is
+ * a stock torch op reached through the Python nn.Module API.  This
+ * header therefore *defines* the boundary a maintainer binds instead of those torch
+ * ops; each entry cites the reference call site it replaces (paths relative to the
+ * reference checkout).  INTEGRATION.md shows the ctypes stub on the reference side.
+ *
+ * Conventions
+ *   - plain pointers + sizes, no torch types; all pointers are DEVICE pointers;
+ *   - every call is asynchronous on `stream` (a hipStream_t passed as void*), never
+ *     allocates, never synchronises; workspaces are caller-owned;
+ *   - return 0 on success, <0 on error (DPC_ERR_*); nothing is printed;
+ *   - activations are channels-last [N][T][H][W][C]; dtype codes: 0 = f32, 1 = bf16.
+ */
+#ifndef DPC_HIP_H
+#define DPC_HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DPC_F32 0
+#define DPC_BF16 1
+
+#define DPC_ERR_ARG (-1)
+#define DPC_ERR_LAUNCH (-2)
+#define DPC_ERR_UNSUPPORTED (-3)
+
+typedef void* dpc_stream_t;
+
+int dpc_abi_version(void);
+
+/* ---- implicit-GEMM convolution / GEMM on the matrix cores ----------------------
+ * Replaces nn.Conv3d forward and its autograd input-gradient in
+ *   backbone/resnet_2d3d.py:14-32 (conv3x3x3 / conv1x3x3), :211 (stem, after the
+ *   space-to-depth repack of dpc_pack_input_s2d), :241-244 (1x1x1 downsample),
+ * nn.Conv2d 1x1 (ConvGRU gates backbone/convrnn.py:13-15,29-33; network_pred
+ *   dpc/model_3d.py:36-40) and torch.matmul for the score (dpc/model_3d.py:83).
+ *
+ *   out[m][co] = sum_{tap,ci} src[gather(m,tap)][ci] * wgt[co][tap*Ci+ci]  (+ addend[m][co])
+ * rows m enumerate (n, rt, rh, rw); mode 0 gathers rt*st-pt+kt (forward), mode 1
+ * gathers (rt+pt-kt)/st when divisible (input-gradient; wgt is then the
+ * [Ci][tap][Co] transpose produced by dpc_pack_weight).  A plain NT GEMM is the
+ * case N=M, all spatial dims 1, one tap.  Strides must be 1 or 2; Ci a power of two
+ * when there is more than one tap; Ci, src_ld, ldw multiples of 16 bytes.
+ * If `stats` != NULL it receives per-program partial sums [rows][2][Co] (sum, sum of
+ * squares of the stored outputs) for the batch-norm that follows; the row count is
+ * dpc_conv_stats_rows(desc).
+ */
+typedef struct dpc_conv_desc {
+    int32_t dtype_in, dtype_out; /* DPC_F32 / DPC_BF16 */
+    int32_t mode;                /* 0 forward gather, 1 input-gradient gather */
+    int32_t N, RT, RH, RW;       /* output positions                         */
+    int32_t ST, SH, SW;          /* source tensor spatial dims               */
+    int32_t Ci, src_ld;          /* channels per tap, source row stride      */
+    int32_t Co, ldw, ldo;        /* output cols, weight row stride, out ld   */
+    int32_t KT, KH, KW;
+    int32_t st, sh, sw;
+    int32_t pt, ph, pw;
+} dpc_conv_desc;
+
+int dpc_conv_stats_rows(const dpc_conv_desc* d);
+int dpc_conv_igemm(const dpc_conv_desc* d, const void* src, const void* wgt, void* out,
+                   const void* addend, float* stats, dpc_stream_t stream);
+
+/* Weight gradient: part[ks][co][tap*Ci+ci] = sum_{m in split ks} dy[m][co]*src[gather(m,tap)][ci]
+ * (autograd of the same convs / 1x1 convs / matmul; f32 partials, reduced by
+ * dpc_reduce_unpack).  Returns the number of K-splits through *nsplit; capacity in
+ * floats of `part` must be >= nsplit*Co*KT*KH*KW*Ci (query with part == NULL). */
+int dpc_conv_wgrad(const dpc_conv_desc* d, const void* src, const void* dy, int32_t dy_ld,
+                   float* part, int32_t* nsplit, dpc_stream_t stream);
+
+/* ---- weight / operand repacking --------------------------------------------------
+ * out[i0][i1][i2] (dtype_out, dense) = in[i0*s0 + i1*s1 + i2*s2] (f32).  Turns the
+ * reference's [Co][Ci][kT][kH][kW] parameters (state_dict layout, §8b) into the
+ * K-contiguous operand layouts above without touching the parameters themselves. */
+int dpc_pack3d(const float* in, void* out, int32_t dtype_out, int32_t d0, int32_t d1, int32_t d2,
+               int64_t s0, int64_t s1, int64_t s2, dpc_stream_t stream);
+/* out[i0*s0+i1*s1+i2*s2] (f32) = sum_{k<nsplit} part[k][i0][i1][i2]  (+ out if accumulate) */
+int dpc_reduce_unpack(const float* part, int32_t nsplit, float* out, int32_t d0, int32_t d1, int32_t d2,
+                      int64_t s0, int64_t s1, int64_t s2, int32_t accumulate, dpc_stream_t stream);
+/* 2-D transpose/convert between element types: out[j][i] = in[i][j] */
+int dpc_transpose2d(const void* in, int32_t dtype_in, int32_t ld_in, void* out, int32_t dtype_out, int32_t ld_out,
+                    int32_t rows, int32_t cols, dpc_stream_t stream);
+
+/* Stem: Conv3d(3,64,(1,7,7),s(1,2,2),p(0,3,3)) (resnet_2d3d.py:211) is run as a 1x4x4
+ * stride-1 conv over a 2x2 space-to-depth image with 16 channels (12 used).
+ * dpc_pack_input_s2d: block [BN][3][T][H][W] f32 NCDHW (dpc/model_3d.py:49-50) ->
+ *   [BN][T][H/2][W/2][16]; channel = (sy*2+sx)*3 + c.
+ * dpc_pack_stem_weight: [Co][3][1][7][7] f32 -> [Co][16 taps][16]; dpc_unpack_stem_wgrad the inverse for grads. */
+int dpc_pack_input_s2d(const float* block, void* out, int32_t dtype_out, int32_t BN, int32_t T, int32_t H, int32_t W,
+                       dpc_stream_t stream);
+int dpc_pack_stem_weight(const float* w, void* out, int32_t dtype_out, int32_t Co, dpc_stream_t stream);
+int dpc_unpack_stem_wgrad(const float* part, int32_t nsplit, float* dw, int32_t Co, dpc_stream_t stream);
+
+/* ---- batch norm with batch statistics (track_running_stats=False, dpc/model_3d.py:28;
+ *      nn.BatchNorm3d at resnet_2d3d.py:55,59,93,97,212,243) -------------------------
+ * finalize: partial sums [rows][2][C] -> mean, invstd, scale=gamma*invstd, shift=beta-mean*scale
+ *           (f64 accumulation; count = elements per channel). */
+int dpc_bn_finalize(const float* partials, int32_t rows, int32_t C, double count, const float* gamma,
+                    const float* beta, float eps, float* mean, float* invstd, float* scale, float* shift,
+                    dpc_stream_t stream);
+/* y = act( x*scale+shift (+ res*rscale+rshift | + res) ), act = relu if relu!=0
+ * (BasicBlock tail, resnet_2d3d.py:67-80,105-116) */
+int dpc_bn_apply(const void* x, void* y, int32_t dtype, int64_t rows, int32_t C, const float* scale,
+                 const float* shift, const void* res, const float* rscale, const float* rshift, int32_t relu,
+                 dpc_stream_t stream);
+/* backward: dz = dy * (y>0 if relu); partial sums of dz and dz*xhat -> [rows][2][C] */
+int dpc_bn_bwd_reduce(const void* dy, const void* y, const void* x, int32_t dtype, int64_t rows, int32_t C,
+                      const float* mean, const float* invstd, int32_t relu, float* partials, int32_t* prow,
+                      dpc_stream_t stream);
+/* sums [prow][2][C] -> dgamma (+=), dbeta (+=), and coefficients c1=sum_dz/count, c2=sum_dzxhat/count */
+int dpc_bn_bwd_finalize(const float* partials, int32_t prow, int32_t C, double count, float* dgamma, float* dbeta,
+                        float* coef, dpc_stream_t stream);
+/* dx = gamma*invstd*(dz - c1 - xhat*c2); optionally also writes dz (residual branch grad) */
+int dpc_bn_bwd_apply(const void* dy, const void* y, const void* x, int32_t dtype, int64_t rows, int32_t C,
+                     const float* mean, const float* invstd, const float* gamma, const float* coef, int32_t relu,
+                     void* dx, void* dz, dpc_stream_t stream);
+
+/* ---- stem tail: BN+ReLU+MaxPool3d((1,3,3),s(1,2,2),p(0,1,1)) (resnet_2d3d.py:212-214,260-263) */
+int dpc_bn_relu_maxpool_fwd(const void* x, int32_t dtype, int32_t NT, int32_t H, int32_t W, int32_t C,
+                            const float* scale, const float* shift, void* y, uint8_t* argmax, dpc_stream_t stream);
+/* dz (grad at the BN output, ReLU mask applied) from the pooled gradient and the saved argmax */
+int dpc_maxpool_bwd(const void* dy, const uint8_t* argmax, int32_t dtype, int32_t NT, int32_t H, int32_t W, int32_t C,
+                    void* dz, dpc_stream_t stream);
+
+/* ---- temporal mean + ReLU split (dpc/model_3d.py:53-59) -----------------------------
+ * x [B*N][T][SQ][D] -> feat_relu [N][B*SQ][D] (GRU input, time-major) and
+ * feat_inf [B][P][SQ][D] (pre-ReLU, last P blocks, score operand). */
+int dpc_tpool_split_fwd(const void* x, int32_t dtype, int32_t B, int32_t N, int32_t T, int32_t SQ, int32_t D,
+                        int32_t P, void* feat_relu, void* feat_inf, dpc_stream_t stream);
+int dpc_tpool_split_bwd(const void* x, const void* d_relu, const float* d_inf, int32_t dtype, int32_t B, int32_t N,
+                        int32_t T, int32_t SQ, int32_t D, int32_t P, void* dx, dpc_stream_t stream);
+
+/* ---- ConvGRU cell, kernel_size 1 (backbone/convrnn.py:24-34,76-79) ------------------
+ * gates1: u=sig(px_u+ph_u+bu), r=sig(px_r+ph_r+br), hr=h*r      (px [M][3D], ph [M][2D] f32 GEMM outputs)
+ * gates2: o=tanh(px_o+po+bo), hn=h*(1-u)+o*u, hout=hn*drop      (drop = pre-scaled keep mask or NULL) */
+int dpc_gru_gates1(const float* px, const float* ph, const float* bias_u, const float* bias_r, const void* h,
+                   int32_t dtype, int32_t M, int32_t D, float* u, float* r, void* hr, dpc_stream_t stream);
+int dpc_gru_gates2(const float* px, const float* po, const float* bias_o, const void* h, const float* u,
+                   const float* drop, int32_t dtype, int32_t M, int32_t D, float* o, void* hout, dpc_stream_t stream);
+/* backward halves (see DESIGN.md §ConvGRU backward):
+ * bwd1: dhn=dh*drop; dpo=dhn*u*(1-o^2); dpu=dhn*(o-h)*u*(1-u); dhprev=dhn*(1-u);  G[:,0:D]=dpu, G[:,2D:3D]=dpo
+ * bwd2: dr=dhr*h; G[:,D:2D]=dr*r*(1-r); dhprev+=dhr*r */
+int dpc_gru_bwd1(const float* dh, const float* drop, const float* u, const float* o, const void* h, int32_t dtype,
+                 int32_t M, int32_t D, void* G, float* dhprev, dpc_stream_t stream);
+int dpc_gru_bwd2(const float* dhr, const float* r, const void* h, int32_t dtype, int32_t M, int32_t D, void* G,
+                 float* dhprev, dpc_stream_t stream);
+
+/* ---- small fused elementwise pieces of network_pred / the predict loop (model_3d.py:36-40,66-71)
+ * y[rowmap(m)][d] = act(x[m][d] + bias[d]); optional second output y2 = relu(same) (dense rows).
+ * rowmap(m) = (m/SQ*P + p)*SQ + m%SQ when P>0 (writes step p of pred [B][P][SQ][D]). */
+int dpc_bias_act(const float* x, const float* bias, int32_t M, int32_t D, int32_t relu, void* y, int32_t dtype_y,
+                 int32_t P, int32_t p, int32_t SQ, void* y2, int32_t dtype_y2, dpc_stream_t stream);
+/* generic elementwise helpers on f32: out = a*(mask>0) (+ b) ; colsum of [M][D] into out[D] (+=) */
+int dpc_relu_bwd(const float* dy, const void* y, int32_t dtype_y, const float* add, int64_t n, void* out,
+                 int32_t dtype_out, dpc_stream_t stream);
+int dpc_colsum(const void* x, int32_t dtype, int32_t ld, int32_t M, int32_t D, float* out, int32_t accumulate,
+               dpc_stream_t stream);
+int dpc_gather_rows(const float* src, int32_t B, int32_t P, int32_t p, int32_t SQ, int32_t D, float* dst,
+                    const float* add, dpc_stream_t stream);
+int dpc_convert(const void* in, int32_t dtype_in, void* out, int32_t dtype_out, int64_t n, dpc_stream_t stream);
+int dpc_axpy_f32(const float* x, float* y, int64_t n, dpc_stream_t stream);
+
+/* ---- contrastive loss head (dpc/main.py:178-185,213-218; utils/utils.py:38-55) -------
+ * mask: closed form of dpc/model_3d.py:86-96, int8 [B][P][SQ][B][P][SQ] contiguous.
+ * ce_topk: rows x cols logits (ld), target[i] = i (single-GPU closed form of process_output):
+ *   result[0..3] = mean CE loss, top1, top3, top5; dscore (optional, dtype/ld given) = (softmax-onehot)/rows. */
+int dpc_mask_gen(int8_t* mask, int32_t B, int32_t P, int32_t SQ, dpc_stream_t stream);
+int dpc_ce_topk(const float* score, int32_t rows, int32_t cols, int32_t ld, float* row_ws, float* result,
+                void* dscore, int32_t dtype_d, int32_t ld_d, dpc_stream_t stream);
+
+/* ---- Adam with L2 weight decay on flat f32 buffers (dpc/main.py:80-81) --------------- */
+int dpc_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
+             float wd, float bias_corr1, float bias_corr2, float grad_scale, dpc_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DPC_HIP_H */

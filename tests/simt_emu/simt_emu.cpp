@@ -1,0 +1,154 @@
+// simt_emu.cpp -- fiber scheduler for the host-side SIMT simulator (see simt_emu.h).
+// TEST INFRASTRUCTURE ONLY.
+#include "simt_emu.h"
+
+#include <vector>
+
+namespace simt {
+
+Cur cur;
+
+enum State { READY = 0, WAIT_WAVE = 1, WAIT_BLOCK = 2, DONE = 3 };
+
+struct Fiber {
+    void* sp;
+    State st;
+    simt_uint3 tid;
+    int lane, wave;
+};
+
+static constexpr size_t STACK_BYTES = 256 * 1024;
+static constexpr int MAX_THREADS = 1024;
+
+static std::vector<Fiber> fibers;
+static std::vector<Wave> waves;
+static unsigned char* stacks = nullptr;
+static void* sched_sp = nullptr;
+static Fiber* running = nullptr;
+static const std::function<void()>* body_fn = nullptr;
+
+// x86-64 SysV context switch: save callee-saved regs on the current stack, swap sp.
+extern "C" void simt_switch(void** save_sp, void* new_sp);
+asm(R"(
+.text
+.globl simt_switch
+.type simt_switch,@function
+simt_switch:
+    pushq %rbp
+    pushq %rbx
+    pushq %r12
+    pushq %r13
+    pushq %r14
+    pushq %r15
+    movq %rsp, (%rdi)
+    movq %rsi, %rsp
+    popq %r15
+    popq %r14
+    popq %r13
+    popq %r12
+    popq %rbx
+    popq %rbp
+    ret
+.size simt_switch,.-simt_switch
+)");
+
+static void yield_to_sched(State st) {
+    Fiber* f = running;
+    f->st = st;
+    simt_switch(&f->sp, sched_sp);
+}
+
+static void fiber_main() {
+    (*body_fn)();
+    yield_to_sched(DONE);
+    std::fprintf(stderr, "simt: resumed a finished fiber\n");
+    std::abort();
+}
+
+void sync_block() { yield_to_sched(WAIT_BLOCK); }
+void sync_wave() { yield_to_sched(WAIT_WAVE); }
+
+static void resume(Fiber& f) {
+    running = &f;
+    cur.tid = f.tid;
+    cur.lane = f.lane;
+    cur.wave = f.wave;
+    cur.w = &waves[f.wave];
+    simt_switch(&sched_sp, f.sp);
+    running = nullptr;
+}
+
+static void prepare(Fiber& f, int idx) {
+    unsigned char* top = stacks + (size_t)(idx + 1) * STACK_BYTES;
+    uintptr_t t = ((uintptr_t)top) & ~(uintptr_t)15;
+    void** sp = (void**)t;
+    *--sp = nullptr;              // fake return address of fiber_main (keeps rsp = 8 mod 16 at entry)
+    *--sp = (void*)&fiber_main;   // `ret` target of the first switch
+    for (int i = 0; i < 6; ++i) *--sp = nullptr;  // rbp rbx r12..r15
+    f.sp = (void*)sp;
+    f.st = READY;
+}
+
+void launch(dim3 grid, dim3 block, const std::function<void()>& body) {
+    const int nthreads = (int)(block.x * block.y * block.z);
+    if (nthreads <= 0 || nthreads > MAX_THREADS) {
+        std::fprintf(stderr, "simt: bad block size %d\n", nthreads);
+        std::abort();
+    }
+    if (!stacks) stacks = (unsigned char*)std::malloc(STACK_BYTES * MAX_THREADS);
+    const int nwaves = (nthreads + 63) / 64;
+    fibers.resize(nthreads);
+    waves.resize(nwaves);
+    body_fn = &body;
+    cur.bdim = {block.x, block.y, block.z};
+    cur.gdim = {grid.x, grid.y, grid.z};
+    for (unsigned bz = 0; bz < grid.z; ++bz)
+        for (unsigned by = 0; by < grid.y; ++by)
+            for (unsigned bx = 0; bx < grid.x; ++bx) {
+                cur.bid = {bx, by, bz};
+                for (int t = 0; t < nthreads; ++t) {
+                    Fiber& f = fibers[t];
+                    f.tid = {(unsigned)t % block.x, ((unsigned)t / block.x) % block.y, (unsigned)t / (block.x * block.y)};
+                    f.lane = t & 63;
+                    f.wave = t >> 6;
+                    prepare(f, t);
+                }
+                for (;;) {
+                    int done = 0, at_block = 0;
+                    for (int w = 0; w < nwaves; ++w) {
+                        const int lo = w * 64, hi = (lo + 64 < nthreads) ? lo + 64 : nthreads;
+                        for (;;) {
+                            for (int t = lo; t < hi; ++t)
+                                if (fibers[t].st == READY) resume(fibers[t]);
+                            int nw = 0, nb = 0, nd = 0;
+                            for (int t = lo; t < hi; ++t) {
+                                nw += fibers[t].st == WAIT_WAVE;
+                                nb += fibers[t].st == WAIT_BLOCK;
+                                nd += fibers[t].st == DONE;
+                            }
+                            if (nw == 0) break;
+                            if (nb != 0) {
+                                std::fprintf(stderr, "simt: wave %d diverged: %d lanes at a wave collective, %d at __syncthreads\n", w, nw, nb);
+                                std::abort();
+                            }
+                            for (int t = lo; t < hi; ++t)
+                                if (fibers[t].st == WAIT_WAVE) fibers[t].st = READY;
+                        }
+                    }
+                    for (int t = 0; t < nthreads; ++t) {
+                        done += fibers[t].st == DONE;
+                        at_block += fibers[t].st == WAIT_BLOCK;
+                    }
+                    if (done == nthreads) break;
+                    if (done + at_block != nthreads) {
+                        std::fprintf(stderr, "simt: scheduler stuck\n");
+                        std::abort();
+                    }
+                    for (int t = 0; t < nthreads; ++t)
+                        if (fibers[t].st == WAIT_BLOCK) fibers[t].st = READY;
+                }
+            }
+    body_fn = nullptr;
+}
+
+}  // namespace simt

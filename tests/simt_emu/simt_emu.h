@@ -1,0 +1,147 @@
+// simt_emu.h -- host-side functional simulator of the gfx950 execution model.
+//
+// TEST INFRASTRUCTURE ONLY (never linked into dpc_amd/libdpc_hip.so, never
+// loaded by the product path).  It lets the `-m "not gpu"` test tier execute
+// the *same* kernel sources that hipcc compiles for gfx950, on the CPU, so that
+// indexing, tiling, barrier placement and MFMA fragment bookkeeping are checked
+// against the oracle without a GPU:
+//   * one fiber per work-item, 64-lane wavefronts, workgroups run one at a time;
+//   * __syncthreads() / wave collectives are cooperative yield points;
+//   * __shfl*, MFMA 32x32x2 f32 and 32x32x16 bf16 follow the lane->element
+//     maps of /opt/skills/guides/cdna_hip_programming.md §3 (A[i=l&31][k-group=l>>5],
+//     C/D col=l&31,row=(r&3)+8*(r>>2)+4*(l>>5));
+//   * atomics are sequential.  Nothing here models timing.
+#pragma once
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+
+struct dim3 {
+    unsigned x, y, z;
+    dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
+};
+struct simt_uint3 { unsigned x, y, z; };
+
+struct float2 { float x, y; };
+struct float4 { float x, y, z, w; };
+static inline float2 make_float2(float x, float y) { return float2{x, y}; }
+static inline float4 make_float4(float x, float y, float z, float w) { return float4{x, y, z, w}; }
+
+typedef void* hipStream_t;
+typedef int hipError_t;
+#define hipSuccess 0
+static inline hipError_t hipGetLastError() { return 0; }
+static inline const char* hipGetErrorString(hipError_t) { return "emu"; }
+
+namespace simt {
+struct Fiber;
+struct Wave {
+    // exchange area for wave collectives (one 16-byte slot x2 per lane)
+    alignas(16) unsigned char xa[64][16];
+    alignas(16) unsigned char xb[64][16];
+};
+struct Cur {
+    simt_uint3 tid, bid, bdim, gdim;
+    int lane, wave;
+    Wave* w;
+};
+extern Cur cur;
+void sync_block();
+void sync_wave();
+void launch(dim3 grid, dim3 block, const std::function<void()>& body);
+}  // namespace simt
+
+#define threadIdx (simt::cur.tid)
+#define blockIdx (simt::cur.bid)
+#define blockDim (simt::cur.bdim)
+#define gridDim (simt::cur.gdim)
+
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline
+#define __shared__ static
+#define __launch_bounds__(...)
+#define __restrict__
+#define __syncthreads() simt::sync_block()
+
+template <class T>
+static inline T simt_shfl_from(T v, int src) {
+    static_assert(sizeof(T) <= 16, "shfl payload");
+    std::memcpy(simt::cur.w->xa[simt::cur.lane], &v, sizeof(T));
+    simt::sync_wave();
+    T r;
+    std::memcpy(&r, simt::cur.w->xa[src & 63], sizeof(T));
+    simt::sync_wave();
+    return r;
+}
+template <class T> static inline T __shfl_xor(T v, int m) { return simt_shfl_from(v, simt::cur.lane ^ m); }
+template <class T> static inline T __shfl_down(T v, int d) {
+    int s = simt::cur.lane + d;
+    return simt_shfl_from(v, s < 64 ? s : simt::cur.lane);
+}
+template <class T> static inline T __shfl(T v, int src) { return simt_shfl_from(v, src); }
+
+static inline float atomicAdd(float* p, float v) { float o = *p; *p = o + v; return o; }
+static inline double atomicAdd(double* p, double v) { double o = *p; *p = o + v; return o; }
+static inline int atomicAdd(int* p, int v) { int o = *p; *p = o + v; return o; }
+static inline unsigned atomicAdd(unsigned* p, unsigned v) { unsigned o = *p; *p = o + v; return o; }
+
+static inline unsigned __umulhi(unsigned a, unsigned b) { return (unsigned)(((unsigned long long)a * b) >> 32); }
+
+typedef float simt_f32x16 __attribute__((ext_vector_type(16)));
+
+// v_mfma_f32_32x32x2_f32: D = A(32x2) * B(2x32) + C, exact f32 fma chain in k order.
+static inline simt_f32x16 simt_mfma_f32_32x32x2f32(float a, float b, simt_f32x16 c) {
+    const int l = simt::cur.lane;
+    std::memcpy(simt::cur.w->xa[l], &a, 4);
+    std::memcpy(simt::cur.w->xb[l], &b, 4);
+    simt::sync_wave();
+    const int col = l & 31, hi = l >> 5;
+    for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * hi;
+        float acc = c[r];
+        for (int k = 0; k < 2; ++k) {
+            float av, bv;
+            std::memcpy(&av, simt::cur.w->xa[row + 32 * k], 4);
+            std::memcpy(&bv, simt::cur.w->xb[col + 32 * k], 4);
+            acc = std::fmaf(av, bv, acc);
+        }
+        c[r] = acc;
+    }
+    simt::sync_wave();
+    return c;
+}
+
+static inline float simt_bf16_to_f32(unsigned short h) {
+    unsigned u = (unsigned)h << 16;
+    float f;
+    std::memcpy(&f, &u, 4);
+    return f;
+}
+
+// v_mfma_f32_32x32x16_bf16: lane l holds A[i=l&31][k=(l>>5)*8+j], B[k][j=l&31]; f32 accumulate.
+struct simt_bf16x8 { unsigned short v[8]; };
+static inline simt_f32x16 simt_mfma_f32_32x32x16_bf16(simt_bf16x8 a, simt_bf16x8 b, simt_f32x16 c) {
+    const int l = simt::cur.lane;
+    std::memcpy(simt::cur.w->xa[l], &a, 16);
+    std::memcpy(simt::cur.w->xb[l], &b, 16);
+    simt::sync_wave();
+    const int col = l & 31, hi = l >> 5;
+    for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * hi;
+        float acc = c[r];
+        for (int kg = 0; kg < 2; ++kg) {
+            simt_bf16x8 av, bv;
+            std::memcpy(&av, simt::cur.w->xa[row + 32 * kg], 16);
+            std::memcpy(&bv, simt::cur.w->xb[col + 32 * kg], 16);
+            for (int j = 0; j < 8; ++j) acc = std::fmaf(simt_bf16_to_f32(av.v[j]), simt_bf16_to_f32(bv.v[j]), acc);
+        }
+        c[r] = acc;
+    }
+    simt::sync_wave();
+    return c;
+}
