@@ -40,10 +40,10 @@ class DpcError(RuntimeError):
     pass
 
 
-def _p(t) -> C.c_void_p:
-    if t is None:
-        return C.c_void_p(0)
-    return C.c_void_p(t.data_ptr())
+def _p(t):
+    """Kept for readability at call sites: tensors are passed as-is and turned into
+    raw device pointers inside Lib.call (which keeps them alive for the call)."""
+    return t
 
 
 _vp, _i32, _i64, _f32, _f64 = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_double
@@ -117,7 +117,8 @@ class Lib:
         return C.c_void_p(0)
 
     def call(self, name: str, *args) -> int:
-        rc = self._fn(name)(*args)
+        conv = [C.c_void_p(a.data_ptr()) if isinstance(a, torch.Tensor) else a for a in args]
+        rc = self._fn(name)(*conv)
         if rc < 0:
             raise DpcError(f"{name} failed with code {rc}")
         return rc

@@ -1,0 +1,249 @@
+// bn.hip -- BatchNorm3d with batch statistics (track_running_stats=False, dpc/model_3d.py:28;
+// nn.BatchNorm3d at backbone/resnet_2d3d.py:55,59,93,97,212,243) on channels-last tensors,
+// fused with the residual add + ReLU of the BasicBlock tail (resnet_2d3d.py:67-80,105-116).
+// All kernels are HBM-bound: every access is a 16-byte unit (4 f32 / 8 bf16 channels),
+// statistics are accumulated in f32 per thread, f64 across partial rows (deterministic).
+#include "dpc_rt.h"
+#include "../../include/dpc_hip.h"
+
+static inline unsigned grid_for(long long n, int block = 256, int cap = 8192) {
+    long long g = (n + block - 1) / block;
+    if (g < 1) g = 1;
+    if (g > cap) g = cap;
+    return (unsigned)g;
+}
+
+// ------------------------------------------------------------------ forward finalize
+__global__ void bn_finalize_kernel(const float* partials, int rows, int C, double count, const float* gamma,
+                                   const float* beta, float eps, float* mean, float* invstd, float* scale, float* shift) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s1 = 0.0, s2 = 0.0;
+    for (int r = 0; r < rows; ++r) {
+        s1 += (double)partials[((long long)r * 2 + 0) * C + c];
+        s2 += (double)partials[((long long)r * 2 + 1) * C + c];
+    }
+    const double m = s1 / count;
+    double var = s2 / count - m * m;
+    if (var < 0.0) var = 0.0;
+    const double is = 1.0 / sqrt(var + (double)eps);
+    mean[c] = (float)m;
+    invstd[c] = (float)is;
+    const float sc = gamma[c] * (float)is;
+    scale[c] = sc;
+    shift[c] = beta[c] - (float)m * sc;
+}
+
+extern "C" int dpc_bn_finalize(const float* partials, int32_t rows, int32_t C, double count, const float* gamma,
+                               const float* beta, float eps, float* mean, float* invstd, float* scale, float* shift,
+                               dpc_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!partials || rows <= 0 || C <= 0 || count <= 0 || !gamma || !beta || !mean || !invstd || !scale || !shift) return DPC_ERR_ARG;
+    DPC_LAUNCH(bn_finalize_kernel, dim3((C + 63) / 64), dim3(64), stream, partials, rows, C, count, gamma, beta, eps, mean, invstd, scale, shift);
+    return dpc_launch_status();
+}
+
+// ------------------------------------------------------------------ forward apply (+res)(+relu)
+template <class T>
+__global__ void bn_apply_kernel(const T* x, T* y, long long units, int C, const float* scale, const float* shift,
+                                const T* res, const float* rscale, const float* rshift, int relu) {
+    constexpr int E = Elt<T>::PER16;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < units; i += (long long)gridDim.x * blockDim.x) {
+        const int c0 = (int)((i * E) % C);
+        const u32x4 xv = ((const u32x4*)x)[i];
+        u32x4 rv = {0u, 0u, 0u, 0u};
+        if (res) rv = ((const u32x4*)res)[i];
+        u32x4 o;
+        DPC_UNROLL
+        for (int e = 0; e < E; ++e) {
+            float v = unit_get<T>(xv, e) * scale[c0 + e] + shift[c0 + e];
+            if (res) {
+                float r = unit_get<T>(rv, e);
+                if (rscale) r = r * rscale[c0 + e] + rshift[c0 + e];
+                v += r;
+            }
+            if (relu) v = v > 0.f ? v : 0.f;
+            unit_set<T>(o, e, v);
+        }
+        ((u32x4*)y)[i] = o;
+    }
+}
+
+extern "C" int dpc_bn_apply(const void* x, void* y, int32_t dtype, int64_t rows, int32_t C, const float* scale,
+                            const float* shift, const void* res, const float* rscale, const float* rshift, int32_t relu,
+                            dpc_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!x || !y || rows <= 0 || C <= 0 || !scale || !shift) return DPC_ERR_ARG;
+    const int E = dtype == DPC_BF16 ? 8 : 4;
+    if (C % E) return DPC_ERR_UNSUPPORTED;
+    const long long units = rows * C / E;
+    if (dtype == DPC_F32) {
+        DPC_LAUNCH((bn_apply_kernel<float>), dim3(grid_for(units)), dim3(256), stream, (const float*)x, (float*)y, units, C, scale, shift, (const float*)res, rscale, rshift, relu);
+    } else if (dtype == DPC_BF16) {
+        DPC_LAUNCH((bn_apply_kernel<bf16_t>), dim3(grid_for(units)), dim3(256), stream, (const bf16_t*)x, (bf16_t*)y, units, C, scale, shift, (const bf16_t*)res, rscale, rshift, relu);
+    } else {
+        return DPC_ERR_ARG;
+    }
+    return dpc_launch_status();
+}
+
+// ------------------------------------------------------------------ backward reduce
+// dz = dy * (y > 0 if relu);  partial[b][0][c] = sum dz, partial[b][1][c] = sum dz * xhat
+template <class T>
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* dy, const T* y, const T* x, long long rows, int C,
+                                                            const float* mean, const float* invstd, int relu,
+                                                            float* partials, long long rows_per_block) {
+    constexpr int E = Elt<T>::PER16;
+    __shared__ float red[2][256 * E];
+    const int upr = C / E;            // units per row
+    const int rpi = 256 / upr;        // rows per iteration
+    const int tid = threadIdx.x;
+    const int cu = tid % upr, rr = tid / upr;
+    float a1[E], a2[E], mu[E], is[E];
+    DPC_UNROLL
+    for (int e = 0; e < E; ++e) { a1[e] = 0.f; a2[e] = 0.f; }
+    const bool active = rr < rpi;
+    if (active) {
+        DPC_UNROLL
+        for (int e = 0; e < E; ++e) { mu[e] = mean[cu * E + e]; is[e] = invstd[cu * E + e]; }
+        const long long r_begin = (long long)blockIdx.x * rows_per_block;
+        long long r_end = r_begin + rows_per_block;
+        if (r_end > rows) r_end = rows;
+        for (long long r = r_begin + rr; r < r_end; r += rpi) {
+            const long long ui = r * upr + cu;
+            const u32x4 dv = ((const u32x4*)dy)[ui];
+            const u32x4 xv = ((const u32x4*)x)[ui];
+            u32x4 yv = {0u, 0u, 0u, 0u};
+            if (relu) yv = ((const u32x4*)y)[ui];
+            DPC_UNROLL
+            for (int e = 0; e < E; ++e) {
+                float dz = unit_get<T>(dv, e);
+                if (relu && !(unit_get<T>(yv, e) > 0.f)) dz = 0.f;
+                const float xh = (unit_get<T>(xv, e) - mu[e]) * is[e];
+                a1[e] += dz;
+                a2[e] += dz * xh;
+            }
+        }
+    }
+    DPC_UNROLL
+    for (int e = 0; e < E; ++e) {
+        red[0][tid * E + e] = a1[e];
+        red[1][tid * E + e] = a2[e];
+    }
+    __syncthreads();
+    if (tid < C) {
+        // channel tid lives in unit cu2 = tid / E, element e2 = tid % E of every row-group
+        const int cu2 = tid / E, e2 = tid % E;
+        float s1 = 0.f, s2 = 0.f;
+        for (int g = 0; g < rpi; ++g) {
+            const int t2 = g * upr + cu2;
+            s1 += red[0][t2 * E + e2];
+            s2 += red[1][t2 * E + e2];
+        }
+        partials[((long long)blockIdx.x * 2 + 0) * C + tid] = s1;
+        partials[((long long)blockIdx.x * 2 + 1) * C + tid] = s2;
+    }
+}
+
+static int bn_bwd_blocks(long long rows, int C, int E, long long* rows_per_block) {
+    const int rpi = 256 / (C / E);
+    long long per = (long long)rpi * 16;          // >=16 iterations per block
+    long long blocks = (rows + per - 1) / per;
+    if (blocks > 1024) {
+        blocks = 1024;
+        per = (rows + blocks - 1) / blocks;
+        per = (per + rpi - 1) / rpi * rpi;
+        blocks = (rows + per - 1) / per;
+    }
+    *rows_per_block = per;
+    return (int)blocks;
+}
+
+extern "C" int dpc_bn_bwd_reduce(const void* dy, const void* y, const void* x, int32_t dtype, int64_t rows, int32_t C,
+                                 const float* mean, const float* invstd, int32_t relu, float* partials, int32_t* prow,
+                                 dpc_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (rows <= 0 || C <= 0) return DPC_ERR_ARG;
+    const int E = dtype == DPC_BF16 ? 8 : 4;
+    if (C % E || C / E > 256 || C > 256) return DPC_ERR_UNSUPPORTED;
+    long long rpb;
+    const int blocks = bn_bwd_blocks(rows, C, E, &rpb);
+    if (prow) *prow = blocks;
+    if (!partials) return DPC_OK;  // size query
+    if (!dy || !x || !mean || !invstd || (relu && !y)) return DPC_ERR_ARG;
+    if (dtype == DPC_F32) {
+        DPC_LAUNCH((bn_bwd_reduce_kernel<float>), dim3(blocks), dim3(256), stream, (const float*)dy, (const float*)y, (const float*)x, (long long)rows, C, mean, invstd, relu, partials, rpb);
+    } else if (dtype == DPC_BF16) {
+        DPC_LAUNCH((bn_bwd_reduce_kernel<bf16_t>), dim3(blocks), dim3(256), stream, (const bf16_t*)dy, (const bf16_t*)y, (const bf16_t*)x, (long long)rows, C, mean, invstd, relu, partials, rpb);
+    } else {
+        return DPC_ERR_ARG;
+    }
+    return dpc_launch_status();
+}
+
+__global__ void bn_bwd_finalize_kernel(const float* partials, int prow, int C, double count, float* dgamma, float* dbeta, float* coef) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s1 = 0.0, s2 = 0.0;
+    for (int r = 0; r < prow; ++r) {
+        s1 += (double)partials[((long long)r * 2 + 0) * C + c];
+        s2 += (double)partials[((long long)r * 2 + 1) * C + c];
+    }
+    dbeta[c] = (float)s1;
+    dgamma[c] = (float)s2;
+    coef[c] = (float)(s1 / count);
+    coef[C + c] = (float)(s2 / count);
+}
+
+extern "C" int dpc_bn_bwd_finalize(const float* partials, int32_t prow, int32_t C, double count, float* dgamma,
+                                   float* dbeta, float* coef, dpc_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!partials || prow <= 0 || C <= 0 || count <= 0 || !dgamma || !dbeta || !coef) return DPC_ERR_ARG;
+    DPC_LAUNCH(bn_bwd_finalize_kernel, dim3((C + 63) / 64), dim3(64), stream, partials, prow, C, count, dgamma, dbeta, coef);
+    return dpc_launch_status();
+}
+
+// dx = gamma*invstd*(dz - c1 - xhat*c2)
+template <class T>
+__global__ void bn_bwd_apply_kernel(const T* dy, const T* y, const T* x, long long units, int C, const float* mean,
+                                    const float* invstd, const float* gamma, const float* coef, int relu, T* dx, T* dzout) {
+    constexpr int E = Elt<T>::PER16;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < units; i += (long long)gridDim.x * blockDim.x) {
+        const int c0 = (int)((i * E) % C);
+        const u32x4 dv = ((const u32x4*)dy)[i];
+        const u32x4 xv = ((const u32x4*)x)[i];
+        u32x4 yv = {0u, 0u, 0u, 0u};
+        if (relu) yv = ((const u32x4*)y)[i];
+        u32x4 o, oz;
+        DPC_UNROLL
+        for (int e = 0; e < E; ++e) {
+            const int c = c0 + e;
+            float dz = unit_get<T>(dv, e);
+            if (relu && !(unit_get<T>(yv, e) > 0.f)) dz = 0.f;
+            const float is = invstd[c];
+            const float xh = (unit_get<T>(xv, e) - mean[c]) * is;
+            unit_set<T>(o, e, gamma[c] * is * (dz - coef[c] - xh * coef[C + c]));
+            unit_set<T>(oz, e, dz);
+        }
+        ((u32x4*)dx)[i] = o;
+        if (dzout) ((u32x4*)dzout)[i] = oz;
+    }
+}
+
+extern "C" int dpc_bn_bwd_apply(const void* dy, const void* y, const void* x, int32_t dtype, int64_t rows, int32_t C,
+                                const float* mean, const float* invstd, const float* gamma, const float* coef, int32_t relu,
+                                void* dx, void* dz, dpc_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!dy || !x || !dx || rows <= 0 || C <= 0 || !mean || !invstd || !gamma || !coef || (relu && !y)) return DPC_ERR_ARG;
+    const int E = dtype == DPC_BF16 ? 8 : 4;
+    if (C % E) return DPC_ERR_UNSUPPORTED;
+    const long long units = rows * C / E;
+    if (dtype == DPC_F32) {
+        DPC_LAUNCH((bn_bwd_apply_kernel<float>), dim3(grid_for(units)), dim3(256), stream, (const float*)dy, (const float*)y, (const float*)x, units, C, mean, invstd, gamma, coef, relu, (float*)dx, (float*)dz);
+    } else if (dtype == DPC_BF16) {
+        DPC_LAUNCH((bn_bwd_apply_kernel<bf16_t>), dim3(grid_for(units)), dim3(256), stream, (const bf16_t*)dy, (const bf16_t*)y, (const bf16_t*)x, units, C, mean, invstd, gamma, coef, relu, (bf16_t*)dx, (bf16_t*)dz);
+    } else {
+        return DPC_ERR_ARG;
+    }
+    return dpc_launch_status();
+}

@@ -1,0 +1,168 @@
+// loss.hip -- contrastive head and optimizer of the train step:
+//   mask      dpc/model_3d.py:86-96 (closed form; the reference builds it with B + B*SQ
+//             Python index assignments, every step under multi-GPU DataParallel)
+//   ce_topk   nn.CrossEntropyLoss + calc_topk_accuracy(1,3,5) with target = arange
+//             (dpc/main.py:178-185,213-218; utils/utils.py:38-55), plus d(loss)/d(score)
+//   adam      torch.optim.Adam(lr, weight_decay as L2) on the flat parameter buffer (main.py:80-81)
+// All HBM-bound; row reductions use wave64 shuffles then one LDS hop across the 4 waves.
+#include "dpc_rt.h"
+#include "../../include/dpc_hip.h"
+
+static inline unsigned grid_for(long long n, int block = 256, int cap = 8192) {
+    long long g = (n + block - 1) / block;
+    if (g < 1) g = 1;
+    if (g > cap) g = cap;
+    return (unsigned)g;
+}
+
+// mask[b][p][s][b2][n][s2]: 1 pos (b=b2,s=s2,p=n) | -1 temporal neg (b=b2,s=s2,p!=n) | -3 spatial neg (b=b2,s!=s2) | 0
+__global__ void mask_gen_kernel(int8_t* mask, int B, int P, int SQ) {
+    const long long row_len = (long long)B * P * SQ;
+    const long long n = row_len * row_len;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const long long r = i / row_len, c = i % row_len;
+        const int s = (int)(r % SQ), p = (int)((r / SQ) % P), b = (int)(r / ((long long)SQ * P));
+        const int s2 = (int)(c % SQ), n2 = (int)((c / SQ) % P), b2 = (int)(c / ((long long)SQ * P));
+        int8_t v = 0;
+        if (b == b2) v = (s != s2) ? -3 : ((p == n2) ? 1 : -1);
+        mask[i] = v;
+    }
+}
+
+extern "C" int dpc_mask_gen(int8_t* mask, int32_t B, int32_t P, int32_t SQ, dpc_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!mask || B <= 0 || P <= 0 || SQ <= 0) return DPC_ERR_ARG;
+    const long long rl = (long long)B * P * SQ;
+    DPC_LAUNCH(mask_gen_kernel, dim3(grid_for(rl * rl)), dim3(256), stream, mask, B, P, SQ);
+    return dpc_launch_status();
+}
+
+__device__ __forceinline__ float wave_max(float v) {
+    DPC_UNROLL
+    for (int m = 32; m >= 1; m >>= 1) { const float o = __shfl_xor(v, m); v = o > v ? o : v; }
+    return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+    DPC_UNROLL
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
+    return v;
+}
+
+// one workgroup per score row; three L2-resident sweeps (max, sum-exp + rank, gradient)
+template <class TD>
+__global__ __launch_bounds__(256) void ce_row_kernel(const float* score, int rows, int cols, int ld, float* row_ws,
+                                                     TD* dscore, int ld_d) {
+    __shared__ float sh[8];
+    const int row = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const float* s = score + (long long)row * ld;
+    const float tgt = s[row];  // target column = row (closed form of process_output on one GPU)
+    float mx = -3.0e38f;
+    for (int j = tid; j < cols; j += 256) { const float v = s[j]; mx = v > mx ? v : mx; }
+    mx = wave_max(mx);
+    if (lane == 0) sh[wv] = mx;
+    __syncthreads();
+    mx = sh[0];
+    DPC_UNROLL
+    for (int w = 1; w < 4; ++w) mx = sh[w] > mx ? sh[w] : mx;
+    float se = 0.f, rk = 0.f;
+    for (int j = tid; j < cols; j += 256) {
+        const float v = s[j];
+        se += expf(v - mx);
+        rk += (v > tgt) ? 1.f : 0.f;
+    }
+    se = wave_sum(se);
+    rk = wave_sum(rk);
+    __syncthreads();
+    if (lane == 0) { sh[wv] = se; sh[4 + wv] = rk; }
+    __syncthreads();
+    se = sh[0] + sh[1] + sh[2] + sh[3];
+    rk = sh[4] + sh[5] + sh[6] + sh[7];
+    if (tid == 0) {
+        row_ws[2 * row + 0] = logf(se) + mx - tgt;
+        row_ws[2 * row + 1] = rk;
+    }
+    if (dscore) {
+        const float inv = 1.f / se, invr = 1.f / (float)rows;
+        TD* d = dscore + (long long)row * ld_d;
+        for (int j = tid; j < cols; j += 256) {
+            float g = expf(s[j] - mx) * inv;
+            if (j == row) g -= 1.f;
+            d[j] = Elt<TD>::from_f32(g * invr);
+        }
+        for (int j = cols + tid; j < ld_d; j += 256) d[j] = Elt<TD>::from_f32(0.f);
+    }
+}
+
+__global__ __launch_bounds__(256) void ce_finalize_kernel(const float* row_ws, int rows, float* result) {
+    __shared__ float sh[4][4];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    float a[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int r = tid; r < rows; r += 256) {
+        const float rk = row_ws[2 * r + 1];
+        a[0] += row_ws[2 * r];
+        a[1] += rk < 1.f ? 1.f : 0.f;
+        a[2] += rk < 3.f ? 1.f : 0.f;
+        a[3] += rk < 5.f ? 1.f : 0.f;
+    }
+    DPC_UNROLL
+    for (int k = 0; k < 4; ++k) {
+        a[k] = wave_sum(a[k]);
+        if (lane == 0) sh[wv][k] = a[k];
+    }
+    __syncthreads();
+    if (tid < 4) result[tid] = (sh[0][tid] + sh[1][tid] + sh[2][tid] + sh[3][tid]) / (float)rows;
+}
+
+extern "C" int dpc_ce_topk(const float* score, int32_t rows, int32_t cols, int32_t ld, float* row_ws, float* result,
+                           void* dscore, int32_t dtype_d, int32_t ld_d, dpc_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!score || !row_ws || !result || rows <= 0 || cols < rows || ld < cols) return DPC_ERR_ARG;
+    if (dscore && ld_d < cols) return DPC_ERR_ARG;
+    if (!dscore || dtype_d == DPC_F32) {
+        DPC_LAUNCH((ce_row_kernel<float>), dim3(rows), dim3(256), stream, score, rows, cols, ld, row_ws, (float*)dscore, ld_d);
+    } else if (dtype_d == DPC_BF16) {
+        DPC_LAUNCH((ce_row_kernel<bf16_t>), dim3(rows), dim3(256), stream, score, rows, cols, ld, row_ws, (bf16_t*)dscore, ld_d);
+    } else {
+        return DPC_ERR_ARG;
+    }
+    DPC_LAUNCH(ce_finalize_kernel, dim3(1), dim3(256), stream, row_ws, rows, result);
+    return dpc_launch_status();
+}
+
+// Adam, weight decay folded into the gradient (torch.optim.Adam semantics), 16-byte accesses
+__global__ void adam_kernel(float* p, const float* g, float* m, float* v, long long n4, long long n, float lr, float b1,
+                            float b2, float eps, float wd, float bc1, float bc2, float gscale) {
+    const float step = lr / bc1;
+    const float isb2 = 1.f / sqrtf(bc2);
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+        const long long base = i * 4;
+        if (base + 4 <= n) {
+            f32x4 pv = ((f32x4*)p)[i], gv = ((const f32x4*)g)[i], mv = ((f32x4*)m)[i], vv = ((f32x4*)v)[i];
+            DPC_UNROLL
+            for (int e = 0; e < 4; ++e) {
+                const float gg = gv[e] * gscale + wd * pv[e];
+                mv[e] = b1 * mv[e] + (1.f - b1) * gg;
+                vv[e] = b2 * vv[e] + (1.f - b2) * gg * gg;
+                pv[e] -= step * mv[e] / (sqrtf(vv[e]) * isb2 + eps);
+            }
+            ((f32x4*)p)[i] = pv; ((f32x4*)m)[i] = mv; ((f32x4*)v)[i] = vv;
+        } else {
+            for (long long k = base; k < n; ++k) {
+                const float gg = g[k] * gscale + wd * p[k];
+                m[k] = b1 * m[k] + (1.f - b1) * gg;
+                v[k] = b2 * v[k] + (1.f - b2) * gg * gg;
+                p[k] -= step * m[k] / (sqrtf(v[k]) * isb2 + eps);
+            }
+        }
+    }
+}
+
+extern "C" int dpc_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+                        float eps, float wd, float bias_corr1, float bias_corr2, float grad_scale, dpc_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!p || !g || !m || !v || n <= 0 || bias_corr1 <= 0.f || bias_corr2 <= 0.f) return DPC_ERR_ARG;
+    const long long n4 = (n + 3) / 4;
+    DPC_LAUNCH(adam_kernel, dim3(grid_for(n4)), dim3(256), stream, p, g, m, v, n4, (long long)n, lr, beta1, beta2, eps, wd, bias_corr1, bias_corr2, grad_scale);
+    return dpc_launch_status();
+}

@@ -1,0 +1,254 @@
+// pool.hip -- the stem tail BN+ReLU+MaxPool3d((1,3,3),s(1,2,2),p(0,1,1))
+// (backbone/resnet_2d3d.py:212-214,260-263) and the temporal mean / ReLU split that feeds
+// the ConvGRU and the score (dpc/model_3d.py:53-59).  Channels-last, 16-byte units, HBM-bound.
+#include "dpc_rt.h"
+#include "../../include/dpc_hip.h"
+
+static inline unsigned grid_for(long long n, int block = 256, int cap = 16384) {
+    long long g = (n + block - 1) / block;
+    if (g < 1) g = 1;
+    if (g > cap) g = cap;
+    return (unsigned)g;
+}
+
+// y[nt][oh][ow][c] = max_{3x3} relu(x*scale+shift); argmax = kh*3+kw of the FIRST maximum in
+// scan order (torch max_pool semantics), or 9 when the maximum is 0 (ReLU kills the gradient).
+template <class T>
+__global__ void bn_relu_maxpool_fwd_kernel(const T* x, int NT, int H, int W, int C, int Ho, int Wo,
+                                           const float* scale, const float* shift, T* y, uint8_t* argmax) {
+    constexpr int E = Elt<T>::PER16;
+    const int upr = C / E;
+    const long long units = (long long)NT * Ho * Wo * upr;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < units; i += (long long)gridDim.x * blockDim.x) {
+        const int cu = (int)(i % upr);
+        long long q = i / upr;
+        const int ow = (int)(q % Wo);
+        q /= Wo;
+        const int oh = (int)(q % Ho);
+        const int nt = (int)(q / Ho);
+        float sc[E], sh[E], best[E];
+        int bi[E];
+        DPC_UNROLL
+        for (int e = 0; e < E; ++e) {
+            sc[e] = scale[cu * E + e];
+            sh[e] = shift[cu * E + e];
+            best[e] = -1.f;
+            bi[e] = 9;
+        }
+        DPC_UNROLL
+        for (int kh = 0; kh < 3; ++kh) {
+            const int h = 2 * oh - 1 + kh;
+            if (h < 0 || h >= H) continue;
+            DPC_UNROLL
+            for (int kw = 0; kw < 3; ++kw) {
+                const int w = 2 * ow - 1 + kw;
+                if (w < 0 || w >= W) continue;
+                const u32x4 v = ((const u32x4*)x)[(((long long)nt * H + h) * W + w) * upr + cu];
+                DPC_UNROLL
+                for (int e = 0; e < E; ++e) {
+                    float a = unit_get<T>(v, e) * sc[e] + sh[e];
+                    a = a > 0.f ? a : 0.f;
+                    if (a > best[e]) { best[e] = a; bi[e] = kh * 3 + kw; }
+                }
+            }
+        }
+        u32x4 o;
+        DPC_UNROLL
+        for (int e = 0; e < E; ++e) {
+            unit_set<T>(o, e, best[e]);
+            argmax[i * E + e] = (uint8_t)(best[e] > 0.f ? bi[e] : 9);
+        }
+        ((u32x4*)y)[i] = o;
+    }
+}
+
+extern "C" int dpc_bn_relu_maxpool_fwd(const void* x, int32_t dtype, int32_t NT, int32_t H, int32_t W, int32_t C,
+                                       const float* scale, const float* shift, void* y, uint8_t* argmax,
+                                       dpc_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!x || !y || !argmax || !scale || !shift || NT <= 0 || H <= 0 || W <= 0 || C <= 0) return DPC_ERR_ARG;
+    const int E = dtype == DPC_BF16 ? 8 : 4;
+    if (C % E) return DPC_ERR_UNSUPPORTED;
+    const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+    const long long units = (long long)NT * Ho * Wo * (C / E);
+    if (dtype == DPC_F32) {
+        DPC_LAUNCH((bn_relu_maxpool_fwd_kernel<float>), dim3(grid_for(units)), dim3(256), stream, (const float*)x, NT, H, W, C, Ho, Wo, scale, shift, (float*)y, argmax);
+    } else if (dtype == DPC_BF16) {
+        DPC_LAUNCH((bn_relu_maxpool_fwd_kernel<bf16_t>), dim3(grid_for(units)), dim3(256), stream, (const bf16_t*)x, NT, H, W, C, Ho, Wo, scale, shift, (bf16_t*)y, argmax);
+    } else {
+        return DPC_ERR_ARG;
+    }
+    return dpc_launch_status();
+}
+
+// dz[nt][h][w][c] = sum over the (<=4) windows that contain (h,w) and whose argmax is (h,w)
+template <class T>
+__global__ void maxpool_bwd_kernel(const T* dy, const uint8_t* argmax, int NT, int H, int W, int C, int Ho, int Wo, T* dz) {
+    constexpr int E = Elt<T>::PER16;
+    const int upr = C / E;
+    const long long units = (long long)NT * H * W * upr;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < units; i += (long long)gridDim.x * blockDim.x) {
+        const int cu = (int)(i % upr);
+        long long q = i / upr;
+        const int w = (int)(q % W);
+        q /= W;
+        const int h = (int)(q % H);
+        const int nt = (int)(q / H);
+        float acc[E];
+        DPC_UNROLL
+        for (int e = 0; e < E; ++e) acc[e] = 0.f;
+        const int oh0 = h >> 1, ow0 = w >> 1;  // window with kh = (h odd ? 2 : 1); h odd also hits oh0+1 with kh = 0
+        DPC_UNROLL
+        for (int a = 0; a < 2; ++a) {
+            if (a == 1 && !(h & 1)) continue;
+            const int oh = oh0 + a;
+            if (oh >= Ho) continue;
+            const int kh = h - (2 * oh - 1);
+            DPC_UNROLL
+            for (int b = 0; b < 2; ++b) {
+                if (b == 1 && !(w & 1)) continue;
+                const int ow = ow0 + b;
+                if (ow >= Wo) continue;
+                const int kw = w - (2 * ow - 1);
+                const int want = kh * 3 + kw;
+                const long long ui = (((long long)nt * Ho + oh) * Wo + ow) * upr + cu;
+                const u32x4 g = ((const u32x4*)dy)[ui];
+                const uint8_t* am = argmax + ui * E;
+                DPC_UNROLL
+                for (int e = 0; e < E; ++e)
+                    if (am[e] == want) acc[e] += unit_get<T>(g, e);
+            }
+        }
+        u32x4 o;
+        DPC_UNROLL
+        for (int e = 0; e < E; ++e) unit_set<T>(o, e, acc[e]);
+        ((u32x4*)dz)[i] = o;
+    }
+}
+
+extern "C" int dpc_maxpool_bwd(const void* dy, const uint8_t* argmax, int32_t dtype, int32_t NT, int32_t H, int32_t W,
+                               int32_t C, void* dz, dpc_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!dy || !argmax || !dz || NT <= 0 || H <= 0 || W <= 0 || C <= 0) return DPC_ERR_ARG;
+    const int E = dtype == DPC_BF16 ? 8 : 4;
+    if (C % E) return DPC_ERR_UNSUPPORTED;
+    const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+    const long long units = (long long)NT * H * W * (C / E);
+    if (dtype == DPC_F32) {
+        DPC_LAUNCH((maxpool_bwd_kernel<float>), dim3(grid_for(units)), dim3(256), stream, (const float*)dy, argmax, NT, H, W, C, Ho, Wo, (float*)dz);
+    } else if (dtype == DPC_BF16) {
+        DPC_LAUNCH((maxpool_bwd_kernel<bf16_t>), dim3(grid_for(units)), dim3(256), stream, (const bf16_t*)dy, argmax, NT, H, W, C, Ho, Wo, (bf16_t*)dz);
+    } else {
+        return DPC_ERR_ARG;
+    }
+    return dpc_launch_status();
+}
+
+// ---- temporal mean over the T frames left by layer4, ReLU split (dpc/model_3d.py:53-59)
+// x [B*N][T][SQ][D] -> feat_relu [N][B*SQ][D] ; feat_inf [B][P][SQ][D] (blocks n >= N-P, pre-ReLU)
+template <class T>
+__global__ void tpool_split_fwd_kernel(const T* x, int B, int N, int Tt, int SQ, int D, int P, T* feat_relu, T* feat_inf) {
+    constexpr int E = Elt<T>::PER16;
+    const int upr = D / E;
+    const long long units = (long long)B * N * SQ * upr;
+    const float inv = 1.f / (float)Tt;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < units; i += (long long)gridDim.x * blockDim.x) {
+        const int cu = (int)(i % upr);
+        long long q = i / upr;
+        const int s = (int)(q % SQ);
+        q /= SQ;
+        const int n = (int)(q % N);
+        const int b = (int)(q / N);
+        float m[E];
+        DPC_UNROLL
+        for (int e = 0; e < E; ++e) m[e] = 0.f;
+        for (int t = 0; t < Tt; ++t) {
+            const u32x4 v = ((const u32x4*)x)[((((long long)b * N + n) * Tt + t) * SQ + s) * upr + cu];
+            DPC_UNROLL
+            for (int e = 0; e < E; ++e) m[e] += unit_get<T>(v, e);
+        }
+        u32x4 orl, oin;
+        DPC_UNROLL
+        for (int e = 0; e < E; ++e) {
+            const float v = m[e] * inv;
+            unit_set<T>(oin, e, v);
+            unit_set<T>(orl, e, v > 0.f ? v : 0.f);
+        }
+        ((u32x4*)feat_relu)[(((long long)n * B + b) * SQ + s) * upr + cu] = orl;
+        if (n >= N - P) ((u32x4*)feat_inf)[(((long long)b * P + (n - (N - P))) * SQ + s) * upr + cu] = oin;
+    }
+}
+
+extern "C" int dpc_tpool_split_fwd(const void* x, int32_t dtype, int32_t B, int32_t N, int32_t T, int32_t SQ, int32_t D,
+                                   int32_t P, void* feat_relu, void* feat_inf, dpc_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!x || !feat_relu || !feat_inf || B <= 0 || N <= 0 || T <= 0 || SQ <= 0 || D <= 0 || P <= 0 || P > N) return DPC_ERR_ARG;
+    const int E = dtype == DPC_BF16 ? 8 : 4;
+    if (D % E) return DPC_ERR_UNSUPPORTED;
+    const long long units = (long long)B * N * SQ * (D / E);
+    if (dtype == DPC_F32) {
+        DPC_LAUNCH((tpool_split_fwd_kernel<float>), dim3(grid_for(units)), dim3(256), stream, (const float*)x, B, N, T, SQ, D, P, (float*)feat_relu, (float*)feat_inf);
+    } else if (dtype == DPC_BF16) {
+        DPC_LAUNCH((tpool_split_fwd_kernel<bf16_t>), dim3(grid_for(units)), dim3(256), stream, (const bf16_t*)x, B, N, T, SQ, D, P, (bf16_t*)feat_relu, (bf16_t*)feat_inf);
+    } else {
+        return DPC_ERR_ARG;
+    }
+    return dpc_launch_status();
+}
+
+// dx[b*N+n][t][s][d] = (1/T) * ( d_relu[n][b*SQ+s][d]*(mean>0)  [n < N-P]  +  d_inf[b][n-(N-P)][s][d]  [n >= N-P] )
+template <class T>
+__global__ void tpool_split_bwd_kernel(const T* x, const float* d_relu, const float* d_inf, int B, int N, int Tt, int SQ,
+                                       int D, int P, T* dx) {
+    constexpr int E = Elt<T>::PER16;
+    const int upr = D / E;
+    const long long units = (long long)B * N * SQ * upr;
+    const float inv = 1.f / (float)Tt;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < units; i += (long long)gridDim.x * blockDim.x) {
+        const int cu = (int)(i % upr);
+        long long q = i / upr;
+        const int s = (int)(q % SQ);
+        q /= SQ;
+        const int n = (int)(q % N);
+        const int b = (int)(q / N);
+        float g[E];
+        if (n < N - P) {
+            float m[E];
+            DPC_UNROLL
+            for (int e = 0; e < E; ++e) m[e] = 0.f;
+            for (int t = 0; t < Tt; ++t) {
+                const u32x4 v = ((const u32x4*)x)[((((long long)b * N + n) * Tt + t) * SQ + s) * upr + cu];
+                DPC_UNROLL
+                for (int e = 0; e < E; ++e) m[e] += unit_get<T>(v, e);
+            }
+            const float* gr = d_relu + (((long long)n * B + b) * SQ + s) * D + cu * E;
+            DPC_UNROLL
+            for (int e = 0; e < E; ++e) g[e] = (m[e] > 0.f) ? gr[e] * inv : 0.f;
+        } else {
+            const float* gi = d_inf + (((long long)b * P + (n - (N - P))) * SQ + s) * D + cu * E;
+            DPC_UNROLL
+            for (int e = 0; e < E; ++e) g[e] = gi[e] * inv;
+        }
+        u32x4 o;
+        DPC_UNROLL
+        for (int e = 0; e < E; ++e) unit_set<T>(o, e, g[e]);
+        for (int t = 0; t < Tt; ++t) ((u32x4*)dx)[((((long long)b * N + n) * Tt + t) * SQ + s) * upr + cu] = o;
+    }
+}
+
+extern "C" int dpc_tpool_split_bwd(const void* x, const void* d_relu, const float* d_inf, int32_t dtype, int32_t B,
+                                   int32_t N, int32_t T, int32_t SQ, int32_t D, int32_t P, void* dx, dpc_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!x || !d_relu || !d_inf || !dx || B <= 0 || N <= 0 || T <= 0 || SQ <= 0 || D <= 0 || P <= 0 || P > N) return DPC_ERR_ARG;
+    const int E = dtype == DPC_BF16 ? 8 : 4;
+    if (D % E) return DPC_ERR_UNSUPPORTED;
+    const long long units = (long long)B * N * SQ * (D / E);
+    if (dtype == DPC_F32) {
+        DPC_LAUNCH((tpool_split_bwd_kernel<float>), dim3(grid_for(units)), dim3(256), stream, (const float*)x, (const float*)d_relu, d_inf, B, N, T, SQ, D, P, (float*)dx);
+    } else if (dtype == DPC_BF16) {
+        DPC_LAUNCH((tpool_split_bwd_kernel<bf16_t>), dim3(grid_for(units)), dim3(256), stream, (const bf16_t*)x, (const float*)d_relu, d_inf, B, N, T, SQ, D, P, (bf16_t*)dx);
+    } else {
+        return DPC_ERR_ARG;
+    }
+    return dpc_launch_status();
+}

@@ -1,0 +1,447 @@
+"""Kernel parity cases shared by the CPU tier (kernels executed by the host SIMT
+simulator, tests/test_kernels_emu.py) and the GPU tier (the same C ABI of
+libdpc_hip.so on an MI355X, tests/test_kernels_gpu.py).
+
+Every case computes its expectation with plain torch CPU ops (f32, or f64 where
+the quantity is a long reduction) -- the same ops the reference model runs
+(backbone/resnet_2d3d.py, backbone/convrnn.py, dpc/model_3d.py, dpc/main.py) -- and
+calls the kernel through dpc_amd._lib.  Tolerances: f32 mode 1e-4 relative to the
+tensor's max-abs (the reference's own fp32 noise floor is ~1e-4);
+bf16 mode 2^-7 relative (one bf16 rounding of the output).
+"""
+import ctypes as C
+
+import torch
+import torch.nn.functional as F
+
+from dpc_amd import _lib as L
+
+
+def cl(x):  # NCDHW -> channels-last contiguous
+    return x.permute(0, 2, 3, 4, 1).contiguous()
+
+
+def tol(dtype):
+    return 1e-4 if dtype == torch.float32 else 1.0 / 64
+
+
+def q(x, dtype):  # quantise like the device tensor will be
+    return x.to(dtype).float()
+
+
+def relerr(a, b):
+    return (a.float().cpu() - b.float()).abs().max().item() / max(b.abs().max().item(), 1e-6)
+
+
+class K:
+    """binds a Lib + device"""
+
+    def __init__(self, lib, device):
+        self.lib, self.dev = lib, torch.device(device)
+
+    def t(self, x, dtype=None):
+        x = x.to(dtype) if dtype is not None else x
+        return x.contiguous().to(self.dev)
+
+    def empty(self, *shape, dtype=torch.float32):
+        return torch.empty(*shape, dtype=dtype, device=self.dev)
+
+    def zeros(self, *shape, dtype=torch.float32):
+        return torch.zeros(*shape, dtype=dtype, device=self.dev)
+
+    def call(self, name, *args):
+        return self.lib.call(name, *args, self.lib.stream())
+
+    def sync(self):
+        if self.dev.type == "cuda":
+            torch.cuda.synchronize()
+
+
+def conv_desc(dtype_in, dtype_out, mode, N, R, S, Ci, src_ld, Co, ldw, ldo, k, s, p):
+    return L.ConvDesc(L.dtype_code(dtype_in), L.dtype_code(dtype_out), mode, N, R[0], R[1], R[2], S[0], S[1], S[2],
+                      Ci, src_ld, Co, ldw, ldo, k[0], k[1], k[2], s[0], s[1], s[2], p[0], p[1], p[2])
+
+
+# ------------------------------------------------------------------ conv forward (+ BN partial sums)
+def case_conv_fwd(k: K, dtype, N, Ci, Co, T, H, W, ks, st, pd, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    x = q(torch.randn(N, Ci, T, H, W, generator=g), dtype)
+    w = q(torch.randn(Co, Ci, *ks, generator=g) * 0.1, dtype)
+    y = F.conv3d(x, w, None, st, pd)
+    To, Ho, Wo = y.shape[2:]
+    taps = ks[0] * ks[1] * ks[2]
+    d = conv_desc(dtype, dtype, 0, N, (To, Ho, Wo), (T, H, W), Ci, Ci, Co, taps * Ci, Co, ks, st, pd)
+    src = k.t(cl(x), dtype)
+    wp = k.t(w.permute(0, 2, 3, 4, 1).reshape(Co, taps * Ci), dtype)
+    out = k.empty(N, To, Ho, Wo, Co, dtype=dtype)
+    rows = k.lib.call("dpc_conv_stats_rows", C.byref(d))
+    stats = k.zeros(rows, 2, Co)
+    k.call("dpc_conv_igemm", C.byref(d), L._p(src), L._p(wp), L._p(out), None, L._p(stats))
+    k.sync()
+    assert relerr(out, cl(y)) < tol(dtype)
+    o = out.float().cpu().reshape(-1, Co).double()
+    s = stats.cpu().double()
+    assert (s[:, 0].sum(0) - o.sum(0)).abs().max().item() < 1e-3 * max(1.0, o.abs().sum(0).max().item())
+    assert (s[:, 1].sum(0) - (o * o).sum(0)).abs().max().item() < 1e-4 * (o * o).sum(0).max().item()
+
+
+def case_conv_dgrad(k: K, dtype, N, Ci, Co, T, H, W, ks, st, pd, seed=1):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(N, Ci, T, H, W, generator=g).requires_grad_()
+    w = q(torch.randn(Co, Ci, *ks, generator=g) * 0.1, dtype)
+    y = F.conv3d(x, w, None, st, pd)
+    gy = q(torch.randn(y.shape, generator=g), dtype)
+    gx = torch.autograd.grad(y, x, gy)[0]
+    To, Ho, Wo = y.shape[2:]
+    taps = ks[0] * ks[1] * ks[2]
+    d = conv_desc(dtype, dtype, 1, N, (T, H, W), (To, Ho, Wo), Co, Co, Ci, taps * Co, Ci, ks, st, pd)
+    add = q(torch.randn(N, T, H, W, Ci, generator=g), dtype)
+    out = k.empty(N, T, H, W, Ci, dtype=dtype)
+    wd = k.t(w.permute(1, 2, 3, 4, 0).reshape(Ci, taps * Co), dtype)
+    k.call("dpc_conv_igemm", C.byref(d), L._p(k.t(cl(gy), dtype)), L._p(wd), L._p(out), L._p(k.t(add, dtype)), None)
+    k.sync()
+    assert relerr(out, cl(gx) + add) < tol(dtype)
+
+
+def case_conv_wgrad(k: K, dtype, N, Ci, Co, T, H, W, ks, st, pd, seed=2):
+    g = torch.Generator().manual_seed(seed)
+    x = q(torch.randn(N, Ci, T, H, W, generator=g), dtype)
+    w = (torch.randn(Co, Ci, *ks, generator=g) * 0.1).requires_grad_()
+    y = F.conv3d(x, w, None, st, pd)
+    gy = q(torch.randn(y.shape, generator=g), dtype)
+    gw = torch.autograd.grad(y, w, gy)[0]
+    To, Ho, Wo = y.shape[2:]
+    taps = ks[0] * ks[1] * ks[2]
+    d = conv_desc(dtype, torch.float32, 0, N, (To, Ho, Wo), (T, H, W), Ci, Ci, Co, taps * Ci, Co, ks, st, pd)
+    ns = C.c_int32(0)
+    k.call("dpc_conv_wgrad", C.byref(d), None, None, Co, None, C.byref(ns))
+    part = k.zeros(ns.value, Co, taps * Ci)
+    k.call("dpc_conv_wgrad", C.byref(d), L._p(k.t(cl(x), dtype)), L._p(k.t(cl(gy), dtype)), Co, L._p(part), C.byref(ns))
+    dw = k.zeros(*gw.shape)
+    k.call("dpc_reduce_unpack", L._p(part), ns.value, L._p(dw), Co, taps, Ci, Ci * taps, 1, taps, 0)
+    k.sync()
+    assert relerr(dw, gw) < 1e-4  # f32 accumulation in both modes
+
+
+def case_gemm_nt(k: K, dtype, M, N, Kd, seed=3):
+    g = torch.Generator().manual_seed(seed)
+    A = q(torch.randn(M, Kd, generator=g), dtype)
+    B = q(torch.randn(N, Kd, generator=g), dtype)
+    d = conv_desc(dtype, torch.float32, 0, M, (1, 1, 1), (1, 1, 1), Kd, Kd, N, Kd, N, (1, 1, 1), (1, 1, 1), (0, 0, 0))
+    out = k.empty(M, N)
+    k.call("dpc_conv_igemm", C.byref(d), L._p(k.t(A, dtype)), L._p(k.t(B, dtype)), L._p(out), None, None)
+    k.sync()
+    assert relerr(out, A.double() @ B.double().t()) < 1e-5
+
+
+def case_stem(k: K, dtype, BN, T, H, W, Co=64, seed=4):
+    """Conv3d(3,Co,(1,7,7),s(1,2,2),p(0,3,3)) (resnet_2d3d.py:211) through the space-to-depth path."""
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(BN, 3, T, H, W, generator=g)
+    w = (torch.randn(Co, 3, 1, 7, 7, generator=g) * 0.1)
+    wq = q(w, dtype).requires_grad_()
+    y = F.conv3d(q(x, dtype), wq, None, (1, 2, 2), (0, 3, 3))
+    xs = k.empty(BN, T, H // 2, W // 2, 16, dtype=dtype)
+    k.call("dpc_pack_input_s2d", L._p(k.t(x)), L._p(xs), L.dtype_code(dtype), BN, T, H, W)
+    wp = k.empty(Co, 16, 16, dtype=dtype)
+    k.call("dpc_pack_stem_weight", L._p(k.t(w)), L._p(wp), L.dtype_code(dtype), Co)
+    d = conv_desc(dtype, dtype, 0, BN, (T, H // 2, W // 2), (T, H // 2, W // 2), 16, 16, Co, 256, Co, (1, 4, 4), (1, 1, 1), (0, 2, 2))
+    out = k.empty(BN, T, H // 2, W // 2, Co, dtype=dtype)
+    k.call("dpc_conv_igemm", C.byref(d), L._p(xs), L._p(wp), L._p(out), None, None)
+    k.sync()
+    assert relerr(out, cl(y)) < tol(dtype)
+    gy = q(torch.randn(y.shape, generator=g), dtype)
+    gw = torch.autograd.grad(y, wq, gy)[0]
+    ns = C.c_int32(0)
+    k.call("dpc_conv_wgrad", C.byref(d), None, None, Co, None, C.byref(ns))
+    part = k.zeros(ns.value, Co, 256)
+    k.call("dpc_conv_wgrad", C.byref(d), L._p(xs), L._p(k.t(cl(gy), dtype)), Co, L._p(part), C.byref(ns))
+    dw = k.zeros(Co, 3, 1, 7, 7)
+    k.call("dpc_unpack_stem_wgrad", L._p(part), ns.value, L._p(dw), Co)
+    k.sync()
+    assert relerr(dw, gw) < 1e-4
+
+
+# ------------------------------------------------------------------ batch norm
+def _bn_ref(x, gamma, beta, res, rs, rb, relu):
+    """x [rows,C] f64: returns y, mean, invstd"""
+    mean = x.mean(0)
+    var = x.var(0, unbiased=False)
+    invstd = 1.0 / torch.sqrt(var + 1e-5)
+    y = (x - mean) * invstd * gamma + beta
+    if res is not None:
+        y = y + (res * rs + rb if rs is not None else res)
+    if relu:
+        y = F.relu(y)
+    return y, mean, invstd
+
+
+def case_bn_fwd_bwd(k: K, dtype, rows, Cc, relu, res_mode, seed=5):
+    """res_mode: 0 none, 1 identity residual, 2 residual with its own scale/shift (downsample BN)"""
+    g = torch.Generator().manual_seed(seed)
+    x = q(torch.randn(rows, Cc, generator=g) * 2 + 0.5, dtype)
+    gamma = torch.rand(Cc, generator=g) + 0.5
+    beta = torch.randn(Cc, generator=g) * 0.3
+    res = q(torch.randn(rows, Cc, generator=g), dtype) if res_mode else None
+    rs = torch.rand(Cc, generator=g) + 0.5 if res_mode == 2 else None
+    rb = torch.randn(Cc, generator=g) if res_mode == 2 else None
+    xd = x.double().requires_grad_()
+    gd = gamma.double().requires_grad_()
+    bd = beta.double().requires_grad_()
+    y, mean, invstd = _bn_ref(xd, gd, bd, None if res is None else res.double(),
+                              None if rs is None else rs.double(), None if rb is None else rb.double(), relu)
+    # partial sums as the conv epilogue would deliver them (3 rows of partials)
+    parts = torch.zeros(3, 2, Cc)
+    for i, ch in enumerate(torch.chunk(x, 3, 0)):
+        parts[i, 0] = ch.sum(0)
+        parts[i, 1] = (ch * ch).sum(0)
+    dm, di, dsc, dsh = (k.empty(Cc) for _ in range(4))
+    k.call("dpc_bn_finalize", L._p(k.t(parts)), 3, Cc, float(rows), L._p(k.t(gamma)), L._p(k.t(beta)), 1e-5,
+           L._p(dm), L._p(di), L._p(dsc), L._p(dsh))
+    k.sync()
+    assert relerr(dm, mean.detach()) < 1e-5 and relerr(di, invstd.detach()) < 1e-4
+    xk = k.t(x, dtype)
+    yk = k.empty(rows, Cc, dtype=dtype)
+    k.call("dpc_bn_apply", L._p(xk), L._p(yk), L.dtype_code(dtype), rows, Cc, L._p(dsc), L._p(dsh),
+           L._p(None if res is None else k.t(res, dtype)), L._p(None if rs is None else k.t(rs)),
+           L._p(None if rb is None else k.t(rb)), int(relu))
+    k.sync()
+    assert relerr(yk, y.detach()) < tol(dtype)
+    # backward
+    gy = q(torch.randn(rows, Cc, generator=g), dtype)
+    y.backward(gy.double())
+    yq = k.t(y.detach().float(), dtype)  # saved post-activation output (mask source)
+    gyk = k.t(gy, dtype)
+    prow = C.c_int32(0)
+    k.call("dpc_bn_bwd_reduce", None, None, None, L.dtype_code(dtype), rows, Cc, None, None, int(relu), None, C.byref(prow))
+    bp = k.zeros(prow.value, 2, Cc)
+    k.call("dpc_bn_bwd_reduce", L._p(gyk), L._p(yq), L._p(xk), L.dtype_code(dtype), rows, Cc, L._p(dm), L._p(di),
+           int(relu), L._p(bp), C.byref(prow))
+    dgam, dbet, coef = k.empty(Cc), k.empty(Cc), k.empty(2, Cc)
+    k.call("dpc_bn_bwd_finalize", L._p(bp), prow.value, Cc, float(rows), L._p(dgam), L._p(dbet), L._p(coef))
+    dx = k.empty(rows, Cc, dtype=dtype)
+    dz = k.empty(rows, Cc, dtype=dtype)
+    k.call("dpc_bn_bwd_apply", L._p(gyk), L._p(yq), L._p(xk), L.dtype_code(dtype), rows, Cc, L._p(dm), L._p(di),
+           L._p(k.t(gamma)), L._p(coef), int(relu), L._p(dx), L._p(dz))
+    k.sync()
+    t = 2e-3 if dtype == torch.float32 else 3e-2  # relu-mask flips of y~0 elements are excluded by construction
+    assert relerr(dgam, gd.grad) < t and relerr(dbet, bd.grad) < t
+    assert relerr(dx, xd.grad) < t
+    dz_ref = gy.double() * ((y.detach() > 0).double() if relu else 1.0)
+    assert relerr(dz, dz_ref) < tol(dtype)
+
+
+def case_stem_pool(k: K, dtype, NT, H, W, Cc, seed=6):
+    """relu(bn(x)) -> MaxPool3d((1,3,3),(1,2,2),(0,1,1)) and its backward (resnet_2d3d.py:212-214)"""
+    g = torch.Generator().manual_seed(seed)
+    x = q(torch.randn(NT, H, W, Cc, generator=g), dtype)
+    sc = torch.rand(Cc, generator=g) + 0.5
+    sh = torch.randn(Cc, generator=g) * 0.2
+    a = (x * sc + sh).permute(0, 3, 1, 2).unsqueeze(2).requires_grad_()  # [NT,C,1,H,W]
+    y = F.max_pool3d(F.relu(a), (1, 3, 3), (1, 2, 2), (0, 1, 1))
+    Ho, Wo = y.shape[3:]
+    yk = k.empty(NT, Ho, Wo, Cc, dtype=dtype)
+    am = torch.empty(NT, Ho, Wo, Cc, dtype=torch.uint8, device=k.dev)
+    k.call("dpc_bn_relu_maxpool_fwd", L._p(k.t(x, dtype)), L.dtype_code(dtype), NT, H, W, Cc, L._p(k.t(sc)), L._p(k.t(sh)),
+           L._p(yk), L._p(am))
+    k.sync()
+    yref = y.detach().squeeze(2).permute(0, 2, 3, 1)
+    assert relerr(yk, yref) < tol(dtype)
+    gy = q(torch.randn(NT, Ho, Wo, Cc, generator=g), dtype)
+    y.backward(gy.permute(0, 3, 1, 2).unsqueeze(2))
+    dz = k.empty(NT, H, W, Cc, dtype=dtype)
+    k.call("dpc_maxpool_bwd", L._p(k.t(gy, dtype)), L._p(am), L.dtype_code(dtype), NT, H, W, Cc, L._p(dz))
+    k.sync()
+    dz_ref = a.grad.squeeze(2).permute(0, 2, 3, 1)
+    assert relerr(dz, dz_ref) < tol(dtype)
+
+
+def case_tpool_split(k: K, dtype, B, N, T, SQ, D, P, seed=7):
+    g = torch.Generator().manual_seed(seed)
+    x = q(torch.randn(B * N, T, SQ, D, generator=g), dtype).requires_grad_()
+    m = x.mean(1).view(B, N, SQ, D)
+    fr_ref = F.relu(m).permute(1, 0, 2, 3).reshape(N, B * SQ, D)
+    fi_ref = m[:, N - P:]
+    fr = k.empty(N, B * SQ, D, dtype=dtype)
+    fi = k.empty(B, P, SQ, D, dtype=dtype)
+    xk = k.t(x.detach(), dtype)
+    k.call("dpc_tpool_split_fwd", L._p(xk), L.dtype_code(dtype), B, N, T, SQ, D, P, L._p(fr), L._p(fi))
+    k.sync()
+    assert relerr(fr, fr_ref.detach()) < tol(dtype) and relerr(fi, fi_ref.detach()) < tol(dtype)
+    d_relu = torch.randn(N - P, B * SQ, D, generator=g)
+    d_inf = torch.randn(B, P, SQ, D, generator=g)
+    loss = (fr_ref[: N - P] * d_relu).sum() + (fi_ref * d_inf).sum()
+    gx = torch.autograd.grad(loss, x)[0]
+    dx = k.empty(B * N, T, SQ, D, dtype=dtype)
+    k.call("dpc_tpool_split_bwd", L._p(xk), L._p(k.t(d_relu)), L._p(k.t(d_inf)), L.dtype_code(dtype), B, N, T, SQ, D, P, L._p(dx))
+    k.sync()
+    assert relerr(dx, gx) < tol(dtype)
+
+
+# ------------------------------------------------------------------ ConvGRU cell pieces
+def case_gru_cell(k: K, dtype, M, D, seed=8):
+    """One ConvGRUCell step (convrnn.py:24-34) + dropout on the new state (:78), forward and backward,
+    assembled from the GEMM kernel and the gate kernels exactly as the engine does."""
+    g = torch.Generator().manual_seed(seed)
+    x = q(torch.randn(M, D, generator=g), dtype)
+    h = q(torch.randn(M, D, generator=g) * 0.5, dtype)
+    W = {n: q(torch.randn(D, 2 * D, generator=g) * 0.2, dtype) for n in "uro"}
+    b = {n: torch.randn(D, generator=g) * 0.1 for n in "uro"}
+    drop = (torch.rand(M, D, generator=g) > 0.1).float() / 0.9
+    xd, hd = x.double().requires_grad_(), h.double().requires_grad_()
+    Wd = {n: W[n].double().requires_grad_() for n in "uro"}
+    bd = {n: b[n].double().requires_grad_() for n in "uro"}
+    comb = torch.cat([xd, hd], 1)
+    u = torch.sigmoid(comb @ Wd["u"].t() + bd["u"])
+    r = torch.sigmoid(comb @ Wd["r"].t() + bd["r"])
+    o = torch.tanh(torch.cat([xd, hd * r], 1) @ Wd["o"].t() + bd["o"])
+    hn = (hd * (1 - u) + o * u) * drop.double()
+    dh = torch.randn(M, D, generator=g)
+    hn.backward(dh.double())
+
+    dc = L.dtype_code(dtype)
+    Wx = k.t(torch.cat([W["u"][:, :D], W["r"][:, :D], W["o"][:, :D]], 0), dtype)     # [3D][D]
+    Whur = k.t(torch.cat([W["u"][:, D:], W["r"][:, D:]], 0), dtype)                    # [2D][D]
+    Woh = k.t(W["o"][:, D:], dtype)                                                     # [D][D]
+    xk, hk = k.t(x, dtype), k.t(h, dtype)
+
+    def gemm(A, Bm, Mm, Nn, Kk, out, add=None, ldo=None):
+        d = conv_desc(dtype, torch.float32, 0, Mm, (1, 1, 1), (1, 1, 1), Kk, A.stride(0), Nn, Bm.stride(0), ldo or Nn, (1, 1, 1), (1, 1, 1), (0, 0, 0))
+        k.call("dpc_conv_igemm", C.byref(d), L._p(A), L._p(Bm), L._p(out), L._p(add), None)
+
+    px, ph, po = k.empty(M, 3 * D), k.empty(M, 2 * D), k.empty(M, D)
+    gemm(xk, Wx, M, 3 * D, D, px)
+    gemm(hk, Whur, M, 2 * D, D, ph)
+    uk, rk, ok = k.empty(M, D), k.empty(M, D), k.empty(M, D)
+    hr = k.empty(M, D, dtype=dtype)
+    k.call("dpc_gru_gates1", L._p(px), L._p(ph), L._p(k.t(b["u"])), L._p(k.t(b["r"])), L._p(hk), dc, M, D, L._p(uk), L._p(rk), L._p(hr))
+    gemm(hr, Woh, M, D, D, po)
+    hout = k.empty(M, D, dtype=dtype)
+    dropk = k.t(drop)
+    k.call("dpc_gru_gates2", L._p(px), L._p(po), L._p(k.t(b["o"])), L._p(hk), L._p(uk), L._p(dropk), dc, M, D, L._p(ok), L._p(hout))
+    k.sync()
+    t = 1e-4 if dtype == torch.float32 else 2e-2
+    assert relerr(hout, hn.detach()) < t
+    # backward
+    G = k.zeros(M, 3 * D, dtype=dtype)
+    dhprev = k.empty(M, D)
+    k.call("dpc_gru_bwd1", L._p(k.t(dh)), L._p(dropk), L._p(uk), L._p(ok), L._p(hk), dc, M, D, L._p(G), L._p(dhprev))
+    WohT = k.t(W["o"][:, D:].t(), dtype)  # dhr = dpo @ Wo_h : NT GEMM against Wo_h^T [D_in][D_out]
+    dhr = k.empty(M, D)
+    gemm(G[:, 2 * D:], WohT, M, D, D, dhr)
+    k.call("dpc_gru_bwd2", L._p(dhr), L._p(rk), L._p(hk), dc, M, D, L._p(G), L._p(dhprev))
+    WxT = k.t(torch.cat([W["u"][:, :D], W["r"][:, :D], W["o"][:, :D]], 0).t(), dtype)   # [D][3D]
+    WhurT = k.t(torch.cat([W["u"][:, D:], W["r"][:, D:]], 0).t(), dtype)                 # [D][2D]
+    dx = k.empty(M, D)
+    gemm(G, WxT, M, D, 3 * D, dx)
+    gemm(G, WhurT, M, D, 2 * D, dhprev, add=dhprev)  # in-place accumulate
+    k.sync()
+    t = 5e-4 if dtype == torch.float32 else 4e-2
+    assert relerr(dx, xd.grad) < t
+    assert relerr(dhprev, hd.grad) < t
+    # weight grads: dWx = G^T x, dWh_ur = G[:, :2D]^T h, dWo_h = G[:, 2D:]^T hr ; biases = colsum(G)
+    def wgrad(dy, dy_ld, Co, X, Kk):
+        d = conv_desc(dtype, torch.float32, 0, M, (1, 1, 1), (1, 1, 1), Kk, X.stride(0), Co, Kk, Co, (1, 1, 1), (1, 1, 1), (0, 0, 0))
+        ns = C.c_int32(0)
+        k.call("dpc_conv_wgrad", C.byref(d), None, None, dy_ld, None, C.byref(ns))
+        part = k.zeros(ns.value, Co, Kk)
+        k.call("dpc_conv_wgrad", C.byref(d), L._p(X), L._p(dy), dy_ld, L._p(part), C.byref(ns))
+        out = k.zeros(Co, Kk)
+        k.call("dpc_reduce_unpack", L._p(part), ns.value, L._p(out), Co, 1, Kk, Kk, 0, 1, 0)
+        return out
+    dWx = wgrad(G, 3 * D, 3 * D, xk, D)
+    dWh = wgrad(G, 3 * D, 2 * D, hk, D)
+    dWo = wgrad(G[:, 2 * D:], 3 * D, D, hr, D)
+    db = k.empty(3 * D)
+    k.call("dpc_colsum", L._p(G), dc, 3 * D, M, 3 * D, L._p(db), 0)
+    k.sync()
+    ref_dWx = torch.cat([Wd["u"].grad[:, :D], Wd["r"].grad[:, :D], Wd["o"].grad[:, :D]], 0)
+    ref_dWh = torch.cat([Wd["u"].grad[:, D:], Wd["r"].grad[:, D:]], 0)
+    assert relerr(dWx, ref_dWx) < t and relerr(dWh, ref_dWh) < t and relerr(dWo, Wd["o"].grad[:, D:]) < t
+    assert relerr(db, torch.cat([bd["u"].grad, bd["r"].grad, bd["o"].grad])) < t
+
+
+def case_bias_act_rows(k: K, dtype, B, P, SQ, D, seed=9):
+    g = torch.Generator().manual_seed(seed)
+    M = B * SQ
+    x = torch.randn(M, D, generator=g)
+    bias = torch.randn(D, generator=g)
+    pred = k.zeros(B, P, SQ, D, dtype=dtype)
+    y2 = k.empty(M, D, dtype=dtype)
+    p = 1 % P
+    k.call("dpc_bias_act", L._p(k.t(x)), L._p(k.t(bias)), M, D, 0, L._p(pred), L.dtype_code(dtype), P, p, SQ, L._p(y2), L.dtype_code(dtype))
+    k.sync()
+    ref = (x + bias).view(B, SQ, D)
+    assert relerr(pred[:, p], ref) < tol(dtype) and relerr(y2, F.relu(x + bias)) < tol(dtype)
+    if P > 1:
+        assert pred[:, (p + 1) % P].abs().max().item() == 0
+    src = torch.randn(B, P, SQ, D, generator=g)
+    add = torch.randn(M, D, generator=g)
+    dst = k.empty(M, D)
+    k.call("dpc_gather_rows", L._p(k.t(src)), B, P, p, SQ, D, L._p(dst), L._p(k.t(add)))
+    dy = torch.randn(M, D, generator=g)
+    out = k.empty(M, D, dtype=dtype)
+    k.call("dpc_relu_bwd", L._p(k.t(dy)), L._p(y2), L.dtype_code(dtype), L._p(k.t(add)), M * D, L._p(out), L.dtype_code(dtype))
+    k.sync()
+    assert relerr(dst, src[:, p].reshape(M, D) + add) < 1e-6
+    assert relerr(out, dy * (y2.float().cpu() > 0) + add) < tol(dtype)
+
+
+# ------------------------------------------------------------------ loss head / optimizer
+def case_mask(k: K, B, P, SQ):
+    from oracle import dpc_oracle as O
+    m = torch.empty(B, P, SQ, B, P, SQ, dtype=torch.int8, device=k.dev)
+    k.call("dpc_mask_gen", L._p(m), B, P, SQ)
+    k.sync()
+    assert torch.equal(m.cpu(), O.mask_closed_form(B, P, SQ))  # bit exact
+
+
+def case_ce_topk(k: K, rows, cols, dtype_d, seed=10):
+    g = torch.Generator().manual_seed(seed)
+    s = torch.randn(rows, cols, generator=g) * 3
+    idx = torch.arange(0, rows, 3)
+    s[idx, idx] += 6.0
+    sd = s.double().requires_grad_()
+    tgt = torch.arange(rows)
+    loss = F.cross_entropy(sd, tgt)
+    loss.backward()
+    _, pred = s.topk(5, 1, True, True)
+    correct = pred.t().eq(tgt.view(1, -1))
+    accs = [correct[:kk].reshape(-1).float().sum().item() / rows for kk in (1, 3, 5)]
+    ld_d = (cols + 7) // 8 * 8
+    ws, res = k.empty(rows, 2), k.empty(4)
+    ds = k.empty(rows, ld_d, dtype=dtype_d)
+    k.call("dpc_ce_topk", L._p(k.t(s)), rows, cols, cols, L._p(ws), L._p(res), L._p(ds), L.dtype_code(dtype_d), ld_d)
+    k.sync()
+    r = res.cpu()
+    assert abs(r[0].item() - loss.item()) < 1e-5 * max(1.0, abs(loss.item()))
+    assert [round(v, 6) for v in r[1:].tolist()] == [round(v, 6) for v in accs]
+    assert relerr(ds[:, :cols], sd.grad) < tol(dtype_d)
+    if ld_d > cols:
+        assert ds[:, cols:].float().abs().max().item() == 0
+
+
+def case_adam(k: K, n, seed=11):
+    from oracle import dpc_oracle as O
+    g = torch.Generator().manual_seed(seed)
+    p = torch.randn(n, generator=g)
+    gr = torch.randn(n, generator=g) * 0.01
+    m = torch.randn(n, generator=g) * 0.01
+    v = torch.rand(n, generator=g) * 1e-4
+    pk, mk, vk = k.t(p.clone()), k.t(m.clone()), k.t(v.clone())
+    step = 3
+    k.call("dpc_adam", L._p(pk), L._p(k.t(gr)), L._p(mk), L._p(vk), n, 1e-3, 0.9, 0.999, 1e-8, 1e-5,
+           1 - 0.9 ** step, 1 - 0.999 ** step, 1.0)
+    k.sync()
+    O.adam_step(p, gr, m, v, step)
+    assert (pk.cpu() - p).abs().max().item() < 1e-6 and relerr(mk, m) < 1e-5 and relerr(vk, v) < 1e-5
+
+
+def case_transpose(k: K, rows, cols, seed=12):
+    g = torch.Generator().manual_seed(seed)
+    a = torch.randn(rows, cols, generator=g)
+    ld = (rows + 7) // 8 * 8
+    o = k.zeros(cols, ld, dtype=torch.bfloat16)
+    k.call("dpc_transpose2d", L._p(k.t(a)), 0, cols, L._p(o), 1, ld, rows, cols)
+    k.sync()
+    assert torch.equal(o[:, :rows].cpu(), a.t().bfloat16())

@@ -1,0 +1,113 @@
+"""CPU tier: the gfx950 kernel sources executed by the host SIMT simulator
+(tests/simt_emu) against torch-CPU expectations.  Small shapes; covers ragged
+tiles, strides, padding, both element types and every C-ABI entry point."""
+import os
+import subprocess
+
+import pytest
+import torch
+
+import kcases as kc
+from dpc_amd import _lib as L
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+F32, BF16 = torch.float32, torch.bfloat16
+
+
+@pytest.fixture(scope="module")
+def k():
+    subprocess.run(["make", "-s", "-j8", "emu"], cwd=ROOT, check=True)
+    return kc.K(L.load_emulator(), "cpu")
+
+
+@pytest.mark.parametrize("dtype", [F32, BF16])
+@pytest.mark.parametrize("shape", [
+    (2, 16, 64, 2, 9, 9, (1, 3, 3), (1, 1, 1), (0, 1, 1)),
+    (2, 64, 72, 3, 8, 8, (3, 3, 3), (2, 2, 2), (1, 1, 1)),
+    (3, 32, 160, 2, 7, 5, (1, 1, 1), (1, 2, 2), (0, 0, 0)),
+    (1, 8, 24, 5, 6, 6, (3, 3, 3), (1, 1, 1), (1, 1, 1)),
+])
+def test_conv_fwd(k, dtype, shape):
+    kc.case_conv_fwd(k, dtype, *shape)
+
+
+@pytest.mark.parametrize("dtype", [F32, BF16])
+@pytest.mark.parametrize("shape", [
+    (2, 16, 64, 2, 9, 9, (1, 3, 3), (1, 2, 2), (0, 1, 1)),
+    (2, 16, 32, 5, 8, 8, (3, 3, 3), (2, 2, 2), (1, 1, 1)),
+    (1, 32, 32, 3, 6, 6, (3, 3, 3), (1, 1, 1), (1, 1, 1)),
+    (2, 8, 16, 2, 8, 8, (1, 1, 1), (1, 2, 2), (0, 0, 0)),
+])
+def test_conv_dgrad(k, dtype, shape):
+    kc.case_conv_dgrad(k, dtype, *shape)
+
+
+@pytest.mark.parametrize("dtype", [F32, BF16])
+@pytest.mark.parametrize("shape", [
+    (2, 16, 64, 2, 9, 9, (1, 3, 3), (1, 1, 1), (0, 1, 1)),
+    (2, 64, 72, 3, 8, 8, (3, 3, 3), (2, 2, 2), (1, 1, 1)),
+    (3, 32, 160, 2, 7, 5, (1, 1, 1), (1, 2, 2), (0, 0, 0)),
+    (5, 8, 24, 2, 6, 6, (1, 3, 3), (1, 2, 2), (0, 1, 1)),
+])
+def test_conv_wgrad(k, dtype, shape):
+    kc.case_conv_wgrad(k, dtype, *shape)
+
+
+@pytest.mark.parametrize("dtype", [F32, BF16])
+@pytest.mark.parametrize("mnk", [(200, 100, 264), (24, 24, 256), (130, 70, 64)])
+def test_gemm_nt(k, dtype, mnk):
+    kc.case_gemm_nt(k, dtype, *mnk)
+
+
+@pytest.mark.parametrize("dtype", [F32, BF16])
+def test_stem_s2d(k, dtype):
+    kc.case_stem(k, dtype, 2, 2, 16, 20)
+
+
+@pytest.mark.parametrize("dtype", [F32, BF16])
+@pytest.mark.parametrize("relu,res_mode,C", [(True, 0, 64), (True, 1, 16), (False, 2, 48), (True, 2, 256)])
+def test_bn(k, dtype, relu, res_mode, C):
+    kc.case_bn_fwd_bwd(k, dtype, 333, C, relu, res_mode)
+
+
+@pytest.mark.parametrize("dtype", [F32, BF16])
+@pytest.mark.parametrize("hw", [(8, 8), (7, 10)])
+def test_stem_pool(k, dtype, hw):
+    kc.case_stem_pool(k, dtype, 3, hw[0], hw[1], 16)
+
+
+@pytest.mark.parametrize("dtype", [F32, BF16])
+def test_tpool_split(k, dtype):
+    kc.case_tpool_split(k, dtype, 2, 8, 2, 4, 32, 3)
+    kc.case_tpool_split(k, dtype, 3, 5, 1, 9, 16, 2)
+
+
+@pytest.mark.parametrize("dtype", [F32, BF16])
+def test_gru_cell(k, dtype):
+    kc.case_gru_cell(k, dtype, 36, 32)
+
+
+@pytest.mark.parametrize("dtype", [F32, BF16])
+def test_bias_act_rows(k, dtype):
+    kc.case_bias_act_rows(k, dtype, 3, 3, 4, 16)
+    kc.case_bias_act_rows(k, dtype, 2, 1, 9, 8)
+
+
+@pytest.mark.parametrize("bps", [(4, 3, 16), (2, 1, 4), (3, 5, 9)])
+def test_mask(k, bps):
+    kc.case_mask(k, *bps)
+
+
+@pytest.mark.parametrize("dtype_d", [F32, BF16])
+def test_ce_topk(k, dtype_d):
+    kc.case_ce_topk(k, 24, 24, dtype_d)
+    kc.case_ce_topk(k, 300, 300, dtype_d)
+    kc.case_ce_topk(k, 37, 37, dtype_d)
+
+
+def test_adam(k):
+    kc.case_adam(k, 1027)
+
+
+def test_transpose(k):
+    kc.case_transpose(k, 70, 45)
