@@ -1,0 +1,634 @@
+"""Static-schedule engine for the DPC-RNN training step on one MI355X.
+
+Host side of the hot path named in BASELINE.json: it owns the device buffers
+(torch tensors are used only as device memory), the flat f32 parameter /
+gradient / Adam-state arenas, and issues the hand-written gfx950 kernels of
+``libdpc_hip.so`` through the C ABI (include/dpc_hip.h) on torch's current HIP
+stream.  No autograd graph, no eager-PyTorch math: forward, loss, backward and
+the optimizer are explicit kernel sequences with a fixed buffer plan, so the
+step is capturable in a hipGraph and the backward can hand finished gradient
+ranges to RCCL while it is still running.
+
+What it restates (reference file:line):
+  forward        dpc/model_3d.py:46-98, backbone/resnet_2d3d.py:259-270,47-116,
+                 backbone/convrnn.py:24-34,62-88
+  loss / top-k   dpc/main.py:178-185,213-218, utils/utils.py:38-55
+  backward       torch autograd of the above (dpc/main.py:229-230)
+  optimizer      torch.optim.Adam(lr, weight_decay) dpc/main.py:80-81,231
+
+Data layout in HBM: activations channels-last [N][T][H][W][C] in the compute
+dtype (f32 parity mode / bf16 throughput mode); parameters stay f32 in the
+reference's state_dict layout and are repacked (K-contiguous, compute dtype) once
+per optimizer step.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+
+from . import _lib as L
+
+LAYER_PLAN = {"resnet18": (2, 2, 2, 2), "resnet34": (3, 4, 6, 3)}  # backbone/resnet_2d3d.py:274-284
+LAYER_WIDTH = (64, 128, 256, 256)                                    # resnet_2d3d.py:217-223
+BN_EPS = 1e-5
+
+
+def param_shapes(network: str, widths: Sequence[int] = LAYER_WIDTH) -> "Dict[str, Tuple[int, ...]]":
+    """state_dict keys/shapes of the reference DPC_RNN (without the agg.cell_list alias;
+    dpc/model_3d.py:28-40, backbone/resnet_2d3d.py:205-257, backbone/convrnn.py:13-15)."""
+    if network not in LAYER_PLAN:
+        raise IOError("model type is wrong")  # backbone/select_backbone.py:19
+    plan = LAYER_PLAN[network]
+    D = widths[3]
+    out: Dict[str, Tuple[int, ...]] = {}
+    out["backbone.conv1.weight"] = (widths[0], 3, 1, 7, 7)
+    out["backbone.bn1.weight"] = (widths[0],)
+    out["backbone.bn1.bias"] = (widths[0],)
+    inplanes = widths[0]
+    for li in range(4):
+        planes = widths[li]
+        k = (3, 3, 3) if li >= 2 else (1, 3, 3)
+        stride = 1 if li == 0 else 2
+        for bi in range(plan[li]):
+            pre = f"backbone.layer{li + 1}.{bi}."
+            cin = inplanes if bi == 0 else planes
+            out[pre + "conv1.weight"] = (planes, cin) + k
+            out[pre + "bn1.weight"] = (planes,)
+            out[pre + "bn1.bias"] = (planes,)
+            out[pre + "conv2.weight"] = (planes, planes) + k
+            out[pre + "bn2.weight"] = (planes,)
+            out[pre + "bn2.bias"] = (planes,)
+            if bi == 0 and (stride != 1 or inplanes != planes):
+                out[pre + "downsample.0.weight"] = (planes, inplanes, 1, 1, 1)
+                out[pre + "downsample.1.weight"] = (planes,)
+                out[pre + "downsample.1.bias"] = (planes,)
+        inplanes = planes
+    for gate in ("reset_gate", "update_gate", "out_gate"):
+        out[f"agg.ConvGRUCell_00.{gate}.weight"] = (D, 2 * D, 1, 1)
+        out[f"agg.ConvGRUCell_00.{gate}.bias"] = (D,)
+    for idx in (0, 2):
+        out[f"network_pred.{idx}.weight"] = (D, D, 1, 1)
+        out[f"network_pred.{idx}.bias"] = (D,)
+    return out
+
+
+class _ConvBN:
+    """one Conv3d (no bias) + BatchNorm3d(batch stats) unit and its saved tensors"""
+
+    def __init__(self, eng: "DPCEngine", wname: str, bnname: str, Ci: int, Co: int, k, s, p, in_shape, stem=False):
+        self.eng, self.wname, self.bnname = eng, wname, bnname
+        self.Ci, self.Co, self.k, self.s, self.p, self.stem = Ci, Co, k, s, p, stem
+        N, T, H, W = in_shape
+        self.in_shape = in_shape
+        if stem:
+            self.out_shape = (N, T, H, W)  # s2d grid == output grid
+        else:
+            self.out_shape = (N, (T + 2 * p[0] - k[0]) // s[0] + 1, (H + 2 * p[1] - k[1]) // s[1] + 1,
+                              (W + 2 * p[2] - k[2]) // s[2] + 1)
+        self.taps = k[0] * k[1] * k[2]
+        dt = eng.cdtype
+        dc = L.dtype_code(dt)
+        No, To, Ho, Wo = self.out_shape
+        self.rows = No * To * Ho * Wo
+        Kp = self.taps * Ci
+        self.desc_f = L.ConvDesc(dc, dc, 0, N, To, Ho, Wo, T, H, W, Ci, Ci, Co, Kp, Co, *k, *s, *p)
+        # input-gradient: rows enumerate the forward input grid, source is dy on the output grid
+        self.desc_d = L.ConvDesc(dc, dc, 1, N, T, H, W, To, Ho, Wo, Co, Co, Ci, self.taps * Co, Ci, *k, *s, *p)
+        self.desc_w = L.ConvDesc(dc, L.F32, 0, N, To, Ho, Wo, T, H, W, Ci, Ci, Co, Kp, Co, *k, *s, *p)
+        self.wp = eng.empty((Co, Kp), dt)
+        self.wd = None if stem else eng.empty((Ci, self.taps * Co), dt)
+        self.raw = eng.empty((No, To, Ho, Wo, Co), dt)
+        self.stat_rows = eng.lib.call("dpc_conv_stats_rows", C.byref(self.desc_f))
+        eng.need_stats(self.stat_rows * 2 * Co)
+        self.mean, self.invstd, self.scale, self.shift = (eng.empty((Co,), torch.float32) for _ in range(4))
+        ns = C.c_int32(0)
+        eng.lib.call("dpc_conv_wgrad", C.byref(self.desc_w), None, None, Co, None, C.byref(ns), eng.lib.stream())
+        eng.need_part(ns.value * Co * Kp)
+        pr = C.c_int32(0)
+        eng.lib.call("dpc_bn_bwd_reduce", None, None, None, dc, self.rows, Co, None, None, 0, None, C.byref(pr), eng.lib.stream())
+        eng.need_stats(pr.value * 2 * Co)
+
+    # ---- per-optimizer-step repack of the f32 parameter into MFMA operand layouts
+    def pack(self):
+        e = self.eng
+        w = e.PRM[self.wname]
+        dc = L.dtype_code(e.cdtype)
+        if self.stem:
+            e.call("dpc_pack_stem_weight", w, self.wp, dc, self.Co)
+            return
+        Ci, Co, t = self.Ci, self.Co, self.taps
+        # wp[co][tap][ci] = w[co][ci][tap] ; wd[ci][tap][co] = w[co][ci][tap]
+        e.call("dpc_pack3d", w, self.wp, dc, Co, t, Ci, Ci * t, 1, t)
+        e.call("dpc_pack3d", w, self.wd, dc, Ci, t, Co, t, 1, Ci * t)
+
+    def forward(self, x: torch.Tensor):
+        e = self.eng
+        e.call("dpc_conv_igemm", C.byref(self.desc_f), x, self.wp, self.raw, None, e.stats)
+        e.call("dpc_bn_finalize", e.stats, self.stat_rows, self.Co, float(self.rows), e.PRM[self.bnname + ".weight"],
+               e.PRM[self.bnname + ".bias"], BN_EPS, self.mean, self.invstd, self.scale, self.shift)
+
+    def apply(self, y: torch.Tensor, relu: bool, res: Optional[torch.Tensor] = None, res_unit: "Optional[_ConvBN]" = None):
+        e = self.eng
+        e.call("dpc_bn_apply", self.raw, y, L.dtype_code(e.cdtype), self.rows, self.Co, self.scale, self.shift, res,
+               res_unit.scale if res_unit else None, res_unit.shift if res_unit else None, int(relu))
+
+    # ---- backward pieces
+    def bn_backward(self, dy: torch.Tensor, y: Optional[torch.Tensor], relu: bool, dx: torch.Tensor,
+                    dz: Optional[torch.Tensor]):
+        e = self.eng
+        dc = L.dtype_code(e.cdtype)
+        pr = C.c_int32(0)
+        e.call("dpc_bn_bwd_reduce", dy, y, self.raw, dc, self.rows, self.Co, self.mean, self.invstd, int(relu), e.stats,
+               C.byref(pr))
+        e.call("dpc_bn_bwd_finalize", e.stats, pr.value, self.Co, float(self.rows), e.G[self.bnname + ".weight"],
+               e.G[self.bnname + ".bias"], e.coef)
+        e.call("dpc_bn_bwd_apply", dy, y, self.raw, dc, self.rows, self.Co, self.mean, self.invstd,
+               e.PRM[self.bnname + ".weight"], e.coef, int(relu), dx, dz)
+
+    def wgrad(self, x: torch.Tensor, draw: torch.Tensor):
+        e = self.eng
+        ns = C.c_int32(0)
+        e.call("dpc_conv_wgrad", C.byref(self.desc_w), x, draw, self.Co, e.part, C.byref(ns))
+        g = e.G[self.wname]
+        if self.stem:
+            e.call("dpc_unpack_stem_wgrad", e.part, ns.value, g, self.Co)
+        else:
+            Ci, t = self.Ci, self.taps
+            e.call("dpc_reduce_unpack", e.part, ns.value, g, self.Co, t, Ci, Ci * t, 1, t, 0)
+
+    def dgrad(self, draw: torch.Tensor, dx: torch.Tensor, addend: Optional[torch.Tensor]):
+        self.eng.call("dpc_conv_igemm", C.byref(self.desc_d), draw, self.wd, dx, addend, None)
+
+
+class _Block:
+    """BasicBlock2d / BasicBlock3d (backbone/resnet_2d3d.py:47-116)"""
+
+    def __init__(self, eng, pre: str, Ci: int, Co: int, is3d: bool, stride: int, in_shape, has_ds: bool, final_relu: bool):
+        self.eng = eng
+        k = (3, 3, 3) if is3d else (1, 3, 3)
+        p = (1, 1, 1) if is3d else (0, 1, 1)
+        s = (stride,) * 3 if is3d else (1, stride, stride)
+        self.c1 = _ConvBN(eng, pre + "conv1.weight", pre + "bn1", Ci, Co, k, s, p, in_shape)
+        self.c2 = _ConvBN(eng, pre + "conv2.weight", pre + "bn2", Co, Co, k, (1, 1, 1), p, self.c1.out_shape)
+        self.ds = _ConvBN(eng, pre + "downsample.0.weight", pre + "downsample.1", Ci, Co, (1, 1, 1), s, (0, 0, 0),
+                          in_shape) if has_ds else None
+        self.final_relu = final_relu
+        self.out_shape = self.c2.out_shape
+        self.Co = Co
+        self.act1 = eng.empty(self.c1.out_shape + (Co,), eng.cdtype)
+        self.out = eng.empty(self.out_shape + (Co,), eng.cdtype)
+        self.x_in: Optional[torch.Tensor] = None
+
+    def units(self):
+        return [u for u in (self.c1, self.c2, self.ds) if u is not None]
+
+    def forward(self, x):
+        self.x_in = x
+        self.c1.forward(x)
+        self.c1.apply(self.act1, relu=True)
+        self.c2.forward(self.act1)
+        if self.ds is not None:
+            self.ds.forward(x)
+            self.c2.apply(self.out, relu=self.final_relu, res=self.ds.raw, res_unit=self.ds)
+        else:
+            self.c2.apply(self.out, relu=self.final_relu, res=x)
+        return self.out
+
+    def backward(self, dout: torch.Tensor, need_dx: bool = True) -> Optional[torch.Tensor]:
+        e = self.eng
+        oshape = tuple(self.out.shape)
+        ishape = tuple(self.x_in.shape)
+        draw2 = e.scratch(oshape, exclude=[dout])
+        dz = e.scratch(oshape, exclude=[dout, draw2])
+        self.c2.bn_backward(dout, self.out if self.final_relu else None, self.final_relu, draw2, dz)
+        # dout is dead from here on
+        partial = None
+        if self.ds is not None:
+            draw_d = dout  # reuse
+            self.ds.bn_backward(dz, None, False, draw_d, None)
+            self.ds.wgrad(self.x_in, draw_d)
+            if need_dx:
+                partial = e.scratch(ishape, exclude=[])
+                self.ds.dgrad(draw_d, partial, None)
+        self.c2.wgrad(self.act1, draw2)
+        dact1 = dout  # out-shape buffer, free again
+        self.c2.dgrad(draw2, dact1, None)
+        draw1 = draw2  # in place over the consumed draw2
+        self.c1.bn_backward(dact1, self.act1, True, draw1, None)
+        self.c1.wgrad(self.x_in, draw1)
+        if not need_dx:
+            return None
+        if self.ds is not None:
+            dx = e.scratch(ishape, exclude=[partial])
+            self.c1.dgrad(draw1, dx, partial)
+        else:
+            dx = dact1  # same shape as the input; dact1 is dead
+            self.c1.dgrad(draw1, dx, dz)
+        return dx
+
+
+class DPCEngine:
+    def __init__(self, network: str = "resnet18", sample_size: int = 128, num_seq: int = 8, seq_len: int = 5,
+                 pred_step: int = 3, batch: int = 4, device="cuda", compute_dtype=torch.float32,
+                 widths: Sequence[int] = LAYER_WIDTH, lib: Optional[L.Lib] = None,
+                 lr: float = 1e-3, wd: float = 1e-5, dropout: float = 0.1):
+        self.device = torch.device(device)
+        self.lib = L.lib_for(self.device, lib)  # raises unless HIP device (or an explicit simulator handle in tests)
+        self.cdtype = compute_dtype
+        self.network, self.size, self.N, self.SL, self.P, self.B = network, sample_size, num_seq, seq_len, pred_step, batch
+        self.widths = tuple(widths)
+        self.D = widths[3]
+        self.lr, self.wd, self.p_drop = lr, wd, dropout
+        self.last_duration = int(math.ceil(seq_len / 4))   # dpc/model_3d.py:24
+        self.last_size = int(math.ceil(sample_size / 32))  # dpc/model_3d.py:25
+        self.SQ = self.last_size ** 2
+        if sample_size % 2:
+            raise ValueError("sample_size must be even (space-to-depth stem)")
+        self._stats_need = 0
+        self._part_need = 0
+        self._scratch: Dict[Tuple[int, ...], List[torch.Tensor]] = {}
+        self.step_count = 0
+
+        # ---- flat f32 arenas: parameters, gradients, Adam moments
+        self.shapes = param_shapes(network, widths)
+        self.offsets: Dict[str, Tuple[int, int]] = {}
+        off = 0
+        for k, shp in self.shapes.items():
+            n = int(math.prod(shp))
+            self.offsets[k] = (off, n)
+            off += (n + 3) // 4 * 4  # keep every tensor 16-byte aligned
+        self.numel = off
+        self.flat_p = torch.zeros(off, dtype=torch.float32, device=self.device)
+        self.flat_g = torch.zeros_like(self.flat_p)
+        self.flat_m = torch.zeros_like(self.flat_p)
+        self.flat_v = torch.zeros_like(self.flat_p)
+        self.PRM = {k: self.flat_p[o:o + n].view(self.shapes[k]) for k, (o, n) in self.offsets.items()}
+        self.G = {k: self.flat_g[o:o + n].view(self.shapes[k]) for k, (o, n) in self.offsets.items()}
+
+        # ---- backbone plan
+        BN, H = batch * num_seq, sample_size
+        dt = self.cdtype
+        self.x_s2d = self.empty((BN, seq_len, H // 2, H // 2, 16), dt)
+        self.stem = _ConvBN(self, "backbone.conv1.weight", "backbone.bn1", 16, widths[0], (1, 4, 4), (1, 1, 1), (0, 2, 2),
+                            (BN, seq_len, H // 2, H // 2), stem=True)
+        hp = (H // 2 - 1) // 2 + 1
+        self.pool_shape = (BN, seq_len, hp, hp)
+        self.pooled = self.empty(self.pool_shape + (widths[0],), dt)
+        self.pool_arg = torch.empty(self.pool_shape + (widths[0],), dtype=torch.uint8, device=self.device)
+        self.blocks: List[_Block] = []
+        shape, inplanes = self.pool_shape, widths[0]
+        plan = LAYER_PLAN[network]
+        for li in range(4):
+            planes = widths[li]
+            for bi in range(plan[li]):
+                stride = 2 if (li > 0 and bi == 0) else 1
+                has_ds = bi == 0 and (stride != 1 or inplanes != planes)
+                last = li == 3 and bi == plan[li] - 1
+                blk = _Block(self, f"backbone.layer{li + 1}.{bi}.", inplanes if bi == 0 else planes, planes, li >= 2, stride,
+                             shape, has_ds, final_relu=not last)
+                self.blocks.append(blk)
+                shape, inplanes = blk.out_shape, planes
+        self.feat_shape = shape
+        if shape[1] != self.last_duration or shape[2] != self.last_size or shape[3] != self.last_size:
+            raise ValueError(f"backbone output {shape} does not match last_duration/last_size "
+                             f"({self.last_duration},{self.last_size}); see dpc/model_3d.py:24-25,53-55")
+        self.units: List[_ConvBN] = [self.stem] + [u for b in self.blocks for u in b.units()]
+
+        # ---- ConvGRU / predictor / score buffers.  rows M = (b, s)
+        B, P, SQ, D, N = batch, pred_step, self.SQ, self.D, num_seq
+        M = B * SQ
+        self.M = M
+        self.n_agg = N - P                     # aggregation steps (dpc/model_3d.py:62)
+        self.n_steps = self.n_agg + P - 1      # the GRU step after the last prediction is dead code (model_3d.py:70-72)
+        f32 = torch.float32
+        self.feat_relu = self.empty((N, M, D), dt)    # [n][(b,s)][d]; slots [0,n_steps) double as the GRU inputs
+        self.feat_inf = self.empty((B, P, SQ, D), dt)
+        self.pred = self.empty((B, P, SQ, D), dt)
+        ns = self.n_steps
+        self.X_all = self.feat_relu[:ns]              # GRU inputs x_t (agg: feat_relu[t]; predict: relu(p_t) overwrites
+                                                      # the slots of the last P blocks, whose ReLU'd features are unused)
+        self.H_all = self.empty((ns + 1, M, D), dt)   # h_0 = 0, h_t after dropout
+        self.HR_all = self.empty((ns, M, D), dt)
+        self.G_all = self.empty((ns, M, 3 * D), dt)   # [dpu | dpr | dpo] per step
+        self.U_all, self.R_all, self.O_all = (self.empty((ns, M, D), f32) for _ in range(3))
+        self.drop_all: Optional[torch.Tensor] = None
+        self.px = self.empty((ns, M, 3 * D), f32)
+        self.ph = self.empty((M, 2 * D), f32)
+        self.po = self.empty((M, D), f32)
+        self.p1_pre = self.empty((M, D), f32)
+        self.P1_all = self.empty((P, M, D), dt)       # relu(W1 h + b1)
+        self.p2_pre = self.empty((M, D), f32)
+        self.dP1 = self.empty((P, M, D), dt)          # grads at the pre-activations of network_pred
+        self.dP2 = self.empty((P, M, D), dt)
+        self.Hpred = self.H_all[self.n_agg:]          # hidden state each prediction was made from
+        self.tmp_f = [self.empty((M, D), f32) for _ in range(4)]
+        self.tmp_3d = self.empty((M, 3 * D), f32)
+        R = B * P * SQ
+        self.R = R
+        self.score = self.empty((R, R), f32)
+        E = 8 if dt == torch.bfloat16 else 4
+        self.ld_d = (R + E - 1) // E * E
+        self.dscore = self.empty((R, self.ld_d), dt)
+        self.row_ws = self.empty((R, 2), f32)
+        self.result = self.empty((4,), f32)
+        self.predT = self.empty((D, self.ld_d), dt)   # operands of the score backward
+        self.finfT = self.empty((D, self.ld_d), dt)
+        self.d_pred = self.empty((B, P, SQ, D), f32)
+        self.d_finf = self.empty((B, P, SQ, D), f32)
+        self.d_featrelu = self.empty((self.n_agg, M, D), f32)
+        self.d_feat = self.empty(self.feat_shape + (widths[3],), dt)
+        self.mask: Optional[torch.Tensor] = None
+        # packed GEMM weights (compute dtype)
+        self.Wx = self.empty((3 * D, D), dt)     # rows [Wu_x; Wr_x; Wo_x]
+        self.Whur = self.empty((2 * D, D), dt)   # rows [Wu_h; Wr_h]
+        self.Woh = self.empty((D, D), dt)
+        self.WxT = self.empty((D, 3 * D), dt)
+        self.WhurT = self.empty((D, 2 * D), dt)
+        self.WohT = self.empty((D, D), dt)
+        self.W1 = self.empty((D, D), dt)
+        self.W2 = self.empty((D, D), dt)
+        self.W1T = self.empty((D, D), dt)
+        self.W2T = self.empty((D, D), dt)
+        self.dWx = self.empty((3 * D, D), f32)
+        self.dWh = self.empty((2 * D, D), f32)
+        self.dWo = self.empty((D, D), f32)
+        self.db = self.empty((3 * D,), f32)
+        for (co, kk) in ((3 * D, D), (2 * D, D), (D, D)):
+            self._need_wgrad(ns * M, co, kk)
+        self._need_wgrad(R, R, D)
+        self.coef = self.empty((2, max(widths)), f32)
+        self.stats = self.empty((max(self._stats_need, 1),), f32)
+        self.part = self.empty((max(self._part_need, 1),), f32)
+        self.stem_dz = self.empty(tuple(self.stem.raw.shape), dt)
+        self.packed_for_step = -1
+
+    # ------------------------------------------------------------------ plumbing
+    def empty(self, shape, dtype):
+        return torch.empty(tuple(shape), dtype=dtype, device=self.device)
+
+    def need_stats(self, n):
+        self._stats_need = max(self._stats_need, int(n))
+
+    def need_part(self, n):
+        self._part_need = max(self._part_need, int(n))
+
+    def _need_wgrad(self, M, Co, K):
+        d = self._gemm_desc(M, Co, K, K, K, Co, out_f32=True)
+        ns = C.c_int32(0)
+        self.lib.call("dpc_conv_wgrad", C.byref(d), None, None, (Co + 7) // 8 * 8, None, C.byref(ns), self.lib.stream())
+        self.need_part(ns.value * Co * K)
+
+    def call(self, name, *args):
+        return self.lib.call(name, *args, self.lib.stream())
+
+    def scratch(self, shape, exclude):
+        """gradient scratch of a given activation shape; at most 3 live per shape by construction"""
+        pool = self._scratch.setdefault(tuple(shape), [])
+        for t in pool:
+            if all(t is not x for x in exclude if x is not None):
+                return t
+        t = self.empty(shape, self.cdtype)
+        pool.append(t)
+        return t
+
+    def _gemm_desc(self, M, N, K, lda, ldb, ldo, out_f32=True):
+        dc = L.dtype_code(self.cdtype)
+        return L.ConvDesc(dc, L.F32 if out_f32 else dc, 0, M, 1, 1, 1, 1, 1, 1, K, lda, N, ldb, ldo, 1, 1, 1, 1, 1, 1, 0, 0, 0)
+
+    def gemm(self, A, Bm, out, M, N, K, lda=None, ldb=None, ldo=None, addend=None, out_f32=True):
+        """out[M][N] = A[M][K] @ Bm[N][K]^T (+ addend) on the matrix cores"""
+        d = self._gemm_desc(M, N, K, lda or K, ldb or K, ldo or N, out_f32)
+        self.call("dpc_conv_igemm", C.byref(d), A, Bm, out, addend, None)
+
+    def gemm_tn(self, dy, dy_ld, X, x_ld, out, M, Co, K):
+        """out[Co][K] = dy[M][Co]^T @ X[M][K] (f32), split-K + deterministic reduce"""
+        d = self._gemm_desc(M, Co, K, x_ld, K, Co)
+        ns = C.c_int32(0)
+        self.call("dpc_conv_wgrad", C.byref(d), X, dy, dy_ld, self.part, C.byref(ns))
+        self.call("dpc_reduce_unpack", self.part, ns.value, out, Co, 1, K, K, 0, 1, 0)
+
+    # ------------------------------------------------------------------ parameters
+    def load_params(self, params: Dict[str, torch.Tensor]):
+        """copy a reference-layout state_dict (alias / module. prefixes tolerated) into the flat arena"""
+        for k, v in params.items():
+            k = k[7:] if k.startswith("module.") else k
+            if k.startswith("agg.cell_list.0."):
+                continue  # alias of agg.ConvGRUCell_00 (backbone/convrnn.py:55-58)
+            if k not in self.PRM:
+                raise KeyError(k)
+            self.PRM[k].copy_(v.to(torch.float32).reshape(self.shapes[k]))
+        self.packed_for_step = -1
+
+    def state_dict(self) -> Dict[str, torch.Tensor]:
+        sd = {k: v.detach().clone() for k, v in self.PRM.items()}
+        for k in list(sd):
+            if k.startswith("agg.ConvGRUCell_00."):
+                sd[k.replace("agg.ConvGRUCell_00.", "agg.cell_list.0.")] = sd[k]
+        return sd
+
+    def pack_weights(self):
+        if self.packed_for_step == self.step_count:
+            return
+        dc = L.dtype_code(self.cdtype)
+        for u in self.units:
+            u.pack()
+        D = self.D
+        gates = {g: self.PRM[f"agg.ConvGRUCell_00.{n}.weight"] for g, n in
+                 (("u", "update_gate"), ("r", "reset_gate"), ("o", "out_gate"))}
+        for i, g in enumerate("uro"):  # x half: columns [0,D) of [D][2D]
+            self.call("dpc_pack3d", gates[g], self.Wx[i * D:(i + 1) * D], dc, D, 1, D, 2 * D, 0, 1)
+        for i, g in enumerate("ur"):   # h half: columns [D,2D)
+            self.call("dpc_pack3d", gates[g][:, D:], self.Whur[i * D:(i + 1) * D], dc, D, 1, D, 2 * D, 0, 1)
+        self.call("dpc_pack3d", gates["o"][:, D:], self.Woh, dc, D, 1, D, 2 * D, 0, 1)
+        self.call("dpc_pack3d", self.PRM["network_pred.0.weight"], self.W1, dc, D, 1, D, D, 0, 1)
+        self.call("dpc_pack3d", self.PRM["network_pred.2.weight"], self.W2, dc, D, 1, D, D, 0, 1)
+        for src, dst, r, c in ((self.Wx, self.WxT, 3 * D, D), (self.Whur, self.WhurT, 2 * D, D), (self.Woh, self.WohT, D, D),
+                               (self.W1, self.W1T, D, D), (self.W2, self.W2T, D, D)):
+            self.call("dpc_transpose2d", src, dc, c, dst, dc, r, r, c)
+        self.packed_for_step = self.step_count
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, block: torch.Tensor, train: bool = False, dropout_masks: Optional[torch.Tensor] = None):
+        """block [B,N,3,SL,H,W] f32 on the device.  Returns the score tensor [B,P,SQ,B,P,SQ] (f32, engine-owned).
+        dropout_masks: optional [n_steps,M,D] pre-scaled keep masks (tests); train=True draws them on the device."""
+        B, N, P, SQ, D, M = self.B, self.N, self.P, self.SQ, self.D, self.M
+        if tuple(block.shape) != (B, N, 3, self.SL, self.size, self.size) or block.dtype != torch.float32:
+            raise ValueError(f"block must be float32 [B,N,3,SL,H,W] = {(B, N, 3, self.SL, self.size, self.size)}, got {tuple(block.shape)}")
+        if block.device != self.device:
+            raise ValueError("block is on the wrong device")
+        block = block.contiguous()
+        dc = L.dtype_code(self.cdtype)
+        self.pack_weights()
+        # backbone
+        self.call("dpc_pack_input_s2d", block, self.x_s2d, dc, B * N, self.SL, self.size, self.size)
+        self.stem.forward(self.x_s2d)
+        st = self.stem.out_shape
+        self.call("dpc_bn_relu_maxpool_fwd", self.stem.raw, dc, st[0] * st[1], st[2], st[3], self.widths[0], self.stem.scale,
+                  self.stem.shift, self.pooled, self.pool_arg)
+        x = self.pooled
+        for blk in self.blocks:
+            x = blk.forward(x)
+        fs = self.feat_shape
+        self.call("dpc_tpool_split_fwd", x, dc, B, N, fs[1], SQ, D, P, self.feat_relu, self.feat_inf)
+        # dropout masks on the carried hidden state (backbone/convrnn.py:78)
+        if dropout_masks is not None:
+            self.drop_all = dropout_masks.to(self.device, torch.float32).contiguous()
+        elif train and self.p_drop > 0:
+            keep = 1.0 - self.p_drop
+            self.drop_all = (torch.rand((self.n_steps, M, D), device=self.device) < keep).to(torch.float32) / keep
+        else:
+            self.drop_all = None
+        # aggregate: x-side gate pre-activations of all n_agg steps in one GEMM
+        na = self.n_agg
+        self.H_all[0].zero_()
+        self.gemm(self.X_all, self.Wx, self.px, na * M, 3 * D, D)
+        step = 0
+        for t in range(na):
+            self._gru_step(step, px_ready=True)
+            step += 1
+        # predict (dpc/model_3d.py:65-72)
+        for i in range(P):
+            h = self.H_all[step]
+            self.gemm(h, self.W1, self.p1_pre, M, D, D)
+            self.call("dpc_bias_act", self.p1_pre, self.PRM["network_pred.0.bias"], M, D, 1, self.P1_all[i], dc, 0, 0, SQ, None, dc)
+            self.gemm(self.P1_all[i], self.W2, self.p2_pre, M, D, D)
+            y2 = self.X_all[step] if i < P - 1 else None
+            self.call("dpc_bias_act", self.p2_pre, self.PRM["network_pred.2.bias"], M, D, 0, self.pred, dc, P, i, SQ, y2, dc)
+            if i < P - 1:
+                self._gru_step(step, px_ready=False)
+                step += 1
+        # score (dpc/model_3d.py:79-84): pred [R][D] x feat_inf [R][D]^T
+        R = self.R
+        self.gemm(self.pred, self.feat_inf, self.score, R, R, D)
+        return self.score.view(B, P, SQ, B, P, SQ)
+
+    def _gru_step(self, s: int, px_ready: bool):
+        D, M = self.D, self.M
+        dc = L.dtype_code(self.cdtype)
+        x, h = self.X_all[s], self.H_all[s]
+        if not px_ready:
+            self.gemm(x, self.Wx, self.px[s], M, 3 * D, D)
+        self.gemm(h, self.Whur, self.ph, M, 2 * D, D)
+        Pm = self.PRM
+        self.call("dpc_gru_gates1", self.px[s], self.ph, Pm["agg.ConvGRUCell_00.update_gate.bias"],
+                  Pm["agg.ConvGRUCell_00.reset_gate.bias"], h, dc, M, D, self.U_all[s], self.R_all[s], self.HR_all[s])
+        self.gemm(self.HR_all[s], self.Woh, self.po, M, D, D)
+        drop = self.drop_all[s] if self.drop_all is not None else None
+        self.call("dpc_gru_gates2", self.px[s], self.po, Pm["agg.ConvGRUCell_00.out_gate.bias"], h, self.U_all[s], drop, dc,
+                  M, D, self.O_all[s], self.H_all[s + 1])
+
+    def get_mask(self) -> torch.Tensor:
+        if self.mask is None:
+            B, P, SQ = self.B, self.P, self.SQ
+            self.mask = torch.empty((B, P, SQ, B, P, SQ), dtype=torch.int8, device=self.device)
+            self.call("dpc_mask_gen", self.mask, B, P, SQ)
+        return self.mask
+
+    # ------------------------------------------------------------------ loss
+    def loss_topk(self, with_grad: bool = True) -> torch.Tensor:
+        """[loss, top1, top3, top5] (device f32[4]); fills dscore when with_grad"""
+        R = self.R
+        self.call("dpc_ce_topk", self.score, R, R, R, self.row_ws, self.result, self.dscore if with_grad else None,
+                  L.dtype_code(self.cdtype), self.ld_d)
+        return self.result
+
+    # ------------------------------------------------------------------ backward
+    def backward(self, dscore_external: Optional[torch.Tensor] = None):
+        """gradients of everything w.r.t. the loss whose d/dscore sits in self.dscore (or is given, [R][R] f32)"""
+        B, N, P, SQ, D, M, R = self.B, self.N, self.P, self.SQ, self.D, self.M, self.R
+        dc = L.dtype_code(self.cdtype)
+        if dscore_external is not None:
+            src = dscore_external.reshape(R, R).to(torch.float32).contiguous()
+            if self.ld_d != R:
+                self.dscore.zero_()
+            self.dscore[:, :R].copy_(src)
+        # score = pred @ finf^T  ->  d_pred = dS @ finf ; d_finf = dS^T @ pred
+        self.call("dpc_transpose2d", self.feat_inf, dc, D, self.finfT, dc, self.ld_d, R, D)
+        if self.ld_d != R:
+            self.finfT[:, R:].zero_()
+        self.gemm(self.dscore, self.finfT, self.d_pred, R, D, self.ld_d, lda=self.ld_d, ldb=self.ld_d)
+        self.gemm_tn(self.dscore, self.ld_d, self.pred, D, self.d_finf, R, R, D)
+        # ---- predict loop + aggregation, reversed
+        ns, na = self.n_steps, self.n_agg
+        dh = self.tmp_f[0]       # grad w.r.t. the current hidden state (f32)
+        dh.zero_()
+        dxn = self.tmp_f[1]      # grad w.r.t. x of the GRU step that consumed relu(p_i)
+        step = ns
+        for i in reversed(range(P)):
+            # p_i = W2 relu(W1 h + b1) + b2 ; contributes to score (row-mapped) and, for i < P-1, to GRU step `step`
+            if i < P - 1:
+                step -= 1
+                self._gru_step_backward(step, dh, dxn)            # dh <- grad wrt h_{step}; dxn <- grad wrt x_step
+                t = self.tmp_f[2]
+                self.call("dpc_relu_bwd", dxn, self.X_all[step], dc, None, M * D, t, L.F32)
+                self.call("dpc_gather_rows", self.d_pred, B, P, i, SQ, D, self.tmp_f[3], t)
+            else:
+                self.call("dpc_gather_rows", self.d_pred, B, P, i, SQ, D, self.tmp_f[3], None)
+            self.call("dpc_convert", self.tmp_f[3], L.F32, self.dP2[i], dc, M * D)
+            self.gemm(self.dP2[i], self.W2T, self.tmp_f[2], M, D, D)                       # d relu(p1)
+            self.call("dpc_relu_bwd", self.tmp_f[2], self.P1_all[i], dc, None, M * D, self.dP1[i], dc)
+            self.gemm(self.dP1[i], self.W1T, dh, M, D, D, addend=dh)                       # dh += dP1 @ W1
+        for t in reversed(range(na)):
+            step -= 1
+            self._gru_step_backward(step, dh, self.d_featrelu[t])
+        assert step == 0
+        # ---- weight / bias grads of the ConvGRU and predictor, batched over all steps
+        Gm = self.G
+        self.gemm_tn(self.G_all, 3 * D, self.X_all, D, self.dWx, ns * M, 3 * D, D)
+        self.gemm_tn(self.G_all, 3 * D, self.H_all, D, self.dWh, ns * M, 2 * D, D)
+        self.gemm_tn(self.G_all[:, :, 2 * D:], 3 * D, self.HR_all, D, self.dWo, ns * M, D, D)
+        self.call("dpc_colsum", self.G_all, dc, 3 * D, ns * M, 3 * D, self.db, 0)
+        for i, (g, n) in enumerate((("u", "update_gate"), ("r", "reset_gate"), ("o", "out_gate"))):
+            w = Gm[f"agg.ConvGRUCell_00.{n}.weight"].view(D, 2 * D)
+            w[:, :D].copy_(self.dWx[i * D:(i + 1) * D])
+            w[:, D:].copy_(self.dWh[i * D:(i + 1) * D] if g != "o" else self.dWo)
+            Gm[f"agg.ConvGRUCell_00.{n}.bias"].copy_(self.db[i * D:(i + 1) * D])
+        self.gemm_tn(self.dP1, D, self.Hpred, D, Gm["network_pred.0.weight"].view(D, D), P * M, D, D)
+        self.gemm_tn(self.dP2, D, self.P1_all, D, Gm["network_pred.2.weight"].view(D, D), P * M, D, D)
+        self.call("dpc_colsum", self.dP1, dc, D, P * M, D, Gm["network_pred.0.bias"], 0)
+        self.call("dpc_colsum", self.dP2, dc, D, P * M, D, Gm["network_pred.2.bias"], 0)
+        # ---- temporal pool / split, backbone
+        fs = self.feat_shape
+        self.call("dpc_tpool_split_bwd", self.blocks[-1].out, self.d_featrelu, self.d_finf, dc, B, N, fs[1], SQ, D, P, self.d_feat)
+        d = self.d_feat
+        for blk in reversed(self.blocks):
+            d = blk.backward(d, need_dx=True)
+        # stem: max-pool routing (ReLU mask folded into the saved argmax) -> BN -> weight grad; the video has no grad
+        st = self.stem.out_shape
+        self.call("dpc_maxpool_bwd", d, self.pool_arg, dc, st[0] * st[1], st[2], st[3], self.widths[0], self.stem_dz)
+        self.stem.bn_backward(self.stem_dz, None, False, self.stem_dz, None)
+        self.stem.wgrad(self.x_s2d, self.stem_dz)
+
+    def _gru_step_backward(self, s: int, dh: torch.Tensor, dx_out: torch.Tensor):
+        """in: dh = dL/dh_{s+1} (post-dropout state).  out: dh <- dL/dh_s, dx_out <- dL/dx_s, G_all[s] filled"""
+        D, M = self.D, self.M
+        dc = L.dtype_code(self.cdtype)
+        h = self.H_all[s]
+        drop = self.drop_all[s] if self.drop_all is not None else None
+        dhprev = self.tmp_3d.view(-1)[: M * D].view(M, D)
+        self.call("dpc_gru_bwd1", dh, drop, self.U_all[s], self.O_all[s], h, dc, M, D, self.G_all[s], dhprev)
+        dhr = self.po
+        self.gemm(self.G_all[s][:, 2 * D:], self.WohT, dhr, M, D, D, lda=3 * D)
+        self.call("dpc_gru_bwd2", dhr, self.R_all[s], h, dc, M, D, self.G_all[s], dhprev)
+        self.gemm(self.G_all[s], self.WxT, dx_out, M, D, 3 * D)
+        self.gemm(self.G_all[s], self.WhurT, dh, M, D, 2 * D, lda=3 * D, addend=dhprev)
+
+    # ------------------------------------------------------------------ optimizer / full step
+    def adam_step(self, grad_scale: float = 1.0):
+        self.step_count += 1
+        t = self.step_count
+        self.call("dpc_adam", self.flat_p, self.flat_g, self.flat_m, self.flat_v, self.numel, self.lr, 0.9, 0.999, 1e-8,
+                  self.wd, 1.0 - 0.9 ** t, 1.0 - 0.999 ** t, grad_scale)
+
+    def train_step(self, block: torch.Tensor, dropout_masks: Optional[torch.Tensor] = None, allreduce=None) -> torch.Tensor:
+        """forward + CE/top-k + backward (+ gradient all-reduce) + Adam.  Returns device f32[4] = loss, top1, top3, top5."""
+        self.forward(block, train=True, dropout_masks=dropout_masks)
+        res = self.loss_topk(with_grad=True)
+        self.backward()
+        if allreduce is not None:
+            allreduce(self.flat_g)
+        self.adam_step()
+        return res
