@@ -14,15 +14,32 @@ static inline unsigned grid_for(long long n, int block = 256, int cap = 8192) {
 }
 
 // ------------------------------------------------------------------ forward finalize
-__global__ void bn_finalize_kernel(const float* partials, int rows, int C, double count, const float* gamma,
-                                   const float* beta, float eps, float* mean, float* invstd, float* scale, float* shift) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    double s1 = 0.0, s2 = 0.0;
-    for (int r = 0; r < rows; ++r) {
-        s1 += (double)partials[((long long)r * 2 + 0) * C + c];
-        s2 += (double)partials[((long long)r * 2 + 1) * C + c];
+// one workgroup = 32 channels x 32 row lanes: the partial rows are summed in parallel (f64), then a
+// 32-way LDS tree; a serial per-channel loop over ~1-2k rows was latency-bound (0.4 ms per call).
+__device__ __forceinline__ void partial_rows_sum(const float* partials, int rows, int C, int c, int rl, double& s1, double& s2,
+                                                 double (*red)[32][32]) {
+    s1 = 0.0; s2 = 0.0;
+    if (c < C)
+        for (int r = rl; r < rows; r += 32) {
+            s1 += (double)partials[((long long)r * 2 + 0) * C + c];
+            s2 += (double)partials[((long long)r * 2 + 1) * C + c];
+        }
+    red[0][rl][c & 31] = s1;
+    red[1][rl][c & 31] = s2;
+    __syncthreads();
+    if (rl == 0) {
+        s1 = 0.0; s2 = 0.0;
+        for (int k = 0; k < 32; ++k) { s1 += red[0][k][c & 31]; s2 += red[1][k][c & 31]; }
     }
+}
+
+__global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* partials, int rows, int C, double count, const float* gamma,
+                                   const float* beta, float eps, float* mean, float* invstd, float* scale, float* shift) {
+    __shared__ double red[2][32][32];
+    const int c = blockIdx.x * 32 + (threadIdx.x & 31), rl = threadIdx.x >> 5;
+    double s1, s2;
+    partial_rows_sum(partials, rows, C, c, rl, s1, s2, red);
+    if (rl != 0 || c >= C) return;
     const double m = s1 / count;
     double var = s2 / count - m * m;
     if (var < 0.0) var = 0.0;
@@ -39,29 +56,43 @@ extern "C" int dpc_bn_finalize(const float* partials, int32_t rows, int32_t C, d
                                dpc_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (!partials || rows <= 0 || C <= 0 || count <= 0 || !gamma || !beta || !mean || !invstd || !scale || !shift) return DPC_ERR_ARG;
-    DPC_LAUNCH(bn_finalize_kernel, dim3((C + 63) / 64), dim3(64), stream, partials, rows, C, count, gamma, beta, eps, mean, invstd, scale, shift);
+    DPC_LAUNCH(bn_finalize_kernel, dim3((C + 31) / 32), dim3(1024), stream, partials, rows, C, count, gamma, beta, eps, mean, invstd, scale, shift);
     return dpc_launch_status();
 }
 
 // ------------------------------------------------------------------ forward apply (+res)(+relu)
-template <class T>
+// FIXED: 256*E is a multiple of C, so a thread's channel group never changes across the grid-stride
+// loop and the per-channel coefficients live in registers (no 64-bit modulo, no per-element loads).
+template <class T, bool FIXED>
 __global__ void bn_apply_kernel(const T* x, T* y, long long units, int C, const float* scale, const float* shift,
                                 const T* res, const float* rscale, const float* rshift, int relu) {
     constexpr int E = Elt<T>::PER16;
+    float sc[E], sh[E], rs[E], rb[E];
+    if (FIXED) {
+        const int c0 = (int)((threadIdx.x * E) % C);
+        DPC_UNROLL
+        for (int e = 0; e < E; ++e) {
+            sc[e] = scale[c0 + e]; sh[e] = shift[c0 + e];
+            rs[e] = rscale ? rscale[c0 + e] : 1.f; rb[e] = rscale ? rshift[c0 + e] : 0.f;
+        }
+    }
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < units; i += (long long)gridDim.x * blockDim.x) {
-        const int c0 = (int)((i * E) % C);
+        if (!FIXED) {
+            const int c0 = (int)((i * E) % C);
+            DPC_UNROLL
+            for (int e = 0; e < E; ++e) {
+                sc[e] = scale[c0 + e]; sh[e] = shift[c0 + e];
+                rs[e] = rscale ? rscale[c0 + e] : 1.f; rb[e] = rscale ? rshift[c0 + e] : 0.f;
+            }
+        }
         const u32x4 xv = ((const u32x4*)x)[i];
         u32x4 rv = {0u, 0u, 0u, 0u};
         if (res) rv = ((const u32x4*)res)[i];
         u32x4 o;
         DPC_UNROLL
         for (int e = 0; e < E; ++e) {
-            float v = unit_get<T>(xv, e) * scale[c0 + e] + shift[c0 + e];
-            if (res) {
-                float r = unit_get<T>(rv, e);
-                if (rscale) r = r * rscale[c0 + e] + rshift[c0 + e];
-                v += r;
-            }
+            float v = unit_get<T>(xv, e) * sc[e] + sh[e];
+            if (res) v += unit_get<T>(rv, e) * rs[e] + rb[e];
             if (relu) v = v > 0.f ? v : 0.f;
             unit_set<T>(o, e, v);
         }
@@ -77,10 +108,19 @@ extern "C" int dpc_bn_apply(const void* x, void* y, int32_t dtype, int64_t rows,
     const int E = dtype == DPC_BF16 ? 8 : 4;
     if (C % E) return DPC_ERR_UNSUPPORTED;
     const long long units = rows * C / E;
+    const bool fixed = (256 * E) % C == 0;
     if (dtype == DPC_F32) {
-        DPC_LAUNCH((bn_apply_kernel<float>), dim3(grid_for(units)), dim3(256), stream, (const float*)x, (float*)y, units, C, scale, shift, (const float*)res, rscale, rshift, relu);
+        if (fixed) {
+            DPC_LAUNCH((bn_apply_kernel<float, true>), dim3(grid_for(units)), dim3(256), stream, (const float*)x, (float*)y, units, C, scale, shift, (const float*)res, rscale, rshift, relu);
+        } else {
+            DPC_LAUNCH((bn_apply_kernel<float, false>), dim3(grid_for(units)), dim3(256), stream, (const float*)x, (float*)y, units, C, scale, shift, (const float*)res, rscale, rshift, relu);
+        }
     } else if (dtype == DPC_BF16) {
-        DPC_LAUNCH((bn_apply_kernel<bf16_t>), dim3(grid_for(units)), dim3(256), stream, (const bf16_t*)x, (bf16_t*)y, units, C, scale, shift, (const bf16_t*)res, rscale, rshift, relu);
+        if (fixed) {
+            DPC_LAUNCH((bn_apply_kernel<bf16_t, true>), dim3(grid_for(units)), dim3(256), stream, (const bf16_t*)x, (bf16_t*)y, units, C, scale, shift, (const bf16_t*)res, rscale, rshift, relu);
+        } else {
+            DPC_LAUNCH((bn_apply_kernel<bf16_t, false>), dim3(grid_for(units)), dim3(256), stream, (const bf16_t*)x, (bf16_t*)y, units, C, scale, shift, (const bf16_t*)res, rscale, rshift, relu);
+        }
     } else {
         return DPC_ERR_ARG;
     }
@@ -181,14 +221,12 @@ extern "C" int dpc_bn_bwd_reduce(const void* dy, const void* y, const void* x, i
     return dpc_launch_status();
 }
 
-__global__ void bn_bwd_finalize_kernel(const float* partials, int prow, int C, double count, float* dgamma, float* dbeta, float* coef) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    double s1 = 0.0, s2 = 0.0;
-    for (int r = 0; r < prow; ++r) {
-        s1 += (double)partials[((long long)r * 2 + 0) * C + c];
-        s2 += (double)partials[((long long)r * 2 + 1) * C + c];
-    }
+__global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* partials, int prow, int C, double count, float* dgamma, float* dbeta, float* coef) {
+    __shared__ double red[2][32][32];
+    const int c = blockIdx.x * 32 + (threadIdx.x & 31), rl = threadIdx.x >> 5;
+    double s1, s2;
+    partial_rows_sum(partials, prow, C, c, rl, s1, s2, red);
+    if (rl != 0 || c >= C) return;
     dbeta[c] = (float)s1;
     dgamma[c] = (float)s2;
     coef[c] = (float)(s1 / count);
@@ -199,17 +237,33 @@ extern "C" int dpc_bn_bwd_finalize(const float* partials, int32_t prow, int32_t 
                                    float* dbeta, float* coef, dpc_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (!partials || prow <= 0 || C <= 0 || count <= 0 || !dgamma || !dbeta || !coef) return DPC_ERR_ARG;
-    DPC_LAUNCH(bn_bwd_finalize_kernel, dim3((C + 63) / 64), dim3(64), stream, partials, prow, C, count, dgamma, dbeta, coef);
+    DPC_LAUNCH(bn_bwd_finalize_kernel, dim3((C + 31) / 32), dim3(1024), stream, partials, prow, C, count, dgamma, dbeta, coef);
     return dpc_launch_status();
 }
 
 // dx = gamma*invstd*(dz - c1 - xhat*c2)
-template <class T>
+template <class T, bool FIXED>
 __global__ void bn_bwd_apply_kernel(const T* dy, const T* y, const T* x, long long units, int C, const float* mean,
                                     const float* invstd, const float* gamma, const float* coef, int relu, T* dx, T* dzout) {
     constexpr int E = Elt<T>::PER16;
+    float mu[E], is[E], ga[E], c1[E], c2[E];
+    if (FIXED) {
+        const int c0 = (int)((threadIdx.x * E) % C);
+        DPC_UNROLL
+        for (int e = 0; e < E; ++e) {
+            mu[e] = mean[c0 + e]; is[e] = invstd[c0 + e]; ga[e] = gamma[c0 + e] * is[e];
+            c1[e] = coef[c0 + e]; c2[e] = coef[C + c0 + e];
+        }
+    }
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < units; i += (long long)gridDim.x * blockDim.x) {
-        const int c0 = (int)((i * E) % C);
+        if (!FIXED) {
+            const int c0 = (int)((i * E) % C);
+            DPC_UNROLL
+            for (int e = 0; e < E; ++e) {
+                mu[e] = mean[c0 + e]; is[e] = invstd[c0 + e]; ga[e] = gamma[c0 + e] * is[e];
+                c1[e] = coef[c0 + e]; c2[e] = coef[C + c0 + e];
+            }
+        }
         const u32x4 dv = ((const u32x4*)dy)[i];
         const u32x4 xv = ((const u32x4*)x)[i];
         u32x4 yv = {0u, 0u, 0u, 0u};
@@ -217,12 +271,10 @@ __global__ void bn_bwd_apply_kernel(const T* dy, const T* y, const T* x, long lo
         u32x4 o, oz;
         DPC_UNROLL
         for (int e = 0; e < E; ++e) {
-            const int c = c0 + e;
             float dz = unit_get<T>(dv, e);
             if (relu && !(unit_get<T>(yv, e) > 0.f)) dz = 0.f;
-            const float is = invstd[c];
-            const float xh = (unit_get<T>(xv, e) - mean[c]) * is;
-            unit_set<T>(o, e, gamma[c] * is * (dz - coef[c] - xh * coef[C + c]));
+            const float xh = (unit_get<T>(xv, e) - mu[e]) * is[e];
+            unit_set<T>(o, e, ga[e] * (dz - c1[e] - xh * c2[e]));
             unit_set<T>(oz, e, dz);
         }
         ((u32x4*)dx)[i] = o;
@@ -238,10 +290,19 @@ extern "C" int dpc_bn_bwd_apply(const void* dy, const void* y, const void* x, in
     const int E = dtype == DPC_BF16 ? 8 : 4;
     if (C % E) return DPC_ERR_UNSUPPORTED;
     const long long units = rows * C / E;
+    const bool fixed = (256 * E) % C == 0;
     if (dtype == DPC_F32) {
-        DPC_LAUNCH((bn_bwd_apply_kernel<float>), dim3(grid_for(units)), dim3(256), stream, (const float*)dy, (const float*)y, (const float*)x, units, C, mean, invstd, gamma, coef, relu, (float*)dx, (float*)dz);
+        if (fixed) {
+            DPC_LAUNCH((bn_bwd_apply_kernel<float, true>), dim3(grid_for(units)), dim3(256), stream, (const float*)dy, (const float*)y, (const float*)x, units, C, mean, invstd, gamma, coef, relu, (float*)dx, (float*)dz);
+        } else {
+            DPC_LAUNCH((bn_bwd_apply_kernel<float, false>), dim3(grid_for(units)), dim3(256), stream, (const float*)dy, (const float*)y, (const float*)x, units, C, mean, invstd, gamma, coef, relu, (float*)dx, (float*)dz);
+        }
     } else if (dtype == DPC_BF16) {
-        DPC_LAUNCH((bn_bwd_apply_kernel<bf16_t>), dim3(grid_for(units)), dim3(256), stream, (const bf16_t*)dy, (const bf16_t*)y, (const bf16_t*)x, units, C, mean, invstd, gamma, coef, relu, (bf16_t*)dx, (bf16_t*)dz);
+        if (fixed) {
+            DPC_LAUNCH((bn_bwd_apply_kernel<bf16_t, true>), dim3(grid_for(units)), dim3(256), stream, (const bf16_t*)dy, (const bf16_t*)y, (const bf16_t*)x, units, C, mean, invstd, gamma, coef, relu, (bf16_t*)dx, (bf16_t*)dz);
+        } else {
+            DPC_LAUNCH((bn_bwd_apply_kernel<bf16_t, false>), dim3(grid_for(units)), dim3(256), stream, (const bf16_t*)dy, (const bf16_t*)y, (const bf16_t*)x, units, C, mean, invstd, gamma, coef, relu, (bf16_t*)dx, (bf16_t*)dz);
+        }
     } else {
         return DPC_ERR_ARG;
     }

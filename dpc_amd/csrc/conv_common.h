@@ -120,8 +120,17 @@ __device__ __forceinline__ long long gather_off(const GatherGeom& g, const RowPo
     return pos * g.src_ld + t.ci;
 }
 
-__device__ __forceinline__ u32x4 load_unit(const void* base, long long elem_off, int esize) {
-    u32x4 z = {0u, 0u, 0u, 0u};
-    if (elem_off < 0) return z;
-    return *(const u32x4*)((const char*)base + elem_off * esize);
+// Branch-free on purpose: a conditional load makes hipcc branch around every load and wait
+// vmcnt(0) per element (cdna_hip_programming.md §5 trap (c)), serialising the HBM round trips.
+// Padding/out-of-range units read the (always valid) first 16 bytes and are masked to zero.
+// The mask is applied by the CONSUMER (the LDS store after the MFMA block): masking here would
+// put the s_waitcnt right behind the load and drain the prefetch before the matrix work.
+__device__ __forceinline__ u32x4 load_unit_raw(const void* base, long long elem_off, int esize) {
+    const long long o = elem_off >= 0 ? elem_off : 0;
+    return *(const u32x4*)((const char*)base + o * esize);
+}
+__device__ __forceinline__ u32x4 mask_unit(u32x4 v, bool ok) {
+    const uint32_t m = ok ? 0xffffffffu : 0u;
+    v[0] &= m; v[1] &= m; v[2] &= m; v[3] &= m;
+    return v;
 }

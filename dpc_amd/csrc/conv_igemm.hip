@@ -69,25 +69,32 @@ __global__ __launch_bounds__(256) void igemm_kernel(IGemmParams p) {
                 for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
         u32x4 ra[4], rb[BROWS];
+        unsigned okbits = 0;  // validity of the units in flight, applied when they are stored to LDS
         auto load_chunk = [&](int kc) {
             const int k = kc * BKE + u * EPU;
             const TapPos tp = decode_k(g, k);
+            okbits = 0;
             DPC_UNROLL
-            for (int i = 0; i < 4; ++i) ra[i] = load_unit(p.src, gather_off(g, rp[i], tp), esz);
+            for (int i = 0; i < 4; ++i) {
+                const long long off = gather_off(g, rp[i], tp);
+                okbits |= (off >= 0 ? 1u : 0u) << i;
+                ra[i] = load_unit_raw(p.src, off, esz);
+            }
             DPC_UNROLL
             for (int i = 0; i < BROWS; ++i) {
                 const int n = n_tile * BN + r0 + 32 * i;
-                const long long off = (tp.ok && n < p.Ncol) ? ((long long)n * p.ldw + k) : -1;
-                rb[i] = load_unit(p.wgt, off, esz);
+                const bool ok = tp.ok && n < p.Ncol;
+                okbits |= (ok ? 1u : 0u) << (4 + i);
+                rb[i] = load_unit_raw(p.wgt, ok ? ((long long)n * p.ldw + k) : -1, esz);
             }
         };
         auto store_chunk = [&](int buf) {
             unsigned char* As = lds + buf * (BM + BN) * 128;
             unsigned char* Bs = As + BM * 128;
             DPC_UNROLL
-            for (int i = 0; i < 4; ++i) *(u32x4*)(As + lds_unit_off(r0 + 32 * i, u)) = ra[i];
+            for (int i = 0; i < 4; ++i) *(u32x4*)(As + lds_unit_off(r0 + 32 * i, u)) = mask_unit(ra[i], (okbits >> i) & 1u);
             DPC_UNROLL
-            for (int i = 0; i < BROWS; ++i) *(u32x4*)(Bs + lds_unit_off(r0 + 32 * i, u)) = rb[i];
+            for (int i = 0; i < BROWS; ++i) *(u32x4*)(Bs + lds_unit_off(r0 + 32 * i, u)) = mask_unit(rb[i], (okbits >> (4 + i)) & 1u);
         };
 
         load_chunk(0);
@@ -116,6 +123,24 @@ __global__ __launch_bounds__(256) void igemm_kernel(IGemmParams p) {
         }
 
         // epilogue: C/D map col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+        if (p.addend) {  // all addend loads first (clamped, unconditional), one wait, then the adds
+            DPC_UNROLL
+            for (int j = 0; j < NT; ++j) {
+                const int col = n_tile * BN + wn * (BN / 2) + j * 32 + l31;
+                DPC_UNROLL
+                for (int i = 0; i < 2; ++i) {
+                    TO ad[16];
+                    DPC_UNROLL
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                        const bool ok = row < g.M && col < p.Ncol;
+                        ad[r] = ((const TO*)p.addend)[ok ? ((long long)row * p.ldo + col) : 0];
+                    }
+                    DPC_UNROLL
+                    for (int r = 0; r < 16; ++r) acc[i][j][r] += Elt<TO>::to_f32(ad[r]);
+                }
+            }
+        }
         DPC_UNROLL
         for (int j = 0; j < NT; ++j) {
             const int col = n_tile * BN + wn * (BN / 2) + j * 32 + l31;
@@ -128,7 +153,6 @@ __global__ __launch_bounds__(256) void igemm_kernel(IGemmParams p) {
                         if (row < g.M) {
                             const long long o = (long long)row * p.ldo + col;
                             float v = acc[i][j][r];
-                            if (p.addend) v += Elt<TO>::to_f32(((const TO*)p.addend)[o]);
                             const TO q = Elt<TO>::from_f32(v);
                             ((TO*)p.out)[o] = q;
                             const float vq = Elt<TO>::to_f32(q);

@@ -129,27 +129,32 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     u32x4 rv[NU][E];
+    unsigned okb[NU];  // per-unit validity bits, applied when the block is transposed into LDS
     auto load_chunk = [&](int chunk) {
         DPC_UNROLL
         for (int i = 0; i < NU; ++i) {
             const int m_first = chunk * BKP + u_pg[i] * E;
+            okb[i] = 0;
             if (!u_on[i]) continue;
             if (u_isA[i]) {
                 const int co = tile_m * TM + u_cu[i] * E;
+                const bool cok = co + E <= p.dy_ld && co < p.Co;
                 DPC_UNROLL
                 for (int e = 0; e < E; ++e) {
                     const int m = m_first + e;
-                    const long long off = (m < g.M && co + E <= p.dy_ld && co < p.Co) ? ((long long)m * p.dy_ld + co) : -1;
-                    rv[i][e] = load_unit(p.dy, off, esz);
+                    const bool ok = cok && m < g.M;
+                    okb[i] |= (ok ? 1u : 0u) << e;
+                    rv[i][e] = load_unit_raw(p.dy, ok ? ((long long)m * p.dy_ld + co) : -1, esz);
                 }
             } else {
                 RowIt it = rowit_decode(g, m_first < g.M ? m_first : 0);
                 DPC_UNROLL
                 for (int e = 0; e < E; ++e) {
                     const int m = m_first + e;
-                    long long off = -1;
-                    if (m < g.M) off = gather_off(g, rowit_pos(g, it), u_tp[i]);
-                    rv[i][e] = load_unit(p.src, off, esz);
+                    long long off = gather_off(g, rowit_pos(g, it), u_tp[i]);
+                    if (m >= g.M) off = -1;
+                    okb[i] |= (off >= 0 ? 1u : 0u) << e;
+                    rv[i][e] = load_unit_raw(p.src, off, esz);
                     rowit_next(g, it);
                 }
             }
@@ -161,8 +166,10 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
         DPC_UNROLL
         for (int i = 0; i < NU; ++i) {
             if (!u_on[i]) continue;
-            u32x4 o[E];
-            Transposer<T>::run(rv[i], o);
+            u32x4 o[E], mv[E];
+            DPC_UNROLL
+            for (int e = 0; e < E; ++e) mv[e] = mask_unit(rv[i][e], (okb[i] >> e) & 1u);
+            Transposer<T>::run(mv, o);
             unsigned char* base = u_isA[i] ? As : Bs;
             DPC_UNROLL
             for (int c = 0; c < E; ++c) *(u32x4*)(base + lds_unit_off(u_cu[i] * E + c, u_pg[i])) = o[c];

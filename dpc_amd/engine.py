@@ -75,6 +75,63 @@ def param_shapes(network: str, widths: Sequence[int] = LAYER_WIDTH) -> "Dict[str
     return out
 
 
+class KernelTimer:
+    """HIP-event timing of selected C-ABI entry points on the launch stream (bench.py roofline leg).
+    Every timed launch is bracketed by two events recorded on torch's current stream -- the stream the
+    kernel is launched on -- and tagged with its algorithmic FLOPs / bytes."""
+
+    def __init__(self, names):
+        self.names = set(names)
+        self.records = []  # (name, start_event, end_event, flops, bytes)
+        self.enabled = True
+
+    def timed(self, eng, name, args):
+        if not self.enabled:
+            return eng.lib.call(name, *args, eng.lib.stream())
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        rc = eng.lib.call(name, *args, eng.lib.stream())
+        b.record()
+        fl, by = algorithmic_cost(name, args)
+        self.records.append((name, a, b, fl, by))
+        return rc
+
+    def summary(self):
+        torch.cuda.synchronize()
+        out = {}
+        for name, a, b, fl, by in self.records:
+            d = out.setdefault(name, {"launches": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0})
+            d["launches"] += 1
+            d["ms"] += a.elapsed_time(b)
+            d["flops"] += fl
+            d["bytes"] += by
+        return out
+
+
+def algorithmic_cost(name, args):
+    """algorithmic FLOPs and HBM bytes (operands read once + output written once) of one launch"""
+    if name not in ("dpc_conv_igemm", "dpc_conv_wgrad"):
+        return 0.0, 0.0
+    d = args[0]._obj
+    esz = 2 if d.dtype_in == L.BF16 else 4
+    osz = 2 if d.dtype_out == L.BF16 else 4
+    taps = d.KT * d.KH * d.KW
+    rows_out = d.N * d.RT * d.RH * d.RW
+    rows_src = d.N * d.ST * d.SH * d.SW
+    if name == "dpc_conv_igemm" and d.mode == 1:
+        # input-gradient: same MACs as the forward conv it differentiates (rows_src = forward output positions)
+        macs = rows_src * d.Ci * d.Co * taps
+    else:
+        macs = rows_out * d.Co * d.Ci * taps
+    if taps == 16 and d.Ci == 16 and d.KT == 1:  # space-to-depth stem: 147 of the 256 k-slots are real
+        macs = macs * 147 // 256
+    if name == "dpc_conv_igemm":
+        by = rows_src * d.Ci * esz + d.Co * d.Ci * taps * esz + rows_out * d.Co * osz
+    else:
+        by = rows_src * d.Ci * esz + rows_out * d.Co * esz + d.Co * d.Ci * taps * 4
+    return 2.0 * macs, float(by)
+
+
 class _ConvBN:
     """one Conv3d (no bias) + BatchNorm3d(batch stats) unit and its saved tensors"""
 
@@ -251,6 +308,7 @@ class DPCEngine:
         self._part_need = 0
         self._scratch: Dict[Tuple[int, ...], List[torch.Tensor]] = {}
         self.step_count = 0
+        self.timer: Optional["KernelTimer"] = None
 
         # ---- flat f32 arenas: parameters, gradients, Adam moments
         self.shapes = param_shapes(network, widths)
@@ -382,6 +440,9 @@ class DPCEngine:
         self.need_part(ns.value * Co * K)
 
     def call(self, name, *args):
+        tm = self.timer
+        if tm is not None and name in tm.names:
+            return tm.timed(self, name, args)
         return self.lib.call(name, *args, self.lib.stream())
 
     def scratch(self, shape, exclude):

@@ -1,0 +1,138 @@
+"""Drop-in module boundary: ``DPC_RNN(sample_size, num_seq, seq_len, pred_step, network)``
+with ``forward(block) -> [score, mask]`` exactly as dpc/model_3d.py:14-98, backed by the
+MI355X engine.  Same constructor arguments, public attributes (.backbone/.agg/
+.network_pred/.mask/.param/.last_size/.last_duration/.pred_step), state_dict keys
+(including the duplicated ``agg.cell_list.0.*`` alias, backbone/convrnn.py:55-58) and
+error behaviour (``IOError('model type is wrong')``, backbone/select_backbone.py:19).
+
+Parameters are ``nn.Parameter`` views into the engine's flat f32 arena, so
+``load_state_dict`` / ``state_dict`` / any torch optimizer see the reference layout while
+the kernels (and the fused Adam of ``engine.train_step``) work on one contiguous buffer.
+``forward`` returns a score that autograd can differentiate: its backward runs the
+engine's hand-written backward kernels and hands the parameter gradients to autograd.
+There is no CPU path: calling it with CPU tensors raises (dpc_amd._lib.DpcError).
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional
+
+import torch
+import torch.nn as nn
+
+from . import _lib as L
+from .engine import DPCEngine, LAYER_PLAN, LAYER_WIDTH, param_shapes
+
+
+class _Holder(nn.Module):
+    """namespace module so that parameters appear under the reference's dotted names"""
+
+
+def _attach(root: nn.Module, dotted: str, param: nn.Parameter):
+    parts = dotted.split(".")
+    mod = root
+    for p in parts[:-1]:
+        if not hasattr(mod, p):
+            setattr(mod, p, _Holder())
+        mod = getattr(mod, p)
+    mod.register_parameter(parts[-1], param)
+
+
+def _init_reference_style(shapes: Dict[str, tuple], gen: torch.Generator) -> Dict[str, torch.Tensor]:
+    """kaiming_normal(fan_out) convs + BN 1/0 (backbone/resnet_2d3d.py:224-230); orthogonal gain 1,
+    zero bias for agg / network_pred (dpc/model_3d.py:100-106)."""
+    out = {}
+    for k, shp in shapes.items():
+        if k.startswith("backbone") and len(shp) == 5:
+            fan_out = shp[0] * shp[2] * shp[3] * shp[4]
+            out[k] = torch.randn(shp, generator=gen) * math.sqrt(2.0 / fan_out)
+        elif k.startswith("backbone"):
+            out[k] = torch.ones(shp) if k.endswith("weight") else torch.zeros(shp)
+        elif k.endswith("bias"):
+            out[k] = torch.zeros(shp)
+        else:
+            w = torch.empty(shp)
+            nn.init.orthogonal_(w, 1, generator=gen)
+            out[k] = w
+    return out
+
+
+class _DPCScore(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, model, block, train, masks, *params):
+        eng = model._engine
+        score = eng.forward(block, train=train, dropout_masks=masks)
+        ctx.model = model
+        return score.clone()  # engine buffer is reused next step
+
+    @staticmethod
+    def backward(ctx, dscore):
+        eng = ctx.model._engine
+        eng.backward(dscore_external=dscore)
+        grads = tuple(eng.G[k].clone() for k in ctx.model._param_names)
+        return (None, None, None, None) + grads
+
+
+class DPC_RNN(nn.Module):
+    """DPC with RNN (dpc/model_3d.py:14)"""
+
+    def __init__(self, sample_size, num_seq=8, seq_len=5, pred_step=3, network="resnet50",
+                 compute_dtype=torch.float32, widths=LAYER_WIDTH, seed: int = 0):
+        super().__init__()
+        if network not in LAYER_PLAN:
+            raise IOError("model type is wrong")  # select_backbone.py:19 (resnet50+ are outside this build's scope)
+        self.sample_size, self.num_seq, self.seq_len, self.pred_step = sample_size, num_seq, seq_len, pred_step
+        self.network = network
+        self.last_duration = int(math.ceil(seq_len / 4))
+        self.last_size = int(math.ceil(sample_size / 32))
+        self.param = {"feature_size": widths[3], "num_layers": 1, "hidden_size": widths[3]}
+        self.compute_dtype = compute_dtype
+        self.widths = tuple(widths)
+        self.mask = None
+        self._engine: Optional[DPCEngine] = None
+        self._engine_key = None
+        self._param_names: List[str] = []
+        self._forced_masks = None
+        shapes = param_shapes(network, widths)
+        init = _init_reference_style(shapes, torch.Generator().manual_seed(seed))
+        for k, shp in shapes.items():
+            _attach(self, k, nn.Parameter(init[k]))
+            self._param_names.append(k)
+        # the reference registers the single GRU cell twice (convrnn.py:55-58): alias module, same Parameters
+        self.agg.cell_list = nn.ModuleList([self.agg.ConvGRUCell_00])
+
+    # ---- engine lifecycle: parameters live in the engine's flat arena on the current device
+    def _ensure_engine(self, block: torch.Tensor):
+        B = block.shape[0]
+        dev = block.device
+        key = (B, dev, self.compute_dtype)
+        first = self.backbone.conv1.weight
+        if self._engine is not None and self._engine_key == key and first.data_ptr() == self._engine.PRM[self._param_names[0]].data_ptr():
+            return
+        eng = DPCEngine(self.network, self.sample_size, self.num_seq, self.seq_len, self.pred_step, B, dev,
+                        self.compute_dtype, self.widths)
+        named = {k: v for k, v in self.named_parameters()}
+        eng.load_params({k: named[k].detach() for k in self._param_names})
+        for k in self._param_names:
+            named[k].data = eng.PRM[k]  # re-point the Parameter at its slice of the flat arena
+        self._engine, self._engine_key = eng, key
+        self.mask = None
+
+    def forward(self, block):
+        # block: [B, N, C, SL, H, W] (dpc/model_3d.py:47-49)
+        if block.device.type != "cuda":
+            raise L.DpcError("dpc_amd.DPC_RNN runs on MI355X only: move the module and the input to a cuda (HIP) device")
+        self._ensure_engine(block)
+        self._engine.packed_for_step = -1  # parameters may have been changed by an external optimizer
+        params = [dict(self.named_parameters())[k] for k in self._param_names]
+        score = _DPCScore.apply(self, block.float(), self.training, self._forced_masks, *params)
+        if self.mask is None:  # only compute mask once (model_3d.py:86-96); contiguous
+            self.mask = self._engine.get_mask()
+        return [score, self.mask]
+
+    def reset_mask(self):
+        self.mask = None
+
+    @property
+    def engine(self) -> Optional[DPCEngine]:
+        return self._engine

@@ -1,0 +1,51 @@
+"""Host-side boundary checks that need no GPU: the C-ABI library loads and exports every
+symbol include/dpc_hip.h declares; the DPC_RNN module mirrors the reference's constructor,
+attributes and state_dict keys; the product path refuses to run without the HIP device."""
+import os
+import re
+import subprocess
+
+import pytest
+import torch
+
+from dpc_amd import _lib as L
+from oracle import dpc_oracle as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_symbols():
+    src = open(os.path.join(ROOT, "include", "dpc_hip.h")).read()
+    return sorted(set(re.findall(r"\bint\s+(dpc_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_header_and_binding_agree():
+    assert header_symbols() == sorted(L._SIGS)
+
+
+@pytest.mark.parametrize("path", [L.HIP_LIB_PATH, L.EMU_LIB_PATH])
+def test_library_exports_every_declared_symbol(path):
+    subprocess.run(["make", "-s", "-j8", "all", "emu"], cwd=ROOT, check=True)
+    lib = L.Lib(path, "probe")  # dlopen only; no kernel is launched
+    assert lib.missing_symbols() == []
+    assert lib.call("dpc_abi_version") == L.ABI_VERSION
+
+
+def test_module_mirrors_reference_boundary():
+    from dpc_amd.model import DPC_RNN
+    m = DPC_RNN(sample_size=128, num_seq=8, seq_len=5, pred_step=3, network="resnet18")
+    ref = O.param_shapes("resnet18", with_alias=True)
+    sd = m.state_dict()
+    assert list(sd.keys()) == list(ref.keys())
+    assert all(tuple(sd[k].shape) == ref[k] for k in ref)
+    assert sd["agg.cell_list.0.out_gate.weight"].data_ptr() == sd["agg.ConvGRUCell_00.out_gate.weight"].data_ptr()
+    assert sum(p.numel() for p in m.parameters()) == 14583104
+    assert (m.last_size, m.last_duration, m.pred_step, m.param["feature_size"]) == (4, 2, 3, 256)
+    assert m.mask is None
+    m.load_state_dict(O.make_params_pcg("resnet18"), strict=True)
+    with pytest.raises(IOError):
+        DPC_RNN(128, network="resnet50")
+    with pytest.raises(L.DpcError):
+        m(torch.zeros(1, 8, 3, 5, 128, 128))  # CPU tensors: no fallback
+    m34 = DPC_RNN(224, network="resnet34")
+    assert sum(p.numel() for p in m34.parameters()) == 32947776

@@ -1,0 +1,84 @@
+"""CPU tier, end to end: the engine's full kernel schedule (forward, CE/top-k, backward,
+Adam) executed by the host SIMT simulator on a width-reduced 2d3d-ResNet18 (the reference
+block classes are width-parametric, backbone/resnet_2d3d.py:50,86) against the oracle."""
+import os
+import subprocess
+
+import pytest
+import torch
+
+from dpc_amd import _lib as L
+from dpc_amd.engine import DPCEngine, param_shapes
+from oracle import dpc_oracle as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+WIDTHS = (8, 16, 32, 32)
+
+
+@pytest.fixture(scope="module")
+def emu():
+    subprocess.run(["make", "-s", "-j8", "emu"], cwd=ROOT, check=True)
+    return L.load_emulator()
+
+
+def test_param_inventory_matches_reference_keys():
+    for net in ("resnet18", "resnet34"):
+        mine = param_shapes(net)
+        ref = O.param_shapes(net, with_alias=False)
+        assert list(mine.items()) == list(ref.items())
+    with pytest.raises(IOError):
+        param_shapes("resnet50")
+
+
+def test_engine_refuses_cpu_without_simulator():
+    with pytest.raises(L.DpcError):
+        DPCEngine("resnet18", 64, 8, 5, 3, 2, "cpu", torch.float32, WIDTHS)
+
+
+def test_train_step_parity_f32(emu):
+    B, size = 2, 64
+    eng = DPCEngine("resnet18", size, 8, 5, 3, B, "cpu", torch.float32, WIDTHS, lib=emu)
+    p = O.make_params_pcg("resnet18", WIDTHS)
+    eng.load_params(p)
+    x = O.make_input_pcg(B, 8, 5, size)
+    # injected dropout masks: [n_steps, M, D] pre-scaled keep masks, shared with the oracle
+    g = torch.Generator().manual_seed(5)
+    keep = (torch.rand(eng.n_steps, B, eng.last_size, eng.last_size, eng.D, generator=g) > 0.1).float() / 0.9
+    masks_eng = keep.reshape(eng.n_steps, eng.M, eng.D)
+    masks_ref = [keep[i].permute(0, 3, 1, 2).contiguous() for i in range(eng.n_steps)]
+    masks_ref.append(torch.ones_like(masks_ref[0]))  # the reference's last GRU step is dead code (model_3d.py:70-72)
+    loss, accs, grads, ref = O.train_step_reference(p, x, "resnet18", 3, masks_ref)
+    score = eng.forward(x, train=True, dropout_masks=masks_eng)
+    assert (score - ref).abs().max().item() < 1e-3  # north_star tolerance, fp32
+    res = eng.loss_topk(True)
+    assert abs(res[0].item() - loss.item()) < 1e-4
+    assert res[1:].tolist() == pytest.approx(accs, abs=1e-6)
+    eng.backward()
+    for k, r in grads.items():
+        e = (eng.G[k] - r).abs().max().item() / max(r.abs().max().item(), 1e-8)
+        assert e < 1e-3, (k, e)
+    # mask + Adam
+    assert torch.equal(eng.get_mask(), O.mask_closed_form(B, 3, eng.SQ))
+    before = {k: v.clone() for k, v in eng.PRM.items()}
+    eng.adam_step()
+    for k in ("backbone.layer2.0.conv1.weight", "agg.ConvGRUCell_00.out_gate.weight", "network_pred.2.bias"):
+        w = before[k].clone()
+        O.adam_step(w, grads[k], torch.zeros_like(w), torch.zeros_like(w), 1)
+        assert (eng.PRM[k] - w).abs().max().item() < 2.1e-3  # sign flips of ~0 grads move 2*lr
+        assert ((eng.PRM[k] - w).abs() > 1e-5).float().mean().item() < 0.01
+
+
+def test_forward_bf16_smoke(emu):
+    B, size = 2, 64
+    eng = DPCEngine("resnet18", size, 8, 5, 3, B, "cpu", torch.bfloat16, WIDTHS, lib=emu)
+    p = O.make_params_pcg("resnet18", WIDTHS)
+    eng.load_params(p)
+    x = O.make_input_pcg(B, 8, 5, size)
+    score = eng.forward(x, train=False)
+    with torch.no_grad():
+        ref = O.dpc_forward(p, x, "resnet18", 3)
+    # bf16 operands: not a parity claim, only that the throughput mode computes the same function
+    assert (score - ref).abs().max().item() < 0.15 * ref.abs().max().item()
+    res = eng.loss_topk(True)
+    eng.backward()
+    assert torch.isfinite(eng.flat_g).all() and torch.isfinite(res).all()

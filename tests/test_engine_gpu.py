@@ -1,0 +1,172 @@
+"""GPU tier, end to end: the MI355X engine against the golden vectors the reference itself
+produced (tests/golden, fp32, north_star tolerance 1e-3) and, at BASELINE.json's full batch,
+against size-independent properties.  Nothing here reads /root/reference."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from dpc_amd import _lib as L
+from dpc_amd.engine import DPCEngine
+from dpc_amd.model import DPC_RNN
+from oracle import dpc_oracle as O
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-3  # BASELINE.json north_star: outputs within 1e-3 fp32 of the reference CPU path
+DEV = "cuda:0"
+
+
+def gold(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name), allow_pickle=False)
+
+
+def engine(net, size, B, dtype=torch.float32):
+    eng = DPCEngine(net, size, 8, 5, 3, B, DEV, dtype)
+    assert eng.lib.kind == "hip" and eng.lib.path.endswith("libdpc_hip.so")
+    eng.load_params(O.make_params_pcg(net))
+    return eng
+
+
+@pytest.mark.parametrize("tag,net,size,B", [("r18_64_b2", "resnet18", 64, 2), ("r34_64_b2", "resnet34", 64, 2),
+                                            ("r18_128_b4", "resnet18", 128, 4)])
+def test_eval_score_vs_reference(golden_dir, tag, net, size, B):
+    g = gold(golden_dir, "eval_scores.npz")
+    eng = engine(net, size, B)
+    x = O.make_input_pcg(B, 8, 5, size).to(DEV)
+    score = eng.forward(x, train=False).cpu()
+    ref = torch.from_numpy(g["score_" + tag])
+    assert (score - ref).abs().max().item() < TOL
+    res = eng.loss_topk(False).cpu()
+    loss, accs = O.loss_and_topk(ref)
+    assert abs(res[0].item() - loss.item()) < TOL
+    assert res[1:].tolist() == pytest.approx([a.item() for a in accs], abs=1e-6)
+    assert torch.equal(eng.get_mask().cpu(), O.mask_closed_form(B, 3, eng.SQ))
+
+
+def test_train_step_vs_reference(golden_dir):
+    g = gold(golden_dir, "train.npz")
+    eng = engine("resnet18", 64, 2)
+    x = O.make_input_pcg(2, 8, 5, 64).to(DEV)
+    score = eng.forward(x, train=False).cpu()  # golden run had dropout p=0
+    assert (score - torch.from_numpy(g["score_p0"])).abs().max().item() < TOL
+    res = eng.loss_topk(True).cpu()
+    e = g["loss_topk_p0"]
+    assert abs(res[0].item() - e[0]) < TOL and res[1:].tolist() == pytest.approx(list(e[1:]), abs=1e-6)
+    eng.backward()
+    torch.cuda.synchronize()
+    names = [str(n) for n in g["param_names"]]
+    assert names == list(eng.G.keys())
+    # Gradient parity.  The head (ConvGRU, network_pred) and layer4 see no chaotic amplification and are
+    # held to 1e-3 of max-abs.  Upstream of a ReLU whose pre-activation sits within fp32 noise of zero a
+    # single mask flip changes the gradient discretely: the reference's own fp32 run deviates from an
+    # fp64 run of itself by 0.5-4 % (max-abs) in layers 1-2 on this very input (DESIGN.md "ReLU-boundary
+    # flips"; scripts/diag_grads.py prints the flip census), so backbone gradients are held to 3 % in
+    # relative L2 / 1 % in norm instead of an element-wise bound.
+    for i, n in enumerate(names):
+        gn = eng.G[n].norm().item()
+        assert gn == pytest.approx(float(g["grad_norm_p0"][i]), rel=1e-2, abs=1e-6), n
+    for k in g.files:
+        if k.startswith("grad_sub_p0::"):
+            n = k.split("::", 1)[1]
+            stride = int(g["grad_substride_p0::" + n])
+            mine = eng.G[n].cpu().flatten()[::stride].numpy()
+            if n.startswith(("agg.", "network_pred.", "backbone.layer4")):
+                assert np.abs(mine - g[k]).max() < 1e-3 * np.abs(g[k]).max() + 1e-7, n
+            else:
+                assert np.linalg.norm(mine - g[k]) < 3e-2 * np.linalg.norm(g[k]), n
+    eng.adam_step()
+    torch.cuda.synchronize()
+    for i, n in enumerate(names):
+        w = eng.PRM[n].cpu()
+        slack = 2e-3 * (2 + 2e-3 * w.numel())  # first Adam step = lr*sign(g): ~0.1 % of the signs may differ
+        assert w.double().sum().item() == pytest.approx(float(g["adam_sum_p0"][i]), rel=1e-5, abs=slack), n
+
+
+def test_injected_dropout_vs_reference(golden_dir):
+    g = gold(golden_dir, "train.npz")
+    shape = tuple(int(v) for v in g["drop_keep_shape"])
+    keep = np.unpackbits(g["drop_keep_bits"])[: int(np.prod(shape))].reshape(shape).astype(np.float32)  # [8,B,256,2,2]
+    eng = engine("resnet18", 64, 2)
+    masks = torch.from_numpy(keep[: eng.n_steps]).permute(0, 1, 3, 4, 2).reshape(eng.n_steps, eng.M, eng.D) / 0.9
+    x = O.make_input_pcg(2, 8, 5, 64).to(DEV)
+    score = eng.forward(x, train=True, dropout_masks=masks.to(DEV)).cpu()
+    assert (score - torch.from_numpy(g["score_drop"])).abs().max().item() < TOL
+
+
+def test_module_drop_in(golden_dir):
+    """DPC_RNN(...).forward(block) -> [score, mask]; criterion/backward/torch.optim as in dpc/main.py:198-231"""
+    g = gold(golden_dir, "train.npz")
+    model = DPC_RNN(sample_size=64, num_seq=8, seq_len=5, pred_step=3, network="resnet18")
+    model.load_state_dict(O.make_params_pcg("resnet18"), strict=True)
+    model = model.to(DEV)
+    model.eval()  # dropout off, BN still batch-stat (track_running_stats=False)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=1e-5)
+    x = O.make_input_pcg(2, 8, 5, 64).to(DEV)
+    score_, mask_ = model(x)
+    assert (score_.detach().cpu() - torch.from_numpy(g["score_p0"])).abs().max().item() < TOL
+    assert mask_.is_contiguous() and torch.equal(mask_.cpu(), O.mask_closed_form(2, 3, 4))
+    B, NP, SQ, B2, NS, _ = mask_.size()
+    target = (mask_ == 1).view(B * NP * SQ, B2 * NS * SQ).to(int).argmax(dim=1)
+    loss = torch.nn.CrossEntropyLoss()(score_.view(B * NP * SQ, B2 * NS * SQ), target)
+    assert abs(loss.item() - g["loss_topk_p0"][0]) < TOL
+    opt.zero_grad()
+    loss.backward()
+    names = [str(n) for n in g["param_names"]]
+    named = dict(model.named_parameters())
+    for i, n in enumerate(names):
+        assert named[n].grad.norm().item() == pytest.approx(float(g["grad_norm_p0"][i]), rel=1e-2, abs=1e-6), n
+    opt.step()
+    sd = model.state_dict()
+    assert "agg.cell_list.0.reset_gate.weight" in sd
+    for i, n in enumerate(names):
+        w = sd[n].cpu()
+        slack = 2e-3 * (2 + 2e-3 * w.numel())
+        assert w.double().sum().item() == pytest.approx(float(g["adam_sum_p0"][i]), rel=1e-5, abs=slack), n
+    # second forward sees the updated parameters (weights are repacked)
+    s2, _ = model(x)
+    assert (s2.detach() - score_.detach()).abs().max().item() > 1e-4
+
+
+def test_bf16_mode_tracks_fp32(golden_dir):
+    g = gold(golden_dir, "eval_scores.npz")
+    eng = engine("resnet18", 64, 2, torch.bfloat16)
+    x = O.make_input_pcg(2, 8, 5, 64).to(DEV)
+    score = eng.forward(x, train=False).cpu()
+    ref = torch.from_numpy(g["score_r18_64_b2"])
+    # throughput mode (bf16 operands, f32 accumulate): NOT a parity claim; bounded drift only
+    assert (score - ref).abs().max().item() < 0.1 * ref.abs().max().item()
+    eng.loss_topk(True)
+    eng.backward()
+    assert torch.isfinite(eng.flat_g).all()
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_full_batch_properties(dtype):
+    """BASELINE.json configs[1] size (r18, 128^2, B=128/GPU): size-independent invariants."""
+    B = 128
+    eng = DPCEngine("resnet18", 128, 8, 5, 3, B, DEV, dtype)
+    m = DPC_RNN(128, network="resnet18", seed=0)
+    eng.load_params({k: v.detach() for k, v in m.named_parameters()})
+    x = torch.randn(B, 8, 3, 5, 128, 128, device=DEV, generator=torch.Generator(DEV).manual_seed(1))
+    res0 = eng.train_step(x).cpu()
+    R = eng.R
+    assert R == 6144 and torch.isfinite(res0).all()
+    # BN invariant: normalised activations have per-channel mean beta=0 / var gamma^2=1 before ReLU.
+    u = eng.blocks[0].c1
+    raw = u.raw.float().view(-1, u.Co)
+    z = raw * u.scale + u.shift
+    assert z.mean(0).abs().max().item() < 2e-2 and (z.var(0, unbiased=False) - 1).abs().max().item() < 2e-2
+    # CE gradient rows sum to zero; score is the Gram matrix of its operands
+    ds = eng.dscore.float()[:, :R]
+    assert ds.sum(1).abs().max().item() < 1e-3
+    chk = eng.pred.float().view(R, -1)[:64] @ eng.feat_inf.float().view(R, -1).t()
+    assert (chk - eng.score[:64]).abs().max().item() < 1e-2 * chk.abs().max().item()
+    # mask: exactly one positive per row, on the diagonal (target == arange)
+    mk = eng.get_mask().view(R, R)
+    assert torch.equal((mk == 1).sum(1), torch.ones(R, dtype=torch.long, device=DEV))
+    assert torch.equal((mk == 1).to(torch.int8).argmax(1), torch.arange(R, device=DEV))
+    # loss goes down when the same batch is revisited (optimizer + backward are wired correctly)
+    for _ in range(3):
+        res = eng.train_step(x, dropout_masks=None)
+    assert res[0].item() < res0[0].item()

@@ -1,0 +1,118 @@
+"""GPU tier: every C-ABI kernel of libdpc_hip.so on a real MI355X against torch-CPU
+expectations (same cases as the simulator tier, production-like tile counts)."""
+import pytest
+import torch
+
+import kcases as kc
+from dpc_amd import _lib as L
+
+pytestmark = pytest.mark.gpu
+F32, BF16 = torch.float32, torch.bfloat16
+
+
+@pytest.fixture(scope="module")
+def k():
+    assert torch.cuda.is_available(), "GPU tier needs an MI355X"
+    return kc.K(L.load_hip(), "cuda:0")
+
+
+@pytest.mark.parametrize("dtype", [F32, BF16])
+@pytest.mark.parametrize("shape", [
+    (4, 64, 64, 3, 32, 32, (1, 3, 3), (1, 1, 1), (0, 1, 1)),     # layer1
+    (4, 64, 128, 3, 32, 32, (1, 3, 3), (1, 2, 2), (0, 1, 1)),    # layer2.0.conv1
+    (6, 128, 256, 5, 16, 16, (3, 3, 3), (2, 2, 2), (1, 1, 1)),   # layer3.0.conv1
+    (16, 256, 256, 3, 8, 8, (3, 3, 3), (1, 1, 1), (1, 1, 1)),    # layer3 body
+    (16, 256, 256, 2, 4, 4, (3, 3, 3), (1, 1, 1), (1, 1, 1)),    # layer4 body
+    (5, 128, 256, 5, 16, 16, (1, 1, 1), (2, 2, 2), (0, 0, 0)),   # downsample
+    (3, 16, 40, 2, 9, 7, (1, 3, 3), (1, 1, 1), (0, 1, 1)),       # ragged everything
+])
+def test_conv_fwd(k, dtype, shape):
+    kc.case_conv_fwd(k, dtype, *shape)
+
+
+@pytest.mark.parametrize("dtype", [F32, BF16])
+@pytest.mark.parametrize("shape", [
+    (4, 64, 64, 3, 32, 32, (1, 3, 3), (1, 1, 1), (0, 1, 1)),
+    (4, 64, 128, 3, 32, 32, (1, 3, 3), (1, 2, 2), (0, 1, 1)),
+    (6, 128, 256, 5, 16, 16, (3, 3, 3), (2, 2, 2), (1, 1, 1)),
+    (16, 256, 256, 3, 8, 8, (3, 3, 3), (1, 1, 1), (1, 1, 1)),
+    (5, 128, 256, 5, 16, 16, (1, 1, 1), (2, 2, 2), (0, 0, 0)),
+    (3, 16, 32, 2, 9, 7, (1, 3, 3), (1, 2, 2), (0, 1, 1)),
+])
+def test_conv_dgrad(k, dtype, shape):
+    kc.case_conv_dgrad(k, dtype, *shape)
+
+
+@pytest.mark.parametrize("dtype", [F32, BF16])
+@pytest.mark.parametrize("shape", [
+    (4, 64, 64, 3, 32, 32, (1, 3, 3), (1, 1, 1), (0, 1, 1)),
+    (4, 64, 128, 3, 32, 32, (1, 3, 3), (1, 2, 2), (0, 1, 1)),
+    (6, 128, 256, 5, 16, 16, (3, 3, 3), (2, 2, 2), (1, 1, 1)),
+    (16, 256, 256, 3, 8, 8, (3, 3, 3), (1, 1, 1), (1, 1, 1)),
+    (5, 128, 256, 5, 16, 16, (1, 1, 1), (2, 2, 2), (0, 0, 0)),
+    (5, 8, 24, 2, 6, 6, (1, 3, 3), (1, 2, 2), (0, 1, 1)),
+])
+def test_conv_wgrad(k, dtype, shape):
+    kc.case_conv_wgrad(k, dtype, *shape)
+
+
+@pytest.mark.parametrize("dtype", [F32, BF16])
+@pytest.mark.parametrize("mnk", [(6144, 6144, 256), (6468, 6468, 256), (2048, 768, 256), (192, 192, 256), (130, 70, 64)])
+def test_gemm_nt(k, dtype, mnk):
+    kc.case_gemm_nt(k, dtype, *mnk)
+
+
+@pytest.mark.parametrize("dtype", [F32, BF16])
+def test_stem_s2d(k, dtype):
+    kc.case_stem(k, dtype, 4, 5, 64, 64)
+    kc.case_stem(k, dtype, 2, 2, 16, 20)
+
+
+@pytest.mark.parametrize("dtype", [F32, BF16])
+@pytest.mark.parametrize("relu,res_mode,C", [(True, 0, 64), (True, 1, 128), (False, 2, 256), (True, 2, 256), (True, 1, 16)])
+def test_bn(k, dtype, relu, res_mode, C):
+    kc.case_bn_fwd_bwd(k, dtype, 20011, C, relu, res_mode)
+
+
+@pytest.mark.parametrize("dtype", [F32, BF16])
+@pytest.mark.parametrize("hw", [(64, 64), (7, 10)])
+def test_stem_pool(k, dtype, hw):
+    kc.case_stem_pool(k, dtype, 6, hw[0], hw[1], 64)
+
+
+@pytest.mark.parametrize("dtype", [F32, BF16])
+def test_tpool_split(k, dtype):
+    kc.case_tpool_split(k, dtype, 4, 8, 2, 16, 256, 3)
+    kc.case_tpool_split(k, dtype, 3, 8, 2, 49, 256, 5)
+
+
+@pytest.mark.parametrize("dtype", [F32, BF16])
+def test_gru_cell(k, dtype):
+    kc.case_gru_cell(k, dtype, 512, 256)
+    kc.case_gru_cell(k, dtype, 36, 32)
+
+
+@pytest.mark.parametrize("dtype", [F32, BF16])
+def test_bias_act_rows(k, dtype):
+    kc.case_bias_act_rows(k, dtype, 8, 3, 16, 256)
+
+
+@pytest.mark.parametrize("bps", [(4, 3, 16), (2, 1, 4), (3, 5, 49), (16, 3, 16)])
+def test_mask(k, bps):
+    kc.case_mask(k, *bps)
+
+
+@pytest.mark.parametrize("dtype_d", [F32, BF16])
+def test_ce_topk(k, dtype_d):
+    kc.case_ce_topk(k, 24, 24, dtype_d)
+    kc.case_ce_topk(k, 1764, 1764, dtype_d)
+    kc.case_ce_topk(k, 6144, 6144, dtype_d)
+
+
+def test_adam(k):
+    kc.case_adam(k, 1027)
+    kc.case_adam(k, 14583104)
+
+
+def test_transpose(k):
+    kc.case_transpose(k, 6468, 256)
