@@ -30,8 +30,12 @@ struct IGemmParams {
     int gm, ntn, ntm;
 };
 
-template <class T, class TO, int BN>
-__global__ __launch_bounds__(256) void igemm_kernel(IGemmParams p) {
+// FAST: every 128-byte K chunk lies inside one tap (Ci >= chunk, or a plain GEMM) and the gather is
+// affine in the tap (forward conv, or an input-gradient with unit strides).  Tap decode and the tap's
+// address delta are then wave-uniform (SALU) and a row costs 3 adds + 3 compares per chunk instead of
+// a full coordinate->offset recomputation: the kernel is issue-bound, not MFMA-bound, without this.
+template <class T, class TO, int BN, bool FAST>
+__global__ __launch_bounds__(256, (BN == 64 ? 3 : 2)) void igemm_kernel(IGemmParams p) {
     constexpr int EPU = Elt<T>::PER16;
     constexpr int BKE = 8 * EPU;
     constexpr int BM = 128;
@@ -57,8 +61,13 @@ __global__ __launch_bounds__(256) void igemm_kernel(IGemmParams p) {
     for (int mt = m_prog; mt < p.ntm; mt += p.gm) {
         const int m0 = mt * BM;
         RowPos rp[4];
+        int rowbase[4];
         DPC_UNROLL
-        for (int i = 0; i < 4; ++i) rp[i] = decode_row(g, m0 + r0 + 32 * i);
+        for (int i = 0; i < 4; ++i) {
+            rp[i] = decode_row(g, m0 + r0 + 32 * i);
+            rowbase[i] = (int)(((((unsigned)(rp[i].nbase + rp[i].t0) * (unsigned)g.SH + (unsigned)rp[i].h0) * (unsigned)g.SW) +
+                                (unsigned)rp[i].w0) * (unsigned)g.src_ld);
+        }
 
         f32x16 acc[2][NT];
         DPC_UNROLL
@@ -72,13 +81,35 @@ __global__ __launch_bounds__(256) void igemm_kernel(IGemmParams p) {
         unsigned okbits = 0;  // validity of the units in flight, applied when they are stored to LDS
         auto load_chunk = [&](int kc) {
             const int k = kc * BKE + u * EPU;
-            const TapPos tp = decode_k(g, k);
             okbits = 0;
-            DPC_UNROLL
-            for (int i = 0; i < 4; ++i) {
-                const long long off = gather_off(g, rp[i], tp);
-                okbits |= (off >= 0 ? 1u : 0u) << i;
-                ra[i] = load_unit_raw(p.src, off, esz);
+            TapPos tp;
+            if (FAST) {
+                const int k0 = kc * BKE;  // wave-uniform
+                const int tap = (g.taps == 1) ? 0 : (k0 >> g.log2C);
+                const unsigned q = fdiv((unsigned)tap, g.dKW);
+                const int kw = tap - (int)q * g.KW;
+                const unsigned kt = fdiv(q, g.dKH);
+                const int kh = (int)q - (int)kt * g.KH;
+                const int sgn = g.mode == 0 ? 1 : -1;
+                const int dt = sgn * (int)kt, dh = sgn * kh, dw = sgn * kw;
+                const int cbase = (g.taps == 1) ? 0 : (tap << g.log2C);
+                const int tapoff = ((dt * g.SH + dh) * g.SW + dw) * g.src_ld + (k - cbase);
+                tp.ok = k < g.Kp;
+                DPC_UNROLL
+                for (int i = 0; i < 4; ++i) {
+                    const bool ok = tp.ok && (unsigned)(rp[i].t0 + dt) < (unsigned)g.ST && (unsigned)(rp[i].h0 + dh) < (unsigned)g.SH &&
+                                    (unsigned)(rp[i].w0 + dw) < (unsigned)g.SW;
+                    okbits |= (ok ? 1u : 0u) << i;
+                    ra[i] = load_unit_raw(p.src, ok ? (long long)(rowbase[i] + tapoff) : -1, esz);
+                }
+            } else {
+                tp = decode_k(g, k);
+                DPC_UNROLL
+                for (int i = 0; i < 4; ++i) {
+                    const long long off = gather_off(g, rp[i], tp);
+                    okbits |= (off >= 0 ? 1u : 0u) << i;
+                    ra[i] = load_unit_raw(p.src, off, esz);
+                }
             }
             DPC_UNROLL
             for (int i = 0; i < BROWS; ++i) {
@@ -220,10 +251,23 @@ extern "C" int dpc_conv_stats_rows(const dpc_conv_desc* d) {
 template <class T, class TO>
 static int launch_igemm(const IGemmParams& p, int bn, hipStream_t stream) {
     dim3 grid((unsigned)(p.gm * p.ntn)), block(256);
+    const GatherGeom& g = p.g;
+    const int bke = 8 * Elt<T>::PER16;
+    const bool unit_strides = g.st == 1 && g.sh == 1 && g.sw == 1;
+    const bool fits32 = (long long)(g.M / (g.RT * g.RH * g.RW)) * g.ST * g.SH * g.SW * g.src_ld < (1ll << 31);
+    const bool fast = fits32 && (g.taps == 1 || g.Ci >= bke) && (g.mode == 0 || unit_strides);
     if (bn == 64) {
-        DPC_LAUNCH((igemm_kernel<T, TO, 64>), grid, block, stream, p);
+        if (fast) {
+            DPC_LAUNCH((igemm_kernel<T, TO, 64, true>), grid, block, stream, p);
+        } else {
+            DPC_LAUNCH((igemm_kernel<T, TO, 64, false>), grid, block, stream, p);
+        }
     } else {
-        DPC_LAUNCH((igemm_kernel<T, TO, 128>), grid, block, stream, p);
+        if (fast) {
+            DPC_LAUNCH((igemm_kernel<T, TO, 128, true>), grid, block, stream, p);
+        } else {
+            DPC_LAUNCH((igemm_kernel<T, TO, 128, false>), grid, block, stream, p);
+        }
     }
     return dpc_launch_status();
 }

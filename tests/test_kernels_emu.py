@@ -37,6 +37,8 @@ def test_conv_fwd(k, dtype, shape):
     (2, 16, 32, 5, 8, 8, (3, 3, 3), (2, 2, 2), (1, 1, 1)),
     (1, 32, 32, 3, 6, 6, (3, 3, 3), (1, 1, 1), (1, 1, 1)),
     (2, 8, 16, 2, 8, 8, (1, 1, 1), (1, 2, 2), (0, 0, 0)),
+    (1, 16, 64, 3, 5, 5, (3, 3, 3), (1, 1, 1), (1, 1, 1)),
+    (2, 8, 64, 2, 6, 5, (1, 3, 3), (1, 1, 1), (0, 1, 1)),
 ])
 def test_conv_dgrad(k, dtype, shape):
     kc.case_conv_dgrad(k, dtype, *shape)
