@@ -10,13 +10,24 @@
 //   each wave owns 64 x BN/2 = 2 x (BN/64) MFMA 32x32 accumulators;
 //   operands staged global -> VGPR -> LDS (double buffered, one barrier per chunk);
 //   LDS rows are 128 B with the unit slot XOR-swizzled by (row>>1)&7 so that the
-//   ds_read_b128 fragment reads of 16 rows x same unit hit all 64 banks once;
+//   ds_read_b128 fragment reads of 16 rows x same unit hit all 64 banks once
+//   (measured SQ_LDS_BANK_CONFLICT = 0);
 //   f32 uses v_mfma_f32_32x32x2_f32 (exact f32, parity mode), bf16 v_mfma_f32_32x32x16_bf16.
 //   K order inside a chunk is permuted identically for A and B (a lane's 16-byte unit
 //   feeds its own k-group), which leaves the dot products unchanged.
+// The first version of this kernel spent 15 VALU instructions per MFMA (rocprofv3
+// SQ_INSTS_VALU / SQ_INSTS_MFMA) and ran issue-bound at ~27 % MFMA utilisation, so:
+//   * GATHER 1/2 (affine gather: forward conv or unit-stride input-gradient): a row keeps one
+//     element offset and one validity bit-mask per tile; a chunk costs and+cmp+add per row.
+//     GATHER 1 additionally has one tap per chunk (Ci >= chunk) => tap decode is wave-uniform SALU.
+//   * padded / out-of-range units are fetched from a 16-byte zero page instead of being masked;
+//   * the K loop is unrolled by two so LDS buffer offsets are instruction immediates, fragment and
+//     staging addresses are loop-invariant registers;
+//   * the epilogue stages the tile through LDS and leaves as whole 16-byte units (coalesced rows),
+//     the residual/addend comes in the same way, batch-norm partial sums are taken from the
+//     stored (rounded) values.
 // A workgroup walks m-tiles m_prog, m_prog+gm, ... so the per-channel batch-norm partial
-// sums (sum, sum^2 of the *stored* values) accumulate in registers and leave as ONE row
-// of `stats` per program: deterministic, no atomics.
+// sums accumulate in registers and leave as ONE row of `stats` per program: deterministic.
 #include "conv_common.h"
 
 struct IGemmParams {
@@ -28,20 +39,22 @@ struct IGemmParams {
     float* stats;
     int Ncol, ldw, ldo;
     int gm, ntn, ntm;
+    int vec_out;  // Ncol and ldo are multiples of the 16-byte output unit
 };
 
-// FAST: every 128-byte K chunk lies inside one tap (Ci >= chunk, or a plain GEMM) and the gather is
-// affine in the tap (forward conv, or an input-gradient with unit strides).  Tap decode and the tap's
-// address delta are then wave-uniform (SALU) and a row costs 3 adds + 3 compares per chunk instead of
-// a full coordinate->offset recomputation: the kernel is issue-bound, not MFMA-bound, without this.
-template <class T, class TO, int BN, bool FAST>
+template <class T, class TO, int BN, int GATHER>
 __global__ __launch_bounds__(256, (BN == 64 ? 3 : 2)) void igemm_kernel(IGemmParams p) {
     constexpr int EPU = Elt<T>::PER16;
     constexpr int BKE = 8 * EPU;
     constexpr int BM = 128;
-    constexpr int NT = BN / 64;   // 32-wide n-tiles per wave
+    constexpr int NT = BN / 64;     // 32-wide n-tiles per wave
     constexpr int BROWS = BN / 32;  // B-tile rows per thread
-    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * (BM + BN) * 128];
+    constexpr int BUF = (BM + BN) * 128;
+    constexpr int EPO = 16 / (int)sizeof(TO);          // output elements per 16-byte unit
+    constexpr int UPR = BN / EPO;                      // output units per tile row
+    constexpr int OIT = BM * UPR / 256;                // output units per thread
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * BUF];
+    static_assert(BM * BN * (int)sizeof(TO) <= 2 * BUF, "epilogue staging must fit the operand buffers");
 
     const GatherGeom& g = p.g;
     const int tid = threadIdx.x;
@@ -53,20 +66,48 @@ __global__ __launch_bounds__(256, (BN == 64 ? 3 : 2)) void igemm_kernel(IGemmPar
     const int m_prog = blockIdx.x / p.ntn;
     const int nkc = (g.Kp + BKE - 1) / BKE;
     const int esz = (int)sizeof(T);
+    const char* const zero = (const char*)dpc_zero16;
 
-    float s1[NT], s2[NT];
+    // loop-invariant LDS byte offsets (buffer 0); +32 rows == +4096 B keeps the swizzle
+    int frag_a[4], frag_b[4];
     DPC_UNROLL
-    for (int j = 0; j < NT; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
+    for (int kk = 0; kk < 4; ++kk) {
+        frag_a[kk] = lds_unit_off(wm * 64 + l31, 2 * kk + lhi);
+        frag_b[kk] = BM * 128 + lds_unit_off(wn * (BN / 2) + l31, 2 * kk + lhi);
+    }
+    const int stage_off = lds_unit_off(r0, u);  // rows r0+32*i: +4096*i
+
+    // B (weights) rows of this thread: constant over the whole kernel
+    long long wrow[BROWS];
+    DPC_UNROLL
+    for (int i = 0; i < BROWS; ++i) {
+        const int n = n_tile * BN + r0 + 32 * i;
+        wrow[i] = n < p.Ncol ? (long long)n * p.ldw : -1;
+    }
+
+    // batch-norm partial sums of this thread's output columns (fixed: 256 % UPR == 0)
+    float s1[EPO], s2[EPO];
+    DPC_UNROLL
+    for (int e = 0; e < EPO; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
 
     for (int mt = m_prog; mt < p.ntm; mt += p.gm) {
         const int m0 = mt * BM;
         RowPos rp[4];
         int rowbase[4];
+        unsigned vmask[4];
         DPC_UNROLL
         for (int i = 0; i < 4; ++i) {
             rp[i] = decode_row(g, m0 + r0 + 32 * i);
-            rowbase[i] = (int)(((((unsigned)(rp[i].nbase + rp[i].t0) * (unsigned)g.SH + (unsigned)rp[i].h0) * (unsigned)g.SW) +
-                                (unsigned)rp[i].w0) * (unsigned)g.src_ld);
+            if (GATHER != 0) {
+                rowbase[i] = (int)(((((unsigned)(rp[i].nbase + rp[i].t0) * (unsigned)g.SH + (unsigned)rp[i].h0) * (unsigned)g.SW) +
+                                    (unsigned)rp[i].w0) * (unsigned)g.src_ld);
+                const int sgn = g.mode == 0 ? 1 : -1;
+                unsigned m = 0;
+                for (int k = 0; k < g.KT; ++k) m |= ((unsigned)(rp[i].t0 + sgn * k) < (unsigned)g.ST ? 1u : 0u) << k;
+                for (int k = 0; k < g.KH; ++k) m |= ((unsigned)(rp[i].h0 + sgn * k) < (unsigned)g.SH ? 1u : 0u) << (g.KT + k);
+                for (int k = 0; k < g.KW; ++k) m |= ((unsigned)(rp[i].w0 + sgn * k) < (unsigned)g.SW ? 1u : 0u) << (g.KT + g.KH + k);
+                vmask[i] = m;
+            }
         }
 
         f32x16 acc[2][NT];
@@ -78,150 +119,167 @@ __global__ __launch_bounds__(256, (BN == 64 ? 3 : 2)) void igemm_kernel(IGemmPar
                 for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
         u32x4 ra[4], rb[BROWS];
-        unsigned okbits = 0;  // validity of the units in flight, applied when they are stored to LDS
         auto load_chunk = [&](int kc) {
             const int k = kc * BKE + u * EPU;
-            okbits = 0;
-            TapPos tp;
-            if (FAST) {
-                const int k0 = kc * BKE;  // wave-uniform
-                const int tap = (g.taps == 1) ? 0 : (k0 >> g.log2C);
+            const bool kok = k < g.Kp;
+            if (GATHER != 0) {
+                const int kd = (GATHER == 1) ? kc * BKE : k;  // GATHER 1: one tap per chunk -> wave-uniform decode
+                const int tap = (g.taps == 1) ? 0 : (kd >> g.log2C);
                 const unsigned q = fdiv((unsigned)tap, g.dKW);
                 const int kw = tap - (int)q * g.KW;
                 const unsigned kt = fdiv(q, g.dKH);
                 const int kh = (int)q - (int)kt * g.KH;
+                const unsigned sel = (1u << kt) | (1u << (g.KT + kh)) | (1u << (g.KT + g.KH + kw));
                 const int sgn = g.mode == 0 ? 1 : -1;
-                const int dt = sgn * (int)kt, dh = sgn * kh, dw = sgn * kw;
                 const int cbase = (g.taps == 1) ? 0 : (tap << g.log2C);
-                const int tapoff = ((dt * g.SH + dh) * g.SW + dw) * g.src_ld + (k - cbase);
-                tp.ok = k < g.Kp;
+                const int tapoff = sgn * ((((int)kt * g.SH + kh) * g.SW + kw) * g.src_ld) + (k - cbase);
                 DPC_UNROLL
                 for (int i = 0; i < 4; ++i) {
-                    const bool ok = tp.ok && (unsigned)(rp[i].t0 + dt) < (unsigned)g.ST && (unsigned)(rp[i].h0 + dh) < (unsigned)g.SH &&
-                                    (unsigned)(rp[i].w0 + dw) < (unsigned)g.SW;
-                    okbits |= (ok ? 1u : 0u) << i;
-                    ra[i] = load_unit_raw(p.src, ok ? (long long)(rowbase[i] + tapoff) : -1, esz);
+                    const bool ok = kok && (vmask[i] & sel) == sel;
+                    const char* a = (const char*)p.src + (long long)(rowbase[i] + tapoff) * esz;
+                    ra[i] = *(const u32x4*)(ok ? a : zero);
                 }
             } else {
-                tp = decode_k(g, k);
+                const TapPos tp = decode_k(g, k);
                 DPC_UNROLL
                 for (int i = 0; i < 4; ++i) {
                     const long long off = gather_off(g, rp[i], tp);
-                    okbits |= (off >= 0 ? 1u : 0u) << i;
-                    ra[i] = load_unit_raw(p.src, off, esz);
+                    const char* a = (const char*)p.src + off * esz;
+                    ra[i] = *(const u32x4*)(off >= 0 ? a : zero);
                 }
             }
             DPC_UNROLL
             for (int i = 0; i < BROWS; ++i) {
-                const int n = n_tile * BN + r0 + 32 * i;
-                const bool ok = tp.ok && n < p.Ncol;
-                okbits |= (ok ? 1u : 0u) << (4 + i);
-                rb[i] = load_unit_raw(p.wgt, ok ? ((long long)n * p.ldw + k) : -1, esz);
+                const char* b = (const char*)p.wgt + (wrow[i] + k) * esz;
+                rb[i] = *(const u32x4*)((kok && wrow[i] >= 0) ? b : zero);
             }
         };
-        auto store_chunk = [&](int buf) {
-            unsigned char* As = lds + buf * (BM + BN) * 128;
-            unsigned char* Bs = As + BM * 128;
+        auto store_chunk = [&](int bufoff) {
+            unsigned char* base = lds + bufoff + stage_off;
             DPC_UNROLL
-            for (int i = 0; i < 4; ++i) *(u32x4*)(As + lds_unit_off(r0 + 32 * i, u)) = mask_unit(ra[i], (okbits >> i) & 1u);
+            for (int i = 0; i < 4; ++i) *(u32x4*)(base + 4096 * i) = ra[i];
             DPC_UNROLL
-            for (int i = 0; i < BROWS; ++i) *(u32x4*)(Bs + lds_unit_off(r0 + 32 * i, u)) = mask_unit(rb[i], (okbits >> (4 + i)) & 1u);
+            for (int i = 0; i < BROWS; ++i) *(u32x4*)(base + BM * 128 + 4096 * i) = rb[i];
         };
-
-        load_chunk(0);
-        store_chunk(0);
-        __syncthreads();
-        for (int kc = 0; kc < nkc; ++kc) {
-            const int buf = kc & 1;
-            if (kc + 1 < nkc) load_chunk(kc + 1);
-            const unsigned char* As = lds + buf * (BM + BN) * 128;
-            const unsigned char* Bs = As + BM * 128;
+        auto mma_chunk = [&](int bufoff) {
             DPC_UNROLL
             for (int kk = 0; kk < 4; ++kk) {
-                const int unit = 2 * kk + lhi;
                 u32x4 fa[2], fb[NT];
                 DPC_UNROLL
-                for (int i = 0; i < 2; ++i) fa[i] = *(const u32x4*)(As + lds_unit_off(wm * 64 + i * 32 + l31, unit));
+                for (int i = 0; i < 2; ++i) fa[i] = *(const u32x4*)(lds + bufoff + frag_a[kk] + 4096 * i);
                 DPC_UNROLL
-                for (int j = 0; j < NT; ++j) fb[j] = *(const u32x4*)(Bs + lds_unit_off(wn * (BN / 2) + j * 32 + l31, unit));
+                for (int j = 0; j < NT; ++j) fb[j] = *(const u32x4*)(lds + bufoff + frag_b[kk] + 4096 * j);
                 DPC_UNROLL
                 for (int i = 0; i < 2; ++i)
                     DPC_UNROLL
                     for (int j = 0; j < NT; ++j) acc[i][j] = mfma_unit<T>(fa[i], fb[j], acc[i][j]);
             }
-            if (kc + 1 < nkc) store_chunk(buf ^ 1);
+        };
+
+        load_chunk(0);
+        store_chunk(0);
+        __syncthreads();
+        for (int kc = 0; kc < nkc; kc += 2) {
+            if (kc + 1 < nkc) load_chunk(kc + 1);
+            mma_chunk(0);
+            if (kc + 1 < nkc) store_chunk(BUF);
             __syncthreads();
+            if (kc + 1 < nkc) {
+                if (kc + 2 < nkc) load_chunk(kc + 2);
+                mma_chunk(BUF);
+                if (kc + 2 < nkc) store_chunk(0);
+                __syncthreads();
+            }
         }
 
-        // epilogue: C/D map col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
-        if (p.addend) {  // all addend loads first (clamped, unconditional), one wait, then the adds
-            DPC_UNROLL
-            for (int j = 0; j < NT; ++j) {
-                const int col = n_tile * BN + wn * (BN / 2) + j * 32 + l31;
-                DPC_UNROLL
-                for (int i = 0; i < 2; ++i) {
-                    TO ad[16];
-                    DPC_UNROLL
-                    for (int r = 0; r < 16; ++r) {
-                        const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-                        const bool ok = row < g.M && col < p.Ncol;
-                        ad[r] = ((const TO*)p.addend)[ok ? ((long long)row * p.ldo + col) : 0];
-                    }
-                    DPC_UNROLL
-                    for (int r = 0; r < 16; ++r) acc[i][j][r] += Elt<TO>::to_f32(ad[r]);
-                }
-            }
-        }
+        // ---- epilogue: accumulators -> LDS tile [128][BN] of TO -> 16-byte units -> global
+        // C/D map: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+        TO* tile = (TO*)lds;
         DPC_UNROLL
-        for (int j = 0; j < NT; ++j) {
-            const int col = n_tile * BN + wn * (BN / 2) + j * 32 + l31;
-            if (col < p.Ncol) {
+        for (int j = 0; j < NT; ++j)
+            DPC_UNROLL
+            for (int i = 0; i < 2; ++i)
                 DPC_UNROLL
-                for (int i = 0; i < 2; ++i) {
+                for (int r = 0; r < 16; ++r) {
+                    const int row_l = wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                    const int col_l = wn * (BN / 2) + j * 32 + l31;
+                    tile[row_l * BN + col_l] = Elt<TO>::from_f32(acc[i][j][r]);
+                }
+        __syncthreads();
+        const int cu = tid % UPR;
+        const int col0 = n_tile * BN + cu * EPO;
+        if (p.vec_out) {
+            u32x4 ov[OIT], av[OIT];
+            DPC_UNROLL
+            for (int it = 0; it < OIT; ++it) {
+                const int row_l = (tid + 256 * it) / UPR;
+                ov[it] = *(const u32x4*)(lds + (row_l * BN + cu * EPO) * (int)sizeof(TO));
+                const int row = m0 + row_l;
+                const bool ok = row < g.M && col0 < p.Ncol;
+                if (p.addend) {
+                    const char* a = (const char*)p.addend + ((long long)row * p.ldo + col0) * (int)sizeof(TO);
+                    av[it] = *(const u32x4*)(ok ? a : zero);
+                }
+            }
+            DPC_UNROLL
+            for (int it = 0; it < OIT; ++it) {
+                const int row = m0 + (tid + 256 * it) / UPR;
+                if (row < g.M && col0 < p.Ncol) {
+                    u32x4 o = ov[it];
+                    if (p.addend) {
+                        DPC_UNROLL
+                        for (int e = 0; e < EPO; ++e) unit_set<TO>(o, e, unit_get<TO>(o, e) + unit_get<TO>(av[it], e));
+                    }
+                    *(u32x4*)((char*)p.out + ((long long)row * p.ldo + col0) * (int)sizeof(TO)) = o;
                     DPC_UNROLL
-                    for (int r = 0; r < 16; ++r) {
-                        const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-                        if (row < g.M) {
-                            const long long o = (long long)row * p.ldo + col;
-                            float v = acc[i][j][r];
-                            const TO q = Elt<TO>::from_f32(v);
-                            ((TO*)p.out)[o] = q;
-                            const float vq = Elt<TO>::to_f32(q);
-                            s1[j] += vq;
-                            s2[j] += vq * vq;
-                        }
+                    for (int e = 0; e < EPO; ++e) {
+                        const float v = unit_get<TO>(o, e);
+                        s1[e] += v;
+                        s2[e] += v * v;
+                    }
+                }
+            }
+        } else {  // ragged output width: element-wise tail path
+            DPC_UNROLL
+            for (int it = 0; it < OIT; ++it) {
+                const int row_l = (tid + 256 * it) / UPR;
+                const int row = m0 + row_l;
+                DPC_UNROLL
+                for (int e = 0; e < EPO; ++e) {
+                    const int col = col0 + e;
+                    if (row < g.M && col < p.Ncol) {
+                        const long long o = (long long)row * p.ldo + col;
+                        float v = Elt<TO>::to_f32(tile[row_l * BN + cu * EPO + e]);
+                        if (p.addend) v += Elt<TO>::to_f32(((const TO*)p.addend)[o]);
+                        const TO q = Elt<TO>::from_f32(v);
+                        ((TO*)p.out)[o] = q;
+                        const float vq = Elt<TO>::to_f32(q);
+                        s1[e] += vq;
+                        s2[e] += vq * vq;
                     }
                 }
             }
         }
+        __syncthreads();  // the tile buffer is the next m-tile's operand buffer
     }
 
     if (p.stats) {
-        float* red = (float*)lds;  // [wave][2][NT][32]
+        // 256/UPR threads hold partial sums for the same EPO columns: reduce through LDS
+        float* red = (float*)lds;  // [2][256][EPO]
         DPC_UNROLL
-        for (int j = 0; j < NT; ++j) {
-            s1[j] += __shfl_xor(s1[j], 32);
-            s2[j] += __shfl_xor(s2[j], 32);
-        }
-        __syncthreads();
-        if (lhi == 0) {
-            DPC_UNROLL
-            for (int j = 0; j < NT; ++j) {
-                red[((wv * 2 + 0) * NT + j) * 32 + l31] = s1[j];
-                red[((wv * 2 + 1) * NT + j) * 32 + l31] = s2[j];
-            }
+        for (int e = 0; e < EPO; ++e) {
+            red[tid * EPO + e] = s1[e];
+            red[(256 + tid) * EPO + e] = s2[e];
         }
         __syncthreads();
         if (tid < BN) {
-            const int wn2 = tid / (BN / 2), j2 = (tid % (BN / 2)) / 32, l2 = tid % 32;
+            const int cu2 = tid / EPO, e2 = tid % EPO;
             const int col = n_tile * BN + tid;
             if (col < p.Ncol) {
                 float a = 0.f, b = 0.f;
-                DPC_UNROLL
-                for (int w2 = 0; w2 < 2; ++w2) {
-                    const int wave = w2 * 2 + wn2;
-                    a += red[((wave * 2 + 0) * NT + j2) * 32 + l2];
-                    b += red[((wave * 2 + 1) * NT + j2) * 32 + l2];
+                for (int t = cu2; t < 256; t += UPR) {
+                    a += red[t * EPO + e2];
+                    b += red[(256 + t) * EPO + e2];
                 }
                 p.stats[((long long)m_prog * 2 + 0) * p.Ncol + col] = a;
                 p.stats[((long long)m_prog * 2 + 1) * p.Ncol + col] = b;
@@ -248,28 +306,29 @@ extern "C" int dpc_conv_stats_rows(const dpc_conv_desc* d) {
     return gm;
 }
 
+template <class T, class TO, int BN>
+static int launch_igemm_bn(const IGemmParams& p, int gather, hipStream_t stream) {
+    dim3 grid((unsigned)(p.gm * p.ntn)), block(256);
+    if (gather == 1) {
+        DPC_LAUNCH((igemm_kernel<T, TO, BN, 1>), grid, block, stream, p);
+    } else if (gather == 2) {
+        DPC_LAUNCH((igemm_kernel<T, TO, BN, 2>), grid, block, stream, p);
+    } else {
+        DPC_LAUNCH((igemm_kernel<T, TO, BN, 0>), grid, block, stream, p);
+    }
+    return dpc_launch_status();
+}
+
 template <class T, class TO>
 static int launch_igemm(const IGemmParams& p, int bn, hipStream_t stream) {
-    dim3 grid((unsigned)(p.gm * p.ntn)), block(256);
     const GatherGeom& g = p.g;
     const int bke = 8 * Elt<T>::PER16;
     const bool unit_strides = g.st == 1 && g.sh == 1 && g.sw == 1;
     const bool fits32 = (long long)(g.M / (g.RT * g.RH * g.RW)) * g.ST * g.SH * g.SW * g.src_ld < (1ll << 31);
-    const bool fast = fits32 && (g.taps == 1 || g.Ci >= bke) && (g.mode == 0 || unit_strides);
-    if (bn == 64) {
-        if (fast) {
-            DPC_LAUNCH((igemm_kernel<T, TO, 64, true>), grid, block, stream, p);
-        } else {
-            DPC_LAUNCH((igemm_kernel<T, TO, 64, false>), grid, block, stream, p);
-        }
-    } else {
-        if (fast) {
-            DPC_LAUNCH((igemm_kernel<T, TO, 128, true>), grid, block, stream, p);
-        } else {
-            DPC_LAUNCH((igemm_kernel<T, TO, 128, false>), grid, block, stream, p);
-        }
-    }
-    return dpc_launch_status();
+    const bool affine = fits32 && (g.mode == 0 || unit_strides) && (g.KT + g.KH + g.KW <= 32);
+    const int gather = !affine ? 0 : ((g.taps == 1 || g.Ci >= bke) ? 1 : 2);
+    if (bn == 64) return launch_igemm_bn<T, TO, 64>(p, gather, stream);
+    return launch_igemm_bn<T, TO, 128>(p, gather, stream);
 }
 
 extern "C" int dpc_conv_igemm(const dpc_conv_desc* d, const void* src, const void* wgt, void* out,
@@ -284,6 +343,8 @@ extern "C" int dpc_conv_igemm(const dpc_conv_desc* d, const void* src, const voi
     if (d->ldo < d->Co || d->ldw < p.g.Kp) return DPC_ERR_ARG;
     p.src = src; p.wgt = wgt; p.out = out; p.addend = addend; p.stats = stats;
     p.Ncol = d->Co; p.ldw = d->ldw; p.ldo = d->ldo;
+    const int epo = d->dtype_out == DPC_BF16 ? 8 : 4;
+    p.vec_out = (d->Co % epo == 0 && d->ldo % epo == 0 && ((uintptr_t)out % 16 == 0) && ((uintptr_t)addend % 16 == 0)) ? 1 : 0;
     int bn;
     igemm_grid(d, p.g.M, &p.ntm, &p.ntn, &p.gm, &bn);
     if (d->dtype_in == DPC_F32 && d->dtype_out == DPC_F32) return launch_igemm<float, float>(p, bn, stream);

@@ -141,6 +141,21 @@ template <> __device__ __forceinline__ f32x16 mfma_unit<bf16_t>(const u32x4& a, 
     return mfma_32x32x16_bf16(a, b, c);
 }
 
-// LDS tile rows are 128 bytes = 8 units of 16 B; unit u of row r lives at slot u ^ ((r>>1)&7):
-// a ds_read_b128 lane group (16 distinct rows, same logical unit) then touches all 64 banks once.
-__device__ __forceinline__ int lds_unit_off(int row, int unit) { return row * 128 + (((unit ^ (row >> 1)) & 7) << 4); }
+// LDS tile rows are 128 bytes = 8 units of 16 B; unit u of row r lives at slot u ^ swz(r).
+// swz1(r) = (r>>1)&7: a ds_read_b128 lane group (16 distinct rows, same logical unit) touches all 64
+//   banks once, and swz1(r+32) == swz1(r) so +32-row fragments are immediate offsets (conv_igemm.hip).
+// swz3(r) = ((r>>1)&7) ^ ((r>>4)&3): same read property AND the transposing ds_write_b128 of
+//   conv_wgrad.hip (8 lanes -> rows 8 or 4 apart, same unit) is conflict-free (brute-force checked
+//   against the lane groups of MI355X_MICROARCH.md; measured SQ_LDS_BANK_CONFLICT = 0 for swz1).
+__device__ __forceinline__ int lds_swz1(int row) { return (row >> 1) & 7; }
+__device__ __forceinline__ int lds_swz3(int row) { return ((row >> 1) & 7) ^ ((row >> 4) & 3); }
+__device__ __forceinline__ int lds_unit_off(int row, int unit) { return row * 128 + (((unit ^ lds_swz1(row)) & 7) << 4); }
+__device__ __forceinline__ int lds_unit_off3(int row, int unit) { return row * 128 + (((unit ^ lds_swz3(row)) & 7) << 4); }
+
+// 16 bytes of zeros in device memory: the source of every padded / out-of-range operand unit, so the
+// prefetch needs neither branches nor a post-load mask.
+#ifdef DPC_SIMT_EMU
+static const uint32_t dpc_zero16[4] __attribute__((aligned(16))) = {0u, 0u, 0u, 0u};
+#else
+static __device__ const uint32_t dpc_zero16[4] __attribute__((aligned(16))) = {0u, 0u, 0u, 0u};
+#endif
