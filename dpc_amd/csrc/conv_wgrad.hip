@@ -80,7 +80,10 @@ __device__ __forceinline__ RowPos rowit_pos(const GatherGeom& g, const RowIt& r)
     return p;
 }
 
-template <class T, int TM, int TN>
+// ROWFAST: RW % E == 0, so the E consecutive positions of a unit share (n, t, h) and differ only in w:
+// one row decode + one affine offset per unit instead of E coordinate->offset recomputations (the
+// first version spent 22 VALU instructions per MFMA, rocprofv3 SQ_INSTS_VALU / SQ_INSTS_MFMA).
+template <class T, int TM, int TN, bool ROWFAST>
 __global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
     constexpr int E = Elt<T>::PER16;
     constexpr int BKP = 8 * E;            // positions per chunk (128-byte LDS rows)
@@ -128,23 +131,36 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
             DPC_UNROLL
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+    const char* const zero = (const char*)dpc_zero16;
     u32x4 rv[NU][E];
-    unsigned okb[NU];  // per-unit validity bits, applied when the block is transposed into LDS
     auto load_chunk = [&](int chunk) {
         DPC_UNROLL
         for (int i = 0; i < NU; ++i) {
             const int m_first = chunk * BKP + u_pg[i] * E;
-            okb[i] = 0;
             if (!u_on[i]) continue;
             if (u_isA[i]) {
                 const int co = tile_m * TM + u_cu[i] * E;
                 const bool cok = co + E <= p.dy_ld && co < p.Co;
+                const char* a = (const char*)p.dy + ((long long)m_first * p.dy_ld + co) * esz;
                 DPC_UNROLL
                 for (int e = 0; e < E; ++e) {
-                    const int m = m_first + e;
-                    const bool ok = cok && m < g.M;
-                    okb[i] |= (ok ? 1u : 0u) << e;
-                    rv[i][e] = load_unit_raw(p.dy, ok ? ((long long)m * p.dy_ld + co) : -1, esz);
+                    const bool ok = cok && m_first + e < g.M;
+                    rv[i][e] = *(const u32x4*)(ok ? a + (long long)e * p.dy_ld * esz : zero);
+                }
+            } else if (ROWFAST) {
+                // positions m_first..m_first+E-1 = (n, rt, rh, rw0..rw0+E-1)
+                const RowIt it = rowit_decode(g, m_first < g.M ? m_first : 0);
+                const TapPos& tp = u_tp[i];
+                const int ti = it.rt * g.st - g.pt + tp.kt, hi = it.rh * g.sh - g.ph + tp.kh;
+                const int wi0 = it.rw * g.sw - g.pw + tp.kw;
+                const bool rok = tp.ok && m_first < g.M && (unsigned)ti < (unsigned)g.ST && (unsigned)hi < (unsigned)g.SH;
+                const long long off0 = ((((long long)(it.n * g.ST + ti) * g.SH + hi) * g.SW) + wi0) * g.src_ld + tp.ci;
+                const char* a = (const char*)p.src + off0 * esz;
+                const long long step = (long long)g.sw * g.src_ld * esz;
+                DPC_UNROLL
+                for (int e = 0; e < E; ++e) {
+                    const bool ok = rok && (unsigned)(wi0 + e * g.sw) < (unsigned)g.SW;
+                    rv[i][e] = *(const u32x4*)(ok ? a + e * step : zero);
                 }
             } else {
                 RowIt it = rowit_decode(g, m_first < g.M ? m_first : 0);
@@ -153,8 +169,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
                     const int m = m_first + e;
                     long long off = gather_off(g, rowit_pos(g, it), u_tp[i]);
                     if (m >= g.M) off = -1;
-                    okb[i] |= (off >= 0 ? 1u : 0u) << e;
-                    rv[i][e] = load_unit_raw(p.src, off, esz);
+                    rv[i][e] = *(const u32x4*)(off >= 0 ? (const char*)p.src + off * esz : zero);
                     rowit_next(g, it);
                 }
             }
@@ -166,13 +181,11 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
         DPC_UNROLL
         for (int i = 0; i < NU; ++i) {
             if (!u_on[i]) continue;
-            u32x4 o[E], mv[E];
-            DPC_UNROLL
-            for (int e = 0; e < E; ++e) mv[e] = mask_unit(rv[i][e], (okb[i] >> e) & 1u);
-            Transposer<T>::run(mv, o);
+            u32x4 o[E];
+            Transposer<T>::run(rv[i], o);
             unsigned char* base = u_isA[i] ? As : Bs;
             DPC_UNROLL
-            for (int c = 0; c < E; ++c) *(u32x4*)(base + lds_unit_off(u_cu[i] * E + c, u_pg[i])) = o[c];
+            for (int c = 0; c < E; ++c) *(u32x4*)(base + lds_unit_off3(u_cu[i] * E + c, u_pg[i])) = o[c];
         }
     };
 
@@ -191,9 +204,9 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
             const int unit = 2 * kk + lhi;
             u32x4 fa[MI], fb[NT];
             DPC_UNROLL
-            for (int i = 0; i < MI; ++i) fa[i] = *(const u32x4*)(As + lds_unit_off(wm * (TM / 2) + i * 32 + l31, unit));
+            for (int i = 0; i < MI; ++i) fa[i] = *(const u32x4*)(As + lds_unit_off3(wm * (TM / 2) + i * 32 + l31, unit));
             DPC_UNROLL
-            for (int j = 0; j < NT; ++j) fb[j] = *(const u32x4*)(Bs + lds_unit_off(wn * (TN / 2) + j * 32 + l31, unit));
+            for (int j = 0; j < NT; ++j) fb[j] = *(const u32x4*)(Bs + lds_unit_off3(wn * (TN / 2) + j * 32 + l31, unit));
             DPC_UNROLL
             for (int i = 0; i < MI; ++i)
                 DPC_UNROLL
@@ -218,17 +231,23 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
     }
 }
 
-template <class T>
-static int launch_wgrad(const WgradParams& p, int tm, int tn, hipStream_t stream) {
+template <class T, bool RF>
+static int launch_wgrad_rf(const WgradParams& p, int tm, int tn, hipStream_t stream) {
     dim3 grid((unsigned)(p.ntm * p.ntn * p.nks)), block(256);
     if (tm == 64 && tn == 64) {
-        DPC_LAUNCH((wgrad_kernel<T, 64, 64>), grid, block, stream, p);
+        DPC_LAUNCH((wgrad_kernel<T, 64, 64, RF>), grid, block, stream, p);
     } else if (tm == 64 && tn == 128) {
-        DPC_LAUNCH((wgrad_kernel<T, 64, 128>), grid, block, stream, p);
+        DPC_LAUNCH((wgrad_kernel<T, 64, 128, RF>), grid, block, stream, p);
     } else {
-        DPC_LAUNCH((wgrad_kernel<T, 128, 128>), grid, block, stream, p);
+        DPC_LAUNCH((wgrad_kernel<T, 128, 128, RF>), grid, block, stream, p);
     }
     return dpc_launch_status();
+}
+
+template <class T>
+static int launch_wgrad(const WgradParams& p, int tm, int tn, hipStream_t stream) {
+    if (p.g.RW % Elt<T>::PER16 == 0) return launch_wgrad_rf<T, true>(p, tm, tn, stream);
+    return launch_wgrad_rf<T, false>(p, tm, tn, stream);
 }
 
 extern "C" int dpc_conv_wgrad(const dpc_conv_desc* d, const void* src, const void* dy, int32_t dy_ld,
