@@ -30,8 +30,23 @@
 // sums accumulate in registers and leave as ONE row of `stats` per program: deterministic.
 #include "conv_common.h"
 
+// Strided input-gradient ("parity classes"): output positions with the same residues
+// (t%st, h%sh, w%sw) see the same subset of taps, and inside a class the gather is affine again
+// (source = class coordinate + dt(kt)).  M-tiles are laid out class by class, taps that never hit
+// the class are skipped wholesale (7/8 of them for 3x3x3 stride 2) instead of being multiplied by zeros.
+struct ParityInfo {
+    int ncls, N;
+    int tile_start[9];
+    int dimc[3][2];     // class extent per dim (t,h,w) and residue
+    FastDiv div[3][2];
+    int cnt[3][2];      // taps that hit the class, per dim and residue
+    int kl[3][2][4];    // their tap indices
+    int dl[3][2][4];    // their source offsets (rt + pt - kt) / st
+};
+
 struct IGemmParams {
     GatherGeom g;
+    ParityInfo par;
     const void* src;
     const void* wgt;
     void* out;
@@ -67,6 +82,8 @@ __global__ __launch_bounds__(256, (BN == 64 ? 3 : 2)) void igemm_kernel(IGemmPar
     const int nkc = (g.Kp + BKE - 1) / BKE;
     const int esz = (int)sizeof(T);
     const char* const zero = (const char*)dpc_zero16;
+    __shared__ int rowmap[GATHER == 3 ? BM : 1];      // tile row -> output row (parity classes permute rows)
+    __shared__ int taptbl[GATHER == 3 ? 3 * 64 : 1];  // per class tap: {weight k base, source offset, validity select}
 
     // loop-invariant LDS byte offsets (buffer 0); +32 rows == +4096 B keeps the swizzle
     int frag_a[4], frag_b[4];
@@ -95,8 +112,56 @@ __global__ __launch_bounds__(256, (BN == 64 ? 3 : 2)) void igemm_kernel(IGemmPar
         RowPos rp[4];
         int rowbase[4];
         unsigned vmask[4];
+        int nkc_t = nkc, lcpt = 0;
+        if (GATHER == 3) {
+            const ParityInfo& par = p.par;
+            int c = 0;
+            while (c + 1 < par.ncls && mt >= par.tile_start[c + 1]) ++c;
+            const int cw_ = c % g.sw, ch_ = (c / g.sw) % g.sh, ct_ = c / (g.sw * g.sh);
+            const int Tc = par.dimc[0][ct_], Hc = par.dimc[1][ch_], Wc = par.dimc[2][cw_];
+            const int rows_c = par.N * Tc * Hc * Wc;
+            const int lr0 = (mt - par.tile_start[c]) * BM;
+            const int ct_n = par.cnt[0][ct_], ch_n = par.cnt[1][ch_], cw_n = par.cnt[2][cw_];
+            DPC_UNROLL
+            for (int i = 0; i < 4; ++i) {
+                const int lr = lr0 + r0 + 32 * i;
+                int orow = -1;
+                rowbase[i] = 0;
+                vmask[i] = 0;
+                if (lr < rows_c) {
+                    const unsigned q1 = fdiv((unsigned)lr, par.div[2][cw_]);
+                    const int wq = lr - (int)q1 * Wc;
+                    const unsigned q2 = fdiv(q1, par.div[1][ch_]);
+                    const int hq = (int)q1 - (int)q2 * Hc;
+                    const unsigned n = fdiv(q2, par.div[0][ct_]);
+                    const int tq = (int)q2 - (int)n * Tc;
+                    rowbase[i] = (int)(((((unsigned)((int)n * g.ST + tq) * (unsigned)g.SH + (unsigned)hq) * (unsigned)g.SW) + (unsigned)wq) *
+                                       (unsigned)g.src_ld);
+                    unsigned m = 0;
+                    for (int j = 0; j < ct_n; ++j) m |= ((unsigned)(tq + par.dl[0][ct_][j]) < (unsigned)g.ST ? 1u : 0u) << j;
+                    for (int j = 0; j < ch_n; ++j) m |= ((unsigned)(hq + par.dl[1][ch_][j]) < (unsigned)g.SH ? 1u : 0u) << (4 + j);
+                    for (int j = 0; j < cw_n; ++j) m |= ((unsigned)(wq + par.dl[2][cw_][j]) < (unsigned)g.SW ? 1u : 0u) << (8 + j);
+                    vmask[i] = m;
+                    orow = ((((int)n * g.RT + tq * g.st + ct_) * g.RH + hq * g.sh + ch_) * g.RW) + wq * g.sw + cw_;
+                }
+                if (u == 0) rowmap[r0 + 32 * i] = orow;
+            }
+            const int nt = ct_n * ch_n * cw_n;
+            if (tid < nt) {
+                const int jw = tid % cw_n, q = tid / cw_n, jh = q % ch_n, jt = q / ch_n;
+                const int kt = par.kl[0][ct_][jt], kh = par.kl[1][ch_][jh], kw = par.kl[2][cw_][jw];
+                const int dt = par.dl[0][ct_][jt], dh = par.dl[1][ch_][jh], dw = par.dl[2][cw_][jw];
+                taptbl[3 * tid + 0] = ((kt * g.KH + kh) * g.KW + kw) * g.Ci;
+                taptbl[3 * tid + 1] = ((dt * g.SH + dh) * g.SW + dw) * g.src_ld;
+                taptbl[3 * tid + 2] = (int)((1u << jt) | (1u << (4 + jh)) | (1u << (8 + jw)));
+            }
+            lcpt = g.log2C - (EPU == 8 ? 6 : 5);  // log2(chunks per tap)
+            nkc_t = nt << lcpt;
+            __syncthreads();
+        }
         DPC_UNROLL
         for (int i = 0; i < 4; ++i) {
+            if (GATHER == 3) break;
             rp[i] = decode_row(g, m0 + r0 + 32 * i);
             if (GATHER != 0) {
                 rowbase[i] = (int)(((((unsigned)(rp[i].nbase + rp[i].t0) * (unsigned)g.SH + (unsigned)rp[i].h0) * (unsigned)g.SW) +
@@ -120,9 +185,22 @@ __global__ __launch_bounds__(256, (BN == 64 ? 3 : 2)) void igemm_kernel(IGemmPar
 
         u32x4 ra[4], rb[BROWS];
         auto load_chunk = [&](int kc) {
-            const int k = kc * BKE + u * EPU;
-            const bool kok = k < g.Kp;
-            if (GATHER != 0) {
+            int k = kc * BKE + u * EPU;
+            bool kok = k < g.Kp;
+            if (GATHER == 3) {
+                const int tapv = kc >> lcpt;
+                const int cofs = (kc & ((1 << lcpt) - 1)) * BKE + u * EPU;
+                const int tapoff = taptbl[3 * tapv + 1] + cofs;
+                const unsigned sel = (unsigned)taptbl[3 * tapv + 2];
+                k = taptbl[3 * tapv + 0] + cofs;
+                kok = true;
+                DPC_UNROLL
+                for (int i = 0; i < 4; ++i) {
+                    const bool ok = (vmask[i] & sel) == sel;
+                    const char* a = (const char*)p.src + (long long)(rowbase[i] + tapoff) * esz;
+                    ra[i] = *(const u32x4*)(ok ? a : zero);
+                }
+            } else if (GATHER != 0) {
                 const int kd = (GATHER == 1) ? kc * BKE : k;  // GATHER 1: one tap per chunk -> wave-uniform decode
                 const int tap = (g.taps == 1) ? 0 : (kd >> g.log2C);
                 const unsigned q = fdiv((unsigned)tap, g.dKW);
@@ -176,18 +254,20 @@ __global__ __launch_bounds__(256, (BN == 64 ? 3 : 2)) void igemm_kernel(IGemmPar
             }
         };
 
-        load_chunk(0);
-        store_chunk(0);
+        if (nkc_t > 0) {  // a parity class may see no tap at all (strided 1x1x1): its rows are just 0 (+ addend)
+            load_chunk(0);
+            store_chunk(0);
+        }
         __syncthreads();
-        for (int kc = 0; kc < nkc; kc += 2) {
-            if (kc + 1 < nkc) load_chunk(kc + 1);
+        for (int kc = 0; kc < nkc_t; kc += 2) {
+            if (kc + 1 < nkc_t) load_chunk(kc + 1);
             mma_chunk(0);
-            if (kc + 1 < nkc) store_chunk(BUF);
+            if (kc + 1 < nkc_t) store_chunk(BUF);
             __syncthreads();
-            if (kc + 1 < nkc) {
-                if (kc + 2 < nkc) load_chunk(kc + 2);
+            if (kc + 1 < nkc_t) {
+                if (kc + 2 < nkc_t) load_chunk(kc + 2);
                 mma_chunk(BUF);
-                if (kc + 2 < nkc) store_chunk(0);
+                if (kc + 2 < nkc_t) store_chunk(0);
                 __syncthreads();
             }
         }
@@ -208,14 +288,18 @@ __global__ __launch_bounds__(256, (BN == 64 ? 3 : 2)) void igemm_kernel(IGemmPar
         __syncthreads();
         const int cu = tid % UPR;
         const int col0 = n_tile * BN + cu * EPO;
+        auto out_row = [&](int row_l) -> int {  // -1: no such row
+            if (GATHER == 3) return rowmap[row_l];
+            return (m0 + row_l < g.M) ? m0 + row_l : -1;
+        };
         if (p.vec_out) {
             u32x4 ov[OIT], av[OIT];
             DPC_UNROLL
             for (int it = 0; it < OIT; ++it) {
                 const int row_l = (tid + 256 * it) / UPR;
                 ov[it] = *(const u32x4*)(lds + (row_l * BN + cu * EPO) * (int)sizeof(TO));
-                const int row = m0 + row_l;
-                const bool ok = row < g.M && col0 < p.Ncol;
+                const int row = out_row(row_l);
+                const bool ok = row >= 0 && col0 < p.Ncol;
                 if (p.addend) {
                     const char* a = (const char*)p.addend + ((long long)row * p.ldo + col0) * (int)sizeof(TO);
                     av[it] = *(const u32x4*)(ok ? a : zero);
@@ -223,8 +307,8 @@ __global__ __launch_bounds__(256, (BN == 64 ? 3 : 2)) void igemm_kernel(IGemmPar
             }
             DPC_UNROLL
             for (int it = 0; it < OIT; ++it) {
-                const int row = m0 + (tid + 256 * it) / UPR;
-                if (row < g.M && col0 < p.Ncol) {
+                const int row = out_row((tid + 256 * it) / UPR);
+                if (row >= 0 && col0 < p.Ncol) {
                     u32x4 o = ov[it];
                     if (p.addend) {
                         DPC_UNROLL
@@ -243,11 +327,11 @@ __global__ __launch_bounds__(256, (BN == 64 ? 3 : 2)) void igemm_kernel(IGemmPar
             DPC_UNROLL
             for (int it = 0; it < OIT; ++it) {
                 const int row_l = (tid + 256 * it) / UPR;
-                const int row = m0 + row_l;
+                const int row = out_row(row_l);
                 DPC_UNROLL
                 for (int e = 0; e < EPO; ++e) {
                     const int col = col0 + e;
-                    if (row < g.M && col < p.Ncol) {
+                    if (row >= 0 && col < p.Ncol) {
                         const long long o = (long long)row * p.ldo + col;
                         float v = Elt<TO>::to_f32(tile[row_l * BN + cu * EPO + e]);
                         if (p.addend) v += Elt<TO>::to_f32(((const TO*)p.addend)[o]);
@@ -309,7 +393,9 @@ extern "C" int dpc_conv_stats_rows(const dpc_conv_desc* d) {
 template <class T, class TO, int BN>
 static int launch_igemm_bn(const IGemmParams& p, int gather, hipStream_t stream) {
     dim3 grid((unsigned)(p.gm * p.ntn)), block(256);
-    if (gather == 1) {
+    if (gather == 3) {
+        DPC_LAUNCH((igemm_kernel<T, TO, BN, 3>), grid, block, stream, p);
+    } else if (gather == 1) {
         DPC_LAUNCH((igemm_kernel<T, TO, BN, 1>), grid, block, stream, p);
     } else if (gather == 2) {
         DPC_LAUNCH((igemm_kernel<T, TO, BN, 2>), grid, block, stream, p);
@@ -319,14 +405,59 @@ static int launch_igemm_bn(const IGemmParams& p, int gather, hipStream_t stream)
     return dpc_launch_status();
 }
 
+static inline int floordiv(int a, int b) { return (a >= 0) ? a / b : -((-a + b - 1) / b); }
+
+// fills p.par and re-plans the m-tiles class by class; false when the shape is outside the scheme
+static bool plan_parity(IGemmParams& p, int bke) {
+    const GatherGeom& g = p.g;
+    ParityInfo& par = p.par;
+    if (g.log2C < 0 || g.Ci < bke || g.Ci % bke) return false;
+    const int K[3] = {g.KT, g.KH, g.KW}, S[3] = {g.st, g.sh, g.sw}, P[3] = {g.pt, g.ph, g.pw}, R[3] = {g.RT, g.RH, g.RW};
+    for (int d = 0; d < 3; ++d) {
+        if (S[d] > 2) return false;
+        for (int r = 0; r < 2; ++r) {
+            par.cnt[d][r] = 0;
+            par.dimc[d][r] = r < S[d] ? (R[d] - r + S[d] - 1) / S[d] : 0;
+            par.div[d][r] = make_fastdiv(par.dimc[d][r] > 0 ? par.dimc[d][r] : 1);
+            for (int j = 0; j < 4; ++j) { par.kl[d][r][j] = 0; par.dl[d][r][j] = 0; }
+            if (r >= S[d]) continue;
+            for (int k = 0; k < K[d]; ++k) {
+                const int x = r + P[d] - k;
+                if (((x % S[d]) + S[d]) % S[d] != 0) continue;
+                if (par.cnt[d][r] >= 4) return false;
+                par.kl[d][r][par.cnt[d][r]] = k;
+                par.dl[d][r][par.cnt[d][r]] = floordiv(x, S[d]);
+                ++par.cnt[d][r];
+            }
+        }
+    }
+    par.ncls = g.st * g.sh * g.sw;
+    par.N = g.M / (g.RT * g.RH * g.RW);
+    int tiles = 0;
+    for (int c = 0; c < par.ncls; ++c) {
+        const int cw = c % g.sw, ch = (c / g.sw) % g.sh, ct = c / (g.sw * g.sh);
+        par.tile_start[c] = tiles;
+        if (par.cnt[0][ct] * par.cnt[1][ch] * par.cnt[2][cw] > 64) return false;
+        const long long rows = (long long)par.N * par.dimc[0][ct] * par.dimc[1][ch] * par.dimc[2][cw];
+        tiles += (int)((rows + 127) / 128);
+    }
+    for (int c = par.ncls; c < 9; ++c) par.tile_start[c] = tiles;
+    p.ntm = tiles;
+    int cap = 2048 / p.ntn;
+    if (cap < 1) cap = 1;
+    p.gm = p.ntm < cap ? p.ntm : cap;
+    return true;
+}
+
 template <class T, class TO>
-static int launch_igemm(const IGemmParams& p, int bn, hipStream_t stream) {
+static int launch_igemm(IGemmParams& p, int bn, hipStream_t stream) {
     const GatherGeom& g = p.g;
     const int bke = 8 * Elt<T>::PER16;
     const bool unit_strides = g.st == 1 && g.sh == 1 && g.sw == 1;
     const bool fits32 = (long long)(g.M / (g.RT * g.RH * g.RW)) * g.ST * g.SH * g.SW * g.src_ld < (1ll << 31);
     const bool affine = fits32 && (g.mode == 0 || unit_strides) && (g.KT + g.KH + g.KW <= 32);
-    const int gather = !affine ? 0 : ((g.taps == 1 || g.Ci >= bke) ? 1 : 2);
+    int gather = !affine ? 0 : ((g.taps == 1 || g.Ci >= bke) ? 1 : 2);
+    if (gather == 0 && fits32 && g.mode == 1 && !p.stats && plan_parity(p, bke)) gather = 3;
     if (bn == 64) return launch_igemm_bn<T, TO, 64>(p, gather, stream);
     return launch_igemm_bn<T, TO, 128>(p, gather, stream);
 }

@@ -37,18 +37,30 @@ extern "C" int dpc_pack3d(const float* in, void* out, int32_t dtype_out, int32_t
     return dpc_launch_status();
 }
 
-__global__ void reduce_unpack_kernel(const float* part, int nsplit, float* out, int d0, int d1, int d2, long long s0,
+// 256 threads = 32 consecutive outputs x 8 split lanes: the split-K slabs are summed 8-wide in
+// parallel (fixed order => deterministic), then one LDS hop.  A serial loop over up to ~400 slabs
+// per output was latency-bound (0.3 ms for the 9.4k-element stem gradient).
+__global__ __launch_bounds__(256) void reduce_unpack_kernel(const float* part, int nsplit, float* out, int d0, int d1, int d2, long long s0,
                                      long long s1, long long s2, int accumulate) {
+    __shared__ float red[8][32];
     const long long n = (long long)d0 * d1 * d2;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
-        float s = 0.f;
-        for (int k = 0; k < nsplit; ++k) s += part[(long long)k * n + i];
+    const int ol = threadIdx.x & 31, sl = threadIdx.x >> 5;
+    const long long i = (long long)blockIdx.x * 32 + ol;
+    float s = 0.f;
+    if (i < n)
+        for (int k = sl; k < nsplit; k += 8) s += part[(long long)k * n + i];
+    red[sl][ol] = s;
+    __syncthreads();
+    if (sl == 0 && i < n) {
+        float t = 0.f;
+        DPC_UNROLL
+        for (int k = 0; k < 8; ++k) t += red[k][ol];
         const int i2 = (int)(i % d2);
         const long long q = i / d2;
         const int i1 = (int)(q % d1);
         const int i0 = (int)(q / d1);
         float* o = out + i0 * s0 + i1 * s1 + i2 * s2;
-        *o = accumulate ? (*o + s) : s;
+        *o = accumulate ? (*o + t) : t;
     }
 }
 
@@ -57,7 +69,7 @@ extern "C" int dpc_reduce_unpack(const float* part, int32_t nsplit, float* out, 
     hipStream_t stream = (hipStream_t)stream_;
     if (!part || !out || nsplit <= 0 || d0 <= 0 || d1 <= 0 || d2 <= 0) return DPC_ERR_ARG;
     const long long n = (long long)d0 * d1 * d2;
-    DPC_LAUNCH(reduce_unpack_kernel, dim3(grid_for(n)), dim3(256), stream, part, nsplit, out, d0, d1, d2, (long long)s0, (long long)s1, (long long)s2, accumulate);
+    DPC_LAUNCH(reduce_unpack_kernel, dim3((unsigned)((n + 31) / 32)), dim3(256), stream, part, nsplit, out, d0, d1, d2, (long long)s0, (long long)s1, (long long)s2, accumulate);
     return dpc_launch_status();
 }
 
@@ -174,22 +186,32 @@ extern "C" int dpc_pack_stem_weight(const float* w, void* out, int32_t dtype_out
     return dpc_launch_status();
 }
 
-__global__ void unpack_stem_wgrad_kernel(const float* part, int nsplit, float* dw, int Co) {
+__global__ __launch_bounds__(256) void unpack_stem_wgrad_kernel(const float* part, int nsplit, float* dw, int Co) {
+    __shared__ float red[8][32];
     const int n = Co * 147;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const int ol = threadIdx.x & 31, sl = threadIdx.x >> 5;
+    const int i = blockIdx.x * 32 + ol;
+    float s = 0.f;
+    if (i < n) {
         const int kx = i % 7, ky = (i / 7) % 7, c = (i / 49) % 3, co = i / 147;
         const int th = (ky + 1) >> 1, sy = (ky + 1) & 1, tw = (kx + 1) >> 1, sx = (kx + 1) & 1;
         const int src = (co * 16 + th * 4 + tw) * 16 + (sy * 2 + sx) * 3 + c;
-        float s = 0.f;
-        for (int k = 0; k < nsplit; ++k) s += part[(long long)k * Co * 256 + src];
-        dw[i] = s;
+        for (int k = sl; k < nsplit; k += 8) s += part[(long long)k * Co * 256 + src];
+    }
+    red[sl][ol] = s;
+    __syncthreads();
+    if (sl == 0 && i < n) {
+        float t = 0.f;
+        DPC_UNROLL
+        for (int k = 0; k < 8; ++k) t += red[k][ol];
+        dw[i] = t;
     }
 }
 
 extern "C" int dpc_unpack_stem_wgrad(const float* part, int32_t nsplit, float* dw, int32_t Co, dpc_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (!part || !dw || nsplit <= 0 || Co <= 0) return DPC_ERR_ARG;
-    DPC_LAUNCH(unpack_stem_wgrad_kernel, dim3(grid_for(Co * 147)), dim3(256), stream, part, nsplit, dw, Co);
+    DPC_LAUNCH(unpack_stem_wgrad_kernel, dim3((Co * 147 + 31) / 32), dim3(256), stream, part, nsplit, dw, Co);
     return dpc_launch_status();
 }
 

@@ -39,6 +39,10 @@ def test_conv_fwd(k, dtype, shape):
     (2, 8, 16, 2, 8, 8, (1, 1, 1), (1, 2, 2), (0, 0, 0)),
     (1, 16, 64, 3, 5, 5, (3, 3, 3), (1, 1, 1), (1, 1, 1)),
     (2, 8, 64, 2, 6, 5, (1, 3, 3), (1, 1, 1), (0, 1, 1)),
+    (2, 16, 64, 5, 8, 8, (3, 3, 3), (2, 2, 2), (1, 1, 1)),      # parity classes, 8 of them
+    (1, 8, 64, 5, 7, 9, (3, 3, 3), (2, 2, 2), (1, 1, 1)),       # odd extents: unequal classes
+    (2, 8, 64, 2, 8, 8, (1, 1, 1), (1, 2, 2), (0, 0, 0)),       # strided 1x1x1: 3 of 4 classes see no tap
+    (2, 8, 128, 3, 6, 6, (1, 3, 3), (1, 2, 2), (0, 1, 1)),
 ])
 def test_conv_dgrad(k, dtype, shape):
     kc.case_conv_dgrad(k, dtype, *shape)
