@@ -1,0 +1,183 @@
+"""Training entry with the reference's command line (dpc/main.py:27-47), MI355X-native.
+
+    python -m dpc_amd.main --net resnet18 --img_dim 128 --batch_size 128 --gpu 0,1,2,3 --synthetic 50
+
+Same flags and defaults as the reference's ``main.py``.  What differs is the execution model:
+``--gpu 0,1,..`` starts ONE PROCESS PER GPU (the reference wraps the model in nn.DataParallel,
+dpc/main.py:65); each process owns a DPCEngine; ``--batch_size`` is the GLOBAL batch, as in the
+reference (DataParallel scatters it along dim 0), so each GPU sees batch_size / n_gpu clips; gradients
+are averaged with one RCCL all-reduce (dpc_amd/parallel.py).  Datasets / augmentation / tensorboard are outside this build's scope
+(SURVEY.md §2 rows 8,9,11): the input is the synthetic N(0,1) video of ``--synthetic`` batches per
+epoch with the dataset's tensor layout [B, num_seq, 3, seq_len, H, W] (dpc/dataset_3d.py:109-111).
+Checkpoints keep the reference's dictionary layout and ``module.``-prefixed keys
+(dpc/main.py:166-174, utils/utils.py:14-26) so they load in either code base.
+"""
+from __future__ import annotations
+
+import argparse
+import os
+import re
+import time
+
+import torch
+
+
+def build_parser() -> argparse.ArgumentParser:
+    parser = argparse.ArgumentParser()
+    parser.add_argument('--net', default='resnet18', type=str)
+    parser.add_argument('--model', default='dpc-rnn', type=str)
+    parser.add_argument('--dataset', default='ucf101', type=str)
+    parser.add_argument('--seq_len', default=5, type=int, help='number of frames in each video block')
+    parser.add_argument('--num_seq', default=8, type=int, help='number of video blocks')
+    parser.add_argument('--pred_step', default=3, type=int)
+    parser.add_argument('--ds', default=3, type=int, help='frame downsampling rate')
+    parser.add_argument('--batch_size', default=4, type=int)
+    parser.add_argument('--lr', default=1e-3, type=float, help='learning rate')
+    parser.add_argument('--wd', default=1e-5, type=float, help='weight decay')
+    parser.add_argument('--resume', default='', type=str, help='path of model to resume')
+    parser.add_argument('--pretrain', default='', type=str, help='path of pretrained model')
+    parser.add_argument('--epochs', default=10, type=int, help='number of total epochs to run')
+    parser.add_argument('--start-epoch', default=0, type=int, help='manual epoch number (useful on restarts)')
+    parser.add_argument('--gpu', default='0,1', type=str)
+    parser.add_argument('--print_freq', default=5, type=int, help='frequency of printing output during training')
+    parser.add_argument('--reset_lr', action='store_true', help='Reset learning rate when resume training?')
+    parser.add_argument('--prefix', default='tmp', type=str, help='prefix of checkpoint filename')
+    parser.add_argument('--train_what', default='all', type=str)
+    parser.add_argument('--img_dim', default=128, type=int)
+    # additions of this build
+    parser.add_argument('--synthetic', default=20, type=int, help='synthetic batches per epoch (the only data source here)')
+    parser.add_argument('--dtype', default='bf16', choices=['bf16', 'f32'], help='compute dtype (f32 = parity mode)')
+    parser.add_argument('--save_dir', default='', type=str, help='where to write checkpoints (default: none)')
+    return parser
+
+
+class AverageMeter:
+    """utils/utils.py:77-113 (value, running average, 5-step local average)"""
+
+    def __init__(self):
+        self.val = self.avg = self.sum = self.count = 0.0
+        self.local = []
+
+    def update(self, val, n=1):
+        self.val = val
+        self.sum += val * n
+        self.count += n
+        self.avg = self.sum / self.count
+        self.local = (self.local + [val])[-5:]
+
+    @property
+    def local_avg(self):
+        return sum(self.local) / max(len(self.local), 1)
+
+
+def _worker(rank: int, world: int, args, port: int):
+    gpus = [int(g) for g in str(args.gpu).split(',') if g != '']
+    torch.manual_seed(0)  # dpc/main.py:50
+    dev = torch.device('cuda', gpus[rank] if world > 1 else gpus[0])
+    torch.cuda.set_device(dev)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_
+        dist = dist_
+        dist.init_process_group('nccl', init_method=f'tcp://127.0.0.1:{port}', rank=rank, world_size=world, device_id=dev)
+    from .engine import DPCEngine
+    from .model import DPC_RNN
+    from .parallel import make_allreduce
+
+    if args.model != 'dpc-rnn':
+        raise ValueError('wrong model!')  # dpc/main.py:63
+    if args.batch_size % world:
+        raise ValueError('batch_size must be divisible by the number of GPUs (drop_last semantics, dpc/main.py:313)')
+    per_gpu = args.batch_size // world
+    cdt = torch.bfloat16 if args.dtype == 'bf16' else torch.float32
+    eng = DPCEngine(args.net, args.img_dim, args.num_seq, args.seq_len, args.pred_step, per_gpu, dev, cdt, lr=args.lr, wd=args.wd)
+    init = DPC_RNN(args.img_dim, args.num_seq, args.seq_len, args.pred_step, args.net, seed=0)  # same on every rank
+    eng.load_params({k: v.detach() for k, v in init.named_parameters()})
+    best_acc, iteration = 0.0, 0
+    for path, strict in ((args.resume, True), (args.pretrain, False)):
+        if path and os.path.isfile(path):
+            ck = torch.load(path, map_location='cpu')
+            sd = {k[7:] if k.startswith('module.') else k: v for k, v in ck['state_dict'].items()}
+            if not strict:  # neq_load_customized, backbone/resnet_2d3d.py:310-333: key intersection
+                sd = {k: v for k, v in sd.items() if k in eng.PRM or k.startswith('agg.cell_list.0.')}
+            eng.load_params(sd)
+            if strict:
+                args.start_epoch, iteration, best_acc = ck['epoch'], ck['iteration'], ck['best_acc']
+                st = ck.get('optimizer_flat')
+                if st is not None and not args.reset_lr:
+                    eng.flat_m.copy_(st['m']); eng.flat_v.copy_(st['v']); eng.step_count = int(st['step'])
+                m = re.search('_lr(.+?)_', path)
+                if m and rank == 0:
+                    print('resumed; old lr', m.group(1))
+        elif path and rank == 0:
+            print("[Warning] no checkpoint found at '{}'".format(path))
+    allreduce = make_allreduce(dist, world)
+    gen = torch.Generator(dev).manual_seed(1000 + rank)
+    shape = (per_gpu, args.num_seq, 3, args.seq_len, args.img_dim, args.img_dim)
+
+    def run_epoch(train: bool, epoch: int):
+        losses, accs = AverageMeter(), [AverageMeter() for _ in range(3)]
+        nonlocal iteration
+        for idx in range(args.synthetic):
+            tic = time.time()
+            block = torch.randn(shape, device=dev, generator=gen)
+            if train:
+                res = eng.train_step(block, allreduce=allreduce)
+            else:  # validate(): dropout off, BN still batch statistics (dpc/main.py:249-282, model_3d.py:28)
+                eng.forward(block, train=False)
+                res = eng.loss_topk(with_grad=False)
+            if idx % args.print_freq == 0 or not train:
+                vals = res.clone()
+                if dist is not None:
+                    dist.all_reduce(vals, op=dist.ReduceOp.AVG)
+                loss, t1, t3, t5 = vals.cpu().tolist()  # ONE packed D2H (the reference does five .item() syncs per step)
+                losses.update(loss, per_gpu)
+                for a, v in zip(accs, (t1, t3, t5)):
+                    a.update(v, per_gpu)
+                if train and rank == 0:
+                    print('Epoch: [{0}][{1}/{2}]\t Loss {3:.6f} ({4:.4f})\t Acc: top1 {5:.4f}; top3 {6:.4f}; top5 {7:.4f} T:{8:.2f}\t'.format(
+                        epoch, idx, args.synthetic, loss, losses.local_avg, t1, t3, t5, time.time() - tic), flush=True)
+                if train:
+                    iteration += 1
+        return losses.local_avg, accs[0].local_avg, [a.local_avg for a in accs]
+
+    for epoch in range(args.start_epoch, args.epochs):
+        run_epoch(True, epoch)
+        val_loss, val_acc, val_list = run_epoch(False, epoch)
+        if rank == 0:
+            print('[{0}/{1}] Loss {2:.4f}\t Acc: top1 {3:.4f}; top3 {4:.4f}; top5 {5:.4f} \t'.format(epoch, args.epochs, val_loss, *val_list), flush=True)
+            if args.save_dir:
+                os.makedirs(args.save_dir, exist_ok=True)
+                is_best = val_acc > best_acc
+                best_acc = max(val_acc, best_acc)
+                state = {'epoch': epoch + 1, 'net': args.net, 'best_acc': best_acc, 'iteration': iteration,
+                         'state_dict': {'module.' + k: v.cpu() for k, v in eng.state_dict().items()},
+                         'optimizer_flat': {'m': eng.flat_m.cpu(), 'v': eng.flat_v.cpu(), 'step': eng.step_count}}
+                fn = os.path.join(args.save_dir, 'epoch%s.pth.tar' % str(epoch + 1))
+                torch.save(state, fn)
+                last = os.path.join(args.save_dir, 'epoch%s.pth.tar' % str(epoch))
+                if os.path.exists(last):
+                    os.remove(last)  # keep_all=False, utils/utils.py:18-20
+                if is_best:
+                    torch.save(state, os.path.join(args.save_dir, 'model_best_epoch%s.pth.tar' % str(epoch + 1)))
+    if rank == 0:
+        print('Training from ep %d to ep %d finished' % (args.start_epoch, args.epochs))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def main(argv=None):
+    args = build_parser().parse_args(argv)
+    gpus = [g for g in str(args.gpu).split(',') if g != '']
+    world = max(len(gpus), 1)
+    if world == 1:
+        _worker(0, 1, args, 0)
+    else:
+        import torch.multiprocessing as mp
+        port = 29500 + (os.getpid() % 2000)
+        mp.spawn(_worker, args=(world, args, port), nprocs=world, join=True)
+
+
+if __name__ == '__main__':
+    main()

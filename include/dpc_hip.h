@@ -112,7 +112,7 @@ int dpc_bn_apply(const void* x, void* y, int32_t dtype, int64_t rows, int32_t C,
 int dpc_bn_bwd_reduce(const void* dy, const void* y, const void* x, int32_t dtype, int64_t rows, int32_t C,
                       const float* mean, const float* invstd, int32_t relu, float* partials, int32_t* prow,
                       dpc_stream_t stream);
-/* sums [prow][2][C] -> dgamma (+=), dbeta (+=), and coefficients c1=sum_dz/count, c2=sum_dzxhat/count */
+/* sums [prow][2][C] -> dgamma , dbeta, and coefficients c1=sum_dz/count, c2=sum_dzxhat/count */
 int dpc_bn_bwd_finalize(const float* partials, int32_t prow, int32_t C, double count, float* dgamma, float* dbeta,
                         float* coef, dpc_stream_t stream);
 /* dx = gamma*invstd*(dz - c1 - xhat*c2); optionally also writes dz (residual branch grad) */

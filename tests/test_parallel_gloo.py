@@ -1,0 +1,70 @@
+"""Multi-rank path on CPU: world_size 2 over gloo, one process per rank, each rank running the
+engine (kernels on the host SIMT simulator) on ITS shard; the flat gradient arena is averaged with
+one all-reduce (dpc_amd/parallel.py) and Adam steps.  Checks the data-parallel contract of
+SURVEY.md §8e: per-rank negatives / BN statistics / loss (dpc/main.py:180,211-213), averaged
+gradients == mean of the per-shard reference gradients, identical parameters on all ranks after
+the step."""
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+WIDTHS = (8, 16, 32, 32)
+SIZE, BPER = 64, 1
+
+
+def _rank_main(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from dpc_amd import _lib as L
+    from dpc_amd.engine import DPCEngine
+    from dpc_amd.parallel import make_allreduce, shard_of
+    from oracle import dpc_oracle as O
+    eng = DPCEngine("resnet18", SIZE, 8, 5, 3, BPER, "cpu", torch.float32, WIDTHS, lib=L.load_emulator())
+    p = O.make_params_pcg("resnet18", WIDTHS)
+    eng.load_params(p)
+    x_global = O.make_input_pcg(BPER * world, 8, 5, SIZE)
+    x = x_global[shard_of(BPER * world, world, rank)].contiguous()
+    ones = torch.ones(eng.n_steps, eng.M, eng.D)
+    eng.forward(x, train=True, dropout_masks=ones)
+    res = eng.loss_topk(True).clone()
+    eng.backward()
+    local_grad = eng.flat_g.clone()
+    make_allreduce(dist, world)(eng.flat_g)
+    eng.adam_step()
+    torch.save({"local_grad": local_grad, "avg_grad": eng.flat_g.clone(), "params": eng.flat_p.clone(), "res": res,
+                "offsets": eng.offsets}, os.path.join(out_dir, f"rank{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_data_parallel(tmp_path):
+    subprocess.run(["make", "-s", "-j8", "emu"], cwd=ROOT, check=True)
+    world, port = 2, 29600 + os.getpid() % 300
+    mp.spawn(_rank_main, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    r = [torch.load(tmp_path / f"rank{i}.pt") for i in range(world)]
+    # all-reduce averaged the arenas; both ranks hold the same gradient and the same updated parameters
+    assert torch.equal(r[0]["avg_grad"], r[1]["avg_grad"])
+    assert torch.equal(r[0]["params"], r[1]["params"])
+    assert torch.allclose(r[0]["avg_grad"], 0.5 * (r[0]["local_grad"] + r[1]["local_grad"]), rtol=0, atol=1e-7)
+    assert not torch.equal(r[0]["local_grad"], r[1]["local_grad"])
+    # each rank's local gradient is the reference gradient of ITS shard alone (per-GPU negatives and BN)
+    from oracle import dpc_oracle as O
+    p = O.make_params_pcg("resnet18", WIDTHS)
+    xg = O.make_input_pcg(BPER * world, 8, 5, SIZE)
+    for i in range(world):
+        ones = [torch.ones(BPER, WIDTHS[3], 2, 2) for _ in range(8)]
+        loss, accs, grads, _ = O.train_step_reference(p, xg[i * BPER:(i + 1) * BPER], "resnet18", 3, ones)
+        assert abs(r[i]["res"][0].item() - loss.item()) < 1e-4
+        for k, g in grads.items():
+            o, n = r[i]["offsets"][k]
+            mine = r[i]["local_grad"][o:o + n].view(g.shape)
+            assert (mine - g).abs().max().item() < 2e-3 * max(g.abs().max().item(), 1e-6), k
