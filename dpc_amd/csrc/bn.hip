@@ -88,15 +88,15 @@ __global__ void bn_apply_kernel(const T* x, T* y, long long units, int C, const 
         const u32x4 xv = ((const u32x4*)x)[i];
         u32x4 rv = {0u, 0u, 0u, 0u};
         if (res) rv = ((const u32x4*)res)[i];
-        u32x4 o;
+        float ov[E];
         DPC_UNROLL
         for (int e = 0; e < E; ++e) {
             float v = unit_get<T>(xv, e) * sc[e] + sh[e];
             if (res) v += unit_get<T>(rv, e) * rs[e] + rb[e];
             if (relu) v = v > 0.f ? v : 0.f;
-            unit_set<T>(o, e, v);
+            ov[e] = v;
         }
-        ((u32x4*)y)[i] = o;
+        ((u32x4*)y)[i] = unit_pack<T>(ov);
     }
 }
 
@@ -268,17 +268,17 @@ __global__ void bn_bwd_apply_kernel(const T* dy, const T* y, const T* x, long lo
         const u32x4 xv = ((const u32x4*)x)[i];
         u32x4 yv = {0u, 0u, 0u, 0u};
         if (relu) yv = ((const u32x4*)y)[i];
-        u32x4 o, oz;
+        float ov[E], oz[E];
         DPC_UNROLL
         for (int e = 0; e < E; ++e) {
             float dz = unit_get<T>(dv, e);
             if (relu && !(unit_get<T>(yv, e) > 0.f)) dz = 0.f;
             const float xh = (unit_get<T>(xv, e) - mu[e]) * is[e];
-            unit_set<T>(o, e, ga[e] * (dz - c1[e] - xh * c2[e]));
-            unit_set<T>(oz, e, dz);
+            ov[e] = ga[e] * (dz - c1[e] - xh * c2[e]);
+            oz[e] = dz;
         }
-        ((u32x4*)dx)[i] = o;
-        if (dzout) ((u32x4*)dzout)[i] = oz;
+        ((u32x4*)dx)[i] = unit_pack<T>(ov);
+        if (dzout) ((u32x4*)dzout)[i] = unit_pack<T>(oz);
     }
 }
 

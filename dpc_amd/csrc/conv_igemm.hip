@@ -311,8 +311,10 @@ __global__ __launch_bounds__(256, (BN == 64 ? 3 : 2)) void igemm_kernel(IGemmPar
                 if (row >= 0 && col0 < p.Ncol) {
                     u32x4 o = ov[it];
                     if (p.addend) {
+                        float sv[EPO];
                         DPC_UNROLL
-                        for (int e = 0; e < EPO; ++e) unit_set<TO>(o, e, unit_get<TO>(o, e) + unit_get<TO>(av[it], e));
+                        for (int e = 0; e < EPO; ++e) sv[e] = unit_get<TO>(o, e) + unit_get<TO>(av[it], e);
+                        o = unit_pack<TO>(sv);
                     }
                     *(u32x4*)((char*)p.out + ((long long)row * p.ldo + col0) * (int)sizeof(TO)) = o;
                     DPC_UNROLL

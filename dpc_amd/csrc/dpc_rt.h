@@ -43,8 +43,10 @@ __device__ __host__ __forceinline__ float bf16_to_f32(bf16_t h) {
     c.u = (uint32_t)h << 16;
     return c.f;
 }
-// round-to-nearest-even (NaN kept quiet); matches torch's float->bfloat16
-__device__ __host__ __forceinline__ bf16_t f32_to_bf16(float f) {
+// round-to-nearest-even (NaN kept quiet); matches torch's float->bfloat16.  On gfx950 this is the
+// hardware v_cvt_pk_bf16_f32 (one instruction for two values); the arithmetic form below is what the
+// host-side simulator build executes.
+__device__ __host__ __forceinline__ bf16_t f32_to_bf16_sw(float f) {
     union { uint32_t u; float f; } c;
     c.f = f;
     uint32_t u = c.u;
@@ -52,6 +54,20 @@ __device__ __host__ __forceinline__ bf16_t f32_to_bf16(float f) {
     u += 0x7fffu + ((u >> 16) & 1u);
     return (bf16_t)(u >> 16);
 }
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(DPC_SIMT_EMU)
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) { return __builtin_bit_cast(bf16_t, (__bf16)f); }
+__device__ __forceinline__ uint32_t bf16x2_pack(float lo, float hi) {
+    typedef __bf16 bf2_t __attribute__((ext_vector_type(2)));
+    typedef float f2_t __attribute__((ext_vector_type(2)));
+    const f2_t v = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf2_t));
+}
+#else
+__device__ __host__ __forceinline__ bf16_t f32_to_bf16(float f) { return f32_to_bf16_sw(f); }
+__device__ __host__ __forceinline__ uint32_t bf16x2_pack(float lo, float hi) {
+    return (uint32_t)f32_to_bf16_sw(lo) | ((uint32_t)f32_to_bf16_sw(hi) << 16);
+}
+#endif
 
 template <class T> struct Elt;
 template <> struct Elt<float> {
@@ -86,6 +102,25 @@ template <> __device__ __forceinline__ void unit_set<bf16_t>(u32x4& u, int e, fl
     uint32_t h = f32_to_bf16(v);
     uint32_t w = u[e >> 1];
     u[e >> 1] = (e & 1) ? ((w & 0x0000ffffu) | (h << 16)) : ((w & 0xffff0000u) | h);
+}
+
+// pack E floats into one 16-byte unit (bf16: four v_cvt_pk_bf16_f32)
+template <class T> __device__ __forceinline__ u32x4 unit_pack(const float* v);
+template <> __device__ __forceinline__ u32x4 unit_pack<float>(const float* v) {
+    u32x4 u;
+    DPC_UNROLL
+    for (int e = 0; e < 4; ++e) {
+        union { uint32_t u; float f; } c;
+        c.f = v[e];
+        u[e] = c.u;
+    }
+    return u;
+}
+template <> __device__ __forceinline__ u32x4 unit_pack<bf16_t>(const float* v) {
+    u32x4 u;
+    DPC_UNROLL
+    for (int q = 0; q < 4; ++q) u[q] = bf16x2_pack(v[2 * q], v[2 * q + 1]);
+    return u;
 }
 
 // ---------------------------------------------------------------- exact division by a runtime constant

@@ -209,38 +209,54 @@ extern "C" int dpc_relu_bwd(const float* dy, const void* y, int32_t dtype_y, con
     return dpc_launch_status();
 }
 
-// out[d] (+)= sum_m x[m*ld + d]   -- bias gradients.  One workgroup per 32 columns: 8 row
-// groups x 32 columns, wave-local accumulation, LDS tree across the row groups.
+// out[d] (+)= sum_m x[m*ld + d]   -- bias gradients.  Stage 1: grid (D/32, ny), 8 row groups x 32
+// columns per workgroup over a slice of the rows -> ws[ny][D]; stage 2 sums the ny slices in fixed
+// order (deterministic).  One workgroup per column group over all 14k rows was latency-bound.
 template <class T>
-__global__ __launch_bounds__(256) void colsum_kernel(const T* x, int ld, int M, int D, float* out, int accumulate) {
+__global__ __launch_bounds__(256) void colsum_kernel(const T* x, int ld, int M, int D, float* out, int rows_per_y) {
     __shared__ float red[8][32];
     const int col = blockIdx.x * 32 + (threadIdx.x & 31);
     const int rg = threadIdx.x >> 5;
+    const int m0 = blockIdx.y * rows_per_y;
+    const int m1 = (m0 + rows_per_y < M) ? m0 + rows_per_y : M;
     float s = 0.f;
     if (col < D)
-        for (int m = rg; m < M; m += 8) s += Elt<T>::to_f32(x[(long long)m * ld + col]);
+        for (int m = m0 + rg; m < m1; m += 8) s += Elt<T>::to_f32(x[(long long)m * ld + col]);
     red[rg][threadIdx.x & 31] = s;
     __syncthreads();
     if (threadIdx.x < 32 && col < D) {
         float t = 0.f;
         DPC_UNROLL
         for (int g = 0; g < 8; ++g) t += red[g][threadIdx.x];
-        out[col] = accumulate ? out[col] + t : t;
+        out[(long long)blockIdx.y * D + col] = t;
     }
 }
 
+__global__ void colsum_finish_kernel(const float* ws, int ny, int D, float* out, int accumulate) {
+    const int d = blockIdx.x * blockDim.x + threadIdx.x;
+    if (d >= D) return;
+    float t = 0.f;
+    for (int y = 0; y < ny; ++y) t += ws[(long long)y * D + d];
+    out[d] = accumulate ? out[d] + t : t;
+}
+
 extern "C" int dpc_colsum(const void* x, int32_t dtype, int32_t ld, int32_t M, int32_t D, float* out, int32_t accumulate,
-                          dpc_stream_t stream_) {
+                          float* ws, int64_t ws_floats, dpc_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (!x || !out || M <= 0 || D <= 0 || ld < D) return DPC_ERR_ARG;
-    dim3 grid((D + 31) / 32), block(256);
+    int ny = (M + 255) / 256;
+    if (ny > 64) ny = 64;
+    if (!ws || ws_floats < (long long)ny * D) return DPC_ERR_ARG;
+    const int rpy = (M + ny - 1) / ny;
+    dim3 grid((D + 31) / 32, ny), block(256);
     if (dtype == DPC_F32) {
-        DPC_LAUNCH((colsum_kernel<float>), grid, block, stream, (const float*)x, ld, M, D, out, accumulate);
+        DPC_LAUNCH((colsum_kernel<float>), grid, block, stream, (const float*)x, ld, M, D, ws, rpy);
     } else if (dtype == DPC_BF16) {
-        DPC_LAUNCH((colsum_kernel<bf16_t>), grid, block, stream, (const bf16_t*)x, ld, M, D, out, accumulate);
+        DPC_LAUNCH((colsum_kernel<bf16_t>), grid, block, stream, (const bf16_t*)x, ld, M, D, ws, rpy);
     } else {
         return DPC_ERR_ARG;
     }
+    DPC_LAUNCH(colsum_finish_kernel, dim3((D + 255) / 256), dim3(256), stream, (const float*)ws, ny, D, out, accumulate);
     return dpc_launch_status();
 }
 

@@ -52,13 +52,16 @@ __global__ void bn_relu_maxpool_fwd_kernel(const T* x, int NT, int H, int W, int
                 }
             }
         }
-        u32x4 o;
+        uint32_t amw[2] = {0u, 0u};
         DPC_UNROLL
-        for (int e = 0; e < E; ++e) {
-            unit_set<T>(o, e, best[e]);
-            argmax[i * E + e] = (uint8_t)(best[e] > 0.f ? bi[e] : 9);
+        for (int e = 0; e < E; ++e) amw[e >> 2] |= (uint32_t)(best[e] > 0.f ? bi[e] : 9) << (8 * (e & 3));
+        if (E == 8) {
+            u32x2 t = {amw[0], amw[1]};
+            *(u32x2*)(argmax + i * E) = t;
+        } else {
+            *(uint32_t*)(argmax + i * E) = amw[0];
         }
-        ((u32x4*)y)[i] = o;
+        ((u32x4*)y)[i] = unit_pack<T>(best);
     }
 }
 
@@ -81,7 +84,44 @@ extern "C" int dpc_bn_relu_maxpool_fwd(const void* x, int32_t dtype, int32_t NT,
     return dpc_launch_status();
 }
 
-// dz[nt][h][w][c] = sum over the (<=4) windows that contain (h,w) and whose argmax is (h,w)
+// gradient routed by the pooling to full-resolution position (nt,h,w): sum over the (<=4) windows that
+// contain it and whose saved argmax is this position (ReLU mask already folded into the argmax byte)
+template <class T>
+__device__ __forceinline__ void pool_routed_grad(const T* dy, const uint8_t* argmax, int nt, int h, int w, int cu, int Ho, int Wo,
+                                                 int upr, float (&acc)[Elt<T>::PER16]) {
+    constexpr int E = Elt<T>::PER16;
+    DPC_UNROLL
+    for (int e = 0; e < E; ++e) acc[e] = 0.f;
+    const int oh0 = h >> 1, ow0 = w >> 1;  // window with kh = (h odd ? 2 : 1); h odd also hits oh0+1 with kh = 0
+    DPC_UNROLL
+    for (int a = 0; a < 2; ++a) {
+        if (a == 1 && !(h & 1)) continue;
+        const int oh = oh0 + a;
+        if (oh >= Ho) continue;
+        const int kh = h - (2 * oh - 1);
+        DPC_UNROLL
+        for (int b = 0; b < 2; ++b) {
+            if (b == 1 && !(w & 1)) continue;
+            const int ow = ow0 + b;
+            if (ow >= Wo) continue;
+            const int kw = w - (2 * ow - 1);
+            const int want = kh * 3 + kw;
+            const long long ui = (long long)((unsigned)((nt * Ho + oh) * Wo + ow)) * upr + cu;
+            const u32x4 g = ((const u32x4*)dy)[ui];
+            uint32_t amw[E / 4];  // the E argmax bytes of this unit as one 4/8-byte load
+            if (E == 8) {
+                const u32x2 t = *(const u32x2*)(argmax + ui * E);
+                amw[0] = t[0]; amw[E / 4 - 1] = t[1];
+            } else {
+                amw[0] = *(const uint32_t*)(argmax + ui * E);
+            }
+            DPC_UNROLL
+            for (int e = 0; e < E; ++e)
+                if ((int)((amw[e >> 2] >> (8 * (e & 3))) & 0xffu) == want) acc[e] += unit_get<T>(g, e);
+        }
+    }
+}
+
 template <class T>
 __global__ void maxpool_bwd_kernel(const T* dy, const uint8_t* argmax, int NT, int H, int W, int C, int Ho, int Wo, T* dz) {
     constexpr int E = Elt<T>::PER16;
@@ -95,35 +135,159 @@ __global__ void maxpool_bwd_kernel(const T* dy, const uint8_t* argmax, int NT, i
         const int h = (int)(q % H);
         const int nt = (int)(q / H);
         float acc[E];
+        pool_routed_grad<T>(dy, argmax, nt, h, w, cu, Ho, Wo, upr, acc);
+        ((u32x4*)dz)[i] = unit_pack<T>(acc);
+    }
+}
+
+// ---- stem backward without materialising dz: BN backward whose incoming gradient is routed through the
+// pooling on the fly (reads dpool + argmax + raw instead of a 2.7 GB dz tensor, twice)
+template <class T>
+__global__ __launch_bounds__(256) void pool_bn_bwd_reduce_kernel(const T* dy, const uint8_t* argmax, const T* x, int NT, int H, int W,
+                                                                 int C, int Ho, int Wo, const float* mean, const float* invstd,
+                                                                 float* partials, long long rows_per_block) {
+    constexpr int E = Elt<T>::PER16;
+    __shared__ float red[2][256 * E];
+    const int upr = C / E, rpi = 256 / upr;
+    const int tid = threadIdx.x, cu = tid % upr, rr = tid / upr;
+    const long long rows = (long long)NT * H * W;
+    float a1[E], a2[E], mu[E], is[E];
+    DPC_UNROLL
+    for (int e = 0; e < E; ++e) { a1[e] = 0.f; a2[e] = 0.f; }
+    if (rr < rpi) {
         DPC_UNROLL
-        for (int e = 0; e < E; ++e) acc[e] = 0.f;
-        const int oh0 = h >> 1, ow0 = w >> 1;  // window with kh = (h odd ? 2 : 1); h odd also hits oh0+1 with kh = 0
-        DPC_UNROLL
-        for (int a = 0; a < 2; ++a) {
-            if (a == 1 && !(h & 1)) continue;
-            const int oh = oh0 + a;
-            if (oh >= Ho) continue;
-            const int kh = h - (2 * oh - 1);
+        for (int e = 0; e < E; ++e) { mu[e] = mean[cu * E + e]; is[e] = invstd[cu * E + e]; }
+        const long long r_begin = (long long)blockIdx.x * rows_per_block;
+        long long r_end = r_begin + rows_per_block;
+        if (r_end > rows) r_end = rows;
+        for (unsigned r = (unsigned)(r_begin + rr); r < (unsigned)r_end; r += (unsigned)rpi) {  // rows < 2^31: 32-bit index math
+            const unsigned q = r / (unsigned)W;
+            const int w = (int)(r - q * (unsigned)W);
+            const unsigned nt_ = q / (unsigned)H;
+            const int h = (int)(q - nt_ * (unsigned)H), nt = (int)nt_;
+            float dz[E];
+            pool_routed_grad<T>(dy, argmax, nt, h, w, cu, Ho, Wo, upr, dz);
+            const u32x4 xv = ((const u32x4*)x)[(long long)r * upr + cu];
             DPC_UNROLL
-            for (int b = 0; b < 2; ++b) {
-                if (b == 1 && !(w & 1)) continue;
-                const int ow = ow0 + b;
-                if (ow >= Wo) continue;
-                const int kw = w - (2 * ow - 1);
-                const int want = kh * 3 + kw;
-                const long long ui = (((long long)nt * Ho + oh) * Wo + ow) * upr + cu;
-                const u32x4 g = ((const u32x4*)dy)[ui];
-                const uint8_t* am = argmax + ui * E;
-                DPC_UNROLL
-                for (int e = 0; e < E; ++e)
-                    if (am[e] == want) acc[e] += unit_get<T>(g, e);
+            for (int e = 0; e < E; ++e) {
+                a1[e] += dz[e];
+                a2[e] += dz[e] * ((unit_get<T>(xv, e) - mu[e]) * is[e]);
             }
         }
-        u32x4 o;
-        DPC_UNROLL
-        for (int e = 0; e < E; ++e) unit_set<T>(o, e, acc[e]);
-        ((u32x4*)dz)[i] = o;
     }
+    DPC_UNROLL
+    for (int e = 0; e < E; ++e) { red[0][tid * E + e] = a1[e]; red[1][tid * E + e] = a2[e]; }
+    __syncthreads();
+    if (tid < C) {
+        const int cu2 = tid / E, e2 = tid % E;
+        float s1 = 0.f, s2 = 0.f;
+        for (int g = 0; g < rpi; ++g) {
+            s1 += red[0][(g * upr + cu2) * E + e2];
+            s2 += red[1][(g * upr + cu2) * E + e2];
+        }
+        partials[((long long)blockIdx.x * 2 + 0) * C + tid] = s1;
+        partials[((long long)blockIdx.x * 2 + 1) * C + tid] = s2;
+    }
+}
+
+template <class T>
+__global__ __launch_bounds__(256) void pool_bn_bwd_apply_kernel(const T* dy, const uint8_t* argmax, const T* x, int NT, int H, int W, int C,
+                                                                int Ho, int Wo, const float* mean, const float* invstd, const float* gamma,
+                                                                const float* coef, T* dx, long long rows_per_block) {
+    constexpr int E = Elt<T>::PER16;
+    const int upr = C / E, rpi = 256 / upr;
+    const int tid = threadIdx.x, cu = tid % upr, rr = tid / upr;
+    if (rr >= rpi) return;
+    const long long rows = (long long)NT * H * W;
+    float mu[E], is[E], ga[E], c1[E], c2[E];
+    DPC_UNROLL
+    for (int e = 0; e < E; ++e) {
+        const int c = cu * E + e;
+        mu[e] = mean[c]; is[e] = invstd[c]; ga[e] = gamma[c] * is[e]; c1[e] = coef[c]; c2[e] = coef[C + c];
+    }
+    const long long r_begin = (long long)blockIdx.x * rows_per_block;
+    long long r_end = r_begin + rows_per_block;
+    if (r_end > rows) r_end = rows;
+    for (unsigned r = (unsigned)(r_begin + rr); r < (unsigned)r_end; r += (unsigned)rpi) {
+        const unsigned q = r / (unsigned)W;
+        const int w = (int)(r - q * (unsigned)W);
+        const unsigned nt_ = q / (unsigned)H;
+        const int h = (int)(q - nt_ * (unsigned)H), nt = (int)nt_;
+        float dz[E];
+        pool_routed_grad<T>(dy, argmax, nt, h, w, cu, Ho, Wo, upr, dz);
+        const long long ui = (long long)r * upr + cu;
+        const u32x4 xv = ((const u32x4*)x)[ui];
+        float ov[E];
+        DPC_UNROLL
+        for (int e = 0; e < E; ++e) {
+            const float xh = (unit_get<T>(xv, e) - mu[e]) * is[e];
+            ov[e] = ga[e] * (dz[e] - c1[e] - xh * c2[e]);
+        }
+        ((u32x4*)dx)[ui] = unit_pack<T>(ov);
+    }
+}
+
+static int pool_bwd_blocks(long long rows, int C, int E, long long* rows_per_block) {
+    const int rpi = 256 / (C / E);
+    long long per = (long long)rpi * 16;
+    long long blocks = (rows + per - 1) / per;
+    if (blocks > 1024) {
+        blocks = 1024;
+        per = (rows + blocks - 1) / blocks;
+        per = (per + rpi - 1) / rpi * rpi;
+        blocks = (rows + per - 1) / per;
+    }
+    *rows_per_block = per;
+    return (int)blocks;
+}
+
+extern "C" int dpc_pool_bn_bwd_reduce(const void* dy, const uint8_t* argmax, const void* x, int32_t dtype, int32_t NT, int32_t H,
+                                      int32_t W, int32_t C, const float* mean, const float* invstd, float* partials, int32_t* prow,
+                                      dpc_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (NT <= 0 || H <= 0 || W <= 0 || C <= 0) return DPC_ERR_ARG;
+    const int E = dtype == DPC_BF16 ? 8 : 4;
+    if (C % E || C > 256) return DPC_ERR_UNSUPPORTED;
+    long long rpb;
+    const int blocks = pool_bwd_blocks((long long)NT * H * W, C, E, &rpb);
+    if (prow) *prow = blocks;
+    if (!partials) return DPC_OK;
+    if (!dy || !argmax || !x || !mean || !invstd) return DPC_ERR_ARG;
+    const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+    if (dtype == DPC_F32) {
+        DPC_LAUNCH((pool_bn_bwd_reduce_kernel<float>), dim3(blocks), dim3(256), stream, (const float*)dy, argmax, (const float*)x, NT, H, W, C, Ho, Wo, mean, invstd, partials, rpb);
+    } else if (dtype == DPC_BF16) {
+        DPC_LAUNCH((pool_bn_bwd_reduce_kernel<bf16_t>), dim3(blocks), dim3(256), stream, (const bf16_t*)dy, argmax, (const bf16_t*)x, NT, H, W, C, Ho, Wo, mean, invstd, partials, rpb);
+    } else {
+        return DPC_ERR_ARG;
+    }
+    return dpc_launch_status();
+}
+
+extern "C" int dpc_pool_bn_bwd_apply(const void* dy, const uint8_t* argmax, const void* x, int32_t dtype, int32_t NT, int32_t H,
+                                     int32_t W, int32_t C, const float* mean, const float* invstd, const float* gamma,
+                                     const float* coef, void* dx, dpc_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!dy || !argmax || !x || !dx || !mean || !invstd || !gamma || !coef || NT <= 0 || H <= 0 || W <= 0 || C <= 0) return DPC_ERR_ARG;
+    const int E = dtype == DPC_BF16 ? 8 : 4;
+    if (C % E) return DPC_ERR_UNSUPPORTED;
+    if (C > 256) return DPC_ERR_UNSUPPORTED;
+    const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+    const int rpi = 256 / (C / E);
+    const long long rows = (long long)NT * H * W;
+    long long blocks = (rows + (long long)rpi * 8 - 1) / ((long long)rpi * 8);
+    if (blocks > 16384) blocks = 16384;
+    long long rpb = (rows + blocks - 1) / blocks;
+    rpb = (rpb + rpi - 1) / rpi * rpi;
+    blocks = (rows + rpb - 1) / rpb;
+    if (dtype == DPC_F32) {
+        DPC_LAUNCH((pool_bn_bwd_apply_kernel<float>), dim3((unsigned)blocks), dim3(256), stream, (const float*)dy, argmax, (const float*)x, NT, H, W, C, Ho, Wo, mean, invstd, gamma, coef, (float*)dx, rpb);
+    } else if (dtype == DPC_BF16) {
+        DPC_LAUNCH((pool_bn_bwd_apply_kernel<bf16_t>), dim3((unsigned)blocks), dim3(256), stream, (const bf16_t*)dy, argmax, (const bf16_t*)x, NT, H, W, C, Ho, Wo, mean, invstd, gamma, coef, (bf16_t*)dx, rpb);
+    } else {
+        return DPC_ERR_ARG;
+    }
+    return dpc_launch_status();
 }
 
 extern "C" int dpc_maxpool_bwd(const void* dy, const uint8_t* argmax, int32_t dtype, int32_t NT, int32_t H, int32_t W,

@@ -416,6 +416,7 @@ class DPCEngine:
         self.db = self.empty((3 * D,), f32)
         for (co, kk) in ((3 * D, D), (2 * D, D), (D, D)):
             self._need_wgrad(ns * M, co, kk)
+        self.need_part(64 * 3 * D)  # dpc_colsum workspace
         self._need_wgrad(R, R, D)
         self.coef = self.empty((2, max(widths)), f32)
         self.stats = self.empty((max(self._stats_need, 1),), f32)
@@ -641,7 +642,7 @@ class DPCEngine:
         self.gemm_tn(self.G_all, 3 * D, self.X_all, D, self.dWx, ns * M, 3 * D, D)
         self.gemm_tn(self.G_all, 3 * D, self.H_all, D, self.dWh, ns * M, 2 * D, D)
         self.gemm_tn(self.G_all[:, :, 2 * D:], 3 * D, self.HR_all, D, self.dWo, ns * M, D, D)
-        self.call("dpc_colsum", self.G_all, dc, 3 * D, ns * M, 3 * D, self.db, 0)
+        self.call("dpc_colsum", self.G_all, dc, 3 * D, ns * M, 3 * D, self.db, 0, self.part, self.part.numel())
         for i, (g, n) in enumerate((("u", "update_gate"), ("r", "reset_gate"), ("o", "out_gate"))):
             w = Gm[f"agg.ConvGRUCell_00.{n}.weight"].view(D, 2 * D)
             w[:, :D].copy_(self.dWx[i * D:(i + 1) * D])
@@ -649,8 +650,8 @@ class DPCEngine:
             Gm[f"agg.ConvGRUCell_00.{n}.bias"].copy_(self.db[i * D:(i + 1) * D])
         self.gemm_tn(self.dP1, D, self.Hpred, D, Gm["network_pred.0.weight"].view(D, D), P * M, D, D)
         self.gemm_tn(self.dP2, D, self.P1_all, D, Gm["network_pred.2.weight"].view(D, D), P * M, D, D)
-        self.call("dpc_colsum", self.dP1, dc, D, P * M, D, Gm["network_pred.0.bias"], 0)
-        self.call("dpc_colsum", self.dP2, dc, D, P * M, D, Gm["network_pred.2.bias"], 0)
+        self.call("dpc_colsum", self.dP1, dc, D, P * M, D, Gm["network_pred.0.bias"], 0, self.part, self.part.numel())
+        self.call("dpc_colsum", self.dP2, dc, D, P * M, D, Gm["network_pred.2.bias"], 0, self.part, self.part.numel())
         # ---- temporal pool / split, backbone
         fs = self.feat_shape
         self.call("dpc_tpool_split_bwd", self.blocks[-1].out, self.d_featrelu, self.d_finf, dc, B, N, fs[1], SQ, D, P, self.d_feat)
@@ -659,8 +660,14 @@ class DPCEngine:
             d = blk.backward(d, need_dx=True)
         # stem: max-pool routing (ReLU mask folded into the saved argmax) -> BN -> weight grad; the video has no grad
         st = self.stem.out_shape
-        self.call("dpc_maxpool_bwd", d, self.pool_arg, dc, st[0] * st[1], st[2], st[3], self.widths[0], self.stem_dz)
-        self.stem.bn_backward(self.stem_dz, None, False, self.stem_dz, None)
+        u, C0 = self.stem, self.widths[0]
+        pr = C.c_int32(0)
+        self.call("dpc_pool_bn_bwd_reduce", d, self.pool_arg, u.raw, dc, st[0] * st[1], st[2], st[3], C0, u.mean, u.invstd,
+                  self.stats, C.byref(pr))
+        self.call("dpc_bn_bwd_finalize", self.stats, pr.value, C0, float(u.rows), self.G[u.bnname + ".weight"],
+                  self.G[u.bnname + ".bias"], self.coef)
+        self.call("dpc_pool_bn_bwd_apply", d, self.pool_arg, u.raw, dc, st[0] * st[1], st[2], st[3], C0, u.mean, u.invstd,
+                  self.PRM[u.bnname + ".weight"], self.coef, self.stem_dz)
         self.stem.wgrad(self.x_s2d, self.stem_dz)
 
     def _gru_step_backward(self, s: int, dh: torch.Tensor, dx_out: torch.Tensor):

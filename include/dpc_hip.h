@@ -127,6 +127,15 @@ int dpc_bn_relu_maxpool_fwd(const void* x, int32_t dtype, int32_t NT, int32_t H,
 int dpc_maxpool_bwd(const void* dy, const uint8_t* argmax, int32_t dtype, int32_t NT, int32_t H, int32_t W, int32_t C,
                     void* dz, dpc_stream_t stream);
 
+/* stem backward without materialising dz: BN backward whose incoming gradient is routed through the
+ * max-pool on the fly (autograd of resnet_2d3d.py:260-263 in two passes instead of five) */
+int dpc_pool_bn_bwd_reduce(const void* dy, const uint8_t* argmax, const void* x, int32_t dtype, int32_t NT, int32_t H,
+                           int32_t W, int32_t C, const float* mean, const float* invstd, float* partials, int32_t* prow,
+                           dpc_stream_t stream);
+int dpc_pool_bn_bwd_apply(const void* dy, const uint8_t* argmax, const void* x, int32_t dtype, int32_t NT, int32_t H,
+                          int32_t W, int32_t C, const float* mean, const float* invstd, const float* gamma,
+                          const float* coef, void* dx, dpc_stream_t stream);
+
 /* ---- temporal mean + ReLU split (dpc/model_3d.py:53-59) -----------------------------
  * x [B*N][T][SQ][D] -> feat_relu [N][B*SQ][D] (GRU input, time-major) and
  * feat_inf [B][P][SQ][D] (pre-ReLU, last P blocks, score operand). */
@@ -159,7 +168,7 @@ int dpc_bias_act(const float* x, const float* bias, int32_t M, int32_t D, int32_
 int dpc_relu_bwd(const float* dy, const void* y, int32_t dtype_y, const float* add, int64_t n, void* out,
                  int32_t dtype_out, dpc_stream_t stream);
 int dpc_colsum(const void* x, int32_t dtype, int32_t ld, int32_t M, int32_t D, float* out, int32_t accumulate,
-               dpc_stream_t stream);
+               float* ws, int64_t ws_floats /* >= 64*D */, dpc_stream_t stream);
 int dpc_gather_rows(const float* src, int32_t B, int32_t P, int32_t p, int32_t SQ, int32_t D, float* dst,
                     const float* add, dpc_stream_t stream);
 int dpc_convert(const void* in, int32_t dtype_in, void* out, int32_t dtype_out, int64_t n, dpc_stream_t stream);

@@ -254,6 +254,26 @@ def case_stem_pool(k: K, dtype, NT, H, W, Cc, seed=6):
     k.sync()
     dz_ref = a.grad.squeeze(2).permute(0, 2, 3, 1)
     assert relerr(dz, dz_ref) < tol(dtype)
+    # fused form used by the engine: BN backward with the pooled gradient routed on the fly
+    gamma = torch.rand(Cc, generator=g) + 0.5
+    xd = x.double().requires_grad_()
+    mean = xd.mean((0, 1, 2)); var = xd.var((0, 1, 2), unbiased=False); invstd = 1 / torch.sqrt(var + 1e-5)
+    yb = (xd - mean) * invstd * gamma.double()
+    yb.backward(dz_ref.double())
+    rows = NT * H * W
+    prow = C.c_int32(0)
+    k.call("dpc_pool_bn_bwd_reduce", None, None, None, L.dtype_code(dtype), NT, H, W, Cc, None, None, None, C.byref(prow))
+    bp = k.zeros(prow.value, 2, Cc)
+    xk, gyk = k.t(x, dtype), k.t(gy, dtype)
+    km, ki = k.t(mean.detach().float()), k.t(invstd.detach().float())
+    k.call("dpc_pool_bn_bwd_reduce", gyk, am, xk, L.dtype_code(dtype), NT, H, W, Cc, km, ki, bp, C.byref(prow))
+    dgam, dbet, coef = k.empty(Cc), k.empty(Cc), k.empty(2, Cc)
+    k.call("dpc_bn_bwd_finalize", bp, prow.value, Cc, float(rows), dgam, dbet, coef)
+    dx = k.empty(NT, H, W, Cc, dtype=dtype)
+    k.call("dpc_pool_bn_bwd_apply", gyk, am, xk, L.dtype_code(dtype), NT, H, W, Cc, km, ki, k.t(gamma), coef, dx)
+    k.sync()
+    t = 2e-3 if dtype == torch.float32 else 3e-2
+    assert relerr(dx, xd.grad) < t and relerr(dbet, dz_ref.double().sum((0, 1, 2))) < t
 
 
 def case_tpool_split(k: K, dtype, B, N, T, SQ, D, P, seed=7):
@@ -353,7 +373,8 @@ def case_gru_cell(k: K, dtype, M, D, seed=8):
     dWh = wgrad(G, 3 * D, 2 * D, hk, D)
     dWo = wgrad(G[:, 2 * D:], 3 * D, D, hr, D)
     db = k.empty(3 * D)
-    k.call("dpc_colsum", L._p(G), dc, 3 * D, M, 3 * D, L._p(db), 0)
+    ws = k.empty(64 * 3 * D)
+    k.call("dpc_colsum", L._p(G), dc, 3 * D, M, 3 * D, L._p(db), 0, ws, ws.numel())
     k.sync()
     ref_dWx = torch.cat([Wd["u"].grad[:, :D], Wd["r"].grad[:, :D], Wd["o"].grad[:, :D]], 0)
     ref_dWh = torch.cat([Wd["u"].grad[:, D:], Wd["r"].grad[:, D:]], 0)
