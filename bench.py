@@ -81,10 +81,11 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
-    if world > 1:
+    if world > 1 or "RANK" in os.environ:  # under a launcher the RCCL path is exercised even with one rank
         import torch.distributed as dist_
         dist = dist_
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from dpc_amd.engine import DPCEngine, KernelTimer
@@ -98,7 +99,7 @@ def main():
     del init
     g = torch.Generator(dev).manual_seed(1234 + rank)
     block = torch.randn(args.batch, 8, 3, 5, args.img_dim, args.img_dim, device=dev, generator=g)
-    allreduce = make_allreduce(dist, world) if world > 1 else None
+    allreduce = make_allreduce(dist, world, force=dist is not None)
 
     def sync():
         if dist is not None:

@@ -13,9 +13,9 @@ from __future__ import annotations
 import torch
 
 
-def make_allreduce(dist, world: int):
+def make_allreduce(dist, world: int, force: bool = False):
     """returns f(flat_grad) that averages the arena across ranks in place (backend 'nccl' == RCCL)"""
-    if dist is None or world <= 1:
+    if dist is None or (world <= 1 and not force):
         return None
     backend = dist.get_backend()
 

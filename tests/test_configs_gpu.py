@@ -1,0 +1,44 @@
+"""GPU tier: the other BASELINE.json configurations' shapes (resnet34, img_dim 224 => 7x7 feature map,
+pred_step 5, ragged score width) at a small batch, f32, against the CPU oracle run in the same process."""
+import pytest
+import torch
+
+from dpc_amd.engine import DPCEngine
+from oracle import dpc_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.mark.parametrize("net,size,B,P", [("resnet34", 224, 2, 3), ("resnet18", 224, 2, 5), ("resnet18", 96, 3, 2)])
+def test_config_shapes_vs_oracle(net, size, B, P):
+    eng = DPCEngine(net, size, 8, 5, P, B, DEV, torch.float32)
+    p = O.make_params_pcg(net)
+    eng.load_params(p)
+    x = O.make_input_pcg(B, 8, 5, size)
+    score = eng.forward(x.to(DEV), train=False).cpu()
+    res = eng.loss_topk(True).cpu()
+    eng.backward()
+    torch.cuda.synchronize()
+    loss, accs, grads, ref = O.train_step_reference(p, x, net, P, None)
+    assert score.shape == ref.shape
+    assert (score - ref).abs().max().item() < 1e-3
+    assert abs(res[0].item() - loss.item()) < 1e-3
+    assert res[1:].tolist() == pytest.approx(accs, abs=1e-6)
+    assert torch.equal(eng.get_mask().cpu(), O.mask_closed_form(B, P, eng.SQ))
+    for k, g in grads.items():  # relative L2: see DESIGN.md "ReLU-boundary flips"
+        e = ((eng.G[k].cpu() - g).norm() / g.norm().clamp_min(1e-12)).item()
+        assert e < 5e-2, (k, e)
+
+
+def test_bf16_full_config4_shape_runs():
+    """cfg4 shape (r34, 224^2) in throughput mode: finite loss/gradients, BN invariants (size-independent)."""
+    B = 4
+    eng = DPCEngine("resnet34", 224, 8, 5, 3, B, DEV, torch.bfloat16)
+    eng.load_params(O.init_params_reference_style("resnet34", seed=0))
+    x = torch.randn(B, 8, 3, 5, 224, 224, device=DEV, generator=torch.Generator(DEV).manual_seed(3))
+    r0 = eng.train_step(x).cpu()
+    for _ in range(3):
+        r = eng.train_step(x).cpu()
+    assert torch.isfinite(r).all() and torch.isfinite(eng.flat_g).all() and r[0] < r0[0]
+    assert eng.R == B * 3 * 49
