@@ -134,3 +134,10 @@ __device__ __forceinline__ u32x4 mask_unit(u32x4 v, bool ok) {
     v[0] &= m; v[1] &= m; v[2] &= m; v[3] &= m;
     return v;
 }
+
+// conv_halo.hip: LDS-staged-patch kernel for 1xKHxKW stride-1 same-size convs.  _try returns 1 when
+// the shape is not served (the caller then runs the generic implicit-GEMM path); _rows returns the
+// number of batch-norm partial rows that kernel would write (0 = not served).
+int dpc_conv_halo_try(const dpc_conv_desc* d, const void* src, const void* wgt, void* out, const void* addend, float* stats,
+                      hipStream_t stream);
+int dpc_conv_halo_rows(const dpc_conv_desc* d);

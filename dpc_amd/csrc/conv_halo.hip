@@ -1,0 +1,306 @@
+// conv_halo.hip -- 1xKHxKW stride-1 "same" convolutions (BasicBlock2d convs of layer1/layer2,
+// backbone/resnet_2d3d.py:24-32,83-116, and their input-gradients) with the input patch staged ONCE
+// in LDS.
+//
+// Why a second conv kernel: in conv_igemm.hip every tap re-gathers its 128 x 128-byte A chunk
+// through the cache hierarchy (9x amplification for 3x3) and pays the gather arithmetic per chunk;
+// for the small-channel layers (C=64/128, K = 576/1152) that, not the matrix cores, bounds the kernel
+// (~450 TFLOP/s).  Here a workgroup owns a TR x TW patch of one frame (128 output positions):
+//   * the (TR+KH-1) x (TW+KW-1) input halo is loaded once per tile as 16-byte units into LDS,
+//     channels-last, each position padded by 16 B so that the ds_read_b128 of 16 neighbouring
+//     positions touch 16 different bank slots;
+//   * the A fragment of tap (kh,kw) is the same LDS image read at a constant offset
+//     (kh*halo_w + kw) positions further: no per-tap global loads, no gather arithmetic;
+//   * the weights (B) live in REGISTERS for the whole kernel: with 128 bytes per position and <= 64
+//     output channels a wave's B operand (32 channels x KH*KW*128 B) is KH*KW*16 VGPRs per lane
+//     (144 for 3x3), loaded once per workgroup; the tap loop then issues only ds_read_b128 + MFMA --
+//     no global loads, no LDS writes, no barrier.  (Measured dead ends, both slower than the generic
+//     kernel: streaming B through LDS per tap = one L2 round trip + barrier per 256 MFMA cycles and
+//     LDS-write-bound; per-lane B fragments fetched from L2 every tap = TA-bound 16-byte gathers.)
+//   * the halo itself arrives by LDS-DMA (global_load_lds_dwordx4, no VGPR staging -- the register
+//     file belongs to B) into a second buffer while the current tile is in its MFMA phase; fetching
+//     it through registers in small batches cost ~4 exposed HBM round trips per tile;
+//   * MFMA fragments, C/D map, LDS-staged coalesced epilogue, fused BN partial sums and residual add
+//     are the same as in conv_igemm.hip.
+// Serves layer1 of the 2d3d-ResNet (C=64 bf16) -- the layer family where the LDS write bandwidth
+// (~80 B/clk/CU for ds_write_b128) of re-staging A per tap bounded the generic kernel.
+// An input-gradient with unit strides is the same convolution with pad' = K-1-pad and the tap order
+// reversed (the [Ci][tap][Co] weight pack is indexed with the flipped tap).
+#include "conv_common.h"
+
+struct HaloParams {
+    const void* src;
+    const void* wgt;
+    void* out;
+    const void* addend;
+    float* stats;
+    int NF, H, W, C, Co, ldw, ldo;
+    int ph, pw, flip;
+    int TR, TW, lTW, HR, HWd;
+    int tiles_w, tiles_per_frame, ntm, gm;
+    FastDiv d_tpf, d_tw, d_hwd;
+    int vec_out;
+};
+
+template <class T, class TO, int KH, int KW>
+__global__ __launch_bounds__(256, 2) void conv_halo_kernel(HaloParams p) {
+    constexpr int EPU = Elt<T>::PER16;
+    constexpr int BM = 128, BN = 64;
+    constexpr int CBP = 128 + 16;       // one 128-byte position + 16 B pad
+    constexpr int MAXPOS = 228;
+    constexpr int NTAPS = KH * KW;
+    constexpr int EPO = 16 / (int)sizeof(TO);
+    constexpr int UPR = BN / EPO;
+    constexpr int OIT = BM * UPR / 256;
+    constexpr int DMA_IT = 9;                               // 9 x 256 lanes x 16 B >= MAXPOS positions x 9 slots
+    constexpr int HALO_BYTES = DMA_IT * 256 * 16;           // one position = 8 data slots + 1 pad slot of 16 B
+    constexpr int STAGE_BYTES = BM * BN * (int)sizeof(TO);
+    static_assert(MAXPOS * CBP <= HALO_BYTES && STAGE_BYTES <= HALO_BYTES, "halo buffer doubles as the epilogue staging tile");
+    __shared__ __attribute__((aligned(16))) unsigned char lds2[2 * HALO_BYTES];
+    __shared__ int rowmap[BM];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wv = tid >> 6;
+    const int wm = wv >> 1, wn = wv & 1;
+    const int l31 = lane & 31, lhi = lane >> 5;
+    const int m_prog = blockIdx.x;
+    const int esz = (int)sizeof(T);
+    const char* const zero = (const char*)dpc_zero16;
+
+    // ---- B operand: this lane's output channel, its k-group of every (tap, kk): resident in VGPRs
+    u32x4 fbr[NTAPS][4];
+    {
+        const int n = wn * 32 + l31;
+        const char* wp = n < p.Co ? (const char*)p.wgt + ((long long)n * p.ldw + lhi * EPU) * esz : nullptr;
+        DPC_UNROLL
+        for (int tap = 0; tap < NTAPS; ++tap) {
+            const int tapw = p.flip ? (NTAPS - 1 - tap) : tap;
+            DPC_UNROLL
+            for (int kk = 0; kk < 4; ++kk)
+                fbr[tap][kk] = *(const u32x4*)(wp ? wp + ((long long)tapw * p.C * esz) + kk * 32 : zero);
+        }
+    }
+    int frag_a[2];
+    DPC_UNROLL
+    for (int i = 0; i < 2; ++i) {
+        const int row = wm * 64 + i * 32 + l31;
+        const int r = row >> p.lTW, c = row & (p.TW - 1);
+        frag_a[i] = (r * p.HWd + c) * CBP + lhi * 16;
+    }
+    const int npos = p.HR * p.HWd;
+    const int rowpitch = p.HWd * CBP;
+
+    float s1[EPO], s2[EPO];
+    DPC_UNROLL
+    for (int e = 0; e < EPO; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
+
+    // LDS-DMA of the halo of tile `t` into buffer `bufoff`: slot = position*9 + unit, unit 8 = pad
+    auto issue_halo = [&](int t, int bufoff) {
+        const unsigned frame = fdiv((unsigned)t, p.d_tpf);
+        const int tin = t - (int)frame * p.tiles_per_frame;
+        const unsigned th = fdiv((unsigned)tin, p.d_tw);
+        const int tw = tin - (int)th * p.tiles_w;
+        const int hb = (int)th * p.TR - p.ph, wb = tw * p.TW - p.pw;
+        DPC_NOUNROLL
+        for (int it = 0; it < DMA_IT; ++it) {  // rolled on purpose: the register file belongs to the B operand
+            const int slot = it * 256 + tid;
+            const int hpos = slot / 9, cu = slot - hpos * 9;
+            const unsigned hr = fdiv((unsigned)hpos, p.d_hwd);
+            const int hc = hpos - (int)hr * p.HWd;
+            const int h = hb + (int)hr, w = wb + hc;
+            const bool ok = cu < 8 && hpos < npos && (unsigned)h < (unsigned)p.H && (unsigned)w < (unsigned)p.W;
+            const char* a = (const char*)p.src + ((long long)(((int)frame * p.H + h) * p.W + w) * p.C) * esz + cu * 16;
+            glds16(ok ? a : zero, lds2 + bufoff + (it * 256 + wv * 64) * 16, lane);
+        }
+    };
+
+    int bufoff = 0;
+    if (m_prog < p.ntm) issue_halo(m_prog, 0);
+    for (int mt = m_prog; mt < p.ntm; mt += p.gm) {
+        unsigned char* const lds = lds2 + bufoff;
+        const unsigned frame = fdiv((unsigned)mt, p.d_tpf);
+        const int tin = mt - (int)frame * p.tiles_per_frame;
+        const unsigned th = fdiv((unsigned)tin, p.d_tw);
+        const int tw = tin - (int)th * p.tiles_w;
+        const int h0 = (int)th * p.TR, w0 = tw * p.TW;
+
+        if (tid < BM) {
+            const int r = tid >> p.lTW, c = tid & (p.TW - 1);
+            const int h = h0 + r, w = w0 + c;
+            rowmap[tid] = (h < p.H && w < p.W) ? ((int)frame * p.H + h) * p.W + w : -1;
+        }
+
+        f32x16 acc[2];
+        DPC_UNROLL
+        for (int i = 0; i < 2; ++i)
+            DPC_UNROLL
+            for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+        __syncthreads();  // this tile's halo has landed (the barrier drains the DMA), rowmap visible
+        if (mt + p.gm < p.ntm) issue_halo(mt + p.gm, bufoff ^ HALO_BYTES);  // next tile's halo flies during the MFMA phase
+        DPC_UNROLL
+        for (int kh = 0; kh < KH; ++kh) {
+            const int roff = kh * rowpitch;  // wave-uniform
+            DPC_UNROLL
+            for (int kw = 0; kw < KW; ++kw) {
+                DPC_UNROLL
+                for (int kk = 0; kk < 4; ++kk) {
+                    u32x4 fa[2];
+                    DPC_UNROLL
+                    for (int i = 0; i < 2; ++i) fa[i] = *(const u32x4*)(lds + frag_a[i] + roff + kw * CBP + kk * 32);
+                    DPC_UNROLL
+                    for (int i = 0; i < 2; ++i) acc[i] = mfma_unit<T>(fa[i], fbr[kh * KW + kw][kk], acc[i]);
+                }
+            }
+        }
+        barrier_lds_only();  // every wave is done with the halo before it becomes the staging tile (the DMA keeps flying)
+
+        // ---- epilogue (same scheme as conv_igemm.hip): accumulators -> LDS tile -> 16-byte units
+        TO* tile = (TO*)lds;
+        DPC_UNROLL
+        for (int i = 0; i < 2; ++i)
+            DPC_UNROLL
+            for (int r = 0; r < 16; ++r) {
+                const int row_l = wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                tile[row_l * BN + wn * 32 + l31] = Elt<TO>::from_f32(acc[i][r]);
+            }
+        barrier_lds_only();
+        const int cu = tid % UPR;
+        const int col0 = cu * EPO;
+        if (p.vec_out) {
+          DPC_UNROLL
+          for (int hb = 0; hb < OIT; hb += 2) {  // two units at a time: the B operand owns most of the register file
+            u32x4 ov[2], av[2];
+            DPC_UNROLL
+            for (int it = 0; it < 2; ++it) {
+                const int row_l = (tid + 256 * (hb + it)) / UPR;
+                ov[it] = *(const u32x4*)(lds + (row_l * BN + cu * EPO) * (int)sizeof(TO));
+                const int row = rowmap[row_l];
+                const bool ok = row >= 0 && col0 < p.Co;
+                if (p.addend) {
+                    const char* a = (const char*)p.addend + ((long long)row * p.ldo + col0) * (int)sizeof(TO);
+                    av[it] = *(const u32x4*)(ok ? a : zero);
+                }
+            }
+            DPC_UNROLL
+            for (int it = 0; it < 2; ++it) {
+                const int row = rowmap[(tid + 256 * (hb + it)) / UPR];
+                if (row >= 0 && col0 < p.Co) {
+                    u32x4 o = ov[it];
+                    if (p.addend) {
+                        float sv[EPO];
+                        DPC_UNROLL
+                        for (int e = 0; e < EPO; ++e) sv[e] = unit_get<TO>(o, e) + unit_get<TO>(av[it], e);
+                        o = unit_pack<TO>(sv);
+                    }
+                    *(u32x4*)((char*)p.out + ((long long)row * p.ldo + col0) * (int)sizeof(TO)) = o;
+                    DPC_UNROLL
+                    for (int e = 0; e < EPO; ++e) {
+                        const float v = unit_get<TO>(o, e);
+                        s1[e] += v;
+                        s2[e] += v * v;
+                    }
+                }
+            }
+          }
+        } else {
+            DPC_UNROLL
+            for (int it = 0; it < OIT; ++it) {
+                const int row_l = (tid + 256 * it) / UPR;
+                const int row = rowmap[row_l];
+                DPC_UNROLL
+                for (int e = 0; e < EPO; ++e) {
+                    const int col = col0 + e;
+                    if (row >= 0 && col < p.Co) {
+                        const long long o = (long long)row * p.ldo + col;
+                        float v = Elt<TO>::to_f32(tile[row_l * BN + cu * EPO + e]);
+                        if (p.addend) v += Elt<TO>::to_f32(((const TO*)p.addend)[o]);
+                        const TO q = Elt<TO>::from_f32(v);
+                        ((TO*)p.out)[o] = q;
+                        const float vq = Elt<TO>::to_f32(q);
+                        s1[e] += vq;
+                        s2[e] += vq * vq;
+                    }
+                }
+            }
+        }
+        barrier_lds_only();  // staging tile and rowmap are free again
+        bufoff ^= HALO_BYTES;
+    }
+
+    if (p.stats) {
+        float* red = (float*)lds2;  // [2][256][EPO]
+        DPC_UNROLL
+        for (int e = 0; e < EPO; ++e) {
+            red[tid * EPO + e] = s1[e];
+            red[(256 + tid) * EPO + e] = s2[e];
+        }
+        __syncthreads();
+        if (tid < BN && tid < p.Co) {
+            const int cu2 = tid / EPO, e2 = tid % EPO;
+            float a = 0.f, b = 0.f;
+            for (int t = cu2; t < 256; t += UPR) {
+                a += red[t * EPO + e2];
+                b += red[(256 + t) * EPO + e2];
+            }
+            p.stats[((long long)m_prog * 2 + 0) * p.Co + tid] = a;
+            p.stats[((long long)m_prog * 2 + 1) * p.Co + tid] = b;
+        }
+    }
+}
+
+// ---------------------------------------------------------------- host side
+static bool halo_plan(const dpc_conv_desc* d, HaloParams* p) {
+    if (d->KT != 1 || d->st != 1 || d->sh != 1 || d->sw != 1 || d->pt != 0) return false;
+    if (d->RT != d->ST || d->RH != d->SH || d->RW != d->SW) return false;
+    if (d->src_ld != d->Ci || d->KH != 3 || d->KW != 3 || d->Co > 64) return false;
+    if (d->dtype_in != d->dtype_out) return false;
+    const int esz = d->dtype_in == DPC_BF16 ? 2 : 4;
+    if (d->Ci * esz != 128) return false;
+    int tw = 32;
+    while (tw > d->RW && tw > 4) tw >>= 1;
+    p->TW = tw;
+    p->lTW = ilog2_exact(tw);
+    p->TR = 128 / tw;
+    p->HR = p->TR + d->KH - 1;
+    p->HWd = p->TW + d->KW - 1;
+    if (p->HR * p->HWd > 228) return false;
+    p->NF = d->N * d->RT;
+    p->H = d->RH; p->W = d->RW; p->C = d->Ci; p->Co = d->Co; p->ldw = d->ldw; p->ldo = d->ldo;
+    p->flip = d->mode == 1;
+    p->ph = d->mode == 1 ? d->KH - 1 - d->ph : d->ph;
+    p->pw = d->mode == 1 ? d->KW - 1 - d->pw : d->pw;
+    p->tiles_w = (d->RW + p->TW - 1) / p->TW;
+    const int tiles_h = (d->RH + p->TR - 1) / p->TR;
+    p->tiles_per_frame = tiles_h * p->tiles_w;
+    const long long ntm = (long long)p->NF * p->tiles_per_frame;
+    if (ntm >= (1ll << 30) || (long long)p->NF * d->RH * d->RW * d->Ci >= (1ll << 31)) return false;  // 32-bit element offsets
+    p->ntm = (int)ntm;
+    p->gm = p->ntm < 1024 ? p->ntm : 1024;  // persistent workgroups: B is loaded once per workgroup
+    p->d_tpf = make_fastdiv(p->tiles_per_frame);
+    p->d_tw = make_fastdiv(p->tiles_w);
+    p->d_hwd = make_fastdiv(p->HWd);
+    return true;
+}
+
+int dpc_conv_halo_rows(const dpc_conv_desc* d) {
+    HaloParams p;
+    if (!d || !halo_plan(d, &p)) return 0;
+    return p.gm;
+}
+
+// returns 1 when the shape is not served by this kernel (caller falls back to dpc_conv_igemm's generic path)
+int dpc_conv_halo_try(const dpc_conv_desc* d, const void* src, const void* wgt, void* out, const void* addend, float* stats,
+                      hipStream_t stream) {
+    HaloParams p;
+    if (!halo_plan(d, &p)) return 1;
+    p.src = src; p.wgt = wgt; p.out = out; p.addend = addend; p.stats = stats;
+    const int epo = d->dtype_out == DPC_BF16 ? 8 : 4;
+    p.vec_out = (d->Co % epo == 0 && d->ldo % epo == 0 && ((uintptr_t)out % 16 == 0) && ((uintptr_t)addend % 16 == 0)) ? 1 : 0;
+    dim3 grid((unsigned)p.gm), block(256);
+    if (d->dtype_in == DPC_F32) {
+        DPC_LAUNCH((conv_halo_kernel<float, float, 3, 3>), grid, block, stream, p);
+    } else {
+        DPC_LAUNCH((conv_halo_kernel<bf16_t, bf16_t, 3, 3>), grid, block, stream, p);
+    }
+    return dpc_launch_status();
+}

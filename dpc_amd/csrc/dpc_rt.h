@@ -12,11 +12,13 @@
 #define DPC_LAUNCH(kernel, grid, block, stream, ...) \
     simt::launch((grid), (block), [=]() { (kernel)(__VA_ARGS__); })
 #define DPC_UNROLL
+#define DPC_NOUNROLL
 #else
 #include <hip/hip_runtime.h>
 #define DPC_LAUNCH(kernel, grid, block, stream, ...) \
     hipLaunchKernelGGL(kernel, (grid), (block), 0, (stream), __VA_ARGS__)
 #define DPC_UNROLL _Pragma("unroll")
+#define DPC_NOUNROLL _Pragma("unroll 1")
 #endif
 
 #define DPC_OK 0
@@ -194,3 +196,27 @@ static const uint32_t dpc_zero16[4] __attribute__((aligned(16))) = {0u, 0u, 0u, 
 #else
 static __device__ const uint32_t dpc_zero16[4] __attribute__((aligned(16))) = {0u, 0u, 0u, 0u};
 #endif
+
+// LDS-DMA (gfx950 global_load_lds_dwordx4): each lane's 16 global bytes land at
+// wave_base + lane*16 in LDS without passing through VGPRs; asynchronous until the next
+// s_waitcnt vmcnt / __syncthreads().  wave_base must be wave-uniform.
+__device__ __forceinline__ void glds16(const void* gsrc, unsigned char* lds_wave_base, int lane) {
+#ifdef DPC_SIMT_EMU
+    std::memcpy(lds_wave_base + lane * 16, gsrc, 16);
+#else
+    (void)lane;
+    __builtin_amdgcn_global_load_lds(gsrc, (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+#endif
+}
+
+// Workgroup barrier that orders LDS traffic only: unlike __syncthreads() it does NOT wait for
+// outstanding vector-memory operations, so an LDS-DMA prefetch issued earlier keeps flying across it
+// (cdna_hip_programming.md §5 "Pipelining across barriers").  Use only where no global data produced
+// by other waves is consumed after the barrier.
+__device__ __forceinline__ void barrier_lds_only() {
+#ifdef DPC_SIMT_EMU
+    simt::sync_block();
+#else
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#endif
+}

@@ -26,6 +26,10 @@ def k():
     (2, 64, 72, 3, 8, 8, (3, 3, 3), (2, 2, 2), (1, 1, 1)),
     (3, 32, 160, 2, 7, 5, (1, 1, 1), (1, 2, 2), (0, 0, 0)),
     (1, 8, 24, 5, 6, 6, (3, 3, 3), (1, 1, 1), (1, 1, 1)),
+    (2, 64, 64, 2, 9, 33, (1, 3, 3), (1, 1, 1), (0, 1, 1)),   # LDS-staged patch kernel (bf16: 128 B/pos, f32: 256 B/pos)
+    (1, 64, 72, 1, 20, 12, (1, 3, 3), (1, 1, 1), (0, 1, 1)),  # narrow image: 8x16 tiles
+    (2, 32, 64, 2, 6, 7, (1, 3, 3), (1, 1, 1), (0, 1, 1)),    # f32 only takes the patch kernel (128 B/pos)
+    (1, 128, 128, 2, 10, 16, (1, 3, 3), (1, 1, 1), (0, 1, 1)),
 ])
 def test_conv_fwd(k, dtype, shape):
     kc.case_conv_fwd(k, dtype, *shape)
@@ -43,6 +47,8 @@ def test_conv_fwd(k, dtype, shape):
     (1, 8, 64, 5, 7, 9, (3, 3, 3), (2, 2, 2), (1, 1, 1)),       # odd extents: unequal classes
     (2, 8, 64, 2, 8, 8, (1, 1, 1), (1, 2, 2), (0, 0, 0)),       # strided 1x1x1: 3 of 4 classes see no tap
     (2, 8, 128, 3, 6, 6, (1, 3, 3), (1, 2, 2), (0, 1, 1)),
+    (2, 64, 64, 2, 9, 33, (1, 3, 3), (1, 1, 1), (0, 1, 1)),    # patch kernel, flipped taps
+    (1, 128, 128, 1, 10, 16, (1, 3, 3), (1, 1, 1), (0, 1, 1)),
 ])
 def test_conv_dgrad(k, dtype, shape):
     kc.case_conv_dgrad(k, dtype, *shape)
