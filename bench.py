@@ -141,12 +141,21 @@ def main():
             s = timer.summary()
             ig = s.get("dpc_conv_igemm")
             peak = MFMA_PEAK_BF16 if args.dtype == "bf16" else MFMA_PEAK_F32
+            traffic = None
+            try:  # HBM bytes per launch from the rocprofv3 PMC passes (scripts/gpu_pmc.sh + scripts/pmc_traffic.py)
+                import glob
+                cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))
+                if cands and args.dtype == "bf16" and args.batch == 128 and args.net == "resnet18" and args.img_dim == 128:
+                    traffic = round(json.load(open(cands[-1]))["dpc_conv_igemm"]["hbm_bytes_per_launch"] / 1e9, 4)
+            except Exception:
+                traffic = None
             if ig and ig["ms"] > 0:
                 ach = ig["flops"] / (ig["ms"] * 1e-3) / 1e12
                 out["roofline"] = {
-                    "kernel": "igemm_kernel (dpc_conv_igemm: conv fwd + input-grad + 1x1/score GEMMs)",
+                    "kernel": "dpc_conv_igemm (igemm_kernel + conv_halo_kernel: conv fwd + input-grad + 1x1/score GEMMs)",
                     "bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
-                    "traffic": None,
+                    "traffic": traffic, "traffic_unit": "GB of HBM traffic per launch (rocprofv3 PMC, profiles/*_pmc_traffic.json)",
+                    "algorithmic_GB_per_launch": round(ig["bytes"] / ig["launches"] / 1e9, 4),
                     "launches_per_step": ig["launches"] // args.steps,
                     "avg_launch_us": round(1e3 * ig["ms"] / ig["launches"], 2),
                     "flops_per_launch": round(ig["flops"] / ig["launches"] / 1e9, 3),

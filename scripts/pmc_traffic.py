@@ -1,0 +1,27 @@
+"""HBM traffic of the dominant kernel family from the rocprofv3 PMC passes of scripts/gpu_pmc.sh
+(FETCH_SIZE and WRITE_SIZE collected in separate --pmc runs, KiB units).  Correction per
+/opt/skills/guides/MI355X_MICROARCH.md §HBM: on gfx950 FETCH_SIZE reports exactly 1/2 of the bytes of
+wide (16 B/lane) coalesced streaming reads -- every load of these kernels is such a load -- so the read
+side is doubled; WRITE_SIZE is taken as is.  Writes profiles/<tag>_pmc_traffic.json."""
+import json, re, sqlite3, sys
+
+def per_kernel(path, counter):
+    cur = sqlite3.connect(path).cursor()
+    out = {}
+    for kn, v, n in cur.execute("select kernel_name, sum(value), count(distinct dispatch_id) from counters_collection where counter_name=? group by kernel_name", (counter,)):
+        out[re.sub(r"\(.*", "", kn).replace("void ", "")] = (v, n)
+    return out
+
+fetch = per_kernel(sys.argv[1], "FETCH_SIZE")
+write = per_kernel(sys.argv[2], "WRITE_SIZE")
+tag = sys.argv[3]
+res = {}
+for fam, pat in (("dpc_conv_igemm", r"igemm_kernel|conv_halo_kernel"), ("dpc_conv_wgrad", r"wgrad_kernel")):
+    f = sum(v for k, (v, n) in fetch.items() if re.search(pat, k))
+    w = sum(v for k, (v, n) in write.items() if re.search(pat, k))
+    n = sum(n for k, (v, n) in fetch.items() if re.search(pat, k))
+    res[fam] = {"launches": n, "fetch_KiB_raw": f, "write_KiB": w,
+                "hbm_bytes_per_launch": (2.0 * f + w) * 1024.0 / max(n, 1),
+                "note": "FETCH_SIZE x2 (gfx950 wide-load correction), WRITE_SIZE as reported; separate --pmc passes"}
+json.dump(res, open(f"profiles/{tag}_pmc_traffic.json", "w"), indent=1)
+print(json.dumps(res, indent=1))
