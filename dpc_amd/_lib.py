@@ -75,6 +75,7 @@ _SIGS = {
     "dpc_relu_bwd": [_vp, _vp, _i32, _vp, _i64, _vp, _i32, _vp],
     "dpc_colsum": [_vp, _i32, _i32, _i32, _i32, _vp, _i32, _vp, _i64, _vp],
     "dpc_pool_bn_bwd_reduce": [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, C.POINTER(_i32), _vp],
+    "dpc_pooled_bn_bwd_reduce": [_vp, _vp, _vp, _i32, _i64, _i32, _vp, _vp, _vp, C.POINTER(_i32), _vp],
     "dpc_pool_bn_bwd_apply": [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp],
     "dpc_gather_rows": [_vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp],
     "dpc_convert": [_vp, _i32, _vp, _i32, _i64, _vp],

@@ -116,12 +116,14 @@ __global__ void pack_input_s2d_kernel(const float* in, TO* out, int BN, int T, i
     const int Hb = H / 2, Wb = W / 2;
     const long long cells = (long long)BN * T * Hb * Wb;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < cells; i += (long long)gridDim.x * blockDim.x) {
-        const int wb = (int)(i % Wb);
-        long long q = i / Wb;
-        const int hb = (int)(q % Hb);
-        q /= Hb;
-        const int t = (int)(q % T);
-        const int n = (int)(q / T);
+        const unsigned ci = (unsigned)i;  // cells < 2^31: 32-bit index math
+        const unsigned q1 = ci / (unsigned)Wb;
+        const int wb = (int)(ci - q1 * (unsigned)Wb);
+        const unsigned q2 = q1 / (unsigned)Hb;
+        const int hb = (int)(q1 - q2 * (unsigned)Hb);
+        const unsigned n_ = q2 / (unsigned)T;
+        const int t = (int)(q2 - n_ * (unsigned)T);
+        const int n = (int)n_;
         float v[16];
         DPC_UNROLL
         for (int k = 12; k < 16; ++k) v[k] = 0.f;
@@ -134,9 +136,10 @@ __global__ void pack_input_s2d_kernel(const float* in, TO* out, int BN, int T, i
                 v[(sy * 2 + 0) * 3 + c] = x.x;
                 v[(sy * 2 + 1) * 3 + c] = x.y;
             }
-        TO* o = out + i * 16;
+        u32x4* o = (u32x4*)(out + i * 16);  // 16 channels = 2 (bf16) or 4 (f32) 16-byte units
+        constexpr int EPO = Elt<TO>::PER16;
         DPC_UNROLL
-        for (int k = 0; k < 16; ++k) o[k] = Elt<TO>::from_f32(v[k]);
+        for (int k = 0; k < 16 / EPO; ++k) o[k] = unit_pack<TO>(v + k * EPO);
     }
 }
 

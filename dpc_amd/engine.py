@@ -662,8 +662,9 @@ class DPCEngine:
         st = self.stem.out_shape
         u, C0 = self.stem, self.widths[0]
         pr = C.c_int32(0)
-        self.call("dpc_pool_bn_bwd_reduce", d, self.pool_arg, u.raw, dc, st[0] * st[1], st[2], st[3], C0, u.mean, u.invstd,
-                  self.stats, C.byref(pr))
+        ps = self.pool_shape
+        self.call("dpc_pooled_bn_bwd_reduce", d, self.pool_arg, self.pooled, dc, ps[0] * ps[1] * ps[2] * ps[3], C0,
+                  self.PRM[u.bnname + ".weight"], self.PRM[u.bnname + ".bias"], self.stats, C.byref(pr))
         self.call("dpc_bn_bwd_finalize", self.stats, pr.value, C0, float(u.rows), self.G[u.bnname + ".weight"],
                   self.G[u.bnname + ".bias"], self.coef)
         self.call("dpc_pool_bn_bwd_apply", d, self.pool_arg, u.raw, dc, st[0] * st[1], st[2], st[3], C0, u.mean, u.invstd,

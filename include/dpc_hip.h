@@ -132,6 +132,11 @@ int dpc_maxpool_bwd(const void* dy, const uint8_t* argmax, int32_t dtype, int32_
 int dpc_pool_bn_bwd_reduce(const void* dy, const uint8_t* argmax, const void* x, int32_t dtype, int32_t NT, int32_t H,
                            int32_t W, int32_t C, const float* mean, const float* invstd, float* partials, int32_t* prow,
                            dpc_stream_t stream);
+/* the same partial sums from the POOLED tensors only (y at an argmax position is the pooled value):
+ * sum dz = sum_p dp[p], sum dz*xhat = sum_p dp[p]*(ypool[p]-beta)/gamma over valid argmax bytes */
+int dpc_pooled_bn_bwd_reduce(const void* dy, const uint8_t* argmax, const void* ypool, int32_t dtype, int64_t rows,
+                             int32_t C, const float* gamma, const float* beta, float* partials, int32_t* prow,
+                             dpc_stream_t stream);
 int dpc_pool_bn_bwd_apply(const void* dy, const uint8_t* argmax, const void* x, int32_t dtype, int32_t NT, int32_t H,
                           int32_t W, int32_t C, const float* mean, const float* invstd, const float* gamma,
                           const float* coef, void* dx, dpc_stream_t stream);

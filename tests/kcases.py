@@ -274,6 +274,19 @@ def case_stem_pool(k: K, dtype, NT, H, W, Cc, seed=6):
     k.sync()
     t = 2e-3 if dtype == torch.float32 else 3e-2
     assert relerr(dx, xd.grad) < t and relerr(dbet, dz_ref.double().sum((0, 1, 2))) < t
+    # pooled-tensor form of the same partial sums (y at an argmax position is the pooled value): feed it the
+    # scale/shift the forward used as gamma*invstd / beta-mean*scale, i.e. gamma'=sc, beta'=sh, xhat'=x
+    prow2 = C.c_int32(0)
+    rows_p = NT * Ho * Wo
+    k.call("dpc_pooled_bn_bwd_reduce", None, None, None, L.dtype_code(dtype), rows_p, Cc, None, None, None, C.byref(prow2))
+    bp2 = k.zeros(prow2.value, 2, Cc)
+    k.call("dpc_pooled_bn_bwd_reduce", gyk, am, yk, L.dtype_code(dtype), rows_p, Cc, k.t(sc), k.t(sh), bp2, C.byref(prow2))
+    k.sync()
+    s_dz = bp2.cpu().double().sum(0)
+    ref1 = dz_ref.double().sum((0, 1, 2))
+    ref2 = (dz_ref.double() * x.double()).sum((0, 1, 2))   # with gamma'=sc, beta'=sh the recovered "xhat" is x itself
+    assert (s_dz[0] - ref1).abs().max().item() < t * max(ref1.abs().max().item(), 1.0)
+    assert (s_dz[1] - ref2).abs().max().item() < (t if dtype == torch.float32 else 6e-2) * max(ref2.abs().max().item(), 1.0)
 
 
 def case_tpool_split(k: K, dtype, B, N, T, SQ, D, P, seed=7):
