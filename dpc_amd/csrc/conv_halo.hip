@@ -23,7 +23,9 @@
 //   * MFMA fragments, C/D map, LDS-staged coalesced epilogue, fused BN partial sums and residual add
 //     are the same as in conv_igemm.hip.
 // Serves layer1 of the 2d3d-ResNet (C=64 bf16) -- the layer family where the LDS write bandwidth
-// (~80 B/clk/CU for ds_write_b128) of re-staging A per tap bounded the generic kernel.
+// (~80 B/clk/CU for ds_write_b128) of re-staging A per tap bounded the generic kernel -- and, with
+// UPP = 2 (32-byte positions: the 16-channel space-to-depth image), the stem's 1x4x4 convolution,
+// where one 128-byte K chunk is the four kw taps of a kernel row = four neighbouring positions.
 // An input-gradient with unit strides is the same convolution with pad' = K-1-pad and the tap order
 // reversed (the [Ci][tap][Co] weight pack is indexed with the flipped tap).
 #include "conv_common.h"
@@ -42,20 +44,24 @@ struct HaloParams {
     int vec_out;
 };
 
-template <class T, class TO, int KH, int KW>
+// UPP = 16-byte units per position: 8 (one tap = one 128-byte chunk) or 2 (one chunk = 4 kw taps, KW == 4)
+template <class T, class TO, int KH, int KW, int UPP>
 __global__ __launch_bounds__(256, 2) void conv_halo_kernel(HaloParams p) {
     constexpr int EPU = Elt<T>::PER16;
     constexpr int BM = 128, BN = 64;
-    constexpr int CBP = 128 + 16;       // one 128-byte position + 16 B pad
-    constexpr int MAXPOS = 228;
-    constexpr int NTAPS = KH * KW;
+    constexpr int SPP = UPP + 1;        // LDS slots per position: data units + one 16-byte pad slot
+    constexpr int CBP = SPP * 16;       // padded LDS pitch of a position (144 B / 48 B: conflict-free b128 reads)
+    constexpr int MAXPOS = UPP == 8 ? 228 : 252;
+    constexpr int NCH = UPP == 8 ? KW : 1;          // 128-byte K chunks per kernel row
+    constexpr int NTAPS = KH * NCH;                 // B chunks held in registers
+    constexpr int KKSTEP = UPP == 8 ? 32 : CBP;     // A-fragment address step per kk (two units / one position)
+    static_assert(UPP == 8 || (UPP == 2 && KW == 4), "a chunk is one tap, or the 4 kw taps of 32-byte positions");
     constexpr int EPO = 16 / (int)sizeof(TO);
     constexpr int UPR = BN / EPO;
     constexpr int OIT = BM * UPR / 256;
-    constexpr int DMA_IT = 9;                               // 9 x 256 lanes x 16 B >= MAXPOS positions x 9 slots
-    constexpr int HALO_BYTES = DMA_IT * 256 * 16;           // one position = 8 data slots + 1 pad slot of 16 B
+    constexpr int DMA_IT = (MAXPOS * SPP + 255) / 256;      // DMA_IT x 256 lanes x 16 B cover MAXPOS positions
     constexpr int STAGE_BYTES = BM * BN * (int)sizeof(TO);
-    static_assert(MAXPOS * CBP <= HALO_BYTES && STAGE_BYTES <= HALO_BYTES, "halo buffer doubles as the epilogue staging tile");
+    constexpr int HALO_BYTES = DMA_IT * 256 * 16 > STAGE_BYTES ? DMA_IT * 256 * 16 : STAGE_BYTES;  // doubles as the epilogue staging tile
     __shared__ __attribute__((aligned(16))) unsigned char lds2[2 * HALO_BYTES];
     __shared__ int rowmap[BM];
 
@@ -77,7 +83,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(HaloParams p) {
             const int tapw = p.flip ? (NTAPS - 1 - tap) : tap;
             DPC_UNROLL
             for (int kk = 0; kk < 4; ++kk)
-                fbr[tap][kk] = *(const u32x4*)(wp ? wp + ((long long)tapw * p.C * esz) + kk * 32 : zero);
+                fbr[tap][kk] = *(const u32x4*)(wp ? wp + (long long)tapw * 128 + kk * 32 : zero);  // chunk = 128 B of K
         }
     }
     int frag_a[2];
@@ -104,11 +110,11 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(HaloParams p) {
         DPC_NOUNROLL
         for (int it = 0; it < DMA_IT; ++it) {  // rolled on purpose: the register file belongs to the B operand
             const int slot = it * 256 + tid;
-            const int hpos = slot / 9, cu = slot - hpos * 9;
+            const int hpos = slot / SPP, cu = slot - hpos * SPP;
             const unsigned hr = fdiv((unsigned)hpos, p.d_hwd);
             const int hc = hpos - (int)hr * p.HWd;
             const int h = hb + (int)hr, w = wb + hc;
-            const bool ok = cu < 8 && hpos < npos && (unsigned)h < (unsigned)p.H && (unsigned)w < (unsigned)p.W;
+            const bool ok = cu < UPP && hpos < npos && (unsigned)h < (unsigned)p.H && (unsigned)w < (unsigned)p.W;
             const char* a = (const char*)p.src + ((long long)(((int)frame * p.H + h) * p.W + w) * p.C) * esz + cu * 16;
             glds16(ok ? a : zero, lds2 + bufoff + (it * 256 + wv * 64) * 16, lane);
         }
@@ -141,14 +147,14 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(HaloParams p) {
         for (int kh = 0; kh < KH; ++kh) {
             const int roff = kh * rowpitch;  // wave-uniform
             DPC_UNROLL
-            for (int kw = 0; kw < KW; ++kw) {
+            for (int ch = 0; ch < NCH; ++ch) {
                 DPC_UNROLL
                 for (int kk = 0; kk < 4; ++kk) {
                     u32x4 fa[2];
                     DPC_UNROLL
-                    for (int i = 0; i < 2; ++i) fa[i] = *(const u32x4*)(lds + frag_a[i] + roff + kw * CBP + kk * 32);
+                    for (int i = 0; i < 2; ++i) fa[i] = *(const u32x4*)(lds + frag_a[i] + roff + ch * CBP + kk * KKSTEP);
                     DPC_UNROLL
-                    for (int i = 0; i < 2; ++i) acc[i] = mfma_unit<T>(fa[i], fbr[kh * KW + kw][kk], acc[i]);
+                    for (int i = 0; i < 2; ++i) acc[i] = mfma_unit<T>(fa[i], fbr[kh * NCH + ch][kk], acc[i]);
                 }
             }
         }
@@ -252,10 +258,12 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(HaloParams p) {
 static bool halo_plan(const dpc_conv_desc* d, HaloParams* p) {
     if (d->KT != 1 || d->st != 1 || d->sh != 1 || d->sw != 1 || d->pt != 0) return false;
     if (d->RT != d->ST || d->RH != d->SH || d->RW != d->SW) return false;
-    if (d->src_ld != d->Ci || d->KH != 3 || d->KW != 3 || d->Co > 64) return false;
+    if (d->src_ld != d->Ci || d->Co > 64) return false;
     if (d->dtype_in != d->dtype_out) return false;
     const int esz = d->dtype_in == DPC_BF16 ? 2 : 4;
-    if (d->Ci * esz != 128) return false;
+    const bool k33 = d->KH == 3 && d->KW == 3 && d->Ci * esz == 128;                   // BasicBlock2d conv, 128 B per position
+    const bool k44 = d->KH == 4 && d->KW == 4 && d->Ci * esz == 32 && d->mode == 0;    // space-to-depth stem, 32 B per position
+    if (!k33 && !k44) return false;
     int tw = 32;
     while (tw > d->RW && tw > 4) tw >>= 1;
     p->TW = tw;
@@ -263,7 +271,7 @@ static bool halo_plan(const dpc_conv_desc* d, HaloParams* p) {
     p->TR = 128 / tw;
     p->HR = p->TR + d->KH - 1;
     p->HWd = p->TW + d->KW - 1;
-    if (p->HR * p->HWd > 228) return false;
+    if (p->HR * p->HWd > (k33 ? 228 : 252)) return false;
     p->NF = d->N * d->RT;
     p->H = d->RH; p->W = d->RW; p->C = d->Ci; p->Co = d->Co; p->ldw = d->ldw; p->ldo = d->ldo;
     p->flip = d->mode == 1;
@@ -297,10 +305,18 @@ int dpc_conv_halo_try(const dpc_conv_desc* d, const void* src, const void* wgt, 
     const int epo = d->dtype_out == DPC_BF16 ? 8 : 4;
     p.vec_out = (d->Co % epo == 0 && d->ldo % epo == 0 && ((uintptr_t)out % 16 == 0) && ((uintptr_t)addend % 16 == 0)) ? 1 : 0;
     dim3 grid((unsigned)p.gm), block(256);
-    if (d->dtype_in == DPC_F32) {
-        DPC_LAUNCH((conv_halo_kernel<float, float, 3, 3>), grid, block, stream, p);
+    if (d->KH == 3) {
+        if (d->dtype_in == DPC_F32) {
+            DPC_LAUNCH((conv_halo_kernel<float, float, 3, 3, 8>), grid, block, stream, p);
+        } else {
+            DPC_LAUNCH((conv_halo_kernel<bf16_t, bf16_t, 3, 3, 8>), grid, block, stream, p);
+        }
     } else {
-        DPC_LAUNCH((conv_halo_kernel<bf16_t, bf16_t, 3, 3>), grid, block, stream, p);
+        if (d->dtype_in == DPC_F32) {
+            DPC_LAUNCH((conv_halo_kernel<float, float, 4, 4, 2>), grid, block, stream, p);
+        } else {
+            DPC_LAUNCH((conv_halo_kernel<bf16_t, bf16_t, 4, 4, 2>), grid, block, stream, p);
+        }
     }
     return dpc_launch_status();
 }
