@@ -57,8 +57,16 @@ struct IGemmParams {
     int vec_out;  // Ncol and ldo are multiples of the 16-byte output unit
 };
 
+#ifndef DPC_IGEMM_DMA
+#define DPC_IGEMM_DMA 1
+#endif
+
 template <class T, class TO, int BN, int GATHER>
 __global__ __launch_bounds__(256, (BN == 64 ? 3 : 2)) void igemm_kernel(IGemmParams p) {
+    // DMA: operand units go global -> LDS directly (global_load_lds_dwordx4), no VGPR staging and no
+    // ds_write.  The LDS destination of a wave is lane-linear (8 rows x 8 slots), so the XOR swizzle
+    // moves to the SOURCE: the lane that owns slot s of row r fetches logical unit s ^ swz(r).
+    constexpr bool DMA = DPC_IGEMM_DMA != 0;
     constexpr int EPU = Elt<T>::PER16;
     constexpr int BKE = 8 * EPU;
     constexpr int BM = 128;
@@ -73,7 +81,8 @@ __global__ __launch_bounds__(256, (BN == 64 ? 3 : 2)) void igemm_kernel(IGemmPar
 
     const GatherGeom& g = p.g;
     const int tid = threadIdx.x;
-    const int u = tid & 7, r0 = tid >> 3;
+    const int r0 = tid >> 3;
+    const int u = DMA ? ((tid & 7) ^ lds_swz1(r0)) : (tid & 7);  // logical 16-byte unit of the chunk this thread moves
     const int lane = tid & 63, wv = tid >> 6;
     const int wm = wv >> 1, wn = wv & 1;
     const int l31 = lane & 31, lhi = lane >> 5;
@@ -184,7 +193,7 @@ __global__ __launch_bounds__(256, (BN == 64 ? 3 : 2)) void igemm_kernel(IGemmPar
                 for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
         u32x4 ra[4], rb[BROWS];
-        auto load_chunk = [&](int kc) {
+        auto load_chunk = [&](int kc, int dma_buf) {
             int k = kc * BKE + u * EPU;
             bool kok = k < g.Kp;
             if (GATHER == 3) {
@@ -198,7 +207,8 @@ __global__ __launch_bounds__(256, (BN == 64 ? 3 : 2)) void igemm_kernel(IGemmPar
                 for (int i = 0; i < 4; ++i) {
                     const bool ok = (vmask[i] & sel) == sel;
                     const char* a = (const char*)p.src + (long long)(rowbase[i] + tapoff) * esz;
-                    ra[i] = *(const u32x4*)(ok ? a : zero);
+                    if (DMA) glds16(ok ? a : zero, lds + dma_buf + (32 * i + wv * 8) * 128, lane);
+                    else ra[i] = *(const u32x4*)(ok ? a : zero);
                 }
             } else if (GATHER != 0) {
                 const int kd = (GATHER == 1) ? kc * BKE : k;  // GATHER 1: one tap per chunk -> wave-uniform decode
@@ -215,7 +225,8 @@ __global__ __launch_bounds__(256, (BN == 64 ? 3 : 2)) void igemm_kernel(IGemmPar
                 for (int i = 0; i < 4; ++i) {
                     const bool ok = kok && (vmask[i] & sel) == sel;
                     const char* a = (const char*)p.src + (long long)(rowbase[i] + tapoff) * esz;
-                    ra[i] = *(const u32x4*)(ok ? a : zero);
+                    if (DMA) glds16(ok ? a : zero, lds + dma_buf + (32 * i + wv * 8) * 128, lane);
+                    else ra[i] = *(const u32x4*)(ok ? a : zero);
                 }
             } else {
                 const TapPos tp = decode_k(g, k);
@@ -223,16 +234,20 @@ __global__ __launch_bounds__(256, (BN == 64 ? 3 : 2)) void igemm_kernel(IGemmPar
                 for (int i = 0; i < 4; ++i) {
                     const long long off = gather_off(g, rp[i], tp);
                     const char* a = (const char*)p.src + off * esz;
-                    ra[i] = *(const u32x4*)(off >= 0 ? a : zero);
+                    if (DMA) glds16(off >= 0 ? a : zero, lds + dma_buf + (32 * i + wv * 8) * 128, lane);
+                    else ra[i] = *(const u32x4*)(off >= 0 ? a : zero);
                 }
             }
             DPC_UNROLL
             for (int i = 0; i < BROWS; ++i) {
                 const char* b = (const char*)p.wgt + (wrow[i] + k) * esz;
-                rb[i] = *(const u32x4*)((kok && wrow[i] >= 0) ? b : zero);
+                const bool ok = kok && wrow[i] >= 0;
+                if (DMA) glds16(ok ? b : zero, lds + dma_buf + (BM + 32 * i + wv * 8) * 128, lane);
+                else rb[i] = *(const u32x4*)(ok ? b : zero);
             }
         };
         auto store_chunk = [&](int bufoff) {
+            if (DMA) return;
             unsigned char* base = lds + bufoff + stage_off;
             DPC_UNROLL
             for (int i = 0; i < 4; ++i) *(u32x4*)(base + 4096 * i) = ra[i];
@@ -255,17 +270,17 @@ __global__ __launch_bounds__(256, (BN == 64 ? 3 : 2)) void igemm_kernel(IGemmPar
         };
 
         if (nkc_t > 0) {  // a parity class may see no tap at all (strided 1x1x1): its rows are just 0 (+ addend)
-            load_chunk(0);
+            load_chunk(0, 0);
             store_chunk(0);
         }
         __syncthreads();
         for (int kc = 0; kc < nkc_t; kc += 2) {
-            if (kc + 1 < nkc_t) load_chunk(kc + 1);
+            if (kc + 1 < nkc_t) load_chunk(kc + 1, BUF);
             mma_chunk(0);
             if (kc + 1 < nkc_t) store_chunk(BUF);
             __syncthreads();
             if (kc + 1 < nkc_t) {
-                if (kc + 2 < nkc_t) load_chunk(kc + 2);
+                if (kc + 2 < nkc_t) load_chunk(kc + 2, 0);
                 mma_chunk(BUF);
                 if (kc + 2 < nkc_t) store_chunk(0);
                 __syncthreads();
