@@ -12,6 +12,7 @@
 // it in registers (free for f32, one pack per dword for bf16) and writes E 16-byte rows into
 // the swizzled LDS tile [channel][position].  The MFMA loop is the same as conv_igemm.hip.
 #include "conv_common.h"
+#include <stdlib.h>
 
 struct WgradParams {
     GatherGeom g;
@@ -231,6 +232,256 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------
+// Second-generation kernel (power-of-two RH, RW -- every conv of the 128-pixel configurations).
+//
+// The tiles stay in their memory orientation, [position][channel], so both operands are filled by
+// LDS-DMA (global_load_lds_dwordx4: no VGPR staging, no register transposes, no ds_write), and the
+// matrix-core fragments -- reduction index contiguous per lane -- are produced by the LDS transpose
+// read ds_read_b64_tr_b16 (bf16; f32 reads single dwords).  Every operand is cut into sub-tiles of
+// 64 channels x BKP positions = 8 KB; each wave owns one dy sub-tile and one source sub-tile and
+// computes 64 x 64 outputs (4 MFMA per 8 fragment reads: LDS read bytes per MFMA are 2/3 of the
+// 32 x 64 per-wave shape of wgrad_kernel, and there are no LDS writes from the SIMDs at all).
+// bf16 rows are 128 B; the 16-byte slot of row r is XORed with 2*(r&3), which makes the transpose
+// reads bank-conflict free (brute-forced against the ds_read_b64 lane groups); the DMA lands
+// lane-linearly, so the swizzle is applied to the *source* channel each lane fetches.
+struct Wgrad2Params {
+    GatherGeom g;
+    const void* src;
+    const void* dy;
+    float* part;
+    int Co, dy_ld;
+    int nks, kcps;
+    int ntm, ntn;
+    int lRW, lRH;  // log2
+};
+
+template <class T, int NWM, int NWN, bool PU>
+__global__ __launch_bounds__(64 * NWM * NWN, 2) void wgrad2_kernel(Wgrad2Params p) {
+    constexpr int E = Elt<T>::PER16;
+    constexpr int ESZ = (int)sizeof(T);
+    constexpr int BKP = 8 * E;              // positions per chunk: 64 (bf16) / 32 (f32)
+    constexpr int RB = 64 * ESZ;            // sub-tile row bytes: 128 / 256
+    constexpr int SPR = RB / 16;            // 16-byte slots per row: 8 / 16
+    constexpr int RPI = 64 / SPR;           // rows per DMA instruction: 8 / 4
+    constexpr int SUB = BKP * RB;           // 8 KB
+    constexpr int NW = NWM * NWN, NS = NWM + NWN;
+    constexpr int RR = (8 + NW - 1) / NW;   // DMA instructions per wave per sub-tile
+    constexpr int STAGE = NS * SUB;
+    constexpr int TM = 64 * NWM, TN = 64 * NWN;
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * STAGE];
+
+    const GatherGeom& g = p.g;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+#ifdef DPC_SIMT_EMU
+    const int wv = tid >> 6;
+#else
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+#endif
+    const int wm = wv / NWN, wn = wv % NWN;
+    const int l31 = lane & 31, lhi = lane >> 5;
+    int id = blockIdx.x;
+    const int tile_n = id % p.ntn; id /= p.ntn;
+    const int tile_m = id % p.ntm;
+    const int ks = id / p.ntm;
+
+    const int nchunks_total = (g.M + BKP - 1) / BKP;
+    const int c_begin = ks * p.kcps;
+    const int c_end = (c_begin + p.kcps < nchunks_total) ? c_begin + p.kcps : nchunks_total;
+
+    // ---- DMA lane constants: which channel group this lane fetches, which rows
+    const int rowlane = lane / SPR, pslot = lane % SPR;
+    const int lslot = (ESZ == 2) ? (pslot ^ (2 * (rowlane & 3))) : pslot;
+    const int cch = lslot * E;  // channel inside the 64-channel sub-tile
+    int r_row[RR], r_w[RR], r_h[RR], r_q[RR];
+    DPC_UNROLL
+    for (int rr = 0; rr < RR; ++rr) {
+        const int r = (wv + rr * NW) * RPI + rowlane;
+        r_row[rr] = r;
+        r_w[rr] = (r & (g.RW - 1)) * g.sw - g.pw;
+        r_h[rr] = ((r >> p.lRW) & (g.RH - 1)) * g.sh - g.ph;
+        r_q[rr] = r >> (p.lRW + p.lRH);
+    }
+    // Thread-constant parts of every DMA source address.  In a chunk that stays inside one (n, t) plane
+    // (PU) the position of row r is (n, t, h0 + r/RW, r%RW) with only (n, t, h0) -- block-uniform --
+    // changing from chunk to chunk, so
+    //   byte offset = U(chunk) * ld + b_off[rr][sb],  valid <=> t-tap inside && (unsigned)(h0*sh + b_h[rr][sb]) < SH
+    // where b_h also carries the (constant) verdicts "w inside" and "k' < Kp" as an out-of-range value.
+    int a_off[RR][NWM];
+    DPC_UNROLL
+    for (int sa = 0; sa < NWM; ++sa) {
+        const int co = tile_m * TM + sa * 64 + cch;
+        const bool ok = co + E <= p.dy_ld && co < p.Co;
+        DPC_UNROLL
+        for (int rr = 0; rr < RR; ++rr) a_off[rr][sa] = ok ? (r_row[rr] * p.dy_ld + co) * ESZ : -1;
+    }
+    TapPos tp[NWN];
+    int b_off[RR][NWN], b_h[RR][NWN];
+    const int ldb = g.src_ld * ESZ;
+    DPC_UNROLL
+    for (int sb = 0; sb < NWN; ++sb) {
+        tp[sb] = decode_k(g, tile_n * TN + sb * 64 + cch);
+        DPC_UNROLL
+        for (int rr = 0; rr < RR; ++rr) {
+            const int wi = r_w[rr] + tp[sb].kw;
+            const bool ok = tp[sb].ok && (unsigned)wi < (unsigned)g.SW;
+            b_h[rr][sb] = ok ? r_h[rr] + tp[sb].kh : (1 << 29);
+            b_off[rr][sb] = ((tp[sb].kt * g.SH + r_h[rr] + tp[sb].kh) * g.SW + wi) * ldb + tp[sb].ci * ESZ;
+        }
+    }
+
+    f32x16 acc[2][2];
+    DPC_UNROLL
+    for (int i = 0; i < 2; ++i)
+        DPC_UNROLL
+        for (int j = 0; j < 2; ++j)
+            DPC_UNROLL
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const char* const zero = (const char*)dpc_zero16;
+    auto issue = [&](int chunk, int buf) {
+        const int m0 = chunk * BKP;  // block-uniform
+        unsigned char* stage = lds + buf * STAGE;
+        const char* abase = (const char*)p.dy + (long long)m0 * p.dy_ld * ESZ;
+        const unsigned q0 = (unsigned)m0 >> (p.lRW + p.lRH);
+        const int h0 = PU ? (int)(((unsigned)m0 >> p.lRW) & (unsigned)(g.RH - 1)) * g.sh : 0;
+        const char* bbase = (const char*)p.src;
+        bool tv[NWN];
+        if (PU) {
+            const unsigned n = fdiv(q0, g.dRT);
+            const int t00 = ((int)q0 - (int)n * g.RT) * g.st - g.pt;
+            bbase += (long long)(((int)n * g.ST + t00) * g.SH + h0) * g.SW * ldb;
+            DPC_UNROLL
+            for (int sb = 0; sb < NWN; ++sb) tv[sb] = (unsigned)(t00 + tp[sb].kt) < (unsigned)g.ST;
+        }
+        DPC_UNROLL
+        for (int rr = 0; rr < RR; ++rr) {
+            const int rg = wv + rr * NW;
+            if (rg < 8) {
+                const bool mok = m0 + r_row[rr] < g.M;
+                DPC_UNROLL
+                for (int sa = 0; sa < NWM; ++sa)
+                    glds16((mok & (a_off[rr][sa] >= 0)) ? abase + a_off[rr][sa] : zero, stage + sa * SUB + rg * 1024, lane);
+                if (PU) {
+                    DPC_UNROLL
+                    for (int sb = 0; sb < NWN; ++sb) {
+                        const bool ok = mok & tv[sb] & ((unsigned)(h0 + b_h[rr][sb]) < (unsigned)g.SH);
+                        glds16(ok ? bbase + b_off[rr][sb] : zero, stage + (NWM + sb) * SUB + rg * 1024, lane);
+                    }
+                } else {
+                    // the chunk spans several (n, t) planes (RH*RW < BKP): decode the plane per row
+                    const unsigned q = q0 + (unsigned)r_q[rr];
+                    const unsigned n = fdiv(q, g.dRT);
+                    const int t0 = ((int)q - (int)n * g.RT) * g.st - g.pt;
+                    const char* pb = bbase + (long long)(((int)n * g.ST + t0) * g.SH) * g.SW * ldb;
+                    DPC_UNROLL
+                    for (int sb = 0; sb < NWN; ++sb) {
+                        const bool ok = mok & ((unsigned)(t0 + tp[sb].kt) < (unsigned)g.ST) & ((unsigned)b_h[rr][sb] < (unsigned)g.SH);
+                        glds16(ok ? pb + b_off[rr][sb] : zero, stage + (NWM + sb) * SUB + rg * 1024, lane);
+                    }
+                }
+            }
+        }
+    };
+
+    // ---- fragment lane offsets (same for both operands: all sub-tiles share one layout)
+    int fo[2];
+    if (ESZ == 2) {
+        const int gq = lane >> 4, s16 = lane & 15;
+        DPC_UNROLL
+        for (int i = 0; i < 2; ++i) {
+            const int colb = (i * 32 + (gq & 1) * 16 + 4 * (s16 & 3)) * 2;
+            fo[i] = ((gq >> 1) * 8 + (s16 >> 2)) * RB + ((((colb >> 4) ^ (2 * (s16 >> 2))) & 7) << 4) + (colb & 15);
+        }
+    } else {
+        DPC_UNROLL
+        for (int i = 0; i < 2; ++i) fo[i] = lhi * RB + (i * 32 + l31) * 4;
+    }
+
+    auto compute = [&](int buf) {
+        const unsigned char* As = lds + buf * STAGE + wm * SUB;
+        const unsigned char* Bs = lds + buf * STAGE + (NWM + wn) * SUB;
+        if (ESZ == 2) {
+            DPC_UNROLL
+            for (int kk = 0; kk < 4; ++kk) {
+                u32x4 fa[2], fb[2];
+                DPC_UNROLL
+                for (int i = 0; i < 2; ++i) {
+                    const u32x2 a0 = lds_read_tr16(As + fo[i] + (kk * 16) * RB);
+                    const u32x2 a1 = lds_read_tr16(As + fo[i] + (kk * 16 + 4) * RB);
+                    const u32x2 b0 = lds_read_tr16(Bs + fo[i] + (kk * 16) * RB);
+                    const u32x2 b1 = lds_read_tr16(Bs + fo[i] + (kk * 16 + 4) * RB);
+                    u32x4 ta = {a0[0], a0[1], a1[0], a1[1]};
+                    u32x4 tb = {b0[0], b0[1], b1[0], b1[1]};
+                    fa[i] = ta; fb[i] = tb;
+                }
+                DPC_UNROLL
+                for (int i = 0; i < 2; ++i)
+                    DPC_UNROLL
+                    for (int j = 0; j < 2; ++j) acc[i][j] = mfma_32x32x16_bf16(fa[i], fb[j], acc[i][j]);
+            }
+        } else {
+            DPC_UNROLL
+            for (int s2 = 0; s2 < BKP / 2; ++s2) {
+                float fa[2], fb[2];
+                DPC_UNROLL
+                for (int i = 0; i < 2; ++i) {
+                    fa[i] = *(const float*)(As + fo[i] + 2 * s2 * RB);
+                    fb[i] = *(const float*)(Bs + fo[i] + 2 * s2 * RB);
+                }
+                DPC_UNROLL
+                for (int i = 0; i < 2; ++i)
+                    DPC_UNROLL
+                    for (int j = 0; j < 2; ++j) acc[i][j] = mfma_32x32x2_f32(fa[i], fb[j], acc[i][j]);
+            }
+        }
+    };
+
+    if (c_begin < c_end) issue(c_begin, 0);
+    __syncthreads();
+    for (int ch = c_begin; ch < c_end; ++ch) {
+        const int buf = (ch - c_begin) & 1;
+        if (ch + 1 < c_end) issue(ch + 1, buf ^ 1);
+        compute(buf);
+        __syncthreads();
+    }
+
+    DPC_UNROLL
+    for (int j = 0; j < 2; ++j) {
+        const int col = tile_n * TN + wn * 64 + j * 32 + l31;
+        if (col < g.Kp) {
+            DPC_UNROLL
+            for (int i = 0; i < 2; ++i)
+                DPC_UNROLL
+                for (int r = 0; r < 16; ++r) {
+                    const int row = tile_m * TM + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                    if (row < p.Co) p.part[((long long)ks * p.Co + row) * g.Kp + col] = acc[i][j][r];
+                }
+        }
+    }
+}
+
+template <class T, int NWM, int NWN>
+static int launch_wgrad2_t(const Wgrad2Params& p, bool pu, hipStream_t stream) {
+    dim3 grid((unsigned)(p.ntm * p.ntn * p.nks)), block(64 * NWM * NWN);
+    if (pu) {
+        DPC_LAUNCH((wgrad2_kernel<T, NWM, NWN, true>), grid, block, stream, p);
+    } else {
+        DPC_LAUNCH((wgrad2_kernel<T, NWM, NWN, false>), grid, block, stream, p);
+    }
+    return dpc_launch_status();
+}
+
+template <class T>
+static int launch_wgrad2(const Wgrad2Params& p, int nwm, int nwn, bool pu, hipStream_t stream) {
+    if (nwm == 1 && nwn == 3) return launch_wgrad2_t<T, 1, 3>(p, pu, stream);
+    if (nwm == 1 && nwn == 4) return launch_wgrad2_t<T, 1, 4>(p, pu, stream);
+    if (nwm == 2 && nwn == 2) return launch_wgrad2_t<T, 2, 2>(p, pu, stream);
+    return launch_wgrad2_t<T, 2, 3>(p, pu, stream);
+}
+
 template <class T, bool RF>
 static int launch_wgrad_rf(const WgradParams& p, int tm, int tn, hipStream_t stream) {
     dim3 grid((unsigned)(p.ntm * p.ntn * p.nks)), block(256);
@@ -250,6 +501,15 @@ static int launch_wgrad(const WgradParams& p, int tm, int tn, hipStream_t stream
     return launch_wgrad_rf<T, false>(p, tm, tn, stream);
 }
 
+static bool wgrad_use_v1() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("DPC_WGRAD_V1");
+        v = (e && e[0] == '1') ? 1 : 0;
+    }
+    return v == 1;
+}
+
 extern "C" int dpc_conv_wgrad(const dpc_conv_desc* d, const void* src, const void* dy, int32_t dy_ld,
                               float* part, int32_t* nsplit, dpc_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
@@ -259,12 +519,25 @@ extern "C" int dpc_conv_wgrad(const dpc_conv_desc* d, const void* src, const voi
     if (rc) return rc;
     const int per16 = d->dtype_in == DPC_BF16 ? 8 : 4;
     if (dy_ld % per16 || dy_ld < d->Co) return DPC_ERR_UNSUPPORTED;
-    const int tm = d->Co > 64 ? 128 : 64;
-    const int tn = (p.g.Kp >= 128 || tm == 128) ? 128 : 64;
-    p.ntm = (d->Co + tm - 1) / tm;
-    p.ntn = (p.g.Kp + tn - 1) / tn;
     const int bkp = 8 * per16;
     const int nchunks = (p.g.M + bkp - 1) / bkp;
+    const int lrw = ilog2_exact(d->RW), lrh = ilog2_exact(d->RH);
+    const bool v2 = lrw >= 0 && lrh >= 0 && !wgrad_use_v1();
+    int tm, tn, nwm = 0, nwn = 0;
+    if (v2) {
+        // 64 x 64 per wave; the block is NWM x NWN waves.  NWN = 3 fits every 3x3 / 3x3x3 reduction
+        // (Kp = 9*Ci or 27*Ci with 64 | Ci) exactly; otherwise take the width with the least padding.
+        nwm = d->Co > 64 ? 2 : 1;
+        const int na = nwm == 1 ? 4 : 2, nb = 3;
+        const int pa = (p.g.Kp + 64 * na - 1) / (64 * na) * (64 * na), pb = (p.g.Kp + 64 * nb - 1) / (64 * nb) * (64 * nb);
+        nwn = (pb < pa) ? nb : na;
+        tm = 64 * nwm; tn = 64 * nwn;
+    } else {
+        tm = d->Co > 64 ? 128 : 64;
+        tn = (p.g.Kp >= 128 || tm == 128) ? 128 : 64;
+    }
+    p.ntm = (d->Co + tm - 1) / tm;
+    p.ntn = (p.g.Kp + tn - 1) / tn;
     int want = 1536 / (p.ntm * p.ntn);
     if (want < 1) want = 1;
     if (want > nchunks) want = nchunks;
@@ -274,6 +547,14 @@ extern "C" int dpc_conv_wgrad(const dpc_conv_desc* d, const void* src, const voi
     if (!part) return DPC_OK;  // size query
     if (!src || !dy) return DPC_ERR_ARG;
     p.src = src; p.dy = dy; p.part = part; p.Co = d->Co; p.dy_ld = dy_ld;
+    if (v2) {
+        Wgrad2Params q;
+        q.g = p.g; q.src = src; q.dy = dy; q.part = part; q.Co = d->Co; q.dy_ld = dy_ld;
+        q.nks = p.nks; q.kcps = p.kcps; q.ntm = p.ntm; q.ntn = p.ntn; q.lRW = lrw; q.lRH = lrh;
+        const bool pu = (d->RW * d->RH) % bkp == 0;  // a chunk never leaves its (n, t) plane
+        if (d->dtype_in == DPC_F32) return launch_wgrad2<float>(q, nwm, nwn, pu, stream);
+        return launch_wgrad2<bf16_t>(q, nwm, nwn, pu, stream);
+    }
     if (d->dtype_in == DPC_F32) return launch_wgrad<float>(p, tm, tn, stream);
     return launch_wgrad<bf16_t>(p, tm, tn, stream);
 }

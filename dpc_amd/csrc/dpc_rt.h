@@ -220,3 +220,18 @@ __device__ __forceinline__ void barrier_lds_only() {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 #endif
 }
+
+// LDS transpose read (gfx950 ds_read_b64_tr_b16): see tests/simt_emu/simt_emu.h for the lane map.
+// Lane l of a 16-lane group passes the address of row (l>>2), columns 4*(l&3).. of a 4 x 16 block of
+// 16-bit elements and receives column (l&15) of that block (4 elements, row order).
+__device__ __forceinline__ u32x2 lds_read_tr16(const unsigned char* lane_addr) {
+#ifdef DPC_SIMT_EMU
+    const uint64_t v = simt_ds_read_tr16_b64(lane_addr);
+    u32x2 r = {(uint32_t)v, (uint32_t)(v >> 32)};
+    return r;
+#else
+    typedef short v4i16_t __attribute__((ext_vector_type(4)));
+    const v4i16_t v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4i16_t*)lane_addr);
+    return __builtin_bit_cast(u32x2, v);
+#endif
+}

@@ -145,3 +145,23 @@ static inline simt_f32x16 simt_mfma_f32_32x32x16_bf16(simt_bf16x8 a, simt_bf16x8
     simt::sync_wave();
     return c;
 }
+
+// ds_read_b64_tr_b16 (semantics probed on MI355X, scripts/probes/tr16.*): every lane supplies the
+// address of 8 bytes (4 x 16-bit); inside each 16-lane group the 16 x 4 values form a 4 x 16 matrix
+// M[r][c] with M[r][4q..4q+3] = the data of source lane 4r+q; lane i receives column i: elem j = M[j][i].
+static inline uint64_t simt_ds_read_tr16_b64(const unsigned char* lane_addr) {
+    const int l = simt::cur.lane;
+    std::memcpy(simt::cur.w->xa[l], lane_addr, 8);
+    simt::sync_wave();
+    const int g = l >> 4, i = l & 15;
+    unsigned short out[4];
+    for (int j = 0; j < 4; ++j) {
+        unsigned short v[4];
+        std::memcpy(v, simt::cur.w->xa[g * 16 + 4 * j + (i >> 2)], 8);
+        out[j] = v[i & 3];
+    }
+    simt::sync_wave();
+    uint64_t r;
+    std::memcpy(&r, out, 8);
+    return r;
+}

@@ -60,6 +60,10 @@ def test_conv_dgrad(k, dtype, shape):
     (2, 64, 72, 3, 8, 8, (3, 3, 3), (2, 2, 2), (1, 1, 1)),
     (3, 32, 160, 2, 7, 5, (1, 1, 1), (1, 2, 2), (0, 0, 0)),
     (5, 8, 24, 2, 6, 6, (1, 3, 3), (1, 2, 2), (0, 1, 1)),
+    (2, 64, 64, 1, 8, 8, (1, 3, 3), (1, 1, 1), (0, 1, 1)),      # transpose-read kernel, 1x3 waves, chunk inside a plane
+    (2, 64, 136, 2, 8, 16, (1, 1, 1), (1, 2, 2), (0, 0, 0)),    # 2x2 waves, chunk spans planes (bf16)
+    (1, 64, 128, 3, 8, 8, (3, 3, 3), (1, 1, 1), (1, 1, 1)),     # 2x3 waves
+    (2, 256, 64, 1, 8, 8, (1, 1, 1), (1, 1, 1), (0, 0, 0)),     # 1x4 waves
 ])
 def test_conv_wgrad(k, dtype, shape):
     kc.case_conv_wgrad(k, dtype, *shape)
