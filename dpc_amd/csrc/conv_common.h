@@ -141,3 +141,8 @@ __device__ __forceinline__ u32x4 mask_unit(u32x4 v, bool ok) {
 int dpc_conv_halo_try(const dpc_conv_desc* d, const void* src, const void* wgt, void* out, const void* addend, float* stats,
                       hipStream_t stream);
 int dpc_conv_halo_rows(const dpc_conv_desc* d);
+
+// conv_igemm_ws.hip: loader/compute wave-specialised implicit GEMM for Co >= 128 (bf16); same contract.
+int dpc_conv_ws_try(const dpc_conv_desc* d, const void* src, const void* wgt, void* out, const void* addend, float* stats,
+                    hipStream_t stream);
+int dpc_conv_ws_rows(const dpc_conv_desc* d);

@@ -404,6 +404,8 @@ extern "C" int dpc_conv_stats_rows(const dpc_conv_desc* d) {
     if (rc) return rc;
     const int hr = dpc_conv_halo_rows(d);
     if (hr > 0) return hr;
+    const int wr = dpc_conv_ws_rows(d);
+    if (wr > 0) return wr;
     int ntm, ntn, gm, bn;
     igemm_grid(d, g.M, &ntm, &ntn, &gm, &bn);
     return gm;
@@ -492,6 +494,8 @@ extern "C" int dpc_conv_igemm(const dpc_conv_desc* d, const void* src, const voi
     if (d->ldw % per16) return DPC_ERR_UNSUPPORTED;
     if (d->ldo < d->Co || d->ldw < p.g.Kp) return DPC_ERR_ARG;
     rc = dpc_conv_halo_try(d, src, wgt, out, addend, stats, stream);  // LDS-staged patch kernel when the shape allows
+    if (rc != 1) return rc;
+    rc = dpc_conv_ws_try(d, src, wgt, out, addend, stats, stream);    // loader/compute specialised kernel for the wide layers
     if (rc != 1) return rc;
     p.src = src; p.wgt = wgt; p.out = out; p.addend = addend; p.stats = stats;
     p.Ncol = d->Co; p.ldw = d->ldw; p.ldo = d->ldo;

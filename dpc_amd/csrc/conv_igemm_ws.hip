@@ -1,0 +1,408 @@
+// conv_igemm_ws.hip -- implicit-GEMM convolution for the wide layers (Co >= 128: layer2..4 of the
+// 2d3d-ResNet, backbone/resnet_2d3d.py:14-32,241-244, forward and unit-stride input-gradient; the
+// 1x1 ConvGRU / prediction GEMMs, backbone/convrnn.py:13-15, dpc/model_3d.py:36-40), bf16 in / bf16 out.
+//
+// Same math, same LDS image and same fragment reads as conv_igemm.hip; what changes is WHO moves the
+// operands.  Measured on conv_igemm's 128 x 128 tile (rocprofv3 PMC, profiles/): the matrix cores are
+// busy 47 % of the main loop and the rest is the waves sitting in their own LDS-DMA issue -- a
+// 1 KB global_load_lds piece holds its wave for 60..180 cycles (the CU's texture addresser moves
+// 64 B/clk) and that wave cannot issue MFMAs meanwhile -- plus ~8 us per tile of exposed prologue
+// (first chunk from HBM) and epilogue.  Here a workgroup is 8 waves with two roles:
+//   * waves 0..3 (one per SIMD) only compute: 64 rows x 128 columns each of a 256 x 128 tile,
+//     24 ds_read_b128 + 32 MFMA per 128-byte K chunk, nothing else in the loop;
+//   * waves 4..7 (one per SIMD) only load: 12 LDS-DMA pieces per chunk each, three chunks in flight
+//     in a ring of three 48 KB stages, counted s_waitcnt vmcnt(12) (never 0) before the one barrier
+//     per chunk that publishes the oldest stage.  Their issue stalls cost the matrix cores nothing,
+//     and they run ahead across tile boundaries: the next tile's first two chunks land while the
+//     compute waves are in the epilogue, so there is no prologue after the first tile.
+//   * 256-row tiles halve the weight bytes per MFMA: 48 KB per 32 MFMA-per-SIMD = 47 B/clk/CU of
+//     the 64 the addresser can do.
+// Ordering rules (cdna_hip_programming.md, "Read a staged buffer one phase AFTER the wait that retires
+// it"): a stage is read only after the loaders' vmcnt wait AND the barrier that follows it; a stage is
+// refilled only after a barrier that every reader passed with its ds_reads consumed by MFMAs.
+// The epilogue stages each wave's 64 x 128 block through the LDS stage that was read last (free until
+// the next chunk barrier) in two wave-private 32-row passes -- no workgroup barrier inside.
+#include "conv_common.h"
+#include <stdlib.h>
+
+struct WsParams {
+    GatherGeom g;
+    const void* src;
+    const void* wgt;
+    void* out;
+    const void* addend;
+    float* stats;
+    int Ncol, ldw, ldo;
+    int gm, ntn, ntm;
+    unsigned src_bytes, wgt_bytes;
+    int dbg;
+};
+
+__device__ __forceinline__ void wait_vmcnt12() {
+#ifndef DPC_SIMT_EMU
+    asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+#endif
+}
+__device__ __forceinline__ void wait_vmcnt0() {
+#ifndef DPC_SIMT_EMU
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+}
+// instruction-scheduler fence: nothing is moved across it (the hardware sees no instruction)
+__device__ __forceinline__ void sched_fence() {
+#ifndef DPC_SIMT_EMU
+    __builtin_amdgcn_sched_barrier(0);
+#endif
+}
+// workgroup barrier that waits for nothing but this wave's LDS traffic
+__device__ __forceinline__ void ws_barrier() { barrier_lds_only(); }
+
+// ---- compute-wave fragment pipeline -------------------------------------------------------------
+struct FragSet {
+    u32x4 a[2], b[4];
+};
+#ifdef DPC_SIMT_EMU
+__device__ __forceinline__ void frag_read(FragSet& f, const unsigned char* st, int off_a, int off_b) {
+    for (int i = 0; i < 2; ++i) f.a[i] = *(const u32x4*)(st + off_a + 4096 * i);
+    for (int j = 0; j < 4; ++j) f.b[j] = *(const u32x4*)(st + off_b + 4096 * j);
+}
+template <int N> __device__ __forceinline__ void frag_wait(FragSet&) {}
+#else
+// six ds_read_b128 the compiler does not track (it would otherwise add its own, coarser waits)
+__device__ __forceinline__ void frag_read(FragSet& f, const unsigned char* st, int off_a, int off_b) {
+    const uint32_t base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const unsigned char*)st;
+    const uint32_t pa = base + (uint32_t)off_a, pb = base + (uint32_t)off_b;
+    asm volatile("ds_read_b128 %0, %6\n\t"
+                 "ds_read_b128 %1, %6 offset:4096\n\t"
+                 "ds_read_b128 %2, %7\n\t"
+                 "ds_read_b128 %3, %7 offset:4096\n\t"
+                 "ds_read_b128 %4, %7 offset:8192\n\t"
+                 "ds_read_b128 %5, %7 offset:12288"
+                 : "=&v"(f.a[0]), "=&v"(f.a[1]), "=&v"(f.b[0]), "=&v"(f.b[1]), "=&v"(f.b[2]), "=&v"(f.b[3])
+                 : "v"(pa), "v"(pb)
+                 : "memory");
+}
+// wait until at most N of this wave's LDS reads are outstanding; the "+v" ties make every later use of
+// the set depend on the wait
+template <int N> __device__ __forceinline__ void frag_wait(FragSet& f) {
+    asm volatile("s_waitcnt lgkmcnt(%6)"
+                 : "+v"(f.a[0]), "+v"(f.a[1]), "+v"(f.b[0]), "+v"(f.b[1]), "+v"(f.b[2]), "+v"(f.b[3])
+                 : "n"(N)
+                 : "memory");
+}
+#endif
+__device__ __forceinline__ void mma_step(f32x16 (&acc)[2][4], const FragSet& f) {
+    DPC_UNROLL
+    for (int i = 0; i < 2; ++i)
+        DPC_UNROLL
+        for (int j = 0; j < 4; ++j) acc[i][j] = mfma_32x32x16_bf16(f.a[i], f.b[j], acc[i][j]);
+}
+
+__global__ __launch_bounds__(512, 2) void igemm_ws_kernel(WsParams p) {
+    typedef bf16_t T;
+    typedef bf16_t TO;
+    constexpr int BM = 256, BN = 128, BKE = 64;
+    constexpr int STAGE = (BM + BN) * 128;  // 48 KB
+    constexpr int NST = 3;
+    constexpr int EPO = 8, UPR = BN / EPO;  // 16 output units per row
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[NST * STAGE];
+
+    const GatherGeom& g = p.g;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+#ifdef DPC_SIMT_EMU
+    const int wv = tid >> 6;
+#else
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+#endif
+    const int n_tile = blockIdx.x / p.gm;
+    const int m_prog = blockIdx.x % p.gm;
+    const int nkc = g.Kp / BKE;
+    const int my_tiles = (p.ntm - m_prog + p.gm - 1) / p.gm;
+    const int total = my_tiles * nkc;  // chunks this workgroup walks, across its tiles
+    const char* const zero = (const char*)dpc_zero16;
+
+    if (wv >= 4) {
+        // ------------------------------------------------------------------ loader waves
+        const int lw = wv - 4;
+        // piece j covers tile rows 8j..8j+7 (lane>>3 picks the row, lane&7 the 16-byte slot); this wave
+        // owns pieces lw, lw+4, ...: 8 of A, 4 of B.  swz1(row) = (4j + (lane>>4)) & 7 and 4j mod 8 is
+        // the same for all its pieces, so the logical unit u a lane fetches is a kernel constant.
+        const int rl = lane >> 3;
+        const int u = (lane & 7) ^ lds_swz1(8 * lw + rl);
+        // sources as buffer resources: 32-bit offsets, hardware zero-fill for padding / rows beyond M / columns beyond Ncol
+        const BufRsrc rs_a = make_buf_rsrc(p.src, p.src_bytes);
+        const BufRsrc rs_b = make_buf_rsrc(p.wgt, p.wgt_bytes);
+        unsigned wrow[4];
+        DPC_UNROLL
+        for (int i = 0; i < 4; ++i) {
+            const int n = n_tile * BN + 8 * (lw + 4 * i) + rl;
+            wrow[i] = n < p.Ncol ? (unsigned)(n * p.ldw + u * 8) * 2u : DPC_BUF_OOB;
+        }
+        unsigned rowoff[8];   // byte offset of (row, tap 0, this lane's channel group); wraps for rows that start in the padding
+        unsigned vmask[8];
+        auto decode_tile = [&](int mt) {
+            const int m0 = mt * BM;
+            DPC_UNROLL
+            for (int i = 0; i < 8; ++i) {
+                const RowPos rp = decode_row(g, m0 + 8 * (lw + 4 * i) + rl);
+                rowoff[i] = ((((((unsigned)(rp.nbase + rp.t0) * (unsigned)g.SH + (unsigned)rp.h0) * (unsigned)g.SW) + (unsigned)rp.w0) *
+                              (unsigned)g.src_ld) + (unsigned)(u * 8)) * 2u;
+                const int sgn = g.mode == 0 ? 1 : -1;
+                unsigned m = 0;
+                for (int k = 0; k < g.KT; ++k) m |= ((unsigned)(rp.t0 + sgn * k) < (unsigned)g.ST ? 1u : 0u) << k;
+                for (int k = 0; k < g.KH; ++k) m |= ((unsigned)(rp.h0 + sgn * k) < (unsigned)g.SH ? 1u : 0u) << (g.KT + k);
+                for (int k = 0; k < g.KW; ++k) m |= ((unsigned)(rp.w0 + sgn * k) < (unsigned)g.SW ? 1u : 0u) << (g.KT + g.KH + k);
+                vmask[i] = m;
+            }
+        };
+        auto issue = [&](int kc, int stage) {
+            // one tap per chunk (Ci is a multiple of 64): the tap decode is wave-uniform scalar work
+            const int kd = kc * BKE;
+            const int tap = (g.taps == 1) ? 0 : (kd >> g.log2C);
+            const unsigned q = fdiv((unsigned)tap, g.dKW);
+            const int kw = tap - (int)q * g.KW;
+            const unsigned kt = fdiv(q, g.dKH);
+            const int kh = (int)q - (int)kt * g.KH;
+            const unsigned sel = (1u << kt) | (1u << (g.KT + kh)) | (1u << (g.KT + g.KH + kw));
+            const int sgn = g.mode == 0 ? 1 : -1;
+            const int cbase = (g.taps == 1) ? 0 : (tap << g.log2C);
+            const unsigned tapoff = (unsigned)(sgn * ((((int)kt * g.SH + kh) * g.SW + kw) * g.src_ld) + (kd - cbase)) * 2u;
+            unsigned char* st = lds + stage * STAGE;
+            if (p.dbg & 2) return;
+            DPC_UNROLL
+            for (int i = 0; i < 8; ++i) {
+                const bool ok = (vmask[i] & sel) == sel;
+                glds16_buf(rs_a, ok ? rowoff[i] + tapoff : DPC_BUF_OOB, 0u, st + (lw + 4 * i) * 1024, lane);
+            }
+            DPC_UNROLL
+            for (int i = 0; i < 4; ++i) glds16_buf(rs_b, wrow[i], (unsigned)kd * 2u, st + BM * 128 + (lw + 4 * i) * 1024, lane);
+        };
+        // chunk counter -> (tile, kc) of the NEXT chunk to issue
+        int it_tile = 0, it_kc = 0;
+        auto issue_next = [&](int gc) {
+            if (it_kc == 0) decode_tile(m_prog + it_tile * p.gm);
+            issue(it_kc, gc % NST);
+            if (++it_kc == nkc) { it_kc = 0; ++it_tile; }
+        };
+        if (total > 0) issue_next(0);
+        if (total > 1) issue_next(1);
+        int kc_done = 0;  // position of chunk gc inside its tile
+        for (int gc = 0; gc < total; ++gc) {
+            if (gc + 1 < total) wait_vmcnt12(); else wait_vmcnt0();
+            ws_barrier();  // chunk gc is published; every reader is done with chunk gc-1
+            if (gc + 2 < total) issue_next(gc + 2);
+            if (++kc_done == nkc) {
+                kc_done = 0;
+                ws_barrier();  // matches the compute waves' "tile fully read" barrier
+            }
+        }
+    }
+
+    // ---------------------------------------------------------------------- compute waves
+    const int l31 = lane & 31, lhi = lane >> 5;
+    int frag_a[4], frag_b[4];
+    DPC_UNROLL
+    for (int kk = 0; kk < 4; ++kk) {
+        frag_a[kk] = lds_unit_off(wv * 64 + l31, 2 * kk + lhi);          // rows +32: +4096 B
+        frag_b[kk] = BM * 128 + lds_unit_off(l31, 2 * kk + lhi);          // columns +32: +4096 B
+    }
+    // epilogue lane constants: a pass stages 32 rows x 128 columns (8 KB) per wave
+    const int cu = lane & 15, er = lane >> 4;  // output unit column, first row of the lane inside a pass (rows er + 4*it)
+    const int col0 = n_tile * BN + cu * EPO;
+    float s1[EPO], s2[EPO];
+    DPC_UNROLL
+    for (int e = 0; e < EPO; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
+
+    int gc = 0;
+    for (int t = 0; wv < 4 && t < my_tiles; ++t) {
+        const int mt = m_prog + t * p.gm;
+        f32x16 acc[2][4];
+        DPC_UNROLL
+        for (int i = 0; i < 2; ++i)
+            DPC_UNROLL
+            for (int j = 0; j < 4; ++j)
+                DPC_UNROLL
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        // The chunk loop is software-pipelined ACROSS the chunk barrier: the barrier that publishes chunk
+        // gc+1 sits between MFMA steps 2 and 3 of chunk gc (all LDS reads of chunk gc are complete by then, so
+        // it is also the "stage gc may be refilled" point), and the first fragments of chunk gc+1 are read
+        // under the 8 MFMAs of step 3.  Fragment reads are inline asm with hand-counted waits: left to itself
+        // hipcc reuses one register set (every step then waits out a full LDS round trip: 64 % of the MFMA
+        // rate measured) or, given two sets, waits lgkmcnt(0) -- i.e. also for the reads it has just issued.
+        // Barrier sequence per tile, identical to the loaders': B(c0) B(c1) ... B(c_last) B("tile fully read").
+        int stage_last = 0;
+        if (p.dbg & 1) {  // experiment: loaders only
+            for (int kc = 0; kc < nkc; ++kc, ++gc) ws_barrier();
+            stage_last = (gc - 1) % NST;
+            ws_barrier();
+        } else {
+            FragSet f0, f1;
+            ws_barrier();  // first chunk of the tile published
+            const unsigned char* st = lds + (gc % NST) * STAGE;
+            frag_read(f0, st, frag_a[0], frag_b[0]);
+            for (int kc = 0; kc < nkc; ++kc) {
+                frag_read(f1, st, frag_a[1], frag_b[1]);
+                frag_wait<6>(f0);
+                mma_step(acc, f0);
+                sched_fence();
+                frag_read(f0, st, frag_a[2], frag_b[2]);
+                frag_wait<6>(f1);
+                mma_step(acc, f1);
+                sched_fence();
+                frag_read(f1, st, frag_a[3], frag_b[3]);
+                frag_wait<6>(f0);
+                mma_step(acc, f0);
+                sched_fence();
+                frag_wait<0>(f1);
+                ws_barrier();  // next chunk published -- or, after the tile's last chunk, "tile fully read"
+                stage_last = gc % NST;
+                ++gc;
+                if (kc + 1 < nkc) {
+                    st = lds + (gc % NST) * STAGE;
+                    frag_read(f0, st, frag_a[0], frag_b[0]);
+                }
+                mma_step(acc, f1);
+                sched_fence();
+            }
+        }
+
+        // ---- epilogue: two passes of 32 rows through this wave's 8 KB of the free stage
+        unsigned char* mine = lds + stage_last * STAGE + wv * 8192;
+        DPC_UNROLL
+        for (int i = 0; i < 2; ++i) {
+            TO* tile = (TO*)mine;
+            DPC_UNROLL
+            for (int j = 0; j < 4; ++j)
+                DPC_UNROLL
+                for (int r = 0; r < 16; ++r) {
+                    const int row_l = (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                    tile[row_l * BN + j * 32 + l31] = f32_to_bf16(acc[i][j][r]);
+                }
+            wave_lds_fence();  // wave-private region: LDS operations of one wave complete in order, no workgroup barrier
+            u32x4 ov[8], av[8];
+            DPC_UNROLL
+            for (int it = 0; it < 8; ++it) {
+                const int row_l = er + 4 * it;
+                ov[it] = *(const u32x4*)(mine + (row_l * BN + cu * EPO) * 2);
+                const int row = mt * BM + wv * 64 + i * 32 + row_l;
+                const bool ok = row < g.M && col0 < p.Ncol;
+                if (p.addend) {
+                    const char* a = (const char*)p.addend + ((long long)row * p.ldo + col0) * 2;
+                    av[it] = *(const u32x4*)(ok ? a : zero);
+                }
+            }
+            wave_lds_fence();  // the second pass overwrites what this one has just read
+            DPC_UNROLL
+            for (int it = 0; it < 8; ++it) {
+                const int row = mt * BM + wv * 64 + i * 32 + er + 4 * it;
+                if (row < g.M && col0 < p.Ncol) {
+                    u32x4 o = ov[it];
+                    if (p.addend) {
+                        float sv[EPO];
+                        DPC_UNROLL
+                        for (int e = 0; e < EPO; ++e) sv[e] = unit_get<TO>(o, e) + unit_get<TO>(av[it], e);
+                        o = unit_pack<TO>(sv);
+                    }
+                    *(u32x4*)((char*)p.out + ((long long)row * p.ldo + col0) * 2) = o;
+                    DPC_UNROLL
+                    for (int e = 0; e < EPO; ++e) {
+                        const float v = unit_get<TO>(o, e);
+                        s1[e] += v;
+                        s2[e] += v * v;
+                    }
+                }
+            }
+        }
+    }
+
+    if (p.stats) {
+        // 16 lanes x 4 compute waves hold partial sums of the same 8 columns: fold the 4 row-lanes of a wave
+        // by shuffles, then the 4 waves through LDS (the loader waves only keep the barriers company).
+        DPC_UNROLL
+        for (int e = 0; e < EPO; ++e) {
+            s1[e] += __shfl_xor(s1[e], 16); s1[e] += __shfl_xor(s1[e], 32);
+            s2[e] += __shfl_xor(s2[e], 16); s2[e] += __shfl_xor(s2[e], 32);
+        }
+        float* red = (float*)lds;  // [4 waves][2][128]
+        __syncthreads();
+        if (wv < 4 && lane < 16) {
+            DPC_UNROLL
+            for (int e = 0; e < EPO; ++e) {
+                red[(wv * 2 + 0) * BN + cu * EPO + e] = s1[e];
+                red[(wv * 2 + 1) * BN + cu * EPO + e] = s2[e];
+            }
+        }
+        __syncthreads();
+        if (tid < BN) {
+            const int col = n_tile * BN + tid;
+            if (col < p.Ncol) {
+                float a = 0.f, b = 0.f;
+                DPC_UNROLL
+                for (int w = 0; w < 4; ++w) {
+                    a += red[(w * 2 + 0) * BN + tid];
+                    b += red[(w * 2 + 1) * BN + tid];
+                }
+                p.stats[((long long)m_prog * 2 + 0) * p.Ncol + col] = a;
+                p.stats[((long long)m_prog * 2 + 1) * p.Ncol + col] = b;
+            }
+        }
+    }
+}
+
+static int env_int(const char* name, int dflt) {
+    const char* e = getenv(name);
+    return e ? atoi(e) : dflt;
+}
+// knobs for experiments and for the small shapes of the test tiers
+static int ws_enabled() { static int v = env_int("DPC_IGEMM_WS", 1); return v; }
+static int ws_min_rows() { static int v = env_int("DPC_IGEMM_WS_MINROWS", 256 * 64); return v; }
+static int ws_max_programs() { static int v = env_int("DPC_IGEMM_WS_GM", 256); return v; }
+
+static bool ws_plan(const dpc_conv_desc* d, WsParams* p) {
+    if (!ws_enabled()) return false;
+    if (d->dtype_in != DPC_BF16 || d->dtype_out != DPC_BF16) return false;
+    if (d->Co < 128 || d->Co % 8 || d->ldo % 8 || d->ldw % 8) return false;
+    GatherGeom& g = p->g;
+    if (make_gather_geom(d, &g)) return false;
+    if (g.Kp % 64 || (g.taps > 1 && g.Ci % 64)) return false;
+    const bool unit_strides = g.st == 1 && g.sh == 1 && g.sw == 1;
+    // byte offsets stay below DPC_BUF_OOB (2 GB), which therefore is out of range for the buffer resource
+    const bool fits32 = (long long)(g.M / (g.RT * g.RH * g.RW)) * g.ST * g.SH * g.SW * g.src_ld < (1ll << 30);
+    if (!fits32 || !(g.mode == 0 || unit_strides) || g.KT + g.KH + g.KW > 32) return false;
+    if (g.M < ws_min_rows()) return false;  // too few 256-row tiles to feed 256 CUs: the 128-row kernel balances better
+    p->Ncol = d->Co; p->ldw = d->ldw; p->ldo = d->ldo;
+    const long long wbytes = ((long long)(d->Co - 1) * d->ldw + g.Kp) * 2;
+    if (wbytes >= (1ll << 31)) return false;
+    p->src_bytes = (unsigned)((long long)(g.M / (g.RT * g.RH * g.RW)) * g.ST * g.SH * g.SW * g.src_ld * 2);
+    p->wgt_bytes = (unsigned)wbytes;
+    p->ntn = (d->Co + 127) / 128;
+    p->ntm = (g.M + 255) / 256;
+    // one resident workgroup per CU (144 KB of LDS); XCD x gets workgroups x, x+8, ...: keep gm a multiple
+    // of 8 so that the ntn column tiles of one row tile (blockIdx differing by gm) share an L2
+    int gm = ws_max_programs() / p->ntn;
+    if (gm < 1) gm = 1;
+    if (gm > p->ntm) gm = p->ntm;
+    if (gm >= 8) gm &= ~7;
+    p->gm = gm;
+    return true;
+}
+
+int dpc_conv_ws_rows(const dpc_conv_desc* d) {
+    WsParams p;
+    if (!d || !ws_plan(d, &p)) return 0;
+    return p.gm;
+}
+
+// returns 1 when the shape is not served by this kernel
+int dpc_conv_ws_try(const dpc_conv_desc* d, const void* src, const void* wgt, void* out, const void* addend, float* stats,
+                    hipStream_t stream) {
+    WsParams p;
+    if (!ws_plan(d, &p)) return 1;
+    if (((uintptr_t)out % 16) || ((uintptr_t)addend % 16) || ((uintptr_t)src % 16) || ((uintptr_t)wgt % 16)) return 1;
+    p.src = src; p.wgt = wgt; p.out = out; p.addend = addend; p.stats = stats;
+    p.dbg = env_int("DPC_IGEMM_WS_DBG", 0);
+    dim3 grid((unsigned)(p.gm * p.ntn)), block(512);
+    DPC_LAUNCH(igemm_ws_kernel, grid, block, stream, p);
+    return dpc_launch_status();
+}

@@ -255,6 +255,7 @@ struct Wgrad2Params {
     int nks, kcps;
     int ntm, ntn;
     int lRW, lRH;  // log2
+    int xcd_remap;
 };
 
 template <class T, int NWM, int NWN, bool PU>
@@ -282,7 +283,14 @@ __global__ __launch_bounds__(64 * NWM * NWN, 2) void wgrad2_kernel(Wgrad2Params 
 #endif
     const int wm = wv / NWN, wn = wv % NWN;
     const int l31 = lane & 31, lhi = lane >> 5;
+    // Workgroups are dealt to the 8 XCDs round-robin; remap so that an XCD owns a contiguous range of
+    // logical ids: the ntm*ntn tiles of one K-split (same dy rows, same source rows, shifted taps) then run
+    // next to each other under ONE L2 instead of being fetched by all eight.
     int id = blockIdx.x;
+    if (p.xcd_remap) {
+        const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, x = id & 7;
+        id = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (id >> 3);
+    }
     const int tile_n = id % p.ntn; id /= p.ntn;
     const int tile_m = id % p.ntm;
     const int ks = id / p.ntm;
@@ -551,6 +559,7 @@ extern "C" int dpc_conv_wgrad(const dpc_conv_desc* d, const void* src, const voi
         Wgrad2Params q;
         q.g = p.g; q.src = src; q.dy = dy; q.part = part; q.Co = d->Co; q.dy_ld = dy_ld;
         q.nks = p.nks; q.kcps = p.kcps; q.ntm = p.ntm; q.ntn = p.ntn; q.lRW = lrw; q.lRH = lrh;
+        { const char* e = getenv("DPC_WGRAD_XCD"); q.xcd_remap = (e && e[0] == '0') ? 0 : 1; }
         const bool pu = (d->RW * d->RH) % bkp == 0;  // a chunk never leaves its (n, t) plane
         if (d->dtype_in == DPC_F32) return launch_wgrad2<float>(q, nwm, nwn, pu, stream);
         return launch_wgrad2<bf16_t>(q, nwm, nwn, pu, stream);

@@ -235,3 +235,46 @@ __device__ __forceinline__ u32x2 lds_read_tr16(const unsigned char* lane_addr) {
     return __builtin_bit_cast(u32x2, v);
 #endif
 }
+
+// Ordering point for LDS traffic that stays inside ONE wave (write a wave-private region, read it back
+// with another lane mapping).  The hardware executes a wave's LDS instructions in order and the compiler
+// places the lgkmcnt wait; the host simulator runs lanes as fibers and needs the explicit rendezvous.
+__device__ __forceinline__ void wave_lds_fence() {
+#ifdef DPC_SIMT_EMU
+    simt::sync_wave();
+#else
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#endif
+}
+
+// LDS-DMA through a buffer resource (buffer_load_dwordx4 ... offen lds): like glds16, but the source is
+// base + voff + soff with a 32-bit per-lane offset and a wave-uniform scalar offset, and a lane whose
+// offset falls outside [0, nbytes) writes 16 zero bytes to LDS (probed on MI355X, scripts/probes/buflds.*):
+// padding and out-of-range rows cost one v_cndmask instead of a 64-bit address select.
+#ifdef DPC_SIMT_EMU
+struct BufRsrc {
+    const char* base;
+    uint32_t nbytes;
+};
+static inline BufRsrc make_buf_rsrc(const void* p, uint32_t nbytes) {
+    BufRsrc r = {(const char*)p, nbytes};
+    return r;
+}
+static inline void glds16_buf(const BufRsrc& r, uint32_t voff, uint32_t soff, unsigned char* lds_wave_base, int lane) {
+    const uint64_t o = (uint64_t)voff + soff;
+    if (voff < r.nbytes && o + 16 <= r.nbytes) std::memcpy(lds_wave_base + lane * 16, r.base + o, 16);
+    else std::memset(lds_wave_base + lane * 16, 0, 16);
+}
+#else
+typedef __amdgpu_buffer_rsrc_t BufRsrc;
+__device__ __forceinline__ BufRsrc make_buf_rsrc(const void* p, uint32_t nbytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)nbytes, 0x00020000);
+}
+__device__ __forceinline__ void glds16_buf(const BufRsrc& r, uint32_t voff, uint32_t soff, unsigned char* lds_wave_base, int lane) {
+    (void)lane;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)lds_wave_base, 16, (int)voff, (int)soff, 0, 0);
+}
+#endif
+#define DPC_BUF_OOB 0x80000000u

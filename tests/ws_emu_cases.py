@@ -1,0 +1,35 @@
+"""Cases for the loader/compute wave-specialised implicit GEMM (dpc_amd/csrc/conv_igemm_ws.hip) on the host
+SIMT simulator.  Run by tests/test_ws_emu.py in a child process: the kernel's row threshold and program
+count are read from the environment once per process (DPC_IGEMM_WS_MINROWS / DPC_IGEMM_WS_GM), so that
+small shapes reach it and one workgroup walks several tiles (ring of LDS stages across tile boundaries)."""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import kcases as kc  # noqa: E402
+from dpc_amd import _lib as L  # noqa: E402
+
+BF16 = torch.bfloat16
+
+
+def main():
+    assert os.environ.get("DPC_IGEMM_WS_MINROWS") == "1"
+    k = kc.K(L.load_emulator(), "cpu")
+    # forward: 3x3 / 3x3x3 / strided 1x1, ragged last tile, Co = 128 and a ragged second column tile
+    kc.case_conv_fwd(k, BF16, 3, 64, 128, 2, 10, 16, (1, 3, 3), (1, 1, 1), (0, 1, 1))      # 960 rows: 4 tiles, 2 programs
+    kc.case_conv_fwd(k, BF16, 2, 64, 136, 3, 8, 8, (3, 3, 3), (1, 1, 1), (1, 1, 1))        # two column tiles
+    kc.case_conv_fwd(k, BF16, 5, 128, 128, 2, 9, 7, (1, 1, 1), (1, 2, 2), (0, 0, 0))       # one tap, strided rows
+    # unit-stride input gradient (+ residual addend): the GEMM's columns are the conv's input channels
+    kc.case_conv_dgrad(k, BF16, 2, 128, 64, 2, 9, 16, (1, 3, 3), (1, 1, 1), (0, 1, 1))
+    kc.case_conv_dgrad(k, BF16, 1, 128, 128, 3, 6, 6, (3, 3, 3), (1, 1, 1), (1, 1, 1))
+    # plain NT GEMMs
+    kc.case_gemm_nt(k, BF16, 600, 136, 256)
+    kc.case_gemm_nt(k, BF16, 257, 128, 64)
+    print("ws cases ok")
+
+
+if __name__ == "__main__":
+    main()
