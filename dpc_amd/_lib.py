@@ -59,10 +59,10 @@ _SIGS = {
     "dpc_pack_stem_weight": [_vp, _vp, _i32, _i32, _vp],
     "dpc_unpack_stem_wgrad": [_vp, _i32, _vp, _i32, _vp],
     "dpc_bn_finalize": [_vp, _i32, _i32, _f64, _vp, _vp, _f32, _vp, _vp, _vp, _vp, _vp],
-    "dpc_bn_apply": [_vp, _vp, _i32, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _vp],
-    "dpc_bn_bwd_reduce": [_vp, _vp, _vp, _i32, _i64, _i32, _vp, _vp, _i32, _vp, C.POINTER(_i32), _vp],
+    "dpc_bn_apply": [_vp, _vp, _i32, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp],
+    "dpc_bn_bwd_reduce": [_vp, _vp, _vp, _vp, _i32, _i64, _i32, _vp, _vp, _i32, _vp, C.POINTER(_i32), _vp],
     "dpc_bn_bwd_finalize": [_vp, _i32, _i32, _f64, _vp, _vp, _vp, _vp],
-    "dpc_bn_bwd_apply": [_vp, _vp, _vp, _i32, _i64, _i32, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp],
+    "dpc_bn_bwd_apply": [_vp, _vp, _vp, _vp, _i32, _i64, _i32, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp],
     "dpc_bn_relu_maxpool_fwd": [_vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp],
     "dpc_maxpool_bwd": [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp],
     "dpc_tpool_split_fwd": [_vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp],

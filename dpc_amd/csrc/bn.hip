@@ -63,9 +63,17 @@ extern "C" int dpc_bn_finalize(const float* partials, int32_t rows, int32_t C, d
 // ------------------------------------------------------------------ forward apply (+res)(+relu)
 // FIXED: 256*E is a multiple of C, so a thread's channel group never changes across the grid-stride
 // loop and the per-channel coefficients live in registers (no 64-bit modulo, no per-element loads).
+// bit e = element e of the unit is > 0 (the ReLU pass-through mask)
+template <class T> __device__ __forceinline__ unsigned sign_bits(const u32x4& v) {
+    unsigned b = 0;
+    DPC_UNROLL
+    for (int e = 0; e < Elt<T>::PER16; ++e) b |= (unit_get<T>(v, e) > 0.f ? 1u : 0u) << e;
+    return b;
+}
+
 template <class T, bool FIXED>
 __global__ void bn_apply_kernel(const T* x, T* y, long long units, int C, const float* scale, const float* shift,
-                                const T* res, const float* rscale, const float* rshift, int relu) {
+                                const T* res, const float* rscale, const float* rshift, int relu, uint8_t* mask) {
     constexpr int E = Elt<T>::PER16;
     float sc[E], sh[E], rs[E], rb[E];
     if (FIXED) {
@@ -89,6 +97,7 @@ __global__ void bn_apply_kernel(const T* x, T* y, long long units, int C, const 
         u32x4 rv = {0u, 0u, 0u, 0u};
         if (res) rv = ((const u32x4*)res)[i];
         float ov[E];
+        unsigned bits = 0;
         DPC_UNROLL
         for (int e = 0; e < E; ++e) {
             float v = unit_get<T>(xv, e) * sc[e] + sh[e];
@@ -96,13 +105,19 @@ __global__ void bn_apply_kernel(const T* x, T* y, long long units, int C, const 
             if (relu) v = v > 0.f ? v : 0.f;
             ov[e] = v;
         }
-        ((u32x4*)y)[i] = unit_pack<T>(ov);
+        const u32x4 o = unit_pack<T>(ov);
+        ((u32x4*)y)[i] = o;
+        if (mask) {  // one byte per 16-byte unit: bit e = "stored y[e] > 0"; the backward reads this instead of y
+            DPC_UNROLL
+            for (int e = 0; e < E; ++e) bits |= (unit_get<T>(o, e) > 0.f ? 1u : 0u) << e;
+            mask[i] = (uint8_t)bits;
+        }
     }
 }
 
 extern "C" int dpc_bn_apply(const void* x, void* y, int32_t dtype, int64_t rows, int32_t C, const float* scale,
                             const float* shift, const void* res, const float* rscale, const float* rshift, int32_t relu,
-                            dpc_stream_t stream_) {
+                            uint8_t* mask, dpc_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (!x || !y || rows <= 0 || C <= 0 || !scale || !shift) return DPC_ERR_ARG;
     const int E = dtype == DPC_BF16 ? 8 : 4;
@@ -111,15 +126,15 @@ extern "C" int dpc_bn_apply(const void* x, void* y, int32_t dtype, int64_t rows,
     const bool fixed = (256 * E) % C == 0;
     if (dtype == DPC_F32) {
         if (fixed) {
-            DPC_LAUNCH((bn_apply_kernel<float, true>), dim3(grid_for(units)), dim3(256), stream, (const float*)x, (float*)y, units, C, scale, shift, (const float*)res, rscale, rshift, relu);
+            DPC_LAUNCH((bn_apply_kernel<float, true>), dim3(grid_for(units)), dim3(256), stream, (const float*)x, (float*)y, units, C, scale, shift, (const float*)res, rscale, rshift, relu, mask);
         } else {
-            DPC_LAUNCH((bn_apply_kernel<float, false>), dim3(grid_for(units)), dim3(256), stream, (const float*)x, (float*)y, units, C, scale, shift, (const float*)res, rscale, rshift, relu);
+            DPC_LAUNCH((bn_apply_kernel<float, false>), dim3(grid_for(units)), dim3(256), stream, (const float*)x, (float*)y, units, C, scale, shift, (const float*)res, rscale, rshift, relu, mask);
         }
     } else if (dtype == DPC_BF16) {
         if (fixed) {
-            DPC_LAUNCH((bn_apply_kernel<bf16_t, true>), dim3(grid_for(units)), dim3(256), stream, (const bf16_t*)x, (bf16_t*)y, units, C, scale, shift, (const bf16_t*)res, rscale, rshift, relu);
+            DPC_LAUNCH((bn_apply_kernel<bf16_t, true>), dim3(grid_for(units)), dim3(256), stream, (const bf16_t*)x, (bf16_t*)y, units, C, scale, shift, (const bf16_t*)res, rscale, rshift, relu, mask);
         } else {
-            DPC_LAUNCH((bn_apply_kernel<bf16_t, false>), dim3(grid_for(units)), dim3(256), stream, (const bf16_t*)x, (bf16_t*)y, units, C, scale, shift, (const bf16_t*)res, rscale, rshift, relu);
+            DPC_LAUNCH((bn_apply_kernel<bf16_t, false>), dim3(grid_for(units)), dim3(256), stream, (const bf16_t*)x, (bf16_t*)y, units, C, scale, shift, (const bf16_t*)res, rscale, rshift, relu, mask);
         }
     } else {
         return DPC_ERR_ARG;
@@ -130,7 +145,7 @@ extern "C" int dpc_bn_apply(const void* x, void* y, int32_t dtype, int64_t rows,
 // ------------------------------------------------------------------ backward reduce
 // dz = dy * (y > 0 if relu);  partial[b][0][c] = sum dz, partial[b][1][c] = sum dz * xhat
 template <class T>
-__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* dy, const T* y, const T* x, long long rows, int C,
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* dy, const T* y, const uint8_t* mask, const T* x, long long rows, int C,
                                                             const float* mean, const float* invstd, int relu,
                                                             float* partials, long long rows_per_block) {
     constexpr int E = Elt<T>::PER16;
@@ -153,12 +168,12 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* dy, const T
             const long long ui = r * upr + cu;
             const u32x4 dv = ((const u32x4*)dy)[ui];
             const u32x4 xv = ((const u32x4*)x)[ui];
-            u32x4 yv = {0u, 0u, 0u, 0u};
-            if (relu) yv = ((const u32x4*)y)[ui];
+            unsigned bits = ~0u;
+            if (relu) bits = mask ? (unsigned)mask[ui] : sign_bits<T>(((const u32x4*)y)[ui]);
             DPC_UNROLL
             for (int e = 0; e < E; ++e) {
                 float dz = unit_get<T>(dv, e);
-                if (relu && !(unit_get<T>(yv, e) > 0.f)) dz = 0.f;
+                if (!((bits >> e) & 1u)) dz = 0.f;
                 const float xh = (unit_get<T>(xv, e) - mu[e]) * is[e];
                 a1[e] += dz;
                 a2[e] += dz * xh;
@@ -199,7 +214,7 @@ static int bn_bwd_blocks(long long rows, int C, int E, long long* rows_per_block
     return (int)blocks;
 }
 
-extern "C" int dpc_bn_bwd_reduce(const void* dy, const void* y, const void* x, int32_t dtype, int64_t rows, int32_t C,
+extern "C" int dpc_bn_bwd_reduce(const void* dy, const void* y, const uint8_t* mask, const void* x, int32_t dtype, int64_t rows, int32_t C,
                                  const float* mean, const float* invstd, int32_t relu, float* partials, int32_t* prow,
                                  dpc_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
@@ -210,11 +225,11 @@ extern "C" int dpc_bn_bwd_reduce(const void* dy, const void* y, const void* x, i
     const int blocks = bn_bwd_blocks(rows, C, E, &rpb);
     if (prow) *prow = blocks;
     if (!partials) return DPC_OK;  // size query
-    if (!dy || !x || !mean || !invstd || (relu && !y)) return DPC_ERR_ARG;
+    if (!dy || !x || !mean || !invstd || (relu && !y && !mask)) return DPC_ERR_ARG;
     if (dtype == DPC_F32) {
-        DPC_LAUNCH((bn_bwd_reduce_kernel<float>), dim3(blocks), dim3(256), stream, (const float*)dy, (const float*)y, (const float*)x, (long long)rows, C, mean, invstd, relu, partials, rpb);
+        DPC_LAUNCH((bn_bwd_reduce_kernel<float>), dim3(blocks), dim3(256), stream, (const float*)dy, (const float*)y, mask, (const float*)x, (long long)rows, C, mean, invstd, relu, partials, rpb);
     } else if (dtype == DPC_BF16) {
-        DPC_LAUNCH((bn_bwd_reduce_kernel<bf16_t>), dim3(blocks), dim3(256), stream, (const bf16_t*)dy, (const bf16_t*)y, (const bf16_t*)x, (long long)rows, C, mean, invstd, relu, partials, rpb);
+        DPC_LAUNCH((bn_bwd_reduce_kernel<bf16_t>), dim3(blocks), dim3(256), stream, (const bf16_t*)dy, (const bf16_t*)y, mask, (const bf16_t*)x, (long long)rows, C, mean, invstd, relu, partials, rpb);
     } else {
         return DPC_ERR_ARG;
     }
@@ -243,7 +258,7 @@ extern "C" int dpc_bn_bwd_finalize(const float* partials, int32_t prow, int32_t 
 
 // dx = gamma*invstd*(dz - c1 - xhat*c2)
 template <class T, bool FIXED>
-__global__ void bn_bwd_apply_kernel(const T* dy, const T* y, const T* x, long long units, int C, const float* mean,
+__global__ void bn_bwd_apply_kernel(const T* dy, const T* y, const uint8_t* mask, const T* x, long long units, int C, const float* mean,
                                     const float* invstd, const float* gamma, const float* coef, int relu, T* dx, T* dzout) {
     constexpr int E = Elt<T>::PER16;
     float mu[E], is[E], ga[E], c1[E], c2[E];
@@ -266,13 +281,13 @@ __global__ void bn_bwd_apply_kernel(const T* dy, const T* y, const T* x, long lo
         }
         const u32x4 dv = ((const u32x4*)dy)[i];
         const u32x4 xv = ((const u32x4*)x)[i];
-        u32x4 yv = {0u, 0u, 0u, 0u};
-        if (relu) yv = ((const u32x4*)y)[i];
+        unsigned bits = ~0u;
+        if (relu) bits = mask ? (unsigned)mask[i] : sign_bits<T>(((const u32x4*)y)[i]);
         float ov[E], oz[E];
         DPC_UNROLL
         for (int e = 0; e < E; ++e) {
             float dz = unit_get<T>(dv, e);
-            if (relu && !(unit_get<T>(yv, e) > 0.f)) dz = 0.f;
+            if (!((bits >> e) & 1u)) dz = 0.f;
             const float xh = (unit_get<T>(xv, e) - mu[e]) * is[e];
             ov[e] = ga[e] * (dz - c1[e] - xh * c2[e]);
             oz[e] = dz;
@@ -282,26 +297,26 @@ __global__ void bn_bwd_apply_kernel(const T* dy, const T* y, const T* x, long lo
     }
 }
 
-extern "C" int dpc_bn_bwd_apply(const void* dy, const void* y, const void* x, int32_t dtype, int64_t rows, int32_t C,
+extern "C" int dpc_bn_bwd_apply(const void* dy, const void* y, const uint8_t* mask, const void* x, int32_t dtype, int64_t rows, int32_t C,
                                 const float* mean, const float* invstd, const float* gamma, const float* coef, int32_t relu,
                                 void* dx, void* dz, dpc_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
-    if (!dy || !x || !dx || rows <= 0 || C <= 0 || !mean || !invstd || !gamma || !coef || (relu && !y)) return DPC_ERR_ARG;
+    if (!dy || !x || !dx || rows <= 0 || C <= 0 || !mean || !invstd || !gamma || !coef || (relu && !y && !mask)) return DPC_ERR_ARG;
     const int E = dtype == DPC_BF16 ? 8 : 4;
     if (C % E) return DPC_ERR_UNSUPPORTED;
     const long long units = rows * C / E;
     const bool fixed = (256 * E) % C == 0;
     if (dtype == DPC_F32) {
         if (fixed) {
-            DPC_LAUNCH((bn_bwd_apply_kernel<float, true>), dim3(grid_for(units)), dim3(256), stream, (const float*)dy, (const float*)y, (const float*)x, units, C, mean, invstd, gamma, coef, relu, (float*)dx, (float*)dz);
+            DPC_LAUNCH((bn_bwd_apply_kernel<float, true>), dim3(grid_for(units)), dim3(256), stream, (const float*)dy, (const float*)y, mask, (const float*)x, units, C, mean, invstd, gamma, coef, relu, (float*)dx, (float*)dz);
         } else {
-            DPC_LAUNCH((bn_bwd_apply_kernel<float, false>), dim3(grid_for(units)), dim3(256), stream, (const float*)dy, (const float*)y, (const float*)x, units, C, mean, invstd, gamma, coef, relu, (float*)dx, (float*)dz);
+            DPC_LAUNCH((bn_bwd_apply_kernel<float, false>), dim3(grid_for(units)), dim3(256), stream, (const float*)dy, (const float*)y, mask, (const float*)x, units, C, mean, invstd, gamma, coef, relu, (float*)dx, (float*)dz);
         }
     } else if (dtype == DPC_BF16) {
         if (fixed) {
-            DPC_LAUNCH((bn_bwd_apply_kernel<bf16_t, true>), dim3(grid_for(units)), dim3(256), stream, (const bf16_t*)dy, (const bf16_t*)y, (const bf16_t*)x, units, C, mean, invstd, gamma, coef, relu, (bf16_t*)dx, (bf16_t*)dz);
+            DPC_LAUNCH((bn_bwd_apply_kernel<bf16_t, true>), dim3(grid_for(units)), dim3(256), stream, (const bf16_t*)dy, (const bf16_t*)y, mask, (const bf16_t*)x, units, C, mean, invstd, gamma, coef, relu, (bf16_t*)dx, (bf16_t*)dz);
         } else {
-            DPC_LAUNCH((bn_bwd_apply_kernel<bf16_t, false>), dim3(grid_for(units)), dim3(256), stream, (const bf16_t*)dy, (const bf16_t*)y, (const bf16_t*)x, units, C, mean, invstd, gamma, coef, relu, (bf16_t*)dx, (bf16_t*)dz);
+            DPC_LAUNCH((bn_bwd_apply_kernel<bf16_t, false>), dim3(grid_for(units)), dim3(256), stream, (const bf16_t*)dy, (const bf16_t*)y, mask, (const bf16_t*)x, units, C, mean, invstd, gamma, coef, relu, (bf16_t*)dx, (bf16_t*)dz);
         }
     } else {
         return DPC_ERR_ARG;

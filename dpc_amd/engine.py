@@ -158,6 +158,7 @@ class _ConvBN:
         self.wp = eng.empty((Co, Kp), dt)
         self.wd = None if stem else eng.empty((Ci, self.taps * Co), dt)
         self.raw = eng.empty((No, To, Ho, Wo, Co), dt)
+        self.mask = None  # ReLU sign mask of the activation that follows, allocated on first use
         self.stat_rows = eng.lib.call("dpc_conv_stats_rows", C.byref(self.desc_f))
         eng.need_stats(self.stat_rows * 2 * Co)
         self.mean, self.invstd, self.scale, self.shift = (eng.empty((Co,), torch.float32) for _ in range(4))
@@ -165,7 +166,7 @@ class _ConvBN:
         eng.lib.call("dpc_conv_wgrad", C.byref(self.desc_w), None, None, Co, None, C.byref(ns), eng.lib.stream())
         eng.need_part(ns.value * Co * Kp)
         pr = C.c_int32(0)
-        eng.lib.call("dpc_bn_bwd_reduce", None, None, None, dc, self.rows, Co, None, None, 0, None, C.byref(pr), eng.lib.stream())
+        eng.lib.call("dpc_bn_bwd_reduce", None, None, None, None, dc, self.rows, Co, None, None, 0, None, C.byref(pr), eng.lib.stream())
         eng.need_stats(pr.value * 2 * Co)
 
     # ---- per-optimizer-step repack of the f32 parameter into MFMA operand layouts
@@ -189,8 +190,11 @@ class _ConvBN:
 
     def apply(self, y: torch.Tensor, relu: bool, res: Optional[torch.Tensor] = None, res_unit: "Optional[_ConvBN]" = None):
         e = self.eng
+        if relu and self.mask is None:  # byte per 16-byte unit: what the backward reads instead of y
+            self.mask = e.empty((self.rows * self.Co * self.raw.element_size() // 16,), torch.uint8)
         e.call("dpc_bn_apply", self.raw, y, L.dtype_code(e.cdtype), self.rows, self.Co, self.scale, self.shift, res,
-               res_unit.scale if res_unit else None, res_unit.shift if res_unit else None, int(relu))
+               res_unit.scale if res_unit else None, res_unit.shift if res_unit else None, int(relu),
+               self.mask if relu else None)
 
     # ---- backward pieces
     def bn_backward(self, dy: torch.Tensor, y: Optional[torch.Tensor], relu: bool, dx: torch.Tensor,
@@ -198,12 +202,13 @@ class _ConvBN:
         e = self.eng
         dc = L.dtype_code(e.cdtype)
         pr = C.c_int32(0)
-        e.call("dpc_bn_bwd_reduce", dy, y, self.raw, dc, self.rows, self.Co, self.mean, self.invstd, int(relu), e.stats,
-               C.byref(pr))
+        mask = self.mask if relu else None
+        e.call("dpc_bn_bwd_reduce", dy, None if mask is not None else y, mask, self.raw, dc, self.rows, self.Co, self.mean,
+               self.invstd, int(relu), e.stats, C.byref(pr))
         e.call("dpc_bn_bwd_finalize", e.stats, pr.value, self.Co, float(self.rows), e.G[self.bnname + ".weight"],
                e.G[self.bnname + ".bias"], e.coef)
-        e.call("dpc_bn_bwd_apply", dy, y, self.raw, dc, self.rows, self.Co, self.mean, self.invstd,
-               e.PRM[self.bnname + ".weight"], e.coef, int(relu), dx, dz)
+        e.call("dpc_bn_bwd_apply", dy, None if mask is not None else y, mask, self.raw, dc, self.rows, self.Co, self.mean,
+               self.invstd, e.PRM[self.bnname + ".weight"], e.coef, int(relu), dx, dz)
 
     def wgrad(self, x: torch.Tensor, draw: torch.Tensor):
         e = self.eng

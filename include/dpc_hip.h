@@ -107,16 +107,18 @@ int dpc_bn_finalize(const float* partials, int32_t rows, int32_t C, double count
  * (BasicBlock tail, resnet_2d3d.py:67-80,105-116) */
 int dpc_bn_apply(const void* x, void* y, int32_t dtype, int64_t rows, int32_t C, const float* scale,
                  const float* shift, const void* res, const float* rscale, const float* rshift, int32_t relu,
-                 dpc_stream_t stream);
-/* backward: dz = dy * (y>0 if relu); partial sums of dz and dz*xhat -> [rows][2][C] */
-int dpc_bn_bwd_reduce(const void* dy, const void* y, const void* x, int32_t dtype, int64_t rows, int32_t C,
+                 uint8_t* mask, dpc_stream_t stream);
+/* backward: dz = dy * (y>0 if relu); partial sums of dz and dz*xhat -> [rows][2][C].  The ReLU pattern comes
+ * from `mask` (the byte-per-16-byte-unit sign mask dpc_bn_apply wrote: 1/16 of the bytes of y) or, when mask
+ * is NULL, from y itself. */
+int dpc_bn_bwd_reduce(const void* dy, const void* y, const uint8_t* mask, const void* x, int32_t dtype, int64_t rows, int32_t C,
                       const float* mean, const float* invstd, int32_t relu, float* partials, int32_t* prow,
                       dpc_stream_t stream);
 /* sums [prow][2][C] -> dgamma , dbeta, and coefficients c1=sum_dz/count, c2=sum_dzxhat/count */
 int dpc_bn_bwd_finalize(const float* partials, int32_t prow, int32_t C, double count, float* dgamma, float* dbeta,
                         float* coef, dpc_stream_t stream);
 /* dx = gamma*invstd*(dz - c1 - xhat*c2); optionally also writes dz (residual branch grad) */
-int dpc_bn_bwd_apply(const void* dy, const void* y, const void* x, int32_t dtype, int64_t rows, int32_t C,
+int dpc_bn_bwd_apply(const void* dy, const void* y, const uint8_t* mask, const void* x, int32_t dtype, int64_t rows, int32_t C,
                      const float* mean, const float* invstd, const float* gamma, const float* coef, int32_t relu,
                      void* dx, void* dz, dpc_stream_t stream);
 

@@ -29,6 +29,12 @@ def q(x, dtype):  # quantise like the device tensor will be
     return x.to(dtype).float()
 
 
+def bits_of(y, E):
+    """byte-per-unit sign mask of a [rows, C] tensor (what dpc_bn_apply writes)"""
+    b = (y.float().cpu().reshape(-1, E) > 0).to(torch.int32) * (1 << torch.arange(E, dtype=torch.int32))
+    return b.sum(1)
+
+
 def relerr(a, b):
     return (a.float().cpu() - b.float()).abs().max().item() / max(b.abs().max().item(), 1e-6)
 
@@ -202,33 +208,40 @@ def case_bn_fwd_bwd(k: K, dtype, rows, Cc, relu, res_mode, seed=5):
     assert relerr(dm, mean.detach()) < 1e-5 and relerr(di, invstd.detach()) < 1e-4
     xk = k.t(x, dtype)
     yk = k.empty(rows, Cc, dtype=dtype)
+    E = 4 if dtype == torch.float32 else 8
+    mk = k.zeros(rows * Cc // E, dtype=torch.uint8)  # ReLU sign mask, one byte per 16-byte unit
     k.call("dpc_bn_apply", L._p(xk), L._p(yk), L.dtype_code(dtype), rows, Cc, L._p(dsc), L._p(dsh),
            L._p(None if res is None else k.t(res, dtype)), L._p(None if rs is None else k.t(rs)),
-           L._p(None if rb is None else k.t(rb)), int(relu))
+           L._p(None if rb is None else k.t(rb)), int(relu), L._p(mk))
     k.sync()
     assert relerr(yk, y.detach()) < tol(dtype)
+    bits = (yk.float().cpu().reshape(-1, E) > 0).to(torch.int32) * (1 << torch.arange(E, dtype=torch.int32))
+    assert torch.equal(mk.cpu().to(torch.int32), bits.sum(1))
     # backward
     gy = q(torch.randn(rows, Cc, generator=g), dtype)
     y.backward(gy.double())
     yq = k.t(y.detach().float(), dtype)  # saved post-activation output (mask source)
     gyk = k.t(gy, dtype)
     prow = C.c_int32(0)
-    k.call("dpc_bn_bwd_reduce", None, None, None, L.dtype_code(dtype), rows, Cc, None, None, int(relu), None, C.byref(prow))
-    bp = k.zeros(prow.value, 2, Cc)
-    k.call("dpc_bn_bwd_reduce", L._p(gyk), L._p(yq), L._p(xk), L.dtype_code(dtype), rows, Cc, L._p(dm), L._p(di),
-           int(relu), L._p(bp), C.byref(prow))
-    dgam, dbet, coef = k.empty(Cc), k.empty(Cc), k.empty(2, Cc)
-    k.call("dpc_bn_bwd_finalize", L._p(bp), prow.value, Cc, float(rows), L._p(dgam), L._p(dbet), L._p(coef))
-    dx = k.empty(rows, Cc, dtype=dtype)
-    dz = k.empty(rows, Cc, dtype=dtype)
-    k.call("dpc_bn_bwd_apply", L._p(gyk), L._p(yq), L._p(xk), L.dtype_code(dtype), rows, Cc, L._p(dm), L._p(di),
-           L._p(k.t(gamma)), L._p(coef), int(relu), L._p(dx), L._p(dz))
-    k.sync()
-    t = 2e-3 if dtype == torch.float32 else 3e-2  # relu-mask flips of y~0 elements are excluded by construction
-    assert relerr(dgam, gd.grad) < t and relerr(dbet, bd.grad) < t
-    assert relerr(dx, xd.grad) < t
-    dz_ref = gy.double() * ((y.detach() > 0).double() if relu else 1.0)
-    assert relerr(dz, dz_ref) < tol(dtype)
+    k.call("dpc_bn_bwd_reduce", None, None, None, None, L.dtype_code(dtype), rows, Cc, None, None, int(relu), None, C.byref(prow))
+    # the ReLU pattern comes either from the saved output y or from the byte mask of the kernel's own forward
+    mq = k.t((bits_of(yq, E)).to(torch.uint8))
+    for ysrc, msrc in ((yq, None), (None, mq)) if relu else ((None, None),):
+        bp = k.zeros(prow.value, 2, Cc)
+        k.call("dpc_bn_bwd_reduce", L._p(gyk), L._p(ysrc), L._p(msrc), L._p(xk), L.dtype_code(dtype), rows, Cc, L._p(dm), L._p(di),
+               int(relu), L._p(bp), C.byref(prow))
+        dgam, dbet, coef = k.empty(Cc), k.empty(Cc), k.empty(2, Cc)
+        k.call("dpc_bn_bwd_finalize", L._p(bp), prow.value, Cc, float(rows), L._p(dgam), L._p(dbet), L._p(coef))
+        dx = k.empty(rows, Cc, dtype=dtype)
+        dz = k.empty(rows, Cc, dtype=dtype)
+        k.call("dpc_bn_bwd_apply", L._p(gyk), L._p(ysrc), L._p(msrc), L._p(xk), L.dtype_code(dtype), rows, Cc, L._p(dm), L._p(di),
+               L._p(k.t(gamma)), L._p(coef), int(relu), L._p(dx), L._p(dz))
+        k.sync()
+        t = 2e-3 if dtype == torch.float32 else 3e-2  # relu-mask flips of y~0 elements are excluded by construction
+        assert relerr(dgam, gd.grad) < t and relerr(dbet, bd.grad) < t
+        assert relerr(dx, xd.grad) < t
+        dz_ref = gy.double() * ((y.detach() > 0).double() if relu else 1.0)
+        assert relerr(dz, dz_ref) < tol(dtype)
 
 
 def case_stem_pool(k: K, dtype, NT, H, W, Cc, seed=6):
