@@ -146,3 +146,7 @@ int dpc_conv_halo_rows(const dpc_conv_desc* d);
 int dpc_conv_ws_try(const dpc_conv_desc* d, const void* src, const void* wgt, void* out, const void* addend, float* stats,
                     hipStream_t stream);
 int dpc_conv_ws_rows(const dpc_conv_desc* d);
+
+// conv_wgrad_patch.hip: weight gradient of 1x3x3 stride-1 convs from one staged source patch (bf16).
+int dpc_wgrad_patch_try(const dpc_conv_desc* d, const void* src, const void* dy, int dy_ld, float* part, int32_t* nsplit,
+                        hipStream_t stream);

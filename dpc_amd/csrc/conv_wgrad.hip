@@ -527,6 +527,8 @@ extern "C" int dpc_conv_wgrad(const dpc_conv_desc* d, const void* src, const voi
     if (rc) return rc;
     const int per16 = d->dtype_in == DPC_BF16 ? 8 : 4;
     if (dy_ld % per16 || dy_ld < d->Co) return DPC_ERR_UNSUPPORTED;
+    rc = dpc_wgrad_patch_try(d, src, dy, dy_ld, part, nsplit, stream);  // 3x3 stride-1: one staged patch serves all nine taps
+    if (rc != 1) return rc;
     const int bkp = 8 * per16;
     const int nchunks = (p.g.M + bkp - 1) / bkp;
     const int lrw = ilog2_exact(d->RW), lrh = ilog2_exact(d->RH);

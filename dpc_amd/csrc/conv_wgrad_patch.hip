@@ -1,0 +1,213 @@
+// conv_wgrad_patch.hip -- weight gradient of the 1x3x3 stride-1 "same" convolutions (BasicBlock2d convs of
+// layer1 / layer2, backbone/resnet_2d3d.py:24-32,83-116; autograd of F.conv3d w.r.t. the weight), bf16.
+//
+//   part[ks][co][tap*Ci + ci] = sum_{m in split ks} dy[m][co] * x[m shifted by tap][ci]
+//
+// conv_wgrad.hip's generic kernel gathers the source once PER TAP: for a 3x3 kernel 9 of the 10 operand
+// sub-tiles of a chunk are shifted copies of the same pixels, the LDS-DMA stream is 32 KB per 48 MFMAs and
+// the CU's texture addresser (64 B/clk), not the matrix cores, sets the pace (~500 TFLOP/s measured on
+// layer1).  Here a workgroup owns a 64(co) x 64(ci) block of ALL NINE taps:
+//   * per chunk of 64 output positions (whole image rows) it stages dy[64][64 co] (8 KB) and ONE patch of
+//     the source, (rows+2) x (W+4) positions x 64 ci (17 KB for W = 32), zero borders included, by
+//     LDS-DMA through buffer resources (out-of-image pixels are out-of-range lanes -> hardware zero fill);
+//   * both stay in memory orientation [position][channel]; the MFMA fragments (reduction index = position
+//     contiguous per lane) come from ds_read_b64_tr_b16, and the fragment of tap (kh,kw) is the SAME patch
+//     read (kh*(W+4) + kw) positions further -- an instruction immediate, no gather arithmetic;
+//   * 4 waves = 2 (co halves) x 2 (ci halves), each 32 x 32 x 9 taps = 9 accumulators (144 VGPRs);
+//     144 MFMAs per 25 KB staged instead of 48 per 32 KB.
+// LDS rows are 128 B (64 channels); the 16-byte slot of position p is XORed with 2*(p&3): the four
+// positions a transpose read touches are consecutive, so any tap shift keeps the reads conflict free.
+// The patch is W+4 wide so that row starts stay multiples of 4 positions (the swizzle phase of a read then
+// depends on kw only).  Split-K partial slabs and their reduction are shared with conv_wgrad.hip.
+#include "conv_common.h"
+#include <stdlib.h>
+
+struct WgradPatchParams {
+    const void* src;
+    const void* dy;
+    float* part;
+    int Co, Ci, dy_ld, src_ld, Kp;
+    int RH, NF;          // image rows, frames (N*T)
+    int M;
+    int nks, kcps;
+    int ntm, ntc;
+    unsigned src_bytes, dy_bytes;
+    FastDiv d_cpf;       // chunks per frame
+    int cpf;
+};
+
+template <int RW>
+__global__ __launch_bounds__(256, 2) void wgrad_patch_kernel(WgradPatchParams p) {
+    constexpr int ROWS = 64 / RW;          // image rows per chunk
+    constexpr int PR = ROWS + 2, PW = RW + 4;
+    constexpr int NPOS = PR * PW;          // patch positions
+    constexpr int NPB = (NPOS + 7) / 8;    // B pieces (8 positions = 1 KB each)
+    constexpr int NIB = (NPB + 3) / 4;     // B pieces per wave
+    constexpr int STAGE = 8192 + NPB * 1024;
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * STAGE];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+#ifdef DPC_SIMT_EMU
+    const int wv = tid >> 6;
+#else
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+#endif
+    const int wi = wv >> 1, wj = wv & 1;
+    const int l31 = lane & 31, lhi = lane >> 5;
+    // an XCD owns a contiguous range of logical ids: the tiles of one K-split share their dy / source rows in one L2
+    int id = blockIdx.x;
+    {
+        const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, x = id & 7;
+        id = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (id >> 3);
+    }
+    const int tile_c = id % p.ntc; id /= p.ntc;
+    const int tile_m = id % p.ntm;
+    const int ks = id / p.ntm;
+    const int nchunks = p.M / 64;
+    const int c_begin = ks * p.kcps;
+    const int c_end = (c_begin + p.kcps < nchunks) ? c_begin + p.kcps : nchunks;
+
+    // ---- DMA lane constants
+    const BufRsrc rs_a = make_buf_rsrc(p.dy, p.dy_bytes);
+    const BufRsrc rs_b = make_buf_rsrc(p.src, p.src_bytes);
+    const int pl = lane >> 3;                              // position inside a piece
+    const int lslot = (lane & 7) ^ (2 * (pl & 3));         // channel group this lane fetches (swizzle on the source side)
+    unsigned a_off[2];
+    DPC_UNROLL
+    for (int i = 0; i < 2; ++i) a_off[i] = (unsigned)((8 * (wv + 4 * i) + pl) * p.dy_ld + tile_m * 64 + lslot * 8) * 2u;
+    unsigned b_off[NIB];
+    int b_row[NIB];  // patch row - 1 (image row relative to the chunk's first row), or a value no image row can have
+    DPC_UNROLL
+    for (int i = 0; i < NIB; ++i) {
+        const int pp = 8 * (wv + 4 * i) + pl;
+        const int prow = pp / PW, pcol = pp % PW;
+        const bool ok = pp < NPOS && pcol >= 1 && pcol <= RW;
+        b_row[i] = ok ? prow - 1 : (1 << 28);
+        b_off[i] = (unsigned)(((prow - 1) * RW + (pcol - 1)) * p.src_ld + tile_c * 64 + lslot * 8) * 2u;
+    }
+
+    f32x16 acc[9];
+    DPC_UNROLL
+    for (int t = 0; t < 9; ++t)
+        DPC_UNROLL
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    auto issue = [&](int chunk, int buf) {
+        unsigned char* stage = lds + buf * STAGE;
+        const unsigned a_base = (unsigned)chunk * 64u * (unsigned)p.dy_ld * 2u;
+        const unsigned frame = fdiv((unsigned)chunk, p.d_cpf);
+        const int h0 = (chunk - (int)frame * p.cpf) * ROWS;
+        const unsigned b_base = (unsigned)(((int)frame * p.RH + h0) * RW) * (unsigned)p.src_ld * 2u;
+        DPC_UNROLL
+        for (int i = 0; i < 2; ++i) glds16_buf(rs_a, a_base + a_off[i], 0u, stage + (wv + 4 * i) * 1024, lane);
+        DPC_UNROLL
+        for (int i = 0; i < NIB; ++i) {
+            if (wv + 4 * i < NPB) {
+                const bool ok = (unsigned)(h0 + b_row[i]) < (unsigned)p.RH;
+                glds16_buf(rs_b, ok ? b_base + b_off[i] : DPC_BUF_OOB, 0u, stage + 8192 + (wv + 4 * i) * 1024, lane);
+            }
+        }
+    };
+
+    // ---- fragment lane offsets
+    const int gq = lane >> 4, s16 = lane & 15, ph = s16 >> 2;
+    const int lin = ((gq >> 1) * 8 + ph) * 128;
+    auto slot_off = [&](int c0, int phase) {
+        const int colb = (c0 + (gq & 1) * 16 + 4 * (s16 & 3)) * 2;
+        return ((((colb >> 4) ^ (2 * (phase & 3))) & 7) << 4) + (colb & 15);
+    };
+    const int fa = lin + slot_off(wi * 32, ph);
+    int fb[3];
+    DPC_UNROLL
+    for (int kw = 0; kw < 3; ++kw) fb[kw] = 8192 + lin + slot_off(wj * 32, ph + kw);
+
+    auto compute = [&](int buf) {
+        const unsigned char* st = lds + buf * STAGE;
+        DPC_UNROLL
+        for (int kk = 0; kk < 4; ++kk) {
+            const u32x2 a0 = lds_read_tr16(st + fa + (kk * 16) * 128);
+            const u32x2 a1 = lds_read_tr16(st + fa + (kk * 16 + 4) * 128);
+            const u32x4 av = {a0[0], a0[1], a1[0], a1[1]};
+            const int r = (kk * 16) / RW, w0 = (kk * 16) % RW;
+            DPC_UNROLL
+            for (int kh = 0; kh < 3; ++kh)
+                DPC_UNROLL
+                for (int kw = 0; kw < 3; ++kw) {
+                    const int pos = (r + kh) * PW + w0 + kw;
+                    const u32x2 b0 = lds_read_tr16(st + fb[kw] + pos * 128);
+                    const u32x2 b1 = lds_read_tr16(st + fb[kw] + (pos + 4) * 128);
+                    const u32x4 bv = {b0[0], b0[1], b1[0], b1[1]};
+                    acc[kh * 3 + kw] = mfma_32x32x16_bf16(av, bv, acc[kh * 3 + kw]);
+                }
+        }
+    };
+
+    if (c_begin < c_end) issue(c_begin, 0);
+    __syncthreads();
+    for (int ch = c_begin; ch < c_end; ++ch) {
+        const int buf = (ch - c_begin) & 1;
+        if (ch + 1 < c_end) issue(ch + 1, buf ^ 1);
+        compute(buf);
+        __syncthreads();
+    }
+
+    // ---- partial slab: rows = co, columns = tap*Ci + ci
+    const int ci = tile_c * 64 + wj * 32 + l31;
+    DPC_UNROLL
+    for (int t = 0; t < 9; ++t)
+        DPC_UNROLL
+        for (int r = 0; r < 16; ++r) {
+            const int co = tile_m * 64 + wi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+            p.part[((long long)ks * p.Co + co) * p.Kp + t * p.Ci + ci] = acc[t][r];
+        }
+}
+
+static int wgrad_patch_enabled() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("DPC_WGRAD_PATCH");
+        v = (e && e[0] == '0') ? 0 : 1;
+    }
+    return v;
+}
+
+// returns 1 when the shape is not served (caller runs the generic kernels); with part == NULL only *nsplit is set
+int dpc_wgrad_patch_try(const dpc_conv_desc* d, const void* src, const void* dy, int dy_ld, float* part, int32_t* nsplit,
+                        hipStream_t stream) {
+    if (!wgrad_patch_enabled()) return 1;
+    if (d->dtype_in != DPC_BF16 || d->mode != 0) return 1;
+    if (d->KT != 1 || d->KH != 3 || d->KW != 3 || d->st != 1 || d->sh != 1 || d->sw != 1 || d->pt != 0 || d->ph != 1 || d->pw != 1) return 1;
+    if (d->RT != d->ST || d->RH != d->SH || d->RW != d->SW) return 1;
+    if (d->RW != 16 && d->RW != 32) return 1;
+    if ((d->RH * d->RW) % 64 || d->Ci % 64 || d->Co % 64 || d->src_ld % 8 || dy_ld % 8 || dy_ld < d->Co) return 1;
+    const long long M = (long long)d->N * d->RT * d->RH * d->RW;
+    const long long sb = M * d->src_ld * 2, db = M * dy_ld * 2;
+    if (sb >= (1ll << 31) || db >= (1ll << 31)) return 1;  // 32-bit buffer offsets, DPC_BUF_OOB stays out of range
+    WgradPatchParams p;
+    p.Co = d->Co; p.Ci = d->Ci; p.dy_ld = dy_ld; p.src_ld = d->src_ld; p.Kp = 9 * d->Ci;
+    p.RH = d->RH; p.NF = d->N * d->RT; p.M = (int)M;
+    p.ntm = d->Co / 64; p.ntc = d->Ci / 64;
+    p.src_bytes = (unsigned)sb; p.dy_bytes = (unsigned)db;
+    p.cpf = d->RH * d->RW / 64;
+    p.d_cpf = make_fastdiv((uint32_t)p.cpf);
+    const int nchunks = p.M / 64;
+    static const int target_blocks = getenv("DPC_WGRAD_PATCH_BLOCKS") ? atoi(getenv("DPC_WGRAD_PATCH_BLOCKS")) : 512;
+    int want = target_blocks / (p.ntm * p.ntc);
+    if (want < 1) want = 1;
+    if (want > nchunks) want = nchunks;
+    p.kcps = (nchunks + want - 1) / want;
+    p.nks = (nchunks + p.kcps - 1) / p.kcps;
+    if (nsplit) *nsplit = p.nks;
+    if (!part) return DPC_OK;
+    if (!src || !dy) return DPC_ERR_ARG;
+    if (((uintptr_t)src % 16) || ((uintptr_t)dy % 16)) return DPC_ERR_UNSUPPORTED;
+    p.src = src; p.dy = dy; p.part = part;
+    dim3 grid((unsigned)(p.ntm * p.ntc * p.nks)), block(256);
+    if (d->RW == 32) {
+        DPC_LAUNCH((wgrad_patch_kernel<32>), grid, block, stream, p);
+    } else {
+        DPC_LAUNCH((wgrad_patch_kernel<16>), grid, block, stream, p);
+    }
+    return dpc_launch_status();
+}

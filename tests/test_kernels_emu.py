@@ -64,6 +64,8 @@ def test_conv_dgrad(k, dtype, shape):
     (2, 64, 136, 2, 8, 16, (1, 1, 1), (1, 2, 2), (0, 0, 0)),    # 2x2 waves, chunk spans planes (bf16)
     (1, 64, 128, 3, 8, 8, (3, 3, 3), (1, 1, 1), (1, 1, 1)),     # 2x3 waves
     (2, 256, 64, 1, 8, 8, (1, 1, 1), (1, 1, 1), (0, 0, 0)),     # 1x4 waves
+    (3, 64, 64, 1, 8, 32, (1, 3, 3), (1, 1, 1), (0, 1, 1)),     # staged-patch kernel (bf16), W = 32, 2 rows per chunk
+    (2, 128, 64, 2, 8, 16, (1, 3, 3), (1, 1, 1), (0, 1, 1)),    # staged-patch kernel, W = 16, two ci tiles
 ])
 def test_conv_wgrad(k, dtype, shape):
     kc.case_conv_wgrad(k, dtype, *shape)
