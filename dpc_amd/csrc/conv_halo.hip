@@ -29,6 +29,7 @@
 // An input-gradient with unit strides is the same convolution with pad' = K-1-pad and the tap order
 // reversed (the [Ci][tap][Co] weight pack is indexed with the flipped tap).
 #include "conv_common.h"
+#include <stdlib.h>
 
 struct HaloParams {
     const void* src;
@@ -42,6 +43,8 @@ struct HaloParams {
     int tiles_w, tiles_per_frame, ntm, gm;
     FastDiv d_tpf, d_tw, d_hwd;
     int vec_out;
+    unsigned src_bytes;
+    int ws;  // shape served by the role-specialised kernel
 };
 
 // UPP = 16-byte units per position: 8 (one tap = one 128-byte chunk) or 2 (one chunk = 4 kw taps, KW == 4)
@@ -143,18 +146,47 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(HaloParams p) {
             for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
         __syncthreads();  // this tile's halo has landed (the barrier drains the DMA), rowmap visible
         if (mt + p.gm < p.ntm) issue_halo(mt + p.gm, bufoff ^ HALO_BYTES);  // next tile's halo flies during the MFMA phase
-        DPC_UNROLL
-        for (int kh = 0; kh < KH; ++kh) {
-            const int roff = kh * rowpitch;  // wave-uniform
+        if constexpr (sizeof(T) == 2) {
+            // 2 ds_read_b128 + 2 MFMA per step: fragments are fetched two steps ahead into a ring of three
+            // register sets (hand-counted waits, see dpc_rt.h) -- with the compiler's own placement every step
+            // waited out an LDS round trip behind only 64 cycles of MFMA work.
+            constexpr int S = KH * NCH * 4, D = 2, R = 3;
+            u32x4 ring[R][2];
+            const unsigned char* rowp[KH][2];
             DPC_UNROLL
-            for (int ch = 0; ch < NCH; ++ch) {
+            for (int kh = 0; kh < KH; ++kh)
                 DPC_UNROLL
-                for (int kk = 0; kk < 4; ++kk) {
-                    u32x4 fa[2];
+                for (int i = 0; i < 2; ++i) rowp[kh][i] = lds + frag_a[i] + kh * rowpitch;
+            auto fetch = [&](int s) {
+                const int kh = s / (NCH * 4), ch = (s / 4) % NCH, kk = s % 4;
+                DPC_UNROLL
+                for (int i = 0; i < 2; ++i) lds_read_b128_async(ring[s % R][i], rowp[kh][i] + ch * CBP + kk * KKSTEP);
+            };
+            DPC_UNROLL
+            for (int s = 0; s < D; ++s) fetch(s);
+            DPC_UNROLL
+            for (int s = 0; s < S; ++s) {
+                if (s + D < S) fetch(s + D);
+                const int ahead = (S - 1 - s) < D ? (S - 1 - s) : D;
+                lds_wait_tie_n(2 * ahead, ring[s % R][0], ring[s % R][1]);
+                DPC_UNROLL
+                for (int i = 0; i < 2; ++i) acc[i] = mfma_unit<T>(ring[s % R][i], fbr[s / 4][s % 4], acc[i]);
+                sched_fence();
+            }
+        } else {
+            DPC_UNROLL
+            for (int kh = 0; kh < KH; ++kh) {
+                const int roff = kh * rowpitch;  // wave-uniform
+                DPC_UNROLL
+                for (int ch = 0; ch < NCH; ++ch) {
                     DPC_UNROLL
-                    for (int i = 0; i < 2; ++i) fa[i] = *(const u32x4*)(lds + frag_a[i] + roff + ch * CBP + kk * KKSTEP);
-                    DPC_UNROLL
-                    for (int i = 0; i < 2; ++i) acc[i] = mfma_unit<T>(fa[i], fbr[kh * NCH + ch][kk], acc[i]);
+                    for (int kk = 0; kk < 4; ++kk) {
+                        u32x4 fa[2];
+                        DPC_UNROLL
+                        for (int i = 0; i < 2; ++i) fa[i] = *(const u32x4*)(lds + frag_a[i] + roff + ch * CBP + kk * KKSTEP);
+                        DPC_UNROLL
+                        for (int i = 0; i < 2; ++i) acc[i] = mfma_unit<T>(fa[i], fbr[kh * NCH + ch][kk], acc[i]);
+                    }
                 }
             }
         }
@@ -254,6 +286,238 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(HaloParams p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Role-specialised variant for the 3x3 / 128-byte-position case (layer1 of the 2d3d-ResNet, bf16).
+//
+// Timing the phases of conv_halo_kernel separately on layer1 (MI355X, 5.2 M positions): fixed per-tile work
+// (halo address arithmetic, barriers) 114 us, halo DMA issue +80, MFMA loop 216, epilogue 135 -- and the
+// whole kernel 600: the phases of a workgroup run one after the other and two workgroups per CU overlap
+// them only by accident, while the HBM floor of the layer (read x once, write y once) is ~270 us.
+// Here a workgroup is 8 waves and every phase has its own waves, pipelined over consecutive tiles:
+//   waves 0-3  compute   : B operand resident in VGPRs, 36 steps of {2 ds_read_b128, 2 MFMA} on patch t,
+//                          accumulators -> bf16 staging tile t&1;
+//   waves 4-5  load      : LDS-DMA of patch t+2 (ring of three patch buffers) through a buffer resource
+//                          (image borders = out-of-range lanes = hardware zero fill), offsets precomputed
+//                          per lane, counted s_waitcnt vmcnt(15) -- patch t+1 may still be in flight;
+//   waves 6-7  store     : epilogue of tile t-1 from the other staging tile: residual add, 16-byte row
+//                          stores, batch-norm partial sums.
+// Two workgroup barriers per tile: B1(t) "patch t landed, staging t&1 is free", B2(t) "staging t&1 written,
+// patch t released".  One workgroup per CU (125 KB of LDS), persistent over its tiles.
+template <int DUMMY>
+__global__ __launch_bounds__(512, 2) void conv_halo_ws_kernel(HaloParams p) {
+    typedef bf16_t T;
+    typedef bf16_t TO;
+    constexpr int KH = 3, NCH = 3, NTAPS = 9, CBP = 144, SPP = 9, KKSTEP = 32;
+    constexpr int BM = 128, BN = 64, EPO = 8, UPR = BN / EPO;
+    constexpr int LIT = 8;                        // DMA pieces per helper wave and patch: 8 x 256 lanes x 16 B = 32 KB >= 227 positions x 144 B
+    constexpr int PATCH = LIT * 256 * 16;
+    constexpr int STG = BM * BN * 2;
+    constexpr int NPB = 3;
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[NPB * PATCH + 2 * STG];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+#ifdef DPC_SIMT_EMU
+    const int wv = tid >> 6;
+#else
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+#endif
+    const int m_prog = blockIdx.x;
+    const int ntiles = (p.ntm - m_prog + p.gm - 1) / p.gm;  // >= 1
+    const char* const zero = (const char*)dpc_zero16;
+
+    auto tile_origin = [&](int mt, int& frame, int& h0, int& w0) {
+        const unsigned f = fdiv((unsigned)mt, p.d_tpf);
+        const int tin = mt - (int)f * p.tiles_per_frame;
+        const unsigned th = fdiv((unsigned)tin, p.d_tw);
+        frame = (int)f;
+        h0 = (int)th * p.TR;
+        w0 = (tin - (int)th * p.tiles_w) * p.TW;
+    };
+
+    if (wv < 4) {
+        // ------------------------------------------------------------------ compute waves
+        const int wm = wv >> 1, wn = wv & 1;
+        const int l31 = lane & 31, lhi = lane >> 5;
+        u32x4 fbr[NTAPS][4];
+        {
+            const int n = wn * 32 + l31;
+            const char* wp = n < p.Co ? (const char*)p.wgt + ((long long)n * p.ldw + lhi * 8) * 2 : nullptr;
+            DPC_UNROLL
+            for (int tap = 0; tap < NTAPS; ++tap) {
+                const int tapw = p.flip ? (NTAPS - 1 - tap) : tap;
+                DPC_UNROLL
+                for (int kk = 0; kk < 4; ++kk) fbr[tap][kk] = *(const u32x4*)(wp ? wp + (long long)tapw * 128 + kk * 32 : zero);
+            }
+        }
+        int frag_a[2];
+        DPC_UNROLL
+        for (int i = 0; i < 2; ++i) {
+            const int row = wm * 64 + i * 32 + l31;
+            const int r = row >> p.lTW, c = row & (p.TW - 1);
+            frag_a[i] = (r * p.HWd + c) * CBP + lhi * 16;
+        }
+        const int rowpitch = p.HWd * CBP;
+        for (int j = 0; j < ntiles; ++j) {
+            f32x16 acc[2];
+            DPC_UNROLL
+            for (int i = 0; i < 2; ++i)
+                DPC_UNROLL
+                for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+            barrier_lds_only();  // B1(j)
+            const unsigned char* patch = lds + (j % NPB) * PATCH;
+            // 36 steps of {2 ds_read_b128, 2 MFMA}; fragments two steps ahead in a ring of three register sets,
+            // the constant part of every address in the instruction's offset field (hand-counted waits, dpc_rt.h)
+            constexpr int S = KH * NCH * 4, D = 2, R = 3;
+            u32x4 ring[R][2];
+            const unsigned char* rowp[KH][2];
+            DPC_UNROLL
+            for (int kh = 0; kh < KH; ++kh)
+                DPC_UNROLL
+                for (int i = 0; i < 2; ++i) rowp[kh][i] = patch + frag_a[i] + kh * rowpitch;
+            auto fetch = [&](auto sc) {
+                constexpr int s = decltype(sc)::value;
+                constexpr int kh = s / (NCH * 4), ch = (s / 4) % NCH, kk = s % 4;
+                DPC_UNROLL
+                for (int i = 0; i < 2; ++i) lds_read_b128_async_off<ch * CBP + kk * KKSTEP>(ring[s % R][i], rowp[kh][i]);
+            };
+            static_for<D>(fetch);
+            static_for<S>([&](auto sc) {
+                constexpr int s = decltype(sc)::value;
+                if constexpr (s + D < S) fetch(std::integral_constant<int, s + D>{});
+                constexpr int ahead = (S - 1 - s) < D ? (S - 1 - s) : D;
+                lds_wait_tie<2 * ahead>(ring[s % R][0], ring[s % R][1]);
+                DPC_UNROLL
+                for (int i = 0; i < 2; ++i) acc[i] = mfma_32x32x16_bf16(ring[s % R][i], fbr[s / 4][s % 4], acc[i]);
+                sched_fence();
+            });
+            TO* tile = (TO*)(lds + NPB * PATCH + (j & 1) * STG);
+            DPC_UNROLL
+            for (int i = 0; i < 2; ++i)
+                DPC_UNROLL
+                for (int r = 0; r < 16; ++r) {
+                    const int row_l = wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                    tile[row_l * BN + wn * 32 + l31] = f32_to_bf16(acc[i][r]);
+                }
+            barrier_lds_only();  // B2(j)
+        }
+        barrier_lds_only();
+        barrier_lds_only();
+    } else {
+        // ------------------------------------------------------------------ helper waves (one per SIMD)
+        // each moves a quarter of every patch and stores a quarter of every tile, so the VALU work that shares
+        // the issue port with the MFMAs is the same on all four SIMDs
+        const int hw = wv - 4, htid = hw * 64 + lane;
+        const BufRsrc rs = make_buf_rsrc(p.src, p.src_bytes);
+        const int npos = p.HR * p.HWd;
+        unsigned rel[LIT];
+        int hrc[LIT];  // (patch row << 16) | patch column; a row no image has when the slot carries no data
+        DPC_UNROLL
+        for (int it = 0; it < LIT; ++it) {
+            const int slot = it * 256 + htid;
+            const int hpos = slot / SPP, cu = slot - hpos * SPP;
+            const unsigned hr = fdiv((unsigned)hpos, p.d_hwd);
+            const int hc = hpos - (int)hr * p.HWd;
+            const bool ok = cu < 8 && hpos < npos;
+            hrc[it] = ok ? (((int)hr << 16) | hc) : (0x4000 << 16);
+            rel[it] = (unsigned)((((int)hr * p.W + hc) * p.C + cu * 8) * 2);
+        }
+        auto issue = [&](int j) {
+            int frame, h0, w0;
+            tile_origin(m_prog + j * p.gm, frame, h0, w0);
+            const int hb = h0 - p.ph, wb = w0 - p.pw;
+            const unsigned base = (unsigned)(((frame * p.H + hb) * p.W + wb) * p.C * 2);
+            unsigned char* patch = lds + (j % NPB) * PATCH;
+            DPC_UNROLL
+            for (int it = 0; it < LIT; ++it) {
+                const int h = hb + (hrc[it] >> 16), w = wb + (hrc[it] & 0xffff);
+                const bool ok = ((unsigned)h < (unsigned)p.H) & ((unsigned)w < (unsigned)p.W);
+                glds16_buf(rs, ok ? base + rel[it] : DPC_BUF_OOB, 0u, patch + (it * 256 + hw * 64) * 16, lane);
+            }
+        };
+        const int cu = htid & 7, rbase = htid >> 3;  // output unit column; tile rows rbase + 32*q
+        const int col0 = cu * EPO;
+        float s1[EPO], s2[EPO];  // batch-norm partial sums live only in the helper waves' registers
+        DPC_UNROLL
+        for (int e = 0; e < EPO; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
+        auto epilogue = [&](int j) {
+            int frame, h0, w0;
+            tile_origin(m_prog + j * p.gm, frame, h0, w0);
+            const unsigned char* stg = lds + NPB * PATCH + (j & 1) * STG;
+            u32x4 ov[4], av[4];
+            int rows[4];
+            DPC_UNROLL
+            for (int q = 0; q < 4; ++q) {
+                const int row_l = rbase + 32 * q;
+                const int h = h0 + (row_l >> p.lTW), w = w0 + (row_l & (p.TW - 1));
+                const bool ok = h < p.H && w < p.W && col0 < p.Co;
+                rows[q] = ok ? (frame * p.H + h) * p.W + w : -1;
+                ov[q] = *(const u32x4*)(stg + (row_l * BN + col0) * 2);
+                if (p.addend) {
+                    const char* a = (const char*)p.addend + ((long long)rows[q] * p.ldo + col0) * 2;
+                    av[q] = *(const u32x4*)(ok ? a : zero);
+                }
+            }
+            DPC_UNROLL
+            for (int q = 0; q < 4; ++q) {
+                if (rows[q] >= 0) {
+                    u32x4 o = ov[q];
+                    if (p.addend) {
+                        float sv[EPO];
+                        DPC_UNROLL
+                        for (int e = 0; e < EPO; ++e) sv[e] = unit_get<TO>(o, e) + unit_get<TO>(av[q], e);
+                        o = unit_pack<TO>(sv);
+                    }
+                    *(u32x4*)((char*)p.out + ((long long)rows[q] * p.ldo + col0) * 2) = o;
+                    DPC_UNROLL
+                    for (int e = 0; e < EPO; ++e) {
+                        const float v = unit_get<TO>(o, e);
+                        s1[e] += v;
+                        s2[e] += v * v;
+                    }
+                }
+            }
+        };
+        issue(0);
+        if (ntiles > 1) issue(1);
+        for (int j = 0; j <= ntiles; ++j) {
+            // patch j must have landed.  Newer than its pieces are: this wave's stores of tile j-2 and the LIT pieces
+            // of patch j+1.  Loads (LDS-DMA included) complete in order among themselves, so "at most LIT
+            // outstanding" implies every piece of patch j is done whatever the stores do.
+            if (j < ntiles) {
+                if (j + 1 < ntiles) wait_vmcnt<LIT>(); else wait_vmcnt<0>();
+            }
+            barrier_lds_only();  // B1(j)
+            if (j >= 1) epilogue(j - 1);
+            if (j + 2 < ntiles) issue(j + 2);  // into the buffer of patch j-1, released at B2(j-1)
+            barrier_lds_only();  // B2(j)
+        }
+        // every patch has been consumed (last B2 passed): the first patch buffer becomes the reduction scratch
+        float* red = (float*)lds;  // [2][256][EPO]
+        DPC_UNROLL
+        for (int e = 0; e < EPO; ++e) {
+            red[htid * EPO + e] = s1[e];
+            red[(256 + htid) * EPO + e] = s2[e];
+        }
+    }
+
+    if (p.stats) {
+        // 32 helper lanes hold partial sums of the same 8 columns
+        const float* red = (const float*)lds;
+        __syncthreads();
+        if (tid < BN && tid < p.Co) {
+            const int cu2 = tid / EPO, e2 = tid % EPO;
+            float a = 0.f, b = 0.f;
+            for (int t = cu2; t < 256; t += UPR) {
+                a += red[t * EPO + e2];
+                b += red[(256 + t) * EPO + e2];
+            }
+            p.stats[((long long)m_prog * 2 + 0) * p.Co + tid] = a;
+            p.stats[((long long)m_prog * 2 + 1) * p.Co + tid] = b;
+        }
+    }
+}
+
 // ---------------------------------------------------------------- host side
 static bool halo_plan(const dpc_conv_desc* d, HaloParams* p) {
     if (d->KT != 1 || d->st != 1 || d->sh != 1 || d->sw != 1 || d->pt != 0) return false;
@@ -284,6 +548,13 @@ static bool halo_plan(const dpc_conv_desc* d, HaloParams* p) {
     if (ntm >= (1ll << 30) || (long long)p->NF * d->RH * d->RW * d->Ci >= (1ll << 31)) return false;  // 32-bit element offsets
     p->ntm = (int)ntm;
     p->gm = p->ntm < 1024 ? p->ntm : 1024;  // persistent workgroups: B is loaded once per workgroup
+    static const int ws_on = getenv("DPC_HALO_WS") ? atoi(getenv("DPC_HALO_WS")) : 1;
+    const long long sbytes = (long long)p->NF * d->RH * d->RW * d->Ci * esz;
+    p->src_bytes = sbytes < (1ll << 31) ? (unsigned)sbytes : 0u;
+    p->ws = ws_on && k33 && d->dtype_in == DPC_BF16 && p->HR * p->HWd * 9 <= 8 * 256 && p->src_bytes > 0 && d->ldo % 8 == 0 &&
+            d->Co % 8 == 0;
+    static const int ws_gm = getenv("DPC_HALO_WS_GM") ? atoi(getenv("DPC_HALO_WS_GM")) : 256;  // test tiers shrink it
+    if (p->ws) p->gm = p->ntm < ws_gm ? p->ntm : ws_gm;  // one resident workgroup per CU
     p->d_tpf = make_fastdiv(p->tiles_per_frame);
     p->d_tw = make_fastdiv(p->tiles_w);
     p->d_hwd = make_fastdiv(p->HWd);
@@ -305,6 +576,10 @@ int dpc_conv_halo_try(const dpc_conv_desc* d, const void* src, const void* wgt, 
     const int epo = d->dtype_out == DPC_BF16 ? 8 : 4;
     p.vec_out = (d->Co % epo == 0 && d->ldo % epo == 0 && ((uintptr_t)out % 16 == 0) && ((uintptr_t)addend % 16 == 0)) ? 1 : 0;
     dim3 grid((unsigned)p.gm), block(256);
+    if (p.ws && p.vec_out && ((uintptr_t)src % 16 == 0)) {
+        DPC_LAUNCH((conv_halo_ws_kernel<0>), grid, dim3(512), stream, p);
+        return dpc_launch_status();
+    }
     if (d->KH == 3) {
         if (d->dtype_in == DPC_F32) {
             DPC_LAUNCH((conv_halo_kernel<float, float, 3, 3, 8>), grid, block, stream, p);

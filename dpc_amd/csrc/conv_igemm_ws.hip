@@ -38,22 +38,6 @@ struct WsParams {
     int dbg;
 };
 
-__device__ __forceinline__ void wait_vmcnt12() {
-#ifndef DPC_SIMT_EMU
-    asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-#endif
-}
-__device__ __forceinline__ void wait_vmcnt0() {
-#ifndef DPC_SIMT_EMU
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
-}
-// instruction-scheduler fence: nothing is moved across it (the hardware sees no instruction)
-__device__ __forceinline__ void sched_fence() {
-#ifndef DPC_SIMT_EMU
-    __builtin_amdgcn_sched_barrier(0);
-#endif
-}
 // workgroup barrier that waits for nothing but this wave's LDS traffic
 __device__ __forceinline__ void ws_barrier() { barrier_lds_only(); }
 
@@ -189,7 +173,7 @@ __global__ __launch_bounds__(512, 2) void igemm_ws_kernel(WsParams p) {
         if (total > 1) issue_next(1);
         int kc_done = 0;  // position of chunk gc inside its tile
         for (int gc = 0; gc < total; ++gc) {
-            if (gc + 1 < total) wait_vmcnt12(); else wait_vmcnt0();
+            if (gc + 1 < total) wait_vmcnt<12>(); else wait_vmcnt<0>();
             ws_barrier();  // chunk gc is published; every reader is done with chunk gc-1
             if (gc + 2 < total) issue_next(gc + 2);
             if (++kc_done == nkc) {

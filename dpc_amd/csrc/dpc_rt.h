@@ -6,6 +6,7 @@
 // Kernel sources are written once, for gfx950; nothing below is a CUDA shim.
 #pragma once
 #include <stdint.h>
+#include <utility>
 
 #ifdef DPC_SIMT_EMU
 #include "simt_emu.h"
@@ -278,3 +279,55 @@ __device__ __forceinline__ void glds16_buf(const BufRsrc& r, uint32_t voff, uint
 }
 #endif
 #define DPC_BUF_OOB 0x80000000u
+
+// ---- hand-scheduled LDS fragment reads ------------------------------------------------------------
+// hipcc serialises "ds_read -> s_waitcnt lgkmcnt(0) -> MFMA" per K step when the fragment registers are
+// reused (and waits for ALL outstanding reads when they are not), which exposes one LDS round trip per
+// step.  These reads are invisible to its wait-count pass; the caller counts: LDS operations of a wave
+// complete in order, so after lds_wait_tie<N> every read except the newest N has landed.  The "+v" ties
+// make later uses of the registers depend on the wait.  (Scalar loads share the counter but only make
+// the wait more conservative.)
+#ifdef DPC_SIMT_EMU
+__device__ __forceinline__ void lds_read_b128_async(u32x4& d, const unsigned char* p) { d = *(const u32x4*)p; }
+template <int OFF> __device__ __forceinline__ void lds_read_b128_async_off(u32x4& d, const unsigned char* p) { d = *(const u32x4*)(p + OFF); }
+template <int N> __device__ __forceinline__ void lds_wait_tie(u32x4&, u32x4&) {}
+__device__ __forceinline__ void sched_fence() {}
+#else
+// same with the constant part of the address as the instruction's 16-bit offset field (no VALU, no extra VGPR)
+template <int OFF> __device__ __forceinline__ void lds_read_b128_async_off(u32x4& d, const unsigned char* p) {
+    static_assert(OFF >= 0 && OFF < 65536, "ds offset field");
+    const uint32_t a = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const unsigned char*)p;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=&v"(d) : "v"(a), "n"(OFF) : "memory");
+}
+__device__ __forceinline__ void lds_read_b128_async(u32x4& d, const unsigned char* p) {
+    const uint32_t a = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const unsigned char*)p;
+    asm volatile("ds_read_b128 %0, %1" : "=&v"(d) : "v"(a) : "memory");
+}
+template <int N> __device__ __forceinline__ void lds_wait_tie(u32x4& a, u32x4& b) {
+    asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a), "+v"(b) : "n"(N) : "memory");
+}
+// instruction-scheduler fence: nothing is moved across it (no instruction is emitted)
+__device__ __forceinline__ void sched_fence() { __builtin_amdgcn_sched_barrier(0); }
+#endif
+__device__ __forceinline__ void lds_wait_tie_n(int n, u32x4& a, u32x4& b) {  // n is a compile-time value after unrolling
+    if (n >= 6) lds_wait_tie<6>(a, b);
+    else if (n == 4) lds_wait_tie<4>(a, b);
+    else if (n == 2) lds_wait_tie<2>(a, b);
+    else lds_wait_tie<0>(a, b);
+}
+
+// wait until at most N of this wave's vector-memory operations (LDS-DMA pieces included) are outstanding
+template <int N> __device__ __forceinline__ void wait_vmcnt() {
+#ifndef DPC_SIMT_EMU
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+#endif
+}
+
+// compile-time unrolled loop: body(std::integral_constant<int, I>) for I = 0..N-1 (the index is usable as a
+// template argument / instruction immediate inside the body)
+template <class F, int... Is> __device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, Is...>) {
+    (f(std::integral_constant<int, Is>{}), ...);
+}
+template <int N, class F> __device__ __forceinline__ void static_for(F&& f) {
+    static_for_impl(static_cast<F&&>(f), std::make_integer_sequence<int, N>{});
+}

@@ -25,6 +25,7 @@ def k():
     (16, 256, 256, 2, 4, 4, (3, 3, 3), (1, 1, 1), (1, 1, 1)),    # layer4 body
     (5, 128, 256, 5, 16, 16, (1, 1, 1), (2, 2, 2), (0, 0, 0)),   # downsample
     (3, 16, 40, 2, 9, 7, (1, 3, 3), (1, 1, 1), (0, 1, 1)),       # ragged everything
+    (70, 64, 64, 1, 32, 32, (1, 3, 3), (1, 1, 1), (0, 1, 1)),    # 560 patch tiles > 256 workgroups: tile pipeline of the role-specialised kernel
     (70, 128, 128, 1, 16, 16, (1, 3, 3), (1, 1, 1), (0, 1, 1)),  # >= 16384 rows: loader/compute specialised kernel, 70 tiles
     (90, 256, 264, 3, 8, 8, (3, 3, 3), (1, 1, 1), (1, 1, 1)),    # same, 3x3x3, three column tiles (last ragged), ragged last row tile
 ])
@@ -39,6 +40,7 @@ def test_conv_fwd(k, dtype, shape):
     (6, 128, 256, 5, 16, 16, (3, 3, 3), (2, 2, 2), (1, 1, 1)),
     (16, 256, 256, 3, 8, 8, (3, 3, 3), (1, 1, 1), (1, 1, 1)),
     (5, 128, 256, 5, 16, 16, (1, 1, 1), (2, 2, 2), (0, 0, 0)),
+    (66, 64, 64, 1, 32, 32, (1, 3, 3), (1, 1, 1), (0, 1, 1)),    # patch kernel, flipped taps, 528 tiles
     (66, 128, 128, 1, 16, 16, (1, 3, 3), (1, 1, 1), (0, 1, 1)),  # unit-stride input-gradient on the specialised kernel
     (87, 256, 256, 3, 8, 8, (3, 3, 3), (1, 1, 1), (1, 1, 1)),
     (3, 16, 32, 2, 9, 7, (1, 3, 3), (1, 2, 2), (0, 1, 1)),

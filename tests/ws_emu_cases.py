@@ -25,6 +25,10 @@ def main():
     # unit-stride input gradient (+ residual addend): the GEMM's columns are the conv's input channels
     kc.case_conv_dgrad(k, BF16, 2, 128, 64, 2, 9, 16, (1, 3, 3), (1, 1, 1), (0, 1, 1))
     kc.case_conv_dgrad(k, BF16, 1, 128, 128, 3, 6, 6, (3, 3, 3), (1, 1, 1), (1, 1, 1))
+    # role-specialised patch kernel (conv_halo_ws_kernel): DPC_HALO_WS_GM = 3 workgroups walk 24 / 8 tiles each
+    kc.case_conv_fwd(k, BF16, 2, 64, 64, 2, 9, 33, (1, 3, 3), (1, 1, 1), (0, 1, 1))
+    kc.case_conv_fwd(k, BF16, 1, 64, 40, 1, 20, 12, (1, 3, 3), (1, 1, 1), (0, 1, 1))
+    kc.case_conv_dgrad(k, BF16, 2, 64, 64, 2, 9, 33, (1, 3, 3), (1, 1, 1), (0, 1, 1))
     # plain NT GEMMs
     kc.case_gemm_nt(k, BF16, 600, 136, 256)
     kc.case_gemm_nt(k, BF16, 257, 128, 64)
