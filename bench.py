@@ -152,7 +152,7 @@ def main():
             if ig and ig["ms"] > 0:
                 ach = ig["flops"] / (ig["ms"] * 1e-3) / 1e12
                 out["roofline"] = {
-                    "kernel": "dpc_conv_igemm (igemm_kernel + conv_halo_kernel: conv fwd + input-grad + 1x1/score GEMMs)",
+                    "kernel": "dpc_conv_igemm (igemm_ws_kernel + conv_halo(_ws)_kernel + igemm_kernel: conv fwd + input-grad + 1x1/score GEMMs)",
                     "bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
                     "traffic": traffic, "traffic_unit": "GB of HBM traffic per launch (rocprofv3 PMC, profiles/*_pmc_traffic.json)",
                     "algorithmic_GB_per_launch": round(ig["bytes"] / ig["launches"] / 1e9, 4),
