@@ -1,5 +1,6 @@
-// conv_wgrad_patch.hip -- weight gradient of the 1x3x3 stride-1 "same" convolutions (BasicBlock2d convs of
-// layer1 / layer2, backbone/resnet_2d3d.py:24-32,83-116; autograd of F.conv3d w.r.t. the weight), bf16.
+// conv_wgrad_patch.hip -- weight gradient of the 1x3x3 and 3x3x3 stride-1 "same" convolutions (BasicBlock2d /
+// BasicBlock3d convs of layer1..3, backbone/resnet_2d3d.py:14-32,83-116; autograd of F.conv3d w.r.t. the
+// weight), bf16.  A 3x3x3 kernel is three 1x3x3 problems, one per temporal tap, whose source plane is t+kt-1.
 //
 //   part[ks][co][tap*Ci + ci] = sum_{m in split ks} dy[m][co] * x[m shifted by tap][ci]
 //
@@ -34,11 +35,13 @@ struct WgradPatchParams {
     unsigned src_bytes, dy_bytes;
     FastDiv d_cpf;       // chunks per frame
     int cpf;
+    int KT, pt, T;       // temporal taps: a workgroup owns ONE kt; T = frames per clip
+    FastDiv d_T;
 };
 
 template <int RW>
 __global__ __launch_bounds__(256, 2) void wgrad_patch_kernel(WgradPatchParams p) {
-    constexpr int ROWS = 64 / RW;          // image rows per chunk
+    constexpr int ROWS = 64 / RW;          // image rows per chunk (RW = 8: a chunk is one 8x8 plane)
     constexpr int PR = ROWS + 2, PW = RW + 4;
     constexpr int NPOS = PR * PW;          // patch positions
     constexpr int NPB = (NPOS + 7) / 8;    // B pieces (8 positions = 1 KB each)
@@ -62,8 +65,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_patch_kernel(WgradPatchParams p)
         id = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (id >> 3);
     }
     const int tile_c = id % p.ntc; id /= p.ntc;
-    const int tile_m = id % p.ntm;
-    const int ks = id / p.ntm;
+    const int tile_m = id % p.ntm; id /= p.ntm;
+    const int kt = id % p.KT;
+    const int ks = id / p.KT;
     const int nchunks = p.M / 64;
     const int c_begin = ks * p.kcps;
     const int c_end = (c_begin + p.kcps < nchunks) ? c_begin + p.kcps : nchunks;
@@ -98,7 +102,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_patch_kernel(WgradPatchParams p)
         const unsigned a_base = (unsigned)chunk * 64u * (unsigned)p.dy_ld * 2u;
         const unsigned frame = fdiv((unsigned)chunk, p.d_cpf);
         const int h0 = (chunk - (int)frame * p.cpf) * ROWS;
-        const unsigned b_base = (unsigned)(((int)frame * p.RH + h0) * RW) * (unsigned)p.src_ld * 2u;
+        const unsigned b_base = (unsigned)((((int)frame + kt - p.pt) * p.RH + h0) * RW) * (unsigned)p.src_ld * 2u;
         DPC_UNROLL
         for (int i = 0; i < 2; ++i) glds16_buf(rs_a, a_base + a_off[i], 0u, stage + (wv + 4 * i) * 1024, lane);
         DPC_UNROLL
@@ -118,9 +122,11 @@ __global__ __launch_bounds__(256, 2) void wgrad_patch_kernel(WgradPatchParams p)
         return ((((colb >> 4) ^ (2 * (phase & 3))) & 7) << 4) + (colb & 15);
     };
     const int fa = lin + slot_off(wi * 32, ph);
+    // the lane's 8-position group starts (gq>>1)*8 positions into the 16 of a step: for W = 8 that is the next image row
+    const int linb = ((((gq >> 1) * 8) / RW) * PW + ((gq >> 1) * 8) % RW + ph) * 128;
     int fb[3];
     DPC_UNROLL
-    for (int kw = 0; kw < 3; ++kw) fb[kw] = 8192 + lin + slot_off(wj * 32, ph + kw);
+    for (int kw = 0; kw < 3; ++kw) fb[kw] = 8192 + linb + slot_off(wj * 32, ph + kw);
 
     auto compute = [&](int buf) {
         const unsigned char* st = lds + buf * STAGE;
@@ -143,13 +149,27 @@ __global__ __launch_bounds__(256, 2) void wgrad_patch_kernel(WgradPatchParams p)
         }
     };
 
-    if (c_begin < c_end) issue(c_begin, 0);
+    // chunks whose source plane t + kt - pt falls outside the clip contribute nothing: skip them
+    auto next_valid = [&](int c) {
+        if (p.KT == 1) return c;
+        while (c < c_end) {
+            const unsigned frame = fdiv((unsigned)c, p.d_cpf);
+            const int t = (int)frame - (int)fdiv(frame, p.d_T) * p.T;
+            if ((unsigned)(t + kt - p.pt) < (unsigned)p.T) break;
+            ++c;
+        }
+        return c;
+    };
+    int cur = next_valid(c_begin), buf = 0;
+    if (cur < c_end) issue(cur, 0);
     __syncthreads();
-    for (int ch = c_begin; ch < c_end; ++ch) {
-        const int buf = (ch - c_begin) & 1;
-        if (ch + 1 < c_end) issue(ch + 1, buf ^ 1);
+    while (cur < c_end) {
+        const int nxt = next_valid(cur + 1);
+        if (nxt < c_end) issue(nxt, buf ^ 1);
         compute(buf);
         __syncthreads();
+        cur = nxt;
+        buf ^= 1;
     }
 
     // ---- partial slab: rows = co, columns = tap*Ci + ci
@@ -159,7 +179,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_patch_kernel(WgradPatchParams p)
         DPC_UNROLL
         for (int r = 0; r < 16; ++r) {
             const int co = tile_m * 64 + wi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-            p.part[((long long)ks * p.Co + co) * p.Kp + t * p.Ci + ci] = acc[t][r];
+            p.part[((long long)ks * p.Co + co) * p.Kp + (kt * 9 + t) * p.Ci + ci] = acc[t][r];
         }
 }
 
@@ -177,15 +197,17 @@ int dpc_wgrad_patch_try(const dpc_conv_desc* d, const void* src, const void* dy,
                         hipStream_t stream) {
     if (!wgrad_patch_enabled()) return 1;
     if (d->dtype_in != DPC_BF16 || d->mode != 0) return 1;
-    if (d->KT != 1 || d->KH != 3 || d->KW != 3 || d->st != 1 || d->sh != 1 || d->sw != 1 || d->pt != 0 || d->ph != 1 || d->pw != 1) return 1;
+    if (d->KH != 3 || d->KW != 3 || d->st != 1 || d->sh != 1 || d->sw != 1 || d->ph != 1 || d->pw != 1) return 1;
+    if (!((d->KT == 1 && d->pt == 0) || (d->KT == 3 && d->pt == 1))) return 1;
     if (d->RT != d->ST || d->RH != d->SH || d->RW != d->SW) return 1;
-    if (d->RW != 16 && d->RW != 32) return 1;
+    if (d->RW != 8 && d->RW != 16 && d->RW != 32) return 1;
     if ((d->RH * d->RW) % 64 || d->Ci % 64 || d->Co % 64 || d->src_ld % 8 || dy_ld % 8 || dy_ld < d->Co) return 1;
     const long long M = (long long)d->N * d->RT * d->RH * d->RW;
     const long long sb = M * d->src_ld * 2, db = M * dy_ld * 2;
     if (sb >= (1ll << 31) || db >= (1ll << 31)) return 1;  // 32-bit buffer offsets, DPC_BUF_OOB stays out of range
     WgradPatchParams p;
-    p.Co = d->Co; p.Ci = d->Ci; p.dy_ld = dy_ld; p.src_ld = d->src_ld; p.Kp = 9 * d->Ci;
+    p.Co = d->Co; p.Ci = d->Ci; p.dy_ld = dy_ld; p.src_ld = d->src_ld; p.Kp = 9 * d->KT * d->Ci;
+    p.KT = d->KT; p.pt = d->pt; p.T = d->RT; p.d_T = make_fastdiv((uint32_t)d->RT);
     p.RH = d->RH; p.NF = d->N * d->RT; p.M = (int)M;
     p.ntm = d->Co / 64; p.ntc = d->Ci / 64;
     p.src_bytes = (unsigned)sb; p.dy_bytes = (unsigned)db;
@@ -193,7 +215,7 @@ int dpc_wgrad_patch_try(const dpc_conv_desc* d, const void* src, const void* dy,
     p.d_cpf = make_fastdiv((uint32_t)p.cpf);
     const int nchunks = p.M / 64;
     static const int target_blocks = getenv("DPC_WGRAD_PATCH_BLOCKS") ? atoi(getenv("DPC_WGRAD_PATCH_BLOCKS")) : 512;
-    int want = target_blocks / (p.ntm * p.ntc);
+    int want = target_blocks / (p.ntm * p.ntc * p.KT);
     if (want < 1) want = 1;
     if (want > nchunks) want = nchunks;
     p.kcps = (nchunks + want - 1) / want;
@@ -203,9 +225,11 @@ int dpc_wgrad_patch_try(const dpc_conv_desc* d, const void* src, const void* dy,
     if (!src || !dy) return DPC_ERR_ARG;
     if (((uintptr_t)src % 16) || ((uintptr_t)dy % 16)) return DPC_ERR_UNSUPPORTED;
     p.src = src; p.dy = dy; p.part = part;
-    dim3 grid((unsigned)(p.ntm * p.ntc * p.nks)), block(256);
+    dim3 grid((unsigned)(p.ntm * p.ntc * p.KT * p.nks)), block(256);
     if (d->RW == 32) {
         DPC_LAUNCH((wgrad_patch_kernel<32>), grid, block, stream, p);
+    } else if (d->RW == 8) {
+        DPC_LAUNCH((wgrad_patch_kernel<8>), grid, block, stream, p);
     } else {
         DPC_LAUNCH((wgrad_patch_kernel<16>), grid, block, stream, p);
     }

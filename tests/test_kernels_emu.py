@@ -62,7 +62,8 @@ def test_conv_dgrad(k, dtype, shape):
     (5, 8, 24, 2, 6, 6, (1, 3, 3), (1, 2, 2), (0, 1, 1)),
     (2, 64, 64, 1, 8, 8, (1, 3, 3), (1, 1, 1), (0, 1, 1)),      # transpose-read kernel, 1x3 waves, chunk inside a plane
     (2, 64, 136, 2, 8, 16, (1, 1, 1), (1, 2, 2), (0, 0, 0)),    # 2x2 waves, chunk spans planes (bf16)
-    (1, 64, 128, 3, 8, 8, (3, 3, 3), (1, 1, 1), (1, 1, 1)),     # 2x3 waves
+    (1, 64, 128, 3, 8, 8, (3, 3, 3), (1, 1, 1), (1, 1, 1)),     # bf16: staged-patch kernel, 3 temporal taps, W = 8; f32: 2x3 waves
+    (2, 64, 128, 3, 4, 4, (3, 3, 3), (1, 1, 1), (1, 1, 1)),     # 2x3 waves, chunk spans planes
     (2, 256, 64, 1, 8, 8, (1, 1, 1), (1, 1, 1), (0, 0, 0)),     # 1x4 waves
     (3, 64, 64, 1, 8, 32, (1, 3, 3), (1, 1, 1), (0, 1, 1)),     # staged-patch kernel (bf16), W = 32, 2 rows per chunk
     (2, 128, 64, 2, 8, 16, (1, 3, 3), (1, 1, 1), (0, 1, 1)),    # staged-patch kernel, W = 16, two ci tiles
