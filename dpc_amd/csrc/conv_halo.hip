@@ -303,7 +303,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(HaloParams p) {
 //                          stores, batch-norm partial sums.
 // Two workgroup barriers per tile: B1(t) "patch t landed, staging t&1 is free", B2(t) "staging t&1 written,
 // patch t released".  One workgroup per CU (125 KB of LDS), persistent over its tiles.
-template <int DUMMY>
+template <bool HAS_ADD>
 __global__ __launch_bounds__(512, 2) void conv_halo_ws_kernel(HaloParams p) {
     typedef bf16_t T;
     typedef bf16_t TO;
@@ -440,32 +440,47 @@ __global__ __launch_bounds__(512, 2) void conv_halo_ws_kernel(HaloParams p) {
         float s1[EPO], s2[EPO];  // batch-norm partial sums live only in the helper waves' registers
         DPC_UNROLL
         for (int e = 0; e < EPO; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
-        auto epilogue = [&](int j) {
+        // The residual addend of tile j is requested one interval before it is consumed: with the loads issued
+        // inside the epilogue only 4 x 16 B per lane were in flight and the extra 0.67 GB of an input-gradient
+        // with residual cost +270 us (the kernel then moves 2 GB and is HBM-bound).
+        u32x4 av[4];
+        DPC_UNROLL
+        for (int q = 0; q < 4; ++q) av[q] = u32x4{0u, 0u, 0u, 0u};
+        auto tile_rows = [&](int j, int (&rows)[4]) {
             int frame, h0, w0;
             tile_origin(m_prog + j * p.gm, frame, h0, w0);
-            const unsigned char* stg = lds + NPB * PATCH + (j & 1) * STG;
-            u32x4 ov[4], av[4];
-            int rows[4];
             DPC_UNROLL
             for (int q = 0; q < 4; ++q) {
                 const int row_l = rbase + 32 * q;
                 const int h = h0 + (row_l >> p.lTW), w = w0 + (row_l & (p.TW - 1));
                 const bool ok = h < p.H && w < p.W && col0 < p.Co;
                 rows[q] = ok ? (frame * p.H + h) * p.W + w : -1;
-                ov[q] = *(const u32x4*)(stg + (row_l * BN + col0) * 2);
-                if (p.addend) {
-                    const char* a = (const char*)p.addend + ((long long)rows[q] * p.ldo + col0) * 2;
-                    av[q] = *(const u32x4*)(ok ? a : zero);
-                }
             }
+        };
+        auto fetch_addend = [&](int j, u32x4 (&dst)[4]) {
+            int rows[4];
+            tile_rows(j, rows);
+            DPC_UNROLL
+            for (int q = 0; q < 4; ++q) {
+                const char* a = (const char*)p.addend + ((long long)rows[q] * p.ldo + col0) * 2;
+                dst[q] = *(const u32x4*)(rows[q] >= 0 ? a : zero);
+            }
+        };
+        auto epilogue = [&](int j, const u32x4 (&add)[4]) {
+            int rows[4];
+            tile_rows(j, rows);
+            const unsigned char* stg = lds + NPB * PATCH + (j & 1) * STG;
+            u32x4 ov[4];
+            DPC_UNROLL
+            for (int q = 0; q < 4; ++q) ov[q] = *(const u32x4*)(stg + ((rbase + 32 * q) * BN + col0) * 2);
             DPC_UNROLL
             for (int q = 0; q < 4; ++q) {
                 if (rows[q] >= 0) {
                     u32x4 o = ov[q];
-                    if (p.addend) {
+                    if (HAS_ADD) {
                         float sv[EPO];
                         DPC_UNROLL
-                        for (int e = 0; e < EPO; ++e) sv[e] = unit_get<TO>(o, e) + unit_get<TO>(av[q], e);
+                        for (int e = 0; e < EPO; ++e) sv[e] = unit_get<TO>(o, e) + unit_get<TO>(add[q], e);
                         o = unit_pack<TO>(sv);
                     }
                     *(u32x4*)((char*)p.out + ((long long)rows[q] * p.ldo + col0) * 2) = o;
@@ -480,6 +495,7 @@ __global__ __launch_bounds__(512, 2) void conv_halo_ws_kernel(HaloParams p) {
         };
         issue(0);
         if (ntiles > 1) issue(1);
+        if (HAS_ADD) fetch_addend(0, av);
         for (int j = 0; j <= ntiles; ++j) {
             // patch j must have landed.  Newer than its pieces are: this wave's stores of tile j-2 and the LIT pieces
             // of patch j+1.  Loads (LDS-DMA included) complete in order among themselves, so "at most LIT
@@ -488,7 +504,17 @@ __global__ __launch_bounds__(512, 2) void conv_halo_ws_kernel(HaloParams p) {
                 if (j + 1 < ntiles) wait_vmcnt<LIT>(); else wait_vmcnt<0>();
             }
             barrier_lds_only();  // B1(j)
-            if (j >= 1) epilogue(j - 1);
+            if (HAS_ADD) {
+                u32x4 avn[4];
+                DPC_UNROLL
+                for (int q = 0; q < 4; ++q) avn[q] = av[q];
+                if (j < ntiles && j >= 1) fetch_addend(j, avn);
+                if (j >= 1) epilogue(j - 1, av);
+                DPC_UNROLL
+                for (int q = 0; q < 4; ++q) av[q] = avn[q];
+            } else if (j >= 1) {
+                epilogue(j - 1, av);
+            }
             if (j + 2 < ntiles) issue(j + 2);  // into the buffer of patch j-1, released at B2(j-1)
             barrier_lds_only();  // B2(j)
         }
@@ -577,7 +603,11 @@ int dpc_conv_halo_try(const dpc_conv_desc* d, const void* src, const void* wgt, 
     p.vec_out = (d->Co % epo == 0 && d->ldo % epo == 0 && ((uintptr_t)out % 16 == 0) && ((uintptr_t)addend % 16 == 0)) ? 1 : 0;
     dim3 grid((unsigned)p.gm), block(256);
     if (p.ws && p.vec_out && ((uintptr_t)src % 16 == 0)) {
-        DPC_LAUNCH((conv_halo_ws_kernel<0>), grid, dim3(512), stream, p);
+        if (addend) {
+            DPC_LAUNCH((conv_halo_ws_kernel<true>), grid, dim3(512), stream, p);
+        } else {
+            DPC_LAUNCH((conv_halo_ws_kernel<false>), grid, dim3(512), stream, p);
+        }
         return dpc_launch_status();
     }
     if (d->KH == 3) {

@@ -503,6 +503,11 @@ extern "C" int dpc_conv_igemm(const dpc_conv_desc* d, const void* src, const voi
     p.vec_out = (d->Co % epo == 0 && d->ldo % epo == 0 && ((uintptr_t)out % 16 == 0) && ((uintptr_t)addend % 16 == 0)) ? 1 : 0;
     int bn;
     igemm_grid(d, p.g.M, &p.ntm, &p.ntn, &p.gm, &bn);
+    {   // dpc_conv_stats_rows() promised the specialised kernel's row count for this shape; if that kernel declined at
+        // launch time (alignment, addend+stats) keep the promise: the generic kernel is persistent over any gm
+        const int wr = dpc_conv_ws_rows(d);
+        if (wr > 0) p.gm = wr < p.ntm ? wr : p.ntm;
+    }
     if (d->dtype_in == DPC_F32 && d->dtype_out == DPC_F32) return launch_igemm<float, float>(p, bn, stream);
     if (d->dtype_in == DPC_BF16 && d->dtype_out == DPC_BF16) return launch_igemm<bf16_t, bf16_t>(p, bn, stream);
     if (d->dtype_in == DPC_BF16 && d->dtype_out == DPC_F32) return launch_igemm<bf16_t, float>(p, bn, stream);

@@ -82,6 +82,7 @@ __device__ __forceinline__ void mma_step(f32x16 (&acc)[2][4], const FragSet& f) 
         for (int j = 0; j < 4; ++j) acc[i][j] = mfma_32x32x16_bf16(f.a[i], f.b[j], acc[i][j]);
 }
 
+template <bool HAS_ADD>
 __global__ __launch_bounds__(512, 2) void igemm_ws_kernel(WsParams p) {
     typedef bf16_t T;
     typedef bf16_t TO;
@@ -215,6 +216,18 @@ __global__ __launch_bounds__(512, 2) void igemm_ws_kernel(WsParams p) {
         // hipcc reuses one register set (every step then waits out a full LDS round trip: 64 % of the MFMA
         // rate measured) or, given two sets, waits lgkmcnt(0) -- i.e. also for the reads it has just issued.
         // Barrier sequence per tile, identical to the loaders': B(c0) B(c1) ... B(c_last) B("tile fully read").
+        // residual addend (input-gradient of a block's first conv): requested ahead of the epilogue -- issued inside
+        // it, 8 x 16 B per lane in flight made the extra tensor read cost +150 us on layer2
+        u32x4 av0[8], av1[8];
+        auto fetch_addend = [&](int i, u32x4 (&dst)[8]) {
+            DPC_UNROLL
+            for (int it = 0; it < 8; ++it) {
+                const int row = mt * BM + wv * 64 + i * 32 + er + 4 * it;
+                const bool ok = row < g.M && col0 < p.Ncol;
+                const char* a = (const char*)p.addend + ((long long)row * p.ldo + col0) * 2;
+                dst[it] = *(const u32x4*)(ok ? a : zero);
+            }
+        };
         int stage_last = 0;
         if (p.dbg & 1) {  // experiment: loaders only
             for (int kc = 0; kc < nkc; ++kc, ++gc) ws_barrier();
@@ -226,6 +239,7 @@ __global__ __launch_bounds__(512, 2) void igemm_ws_kernel(WsParams p) {
             const unsigned char* st = lds + (gc % NST) * STAGE;
             frag_read(f0, st, frag_a[0], frag_b[0]);
             for (int kc = 0; kc < nkc; ++kc) {
+                if (HAS_ADD && kc + 1 == nkc) fetch_addend(0, av0);  // lands under the last chunk's 32 MFMAs
                 frag_read(f1, st, frag_a[1], frag_b[1]);
                 frag_wait<6>(f0);
                 mma_step(acc, f0);
@@ -264,17 +278,12 @@ __global__ __launch_bounds__(512, 2) void igemm_ws_kernel(WsParams p) {
                     tile[row_l * BN + j * 32 + l31] = f32_to_bf16(acc[i][j][r]);
                 }
             wave_lds_fence();  // wave-private region: LDS operations of one wave complete in order, no workgroup barrier
-            u32x4 ov[8], av[8];
+            if (HAS_ADD && i == 0) fetch_addend(1, av1);  // the first pass's accumulators are dead: room for the second pass's addend
+            u32x4 ov[8];
             DPC_UNROLL
             for (int it = 0; it < 8; ++it) {
                 const int row_l = er + 4 * it;
                 ov[it] = *(const u32x4*)(mine + (row_l * BN + cu * EPO) * 2);
-                const int row = mt * BM + wv * 64 + i * 32 + row_l;
-                const bool ok = row < g.M && col0 < p.Ncol;
-                if (p.addend) {
-                    const char* a = (const char*)p.addend + ((long long)row * p.ldo + col0) * 2;
-                    av[it] = *(const u32x4*)(ok ? a : zero);
-                }
             }
             wave_lds_fence();  // the second pass overwrites what this one has just read
             DPC_UNROLL
@@ -282,25 +291,28 @@ __global__ __launch_bounds__(512, 2) void igemm_ws_kernel(WsParams p) {
                 const int row = mt * BM + wv * 64 + i * 32 + er + 4 * it;
                 if (row < g.M && col0 < p.Ncol) {
                     u32x4 o = ov[it];
-                    if (p.addend) {
+                    if (HAS_ADD) {
+                        const u32x4 a = i == 0 ? av0[it] : av1[it];
                         float sv[EPO];
                         DPC_UNROLL
-                        for (int e = 0; e < EPO; ++e) sv[e] = unit_get<TO>(o, e) + unit_get<TO>(av[it], e);
+                        for (int e = 0; e < EPO; ++e) sv[e] = unit_get<TO>(o, e) + unit_get<TO>(a, e);
                         o = unit_pack<TO>(sv);
                     }
                     *(u32x4*)((char*)p.out + ((long long)row * p.ldo + col0) * 2) = o;
-                    DPC_UNROLL
-                    for (int e = 0; e < EPO; ++e) {
-                        const float v = unit_get<TO>(o, e);
-                        s1[e] += v;
-                        s2[e] += v * v;
+                    if (!HAS_ADD) {  // batch-norm partial sums belong to forward convs; those have no residual addend
+                        DPC_UNROLL
+                        for (int e = 0; e < EPO; ++e) {
+                            const float v = unit_get<TO>(o, e);
+                            s1[e] += v;
+                            s2[e] += v * v;
+                        }
                     }
                 }
             }
         }
     }
 
-    if (p.stats) {
+    if (!HAS_ADD && p.stats) {
         // 16 lanes x 4 compute waves hold partial sums of the same 8 columns: fold the 4 row-lanes of a wave
         // by shuffles, then the 4 waves through LDS (the loader waves only keep the barriers company).
         DPC_UNROLL
@@ -383,10 +395,15 @@ int dpc_conv_ws_try(const dpc_conv_desc* d, const void* src, const void* wgt, vo
                     hipStream_t stream) {
     WsParams p;
     if (!ws_plan(d, &p)) return 1;
+    if (addend && stats) return 1;  // not a combination of this path: the generic kernel serves it
     if (((uintptr_t)out % 16) || ((uintptr_t)addend % 16) || ((uintptr_t)src % 16) || ((uintptr_t)wgt % 16)) return 1;
     p.src = src; p.wgt = wgt; p.out = out; p.addend = addend; p.stats = stats;
     p.dbg = env_int("DPC_IGEMM_WS_DBG", 0);
     dim3 grid((unsigned)(p.gm * p.ntn)), block(512);
-    DPC_LAUNCH(igemm_ws_kernel, grid, block, stream, p);
+    if (addend) {
+        DPC_LAUNCH((igemm_ws_kernel<true>), grid, block, stream, p);
+    } else {
+        DPC_LAUNCH((igemm_ws_kernel<false>), grid, block, stream, p);
+    }
     return dpc_launch_status();
 }

@@ -67,6 +67,8 @@ def main():
                 return lib.call("dpc_conv_igemm", C.byref(d), src, wgt, out, None, stats, st)
             if op == "dgrad":
                 return lib.call("dpc_conv_igemm", C.byref(dd), dy, wgt_d, dx, None, None, st)
+            if op == "dgrada":  # input-gradient with a residual addend (first conv of a BasicBlock)
+                return lib.call("dpc_conv_igemm", C.byref(dd), dy, wgt_d, dx, src, None, st)
             return lib.call("dpc_conv_wgrad", C.byref(dw), src, dy, Co, part, C.byref(ns), st)
 
         for op in args.ops.split(","):
