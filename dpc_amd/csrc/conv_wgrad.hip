@@ -548,7 +548,12 @@ extern "C" int dpc_conv_wgrad(const dpc_conv_desc* d, const void* src, const voi
     }
     p.ntm = (d->Co + tm - 1) / tm;
     p.ntn = (p.g.Kp + tn - 1) / tn;
+    // K-splits: enough workgroups to fill the chip, but every split must amortise its f32 partial slab (a tile
+    // of tm x tn floats written, then re-read by the reduction) over at least `min_chunks` chunks -- the small
+    // ConvGRU gradients ran 4 chunks per 64 KB slab
+    static const int min_chunks = getenv("DPC_WGRAD_MINCHUNKS") ? atoi(getenv("DPC_WGRAD_MINCHUNKS")) : 16;
     int want = 1536 / (p.ntm * p.ntn);
+    if (want > nchunks / min_chunks) want = nchunks / min_chunks;
     if (want < 1) want = 1;
     if (want > nchunks) want = nchunks;
     p.kcps = (nchunks + want - 1) / want;

@@ -354,6 +354,9 @@ class DPCEngine:
                              shape, has_ds, final_relu=not last)
                 self.blocks.append(blk)
                 shape, inplanes = blk.out_shape, planes
+        # gradient-arena split for the overlapped all-reduce: the head = stem + layer1 (finished last by the backward)
+        self.n_head_blocks = plan[0]
+        self.grad_split = self.offsets["backbone.layer2.0.conv1.weight"][0]
         self.feat_shape = shape
         if shape[1] != self.last_duration or shape[2] != self.last_size or shape[3] != self.last_size:
             raise ValueError(f"backbone output {shape} does not match last_duration/last_size "
@@ -603,8 +606,10 @@ class DPCEngine:
         return self.result
 
     # ------------------------------------------------------------------ backward
-    def backward(self, dscore_external: Optional[torch.Tensor] = None):
-        """gradients of everything w.r.t. the loss whose d/dscore sits in self.dscore (or is given, [R][R] f32)"""
+    def backward(self, dscore_external: Optional[torch.Tensor] = None, on_tail_ready=None):
+        """gradients of everything w.r.t. the loss whose d/dscore sits in self.dscore (or is given, [R][R] f32).
+        on_tail_ready(flat_g[split:]) is called once every gradient except the stem's and layer1's is final
+        (data-parallel runs start their all-reduce there, dpc_amd/parallel.py)."""
         B, N, P, SQ, D, M, R = self.B, self.N, self.P, self.SQ, self.D, self.M, self.R
         dc = L.dtype_code(self.cdtype)
         if dscore_external is not None:
@@ -661,8 +666,10 @@ class DPCEngine:
         fs = self.feat_shape
         self.call("dpc_tpool_split_bwd", self.blocks[-1].out, self.d_featrelu, self.d_finf, dc, B, N, fs[1], SQ, D, P, self.d_feat)
         d = self.d_feat
-        for blk in reversed(self.blocks):
-            d = blk.backward(d, need_dx=True)
+        for bi in reversed(range(len(self.blocks))):
+            if on_tail_ready is not None and bi == self.n_head_blocks - 1:
+                on_tail_ready(self.flat_g[self.grad_split:])
+            d = self.blocks[bi].backward(d, need_dx=True)
         # stem: max-pool routing (ReLU mask folded into the saved argmax) -> BN -> weight grad; the video has no grad
         st = self.stem.out_shape
         u, C0 = self.stem, self.widths[0]
@@ -701,8 +708,12 @@ class DPCEngine:
         """forward + CE/top-k + backward (+ gradient all-reduce) + Adam.  Returns device f32[4] = loss, top1, top3, top5."""
         self.forward(block, train=True, dropout_masks=dropout_masks)
         res = self.loss_topk(with_grad=True)
-        self.backward()
-        if allreduce is not None:
-            allreduce(self.flat_g)
+        if allreduce is not None and hasattr(allreduce, "start"):
+            self.backward(on_tail_ready=allreduce.start)
+            allreduce.finish(self.flat_g[:self.grad_split])
+        else:
+            self.backward()
+            if allreduce is not None:
+                allreduce(self.flat_g)
         self.adam_step()
         return res

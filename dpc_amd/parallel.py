@@ -13,19 +13,49 @@ from __future__ import annotations
 import torch
 
 
+class GradAllReduce:
+    """Averages the flat gradient arena across ranks in place (backend 'nccl' == RCCL over xGMI).
+
+    Two buckets so that the exchange hides behind the backward pass: the arena is laid out in forward order
+    (stem, layer1, ..., layer4, ConvGRU, predictor) and the backward pass finishes it back to front, so the
+    tail [split:] -- everything except the stem and layer1, 99 % of the bytes -- is final while layer1 and the
+    stem (the HBM-heavy ~10 ms of the step at r18/128/B=128) are still running.  `start(tail)` launches that
+    all-reduce asynchronously (RCCL runs it on its own stream, ordered after the work already queued);
+    `finish(head)` reduces the small head and joins.  Calling the object reduces the whole arena at once.
+    """
+
+    def __init__(self, dist, world: int):
+        self.dist, self.world = dist, world
+        self.avg = dist.get_backend() == "nccl"  # gloo (CPU tests) has no AVG
+        self._pending = []
+
+    def _launch(self, t: torch.Tensor, async_op: bool):
+        op = self.dist.ReduceOp.AVG if self.avg else self.dist.ReduceOp.SUM
+        return self.dist.all_reduce(t, op=op, async_op=async_op)
+
+    def start(self, tail: torch.Tensor):
+        self._pending.append((self._launch(tail, True), tail))
+
+    def finish(self, head: torch.Tensor):
+        if head.numel():
+            self._launch(head, False)
+            if not self.avg:
+                head.div_(self.world)
+        for work, t in self._pending:
+            work.wait()
+            if not self.avg:
+                t.div_(self.world)
+        self._pending.clear()
+
+    def __call__(self, flat: torch.Tensor):
+        self.finish(flat)
+
+
 def make_allreduce(dist, world: int, force: bool = False):
-    """returns f(flat_grad) that averages the arena across ranks in place (backend 'nccl' == RCCL)"""
+    """returns a GradAllReduce (callable on the whole arena, or start()/finish() on its two buckets), or None"""
     if dist is None or (world <= 1 and not force):
         return None
-    backend = dist.get_backend()
-
-    def allreduce(flat: torch.Tensor):
-        if backend == "nccl":
-            dist.all_reduce(flat, op=dist.ReduceOp.AVG)
-        else:  # gloo (CPU tests): no AVG
-            dist.all_reduce(flat, op=dist.ReduceOp.SUM)
-            flat.div_(world)
-    return allreduce
+    return GradAllReduce(dist, world)
 
 
 def shard_of(global_batch: int, world: int, rank: int) -> slice:

@@ -36,9 +36,18 @@ def _rank_main(rank, world, port, out_dir):
     ones = torch.ones(eng.n_steps, eng.M, eng.D)
     eng.forward(x, train=True, dropout_masks=ones)
     res = eng.loss_topk(True).clone()
-    eng.backward()
-    local_grad = eng.flat_g.clone()
-    make_allreduce(dist, world)(eng.flat_g)
+    # two-bucket exchange exactly as train_step does it: the tail all-reduce starts (asynchronously) while the
+    # backward of layer1 + stem is still to run; the copy of the local tail is taken inside the callback
+    ar = make_allreduce(dist, world)
+    local_tail = []
+
+    def on_tail(tail):
+        local_tail.append(tail.clone())
+        ar.start(tail)
+
+    eng.backward(on_tail_ready=on_tail)
+    local_grad = torch.cat([eng.flat_g[:eng.grad_split].clone(), local_tail[0]])
+    ar.finish(eng.flat_g[:eng.grad_split])
     eng.adam_step()
     torch.save({"local_grad": local_grad, "avg_grad": eng.flat_g.clone(), "params": eng.flat_p.clone(), "res": res,
                 "offsets": eng.offsets}, os.path.join(out_dir, f"rank{rank}.pt"))
