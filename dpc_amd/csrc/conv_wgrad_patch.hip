@@ -28,7 +28,7 @@ struct WgradPatchParams {
     const void* dy;
     float* part;
     int Co, Ci, dy_ld, src_ld, Kp;
-    int RH, NF;          // image rows, frames (N*T)
+    int RH, W, NF;       // image rows, real image width (<= the padded width the kernel is instantiated for), frames (N*T)
     int M;
     int nks, kcps;
     int ntm, ntc;
@@ -39,6 +39,9 @@ struct WgradPatchParams {
     FastDiv d_T;
 };
 
+// RW: image width rounded up to 8/16/32/64.  A chunk is 64/RW image rows of RW columns; columns >= the real
+// width and rows >= the image height are out-of-range lanes of the dy DMA (zeros: they add nothing), so any
+// image up to 64 wide is served (the 224-pixel configurations: 56, 28, 14, 7 -> 64, 32, 16, 8 at 12.5 % padding).
 template <int RW>
 __global__ __launch_bounds__(256, 2) void wgrad_patch_kernel(WgradPatchParams p) {
     constexpr int ROWS = 64 / RW;          // image rows per chunk (RW = 8: a chunk is one 8x8 plane)
@@ -68,7 +71,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_patch_kernel(WgradPatchParams p)
     const int tile_m = id % p.ntm; id /= p.ntm;
     const int kt = id % p.KT;
     const int ks = id / p.KT;
-    const int nchunks = p.M / 64;
+    const int nchunks = p.NF * p.cpf;
     const int c_begin = ks * p.kcps;
     const int c_end = (c_begin + p.kcps < nchunks) ? c_begin + p.kcps : nchunks;
 
@@ -78,17 +81,23 @@ __global__ __launch_bounds__(256, 2) void wgrad_patch_kernel(WgradPatchParams p)
     const int pl = lane >> 3;                              // position inside a piece
     const int lslot = (lane & 7) ^ (2 * (pl & 3));         // channel group this lane fetches (swizzle on the source side)
     unsigned a_off[2];
+    int a_row[2];  // image row relative to the chunk's first row, or a value no image row can have (padding column)
     DPC_UNROLL
-    for (int i = 0; i < 2; ++i) a_off[i] = (unsigned)((8 * (wv + 4 * i) + pl) * p.dy_ld + tile_m * 64 + lslot * 8) * 2u;
+    for (int i = 0; i < 2; ++i) {
+        const int pp = 8 * (wv + 4 * i) + pl;
+        const int r = pp / RW, c = pp % RW;
+        a_row[i] = c < p.W ? r : (1 << 28);
+        a_off[i] = (unsigned)((r * p.W + c) * p.dy_ld + tile_m * 64 + lslot * 8) * 2u;
+    }
     unsigned b_off[NIB];
     int b_row[NIB];  // patch row - 1 (image row relative to the chunk's first row), or a value no image row can have
     DPC_UNROLL
     for (int i = 0; i < NIB; ++i) {
         const int pp = 8 * (wv + 4 * i) + pl;
         const int prow = pp / PW, pcol = pp % PW;
-        const bool ok = pp < NPOS && pcol >= 1 && pcol <= RW;
+        const bool ok = pp < NPOS && pcol >= 1 && pcol <= p.W;
         b_row[i] = ok ? prow - 1 : (1 << 28);
-        b_off[i] = (unsigned)(((prow - 1) * RW + (pcol - 1)) * p.src_ld + tile_c * 64 + lslot * 8) * 2u;
+        b_off[i] = (unsigned)(((prow - 1) * p.W + (pcol - 1)) * p.src_ld + tile_c * 64 + lslot * 8) * 2u;
     }
 
     f32x16 acc[9];
@@ -99,12 +108,15 @@ __global__ __launch_bounds__(256, 2) void wgrad_patch_kernel(WgradPatchParams p)
 
     auto issue = [&](int chunk, int buf) {
         unsigned char* stage = lds + buf * STAGE;
-        const unsigned a_base = (unsigned)chunk * 64u * (unsigned)p.dy_ld * 2u;
         const unsigned frame = fdiv((unsigned)chunk, p.d_cpf);
         const int h0 = (chunk - (int)frame * p.cpf) * ROWS;
-        const unsigned b_base = (unsigned)((((int)frame + kt - p.pt) * p.RH + h0) * RW) * (unsigned)p.src_ld * 2u;
+        const unsigned a_base = (unsigned)(((int)frame * p.RH + h0) * p.W) * (unsigned)p.dy_ld * 2u;
+        const unsigned b_base = (unsigned)((((int)frame + kt - p.pt) * p.RH + h0) * p.W) * (unsigned)p.src_ld * 2u;
         DPC_UNROLL
-        for (int i = 0; i < 2; ++i) glds16_buf(rs_a, a_base + a_off[i], 0u, stage + (wv + 4 * i) * 1024, lane);
+        for (int i = 0; i < 2; ++i) {
+            const bool ok = (unsigned)(h0 + a_row[i]) < (unsigned)p.RH;
+            glds16_buf(rs_a, ok ? a_base + a_off[i] : DPC_BUF_OOB, 0u, stage + (wv + 4 * i) * 1024, lane);
+        }
         DPC_UNROLL
         for (int i = 0; i < NIB; ++i) {
             if (wv + 4 * i < NPB) {
@@ -200,20 +212,22 @@ int dpc_wgrad_patch_try(const dpc_conv_desc* d, const void* src, const void* dy,
     if (d->KH != 3 || d->KW != 3 || d->st != 1 || d->sh != 1 || d->sw != 1 || d->ph != 1 || d->pw != 1) return 1;
     if (!((d->KT == 1 && d->pt == 0) || (d->KT == 3 && d->pt == 1))) return 1;
     if (d->RT != d->ST || d->RH != d->SH || d->RW != d->SW) return 1;
-    if (d->RW != 8 && d->RW != 16 && d->RW != 32) return 1;
-    if ((d->RH * d->RW) % 64 || d->Ci % 64 || d->Co % 64 || d->src_ld % 8 || dy_ld % 8 || dy_ld < d->Co) return 1;
+    if (d->RW > 64) return 1;
+    if (d->Ci % 64 || d->Co % 64 || d->src_ld % 8 || dy_ld % 8 || dy_ld < d->Co) return 1;
+    const int rwp = d->RW <= 8 ? 8 : d->RW <= 16 ? 16 : d->RW <= 32 ? 32 : 64;  // padded width the kernel is instantiated for
+    const int rows = 64 / rwp;
     const long long M = (long long)d->N * d->RT * d->RH * d->RW;
     const long long sb = M * d->src_ld * 2, db = M * dy_ld * 2;
     if (sb >= (1ll << 31) || db >= (1ll << 31)) return 1;  // 32-bit buffer offsets, DPC_BUF_OOB stays out of range
     WgradPatchParams p;
     p.Co = d->Co; p.Ci = d->Ci; p.dy_ld = dy_ld; p.src_ld = d->src_ld; p.Kp = 9 * d->KT * d->Ci;
     p.KT = d->KT; p.pt = d->pt; p.T = d->RT; p.d_T = make_fastdiv((uint32_t)d->RT);
-    p.RH = d->RH; p.NF = d->N * d->RT; p.M = (int)M;
+    p.RH = d->RH; p.W = d->RW; p.NF = d->N * d->RT; p.M = (int)M;
     p.ntm = d->Co / 64; p.ntc = d->Ci / 64;
     p.src_bytes = (unsigned)sb; p.dy_bytes = (unsigned)db;
-    p.cpf = d->RH * d->RW / 64;
+    p.cpf = (d->RH + rows - 1) / rows;
     p.d_cpf = make_fastdiv((uint32_t)p.cpf);
-    const int nchunks = p.M / 64;
+    const int nchunks = p.NF * p.cpf;
     static const int target_blocks = getenv("DPC_WGRAD_PATCH_BLOCKS") ? atoi(getenv("DPC_WGRAD_PATCH_BLOCKS")) : 512;
     int want = target_blocks / (p.ntm * p.ntc * p.KT);
     if (want < 1) want = 1;
@@ -226,9 +240,11 @@ int dpc_wgrad_patch_try(const dpc_conv_desc* d, const void* src, const void* dy,
     if (((uintptr_t)src % 16) || ((uintptr_t)dy % 16)) return DPC_ERR_UNSUPPORTED;
     p.src = src; p.dy = dy; p.part = part;
     dim3 grid((unsigned)(p.ntm * p.ntc * p.KT * p.nks)), block(256);
-    if (d->RW == 32) {
+    if (rwp == 64) {
+        DPC_LAUNCH((wgrad_patch_kernel<64>), grid, block, stream, p);
+    } else if (rwp == 32) {
         DPC_LAUNCH((wgrad_patch_kernel<32>), grid, block, stream, p);
-    } else if (d->RW == 8) {
+    } else if (rwp == 8) {
         DPC_LAUNCH((wgrad_patch_kernel<8>), grid, block, stream, p);
     } else {
         DPC_LAUNCH((wgrad_patch_kernel<16>), grid, block, stream, p);

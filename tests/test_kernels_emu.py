@@ -67,6 +67,9 @@ def test_conv_dgrad(k, dtype, shape):
     (2, 256, 64, 1, 8, 8, (1, 1, 1), (1, 1, 1), (0, 0, 0)),     # 1x4 waves
     (3, 64, 64, 1, 8, 32, (1, 3, 3), (1, 1, 1), (0, 1, 1)),     # staged-patch kernel (bf16), W = 32, 2 rows per chunk
     (2, 128, 64, 2, 8, 16, (1, 3, 3), (1, 1, 1), (0, 1, 1)),    # staged-patch kernel, W = 16, two ci tiles
+    (2, 64, 64, 2, 7, 7, (1, 3, 3), (1, 1, 1), (0, 1, 1)),      # staged-patch kernel, 7x7 image padded to width 8
+    (1, 64, 128, 2, 14, 14, (3, 3, 3), (1, 1, 1), (1, 1, 1)),   # 14x14 -> width 16, ragged last chunk of a plane
+    (1, 64, 64, 1, 5, 56, (1, 3, 3), (1, 1, 1), (0, 1, 1)),     # width 56 -> 64: one image row per chunk
 ])
 def test_conv_wgrad(k, dtype, shape):
     kc.case_conv_wgrad(k, dtype, *shape)

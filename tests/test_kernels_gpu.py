@@ -57,6 +57,10 @@ def test_conv_dgrad(k, dtype, shape):
     (16, 256, 256, 3, 8, 8, (3, 3, 3), (1, 1, 1), (1, 1, 1)),
     (5, 128, 256, 5, 16, 16, (1, 1, 1), (2, 2, 2), (0, 0, 0)),
     (5, 8, 24, 2, 6, 6, (1, 3, 3), (1, 2, 2), (0, 1, 1)),
+    (6, 64, 64, 2, 56, 56, (1, 3, 3), (1, 1, 1), (0, 1, 1)),     # 224-pixel family: staged-patch kernel with padded widths
+    (6, 128, 128, 2, 28, 28, (1, 3, 3), (1, 1, 1), (0, 1, 1)),
+    (8, 256, 256, 3, 14, 14, (3, 3, 3), (1, 1, 1), (1, 1, 1)),
+    (16, 256, 256, 2, 7, 7, (3, 3, 3), (1, 1, 1), (1, 1, 1)),
 ])
 def test_conv_wgrad(k, dtype, shape):
     kc.case_conv_wgrad(k, dtype, *shape)
