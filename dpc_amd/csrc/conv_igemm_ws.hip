@@ -36,6 +36,10 @@ struct WsParams {
     int gm, ntn, ntm;
     unsigned src_bytes, wgt_bytes;
     int dbg;
+    // temporal grouping (3x3x3 stride-1 convs): a tile holds planes of ONE output frame index t, taken from
+    // consecutive clips, so the temporal taps that fall into the zero padding are the same for the whole tile
+    // and are skipped as a K sub-range (22 % of the chunks at T = 3, 33 % at T = 2).
+    int tgroup, lHW, ppt, tpt, cpkt;  // on/off, log2(RH*RW), planes per tile, tiles per t, chunks per temporal tap
 };
 
 // workgroup barrier that waits for nothing but this wave's LDS traffic
@@ -104,7 +108,31 @@ __global__ __launch_bounds__(512, 2) void igemm_ws_kernel(WsParams p) {
     const int m_prog = blockIdx.x % p.gm;
     const int nkc = g.Kp / BKE;
     const int my_tiles = (p.ntm - m_prog + p.gm - 1) / p.gm;
-    const int total = my_tiles * nkc;  // chunks this workgroup walks, across its tiles
+    // tile row -> GEMM row (identity unless the tiles are grouped by output frame index)
+    auto tile_row = [&](int mt, int r) -> int {
+        if (!p.tgroup) return mt * BM + r;
+        const int t = mt / p.tpt;
+        const int clip = (mt - t * p.tpt) * p.ppt + (r >> p.lHW);
+        return clip < g.M / (g.RT << p.lHW) ? (((clip * g.RT + t) << p.lHW) + (r & ((1 << p.lHW) - 1))) : g.M;
+    };
+    // K chunks [lo, hi) of a tile: all of them, or those of the temporal taps that hit real frames
+    auto tile_chunks = [&](int mt, int& lo, int& hi) {
+        lo = 0; hi = nkc;
+        if (!p.tgroup) return;
+        const int t = mt / p.tpt;
+        int klo, khi;
+        if (g.mode == 0) { klo = g.pt - t; khi = g.ST - 1 + g.pt - t; }
+        else { klo = t + g.pt - (g.ST - 1); khi = t + g.pt; }
+        if (klo < 0) klo = 0;
+        if (khi > g.KT - 1) khi = g.KT - 1;
+        lo = klo * p.cpkt; hi = (khi + 1) * p.cpkt;
+    };
+    int total = 0;  // chunks this workgroup walks, across its tiles
+    for (int t = 0; t < my_tiles; ++t) {
+        int lo, hi;
+        tile_chunks(m_prog + t * p.gm, lo, hi);
+        total += hi - lo;
+    }
     const char* const zero = (const char*)dpc_zero16;
 
     if (wv >= 4) {
@@ -127,10 +155,9 @@ __global__ __launch_bounds__(512, 2) void igemm_ws_kernel(WsParams p) {
         unsigned rowoff[8];   // byte offset of (row, tap 0, this lane's channel group); wraps for rows that start in the padding
         unsigned vmask[8];
         auto decode_tile = [&](int mt) {
-            const int m0 = mt * BM;
             DPC_UNROLL
             for (int i = 0; i < 8; ++i) {
-                const RowPos rp = decode_row(g, m0 + 8 * (lw + 4 * i) + rl);
+                const RowPos rp = decode_row(g, tile_row(mt, 8 * (lw + 4 * i) + rl));
                 rowoff[i] = ((((((unsigned)(rp.nbase + rp.t0) * (unsigned)g.SH + (unsigned)rp.h0) * (unsigned)g.SW) + (unsigned)rp.w0) *
                               (unsigned)g.src_ld) + (unsigned)(u * 8)) * 2u;
                 const int sgn = g.mode == 0 ? 1 : -1;
@@ -164,22 +191,38 @@ __global__ __launch_bounds__(512, 2) void igemm_ws_kernel(WsParams p) {
             for (int i = 0; i < 4; ++i) glds16_buf(rs_b, wrow[i], (unsigned)kd * 2u, st + BM * 128 + (lw + 4 * i) * 1024, lane);
         };
         // chunk counter -> (tile, kc) of the NEXT chunk to issue
-        int it_tile = 0, it_kc = 0;
+        int it_tile = 0, it_kc = 0, it_hi = 0;
+        bool it_new = true;
         auto issue_next = [&](int gc) {
-            if (it_kc == 0) decode_tile(m_prog + it_tile * p.gm);
+            if (it_new) {
+                const int mt = m_prog + it_tile * p.gm;
+                decode_tile(mt);
+                tile_chunks(mt, it_kc, it_hi);
+                it_new = false;
+            }
             issue(it_kc, gc % NST);
-            if (++it_kc == nkc) { it_kc = 0; ++it_tile; }
+            if (++it_kc == it_hi) { it_new = true; ++it_tile; }
         };
         if (total > 0) issue_next(0);
         if (total > 1) issue_next(1);
-        int kc_done = 0;  // position of chunk gc inside its tile
+        int kc_done = 0, cur_tile = 0, cur_n;  // position of chunk gc inside its tile, chunks of that tile
+        {
+            int lo, hi;
+            tile_chunks(m_prog, lo, hi);
+            cur_n = hi - lo;
+        }
         for (int gc = 0; gc < total; ++gc) {
             if (gc + 1 < total) wait_vmcnt<12>(); else wait_vmcnt<0>();
             ws_barrier();  // chunk gc is published; every reader is done with chunk gc-1
             if (gc + 2 < total) issue_next(gc + 2);
-            if (++kc_done == nkc) {
+            if (++kc_done == cur_n) {
                 kc_done = 0;
                 ws_barrier();  // matches the compute waves' "tile fully read" barrier
+                if (++cur_tile < my_tiles) {
+                    int lo, hi;
+                    tile_chunks(m_prog + cur_tile * p.gm, lo, hi);
+                    cur_n = hi - lo;
+                }
             }
         }
     }
@@ -202,6 +245,9 @@ __global__ __launch_bounds__(512, 2) void igemm_ws_kernel(WsParams p) {
     int gc = 0;
     for (int t = 0; wv < 4 && t < my_tiles; ++t) {
         const int mt = m_prog + t * p.gm;
+        int kc_lo, kc_hi;
+        tile_chunks(mt, kc_lo, kc_hi);
+        const int nkc_t = kc_hi - kc_lo;
         f32x16 acc[2][4];
         DPC_UNROLL
         for (int i = 0; i < 2; ++i)
@@ -222,7 +268,7 @@ __global__ __launch_bounds__(512, 2) void igemm_ws_kernel(WsParams p) {
         auto fetch_addend = [&](int i, u32x4 (&dst)[8]) {
             DPC_UNROLL
             for (int it = 0; it < 8; ++it) {
-                const int row = mt * BM + wv * 64 + i * 32 + er + 4 * it;
+                const int row = tile_row(mt, wv * 64 + i * 32 + er + 4 * it);
                 const bool ok = row < g.M && col0 < p.Ncol;
                 const char* a = (const char*)p.addend + ((long long)row * p.ldo + col0) * 2;
                 dst[it] = *(const u32x4*)(ok ? a : zero);
@@ -230,7 +276,7 @@ __global__ __launch_bounds__(512, 2) void igemm_ws_kernel(WsParams p) {
         };
         int stage_last = 0;
         if (p.dbg & 1) {  // experiment: loaders only
-            for (int kc = 0; kc < nkc; ++kc, ++gc) ws_barrier();
+            for (int kc = 0; kc < nkc_t; ++kc, ++gc) ws_barrier();
             stage_last = (gc - 1) % NST;
             ws_barrier();
         } else {
@@ -238,8 +284,8 @@ __global__ __launch_bounds__(512, 2) void igemm_ws_kernel(WsParams p) {
             ws_barrier();  // first chunk of the tile published
             const unsigned char* st = lds + (gc % NST) * STAGE;
             frag_read(f0, st, frag_a[0], frag_b[0]);
-            for (int kc = 0; kc < nkc; ++kc) {
-                if (HAS_ADD && kc + 1 == nkc) fetch_addend(0, av0);  // lands under the last chunk's 32 MFMAs
+            for (int kc = 0; kc < nkc_t; ++kc) {
+                if (HAS_ADD && kc + 1 == nkc_t) fetch_addend(0, av0);  // lands under the last chunk's 32 MFMAs
                 frag_read(f1, st, frag_a[1], frag_b[1]);
                 frag_wait<6>(f0);
                 mma_step(acc, f0);
@@ -256,7 +302,7 @@ __global__ __launch_bounds__(512, 2) void igemm_ws_kernel(WsParams p) {
                 ws_barrier();  // next chunk published -- or, after the tile's last chunk, "tile fully read"
                 stage_last = gc % NST;
                 ++gc;
-                if (kc + 1 < nkc) {
+                if (kc + 1 < nkc_t) {
                     st = lds + (gc % NST) * STAGE;
                     frag_read(f0, st, frag_a[0], frag_b[0]);
                 }
@@ -288,7 +334,7 @@ __global__ __launch_bounds__(512, 2) void igemm_ws_kernel(WsParams p) {
             wave_lds_fence();  // the second pass overwrites what this one has just read
             DPC_UNROLL
             for (int it = 0; it < 8; ++it) {
-                const int row = mt * BM + wv * 64 + i * 32 + er + 4 * it;
+                const int row = tile_row(mt, wv * 64 + i * 32 + er + 4 * it);
                 if (row < g.M && col0 < p.Ncol) {
                     u32x4 o = ov[it];
                     if (HAS_ADD) {
@@ -374,6 +420,18 @@ static bool ws_plan(const dpc_conv_desc* d, WsParams* p) {
     p->wgt_bytes = (unsigned)wbytes;
     p->ntn = (d->Co + 127) / 128;
     p->ntm = (g.M + 255) / 256;
+    p->tgroup = 0; p->lHW = 0; p->ppt = 1; p->tpt = 1; p->cpkt = 1;
+    {
+        static const int tg_on = env_int("DPC_IGEMM_WS_TGROUP", 1);
+        const int hw = g.RH * g.RW, lhw = ilog2_exact(hw);
+        if (tg_on && g.KT > 1 && unit_strides && g.RT == g.ST && g.RT > 1 && lhw >= 0 && hw <= 256) {
+            p->tgroup = 1; p->lHW = lhw; p->ppt = 256 / hw;
+            const int nclip = g.M / (g.RT * hw);
+            p->tpt = (nclip + p->ppt - 1) / p->ppt;
+            p->cpkt = g.KH * g.KW * (g.Ci / 64);
+            p->ntm = g.RT * p->tpt;
+        }
+    }
     // one resident workgroup per CU (144 KB of LDS); XCD x gets workgroups x, x+8, ...: keep gm a multiple
     // of 8 so that the ntn column tiles of one row tile (blockIdx differing by gm) share an L2
     int gm = ws_max_programs() / p->ntn;

@@ -22,6 +22,9 @@ def main():
     kc.case_conv_fwd(k, BF16, 3, 64, 128, 2, 10, 16, (1, 3, 3), (1, 1, 1), (0, 1, 1))      # 960 rows: 4 tiles, 2 programs
     kc.case_conv_fwd(k, BF16, 2, 64, 136, 3, 8, 8, (3, 3, 3), (1, 1, 1), (1, 1, 1))        # two column tiles
     kc.case_conv_fwd(k, BF16, 5, 128, 128, 2, 9, 7, (1, 1, 1), (1, 2, 2), (0, 0, 0))       # one tap, strided rows
+    # temporally grouped tiles (3x3x3, power-of-two planes): padding taps skipped as a K sub-range
+    kc.case_conv_fwd(k, BF16, 9, 64, 128, 2, 4, 4, (3, 3, 3), (1, 1, 1), (1, 1, 1))        # T = 2, 16 planes per tile
+    kc.case_conv_dgrad(k, BF16, 3, 128, 64, 3, 4, 8, (3, 3, 3), (1, 1, 1), (1, 1, 1))
     # unit-stride input gradient (+ residual addend): the GEMM's columns are the conv's input channels
     kc.case_conv_dgrad(k, BF16, 2, 128, 64, 2, 9, 16, (1, 3, 3), (1, 1, 1), (0, 1, 1))
     kc.case_conv_dgrad(k, BF16, 1, 128, 128, 3, 6, 6, (3, 3, 3), (1, 1, 1), (1, 1, 1))
