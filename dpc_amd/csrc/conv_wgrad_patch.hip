@@ -216,6 +216,8 @@ int dpc_wgrad_patch_try(const dpc_conv_desc* d, const void* src, const void* dy,
     if (d->Ci % 64 || d->Co % 64 || d->src_ld % 8 || dy_ld % 8 || dy_ld < d->Co) return 1;
     const int rwp = d->RW <= 8 ? 8 : d->RW <= 16 ? 16 : d->RW <= 32 ? 32 : 64;  // padded width the kernel is instantiated for
     const int rows = 64 / rwp;
+    // padded columns / rows are wasted MFMA work: below 60 % useful positions the generic kernels are faster (4x4 images: 25 %)
+    if (d->RH * d->RW * 10 < ((d->RH + rows - 1) / rows) * 64 * 6) return 1;
     const long long M = (long long)d->N * d->RT * d->RH * d->RW;
     const long long sb = M * d->src_ld * 2, db = M * dy_ld * 2;
     if (sb >= (1ll << 31) || db >= (1ll << 31)) return 1;  // 32-bit buffer offsets, DPC_BUF_OOB stays out of range
