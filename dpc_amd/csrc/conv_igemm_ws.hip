@@ -35,7 +35,6 @@ struct WsParams {
     int Ncol, ldw, ldo;
     int gm, ntn, ntm;
     unsigned src_bytes, wgt_bytes;
-    int dbg;
     // temporal grouping (3x3x3 stride-1 convs): a tile holds planes of ONE output frame index t, taken from
     // consecutive clips, so the temporal taps that fall into the zero padding are the same for the whole tile
     // and are skipped as a K sub-range (22 % of the chunks at T = 3, 33 % at T = 2).
@@ -181,7 +180,6 @@ __global__ __launch_bounds__(512, 2) void igemm_ws_kernel(WsParams p) {
             const int cbase = (g.taps == 1) ? 0 : (tap << g.log2C);
             const unsigned tapoff = (unsigned)(sgn * ((((int)kt * g.SH + kh) * g.SW + kw) * g.src_ld) + (kd - cbase)) * 2u;
             unsigned char* st = lds + stage * STAGE;
-            if (p.dbg & 2) return;
             DPC_UNROLL
             for (int i = 0; i < 8; ++i) {
                 const bool ok = (vmask[i] & sel) == sel;
@@ -275,11 +273,7 @@ __global__ __launch_bounds__(512, 2) void igemm_ws_kernel(WsParams p) {
             }
         };
         int stage_last = 0;
-        if (p.dbg & 1) {  // experiment: loaders only
-            for (int kc = 0; kc < nkc_t; ++kc, ++gc) ws_barrier();
-            stage_last = (gc - 1) % NST;
-            ws_barrier();
-        } else {
+        {
             FragSet f0, f1;
             ws_barrier();  // first chunk of the tile published
             const unsigned char* st = lds + (gc % NST) * STAGE;
@@ -456,7 +450,6 @@ int dpc_conv_ws_try(const dpc_conv_desc* d, const void* src, const void* wgt, vo
     if (addend && stats) return 1;  // not a combination of this path: the generic kernel serves it
     if (((uintptr_t)out % 16) || ((uintptr_t)addend % 16) || ((uintptr_t)src % 16) || ((uintptr_t)wgt % 16)) return 1;
     p.src = src; p.wgt = wgt; p.out = out; p.addend = addend; p.stats = stats;
-    p.dbg = env_int("DPC_IGEMM_WS_DBG", 0);
     dim3 grid((unsigned)(p.gm * p.ntn)), block(512);
     if (addend) {
         DPC_LAUNCH((igemm_ws_kernel<true>), grid, block, stream, p);
