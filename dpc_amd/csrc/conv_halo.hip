@@ -303,6 +303,9 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(HaloParams p) {
 //                          stores, batch-norm partial sums.
 // Two workgroup barriers per tile: B1(t) "patch t landed, staging t&1 is free", B2(t) "staging t&1 written,
 // patch t released".  One workgroup per CU (125 KB of LDS), persistent over its tiles.
+#ifndef HALO_WS_D
+#define HALO_WS_D 3
+#endif
 template <bool HAS_ADD>
 __global__ __launch_bounds__(512, 2) void conv_halo_ws_kernel(HaloParams p) {
     typedef bf16_t T;
@@ -366,9 +369,9 @@ __global__ __launch_bounds__(512, 2) void conv_halo_ws_kernel(HaloParams p) {
                 for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
             barrier_lds_only();  // B1(j)
             const unsigned char* patch = lds + (j % NPB) * PATCH;
-            // 36 steps of {2 ds_read_b128, 2 MFMA}; fragments two steps ahead in a ring of three register sets,
+            // 36 steps of {2 ds_read_b128, 2 MFMA}; fragments three steps ahead in a ring of four register sets (two: +3 %; four: no further gain),
             // the constant part of every address in the instruction's offset field (hand-counted waits, dpc_rt.h)
-            constexpr int S = KH * NCH * 4, D = 2, R = 3;
+            constexpr int S = KH * NCH * 4, D = HALO_WS_D, R = HALO_WS_D + 1;
             u32x4 ring[R][2];
             const unsigned char* rowp[KH][2];
             DPC_UNROLL
