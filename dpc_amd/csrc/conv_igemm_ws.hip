@@ -153,18 +153,30 @@ __global__ __launch_bounds__(512, 2) void igemm_ws_kernel(WsParams p) {
         }
         unsigned rowoff[8];   // byte offset of (row, tap 0, this lane's channel group); wraps for rows that start in the padding
         unsigned vmask[8];
+        // Row decode of a tile.  The 8 lanes that share a tile row (one per 16-byte slot) need the same 8 rows
+        // (pieces lw, lw+4, ...): each of them decodes ONE of those rows and the group exchanges the results by
+        // lane shuffles -- 1 decode + 16 shuffles per lane instead of 8 decodes (the decode sits on the loaders'
+        // critical path once per tile: ~4000 cycles before, per tile of only 18 chunks on layer2).
+        auto range_bits = [](int x0, int sgn, int K, int S) -> unsigned {  // bit k set <=> 0 <= x0 + sgn*k < S, k < K
+            int lo, hi;                                                     // sgn = +1: k in [-x0, S-1-x0]; -1: k in [x0-S+1, x0]
+            if (sgn > 0) { lo = -x0; hi = S - 1 - x0; } else { lo = x0 - S + 1; hi = x0; }
+            if (lo < 0) lo = 0;
+            if (hi > K - 1) hi = K - 1;
+            return hi >= lo ? (((2u << hi) - 1u) & ~((1u << lo) - 1u)) : 0u;
+        };
         auto decode_tile = [&](int mt) {
+            const int mine = lane & 7;  // which of the group's 8 rows this lane decodes
+            const RowPos rp = decode_row(g, tile_row(mt, 8 * (lw + 4 * mine) + rl));
+            const unsigned off = (((((unsigned)(rp.nbase + rp.t0) * (unsigned)g.SH + (unsigned)rp.h0) * (unsigned)g.SW) + (unsigned)rp.w0) *
+                                  (unsigned)g.src_ld) * 2u;
+            const int sgn = g.mode == 0 ? 1 : -1;
+            const unsigned m = range_bits(rp.t0, sgn, g.KT, g.ST) | (range_bits(rp.h0, sgn, g.KH, g.SH) << g.KT) |
+                               (range_bits(rp.w0, sgn, g.KW, g.SW) << (g.KT + g.KH));
             DPC_UNROLL
             for (int i = 0; i < 8; ++i) {
-                const RowPos rp = decode_row(g, tile_row(mt, 8 * (lw + 4 * i) + rl));
-                rowoff[i] = ((((((unsigned)(rp.nbase + rp.t0) * (unsigned)g.SH + (unsigned)rp.h0) * (unsigned)g.SW) + (unsigned)rp.w0) *
-                              (unsigned)g.src_ld) + (unsigned)(u * 8)) * 2u;
-                const int sgn = g.mode == 0 ? 1 : -1;
-                unsigned m = 0;
-                for (int k = 0; k < g.KT; ++k) m |= ((unsigned)(rp.t0 + sgn * k) < (unsigned)g.ST ? 1u : 0u) << k;
-                for (int k = 0; k < g.KH; ++k) m |= ((unsigned)(rp.h0 + sgn * k) < (unsigned)g.SH ? 1u : 0u) << (g.KT + k);
-                for (int k = 0; k < g.KW; ++k) m |= ((unsigned)(rp.w0 + sgn * k) < (unsigned)g.SW ? 1u : 0u) << (g.KT + g.KH + k);
-                vmask[i] = m;
+                const int from = (lane & ~7) | i;
+                rowoff[i] = (unsigned)__shfl((int)off, from) + (unsigned)(u * 16);
+                vmask[i] = (unsigned)__shfl((int)m, from);
             }
         };
         auto issue = [&](int kc, int stage) {
