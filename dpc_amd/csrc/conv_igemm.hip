@@ -131,12 +131,13 @@ __global__ __launch_bounds__(256, (BN == 64 ? 3 : 2)) void igemm_kernel(IGemmPar
             const int rows_c = par.N * Tc * Hc * Wc;
             const int lr0 = (mt - par.tile_start[c]) * BM;
             const int ct_n = par.cnt[0][ct_], ch_n = par.cnt[1][ch_], cw_n = par.cnt[2][cw_];
-            DPC_UNROLL
-            for (int i = 0; i < 4; ++i) {
-                const int lr = lr0 + r0 + 32 * i;
-                int orow = -1;
-                rowbase[i] = 0;
-                vmask[i] = 0;
+            // the 8 lanes of a tile row need the same 4 rows (r0 + 32 i): each decodes one, the group exchanges
+            // them by lane shuffles (the decode is per tile, and a parity-class tile has as few as 2 K chunks)
+            {
+                const int my_i = tid & 3;
+                const int lr = lr0 + r0 + 32 * my_i;
+                int orow = -1, rb_mine = 0;
+                unsigned vm_mine = 0;
                 if (lr < rows_c) {
                     const unsigned q1 = fdiv((unsigned)lr, par.div[2][cw_]);
                     const int wq = lr - (int)q1 * Wc;
@@ -144,16 +145,22 @@ __global__ __launch_bounds__(256, (BN == 64 ? 3 : 2)) void igemm_kernel(IGemmPar
                     const int hq = (int)q1 - (int)q2 * Hc;
                     const unsigned n = fdiv(q2, par.div[0][ct_]);
                     const int tq = (int)q2 - (int)n * Tc;
-                    rowbase[i] = (int)(((((unsigned)((int)n * g.ST + tq) * (unsigned)g.SH + (unsigned)hq) * (unsigned)g.SW) + (unsigned)wq) *
-                                       (unsigned)g.src_ld);
+                    rb_mine = (int)(((((unsigned)((int)n * g.ST + tq) * (unsigned)g.SH + (unsigned)hq) * (unsigned)g.SW) + (unsigned)wq) *
+                                    (unsigned)g.src_ld);
                     unsigned m = 0;
                     for (int j = 0; j < ct_n; ++j) m |= ((unsigned)(tq + par.dl[0][ct_][j]) < (unsigned)g.ST ? 1u : 0u) << j;
                     for (int j = 0; j < ch_n; ++j) m |= ((unsigned)(hq + par.dl[1][ch_][j]) < (unsigned)g.SH ? 1u : 0u) << (4 + j);
                     for (int j = 0; j < cw_n; ++j) m |= ((unsigned)(wq + par.dl[2][cw_][j]) < (unsigned)g.SW ? 1u : 0u) << (8 + j);
-                    vmask[i] = m;
+                    vm_mine = m;
                     orow = ((((int)n * g.RT + tq * g.st + ct_) * g.RH + hq * g.sh + ch_) * g.RW) + wq * g.sw + cw_;
                 }
-                if (u == 0) rowmap[r0 + 32 * i] = orow;
+                if ((tid & 7) < 4) rowmap[r0 + 32 * my_i] = orow;
+                DPC_UNROLL
+                for (int i = 0; i < 4; ++i) {
+                    const int from = (lane & ~7) | i;
+                    rowbase[i] = __shfl(rb_mine, from);
+                    vmask[i] = (unsigned)__shfl((int)vm_mine, from);
+                }
             }
             const int nt = ct_n * ch_n * cw_n;
             if (tid < nt) {
@@ -168,20 +175,26 @@ __global__ __launch_bounds__(256, (BN == 64 ? 3 : 2)) void igemm_kernel(IGemmPar
             nkc_t = nt << lcpt;
             __syncthreads();
         }
-        DPC_UNROLL
-        for (int i = 0; i < 4; ++i) {
-            if (GATHER == 3) break;
-            rp[i] = decode_row(g, m0 + r0 + 32 * i);
-            if (GATHER != 0) {
-                rowbase[i] = (int)(((((unsigned)(rp[i].nbase + rp[i].t0) * (unsigned)g.SH + (unsigned)rp[i].h0) * (unsigned)g.SW) +
-                                    (unsigned)rp[i].w0) * (unsigned)g.src_ld);
-                const int sgn = g.mode == 0 ? 1 : -1;
-                unsigned m = 0;
-                for (int k = 0; k < g.KT; ++k) m |= ((unsigned)(rp[i].t0 + sgn * k) < (unsigned)g.ST ? 1u : 0u) << k;
-                for (int k = 0; k < g.KH; ++k) m |= ((unsigned)(rp[i].h0 + sgn * k) < (unsigned)g.SH ? 1u : 0u) << (g.KT + k);
-                for (int k = 0; k < g.KW; ++k) m |= ((unsigned)(rp[i].w0 + sgn * k) < (unsigned)g.SW ? 1u : 0u) << (g.KT + g.KH + k);
-                vmask[i] = m;
+        if (GATHER == 1 || GATHER == 2) {  // affine gather: one row decoded per lane, shared inside the 8-lane row group
+            const int my_i = tid & 3;
+            const RowPos r1 = decode_row(g, m0 + r0 + 32 * my_i);
+            const int rb_mine = (int)(((((unsigned)(r1.nbase + r1.t0) * (unsigned)g.SH + (unsigned)r1.h0) * (unsigned)g.SW) + (unsigned)r1.w0) *
+                                      (unsigned)g.src_ld);
+            const int sgn = g.mode == 0 ? 1 : -1;
+            unsigned m = 0;
+            for (int k = 0; k < g.KT; ++k) m |= ((unsigned)(r1.t0 + sgn * k) < (unsigned)g.ST ? 1u : 0u) << k;
+            for (int k = 0; k < g.KH; ++k) m |= ((unsigned)(r1.h0 + sgn * k) < (unsigned)g.SH ? 1u : 0u) << (g.KT + k);
+            for (int k = 0; k < g.KW; ++k) m |= ((unsigned)(r1.w0 + sgn * k) < (unsigned)g.SW ? 1u : 0u) << (g.KT + g.KH + k);
+            DPC_UNROLL
+            for (int i = 0; i < 4; ++i) {
+                const int from = (lane & ~7) | i;
+                rowbase[i] = __shfl(rb_mine, from);
+                vmask[i] = (unsigned)__shfl((int)m, from);
             }
+        }
+        if (GATHER == 0) {
+            DPC_UNROLL
+            for (int i = 0; i < 4; ++i) rp[i] = decode_row(g, m0 + r0 + 32 * i);
         }
 
         f32x16 acc[2][NT];
