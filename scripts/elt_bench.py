@@ -45,6 +45,10 @@ def main():
         ("bn_bwd_apply        (3 T)", 3 + 1 / 16, lambda: lib.call("dpc_bn_bwd_apply", dy, None, mask, x, 1, rows, Cc, mean, invstd, gamma, coef, 1, dx, None, st)),
         ("bn_bwd_apply + dz   (4 T)", 4 + 1 / 16, lambda: lib.call("dpc_bn_bwd_apply", dy, None, mask, x, 1, rows, Cc, mean, invstd, gamma, coef, 1, dx, dz, st)),
     ]
+    def pair():
+        lib.call("dpc_bn_bwd_reduce", dy, None, mask, x, 1, rows, Cc, mean, invstd, 1, part, C.byref(pr), st)
+        return lib.call("dpc_bn_bwd_apply", dy, None, mask, x, 1, rows, Cc, mean, invstd, gamma, coef, 1, dx, None, st)
+    cases.append(("reduce + apply      (5 T)", 5 + 2 / 16, pair))
     for name, nt, fn in cases:
         assert fn() == 0
         torch.cuda.synchronize()
