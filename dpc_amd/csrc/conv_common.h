@@ -150,3 +150,7 @@ int dpc_conv_ws_rows(const dpc_conv_desc* d);
 // conv_wgrad_patch.hip: weight gradient of 1x3x3 stride-1 convs from one staged source patch (bf16).
 int dpc_wgrad_patch_try(const dpc_conv_desc* d, const void* src, const void* dy, int dy_ld, float* part, int32_t* nsplit,
                         hipStream_t stream);
+
+// conv_wgrad_stem.hip: weight gradient of the space-to-depth stem conv (1x4x4 taps, 16 channels) from one staged patch.
+int dpc_wgrad_stem_try(const dpc_conv_desc* d, const void* src, const void* dy, int dy_ld, float* part, int32_t* nsplit,
+                       hipStream_t stream);

@@ -529,10 +529,14 @@ extern "C" int dpc_conv_wgrad(const dpc_conv_desc* d, const void* src, const voi
     if (dy_ld % per16 || dy_ld < d->Co) return DPC_ERR_UNSUPPORTED;
     rc = dpc_wgrad_patch_try(d, src, dy, dy_ld, part, nsplit, stream);  // 3x3 stride-1: one staged patch serves all nine taps
     if (rc != 1) return rc;
+    rc = dpc_wgrad_stem_try(d, src, dy, dy_ld, part, nsplit, stream);   // space-to-depth stem: same idea, 4x4 taps of 32-byte positions
+    if (rc != 1) return rc;
     const int bkp = 8 * per16;
     const int nchunks = (p.g.M + bkp - 1) / bkp;
     const int lrw = ilog2_exact(d->RW), lrh = ilog2_exact(d->RH);
-    const bool v2 = lrw >= 0 && lrh >= 0 && !wgrad_use_v1();
+    // wgrad2 decomposes a chunk row index as (row % RW, row / RW): needs power-of-two RW, RH and chunks that start
+    // at a row boundary (RW divides the chunk length)
+    const bool v2 = lrw >= 0 && lrh >= 0 && bkp % d->RW == 0 && !wgrad_use_v1();
     int tm, tn, nwm = 0, nwn = 0;
     if (v2) {
         // 64 x 64 per wave; the block is NWM x NWN waves.  NWN = 3 fits every 3x3 / 3x3x3 reduction

@@ -1,0 +1,207 @@
+// conv_wgrad_stem.hip -- weight gradient of the stem convolution in its space-to-depth form (1x4x4 taps over
+// the 16-channel 2x2 space-to-depth image, stride 1; backbone/resnet_2d3d.py:211 = Conv3d(3,64,(1,7,7),
+// s(1,2,2),p(0,3,3)), see dpc_pack_input_s2d), bf16.
+//
+//   part[ks][co][tap*16 + ch] = sum_{positions of split ks} dy[pos][co] * xs[pos shifted by tap][ch]
+//
+// The generic kernel (conv_wgrad.hip) re-gathers the source once per tap: per 64 positions it stages 8 KB of
+// dy and 32 KB of shifted copies of 2 KB of source, 10 LDS-DMA pieces per wave for 16 MFMAs -- DMA-issue bound
+// (1.06 ms for 3.2 GB of unique bytes).  Here a chunk is 64 consecutive positions of ONE image row; the source
+// arrives once as a 4 x 68 position patch (8.7 KB, image borders = out-of-range buffer lanes = zeros), every
+// tap is the same patch read a few positions further (an instruction immediate), and the fragments come from
+// ds_read_b64_tr_b16 as in conv_wgrad_patch.hip: 17 pieces per chunk instead of 40.
+// A workgroup owns 64 co x all 256 reduction columns: wave (wi, wj) = co half wi x kernel rows {2wj, 2wj+1}
+// (four 32 x 32 accumulators: a column block is the pair of taps kw = 2c, 2c+1 of one kernel row x 16 channels).
+// The patch needs no swizzle: with 32-byte positions a transpose read's 16 lanes cover 128 contiguous bytes.
+#include "conv_common.h"
+#include <stdlib.h>
+
+struct WgradStemParams {
+    const void* src;
+    const void* dy;
+    float* part;
+    int Co, dy_ld;
+    int H, W, NF, nseg;   // image, frames, 64-position segments per row
+    int ph, pw;
+    int nks, kcps, ntm;
+    long long src_bytes, dy_bytes;
+    FastDiv d_cpf, d_nseg;
+    int cpf;              // chunks per frame = H * nseg
+};
+
+__global__ __launch_bounds__(256, 3) void wgrad_stem_kernel(WgradStemParams p) {
+    constexpr int PW = 68, NPOS = 4 * PW;       // patch: 4 rows x (64 + 3, padded to 68) positions of 32 bytes
+    constexpr int NPB = (NPOS + 31) / 32;        // 9 pieces of 32 positions
+    constexpr int NIB = (NPB + 3) / 4;
+    constexpr int STAGE = 8192 + NPB * 1024;
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * STAGE];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+#ifdef DPC_SIMT_EMU
+    const int wv = tid >> 6;
+#else
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+#endif
+    const int wi = wv >> 1, wj = wv & 1;
+    const int l31 = lane & 31, lhi = lane >> 5;
+    int id = blockIdx.x;
+    {
+        const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, x = id & 7;
+        id = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (id >> 3);
+    }
+    const int tile_m = id % p.ntm;
+    const int ks = id / p.ntm;
+    const int nchunks = p.NF * p.cpf;
+    const int c_begin = ks * p.kcps;
+    const int c_end = (c_begin + p.kcps < nchunks) ? c_begin + p.kcps : nchunks;
+
+    // The stem's dy is 2.7 GB at batch 128 and buffer offsets are 32-bit: every workgroup addresses its own window,
+    // which starts at its first chunk (minus the patch's top/left margin for the source) and is far below 2 GB long.
+    long long a_lo, b_lo;
+    {
+        const unsigned frame = fdiv((unsigned)c_begin, p.d_cpf);
+        const int rem = c_begin - (int)frame * p.cpf;
+        const unsigned h = fdiv((unsigned)rem, p.d_nseg);
+        const int w0 = (rem - (int)h * p.nseg) * 64;
+        const long long pos = ((long long)frame * p.H + (int)h) * p.W + w0;
+        a_lo = pos * p.dy_ld * 2;
+        b_lo = (pos - (long long)p.ph * p.W - p.pw) * 32;
+        if (b_lo < 0) b_lo = 0;
+    }
+    const long long a_len = p.dy_bytes - a_lo, b_len = p.src_bytes - b_lo;
+    const BufRsrc rs_a = make_buf_rsrc((const char*)p.dy + a_lo, (unsigned)(a_len < 0x7fffffffll ? a_len : 0x7fffffffll));
+    const BufRsrc rs_b = make_buf_rsrc((const char*)p.src + b_lo, (unsigned)(b_len < 0x7fffffffll ? b_len : 0x7fffffffll));
+    // dy sub-tile [64 positions][64 co], 128-byte rows, slot swizzled by 2*(position & 3) (source side)
+    const int pl = lane >> 3;
+    const int lslot = (lane & 7) ^ (2 * (pl & 3));
+    unsigned a_off[2];
+    int a_pos[2];
+    DPC_UNROLL
+    for (int i = 0; i < 2; ++i) {
+        a_pos[i] = 8 * (wv + 4 * i) + pl;
+        a_off[i] = (unsigned)(a_pos[i] * p.dy_ld + tile_m * 64 + lslot * 8) * 2u;
+    }
+    // source patch [4 rows][68 positions][16 ch], linear
+    unsigned b_off[NIB];
+    int b_row[NIB], b_col[NIB];  // patch row / column of this lane's position; row = huge when the slot is beyond the patch
+    DPC_UNROLL
+    for (int i = 0; i < NIB; ++i) {
+        const int pp = 32 * (wv + 4 * i) + (lane >> 1);
+        const int prow = pp / PW, pcol = pp % PW;
+        b_row[i] = pp < NPOS ? prow : (1 << 28);
+        b_col[i] = pcol;
+        b_off[i] = (unsigned)((prow * p.W + pcol) * 32 + (lane & 1) * 16);
+    }
+
+    f32x16 acc[4];
+    DPC_UNROLL
+    for (int t = 0; t < 4; ++t)
+        DPC_UNROLL
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    auto issue = [&](int chunk, int buf) {
+        unsigned char* stage = lds + buf * STAGE;
+        const unsigned frame = fdiv((unsigned)chunk, p.d_cpf);
+        const int rem = chunk - (int)frame * p.cpf;
+        const unsigned h = fdiv((unsigned)rem, p.d_nseg);
+        const int w0 = (rem - (int)h * p.nseg) * 64;
+        const long long pos = ((long long)frame * p.H + (int)h) * p.W + w0;
+        const unsigned a_base = (unsigned)(pos * p.dy_ld * 2 - a_lo);
+        // patch origin = image (h - ph, w0 - pw); offsets may wrap below zero for border positions (those lanes are masked)
+        const unsigned b_base = (unsigned)((pos - (long long)p.ph * p.W - p.pw) * 32 - b_lo);
+        DPC_UNROLL
+        for (int i = 0; i < 2; ++i) {
+            const bool ok = w0 + a_pos[i] < p.W;
+            glds16_buf(rs_a, ok ? a_base + a_off[i] : DPC_BUF_OOB, 0u, stage + (wv + 4 * i) * 1024, lane);
+        }
+        DPC_UNROLL
+        for (int i = 0; i < NIB; ++i) {
+            if (wv + 4 * i < NPB) {
+                const bool ok = ((unsigned)((int)h - p.ph + b_row[i]) < (unsigned)p.H) & ((unsigned)(w0 - p.pw + b_col[i]) < (unsigned)p.W);
+                glds16_buf(rs_b, ok ? b_base + b_off[i] : DPC_BUF_OOB, 0u, stage + 8192 + (wv + 4 * i) * 1024, lane);
+            }
+        }
+    };
+
+    // fragment lane offsets
+    const int gq = lane >> 4, s16 = lane & 15, ph4 = s16 >> 2;
+    int fa;
+    {
+        const int colb = (wi * 32 + (gq & 1) * 16 + 4 * (s16 & 3)) * 2;
+        fa = ((gq >> 1) * 8 + ph4) * 128 + ((((colb >> 4) ^ (2 * ph4)) & 7) << 4) + (colb & 15);
+    }
+    // patch: position (gq>>1)*8 + ph4, + (gq&1) for the odd tap of the column block's pair, channels 4*(s16&3)..
+    const int fb = 8192 + ((gq >> 1) * 8 + ph4 + (gq & 1)) * 32 + 8 * (s16 & 3);
+
+    auto compute = [&](int buf) {
+        const unsigned char* st = lds + buf * STAGE;
+        DPC_UNROLL
+        for (int kk = 0; kk < 4; ++kk) {
+            const u32x2 a0 = lds_read_tr16(st + fa + (kk * 16) * 128);
+            const u32x2 a1 = lds_read_tr16(st + fa + (kk * 16 + 4) * 128);
+            const u32x4 av = {a0[0], a0[1], a1[0], a1[1]};
+            DPC_UNROLL
+            for (int c = 0; c < 4; ++c) {  // column block: kernel row 2*wj + (c>>1), taps kw = 2*(c&1), 2*(c&1)+1
+                const unsigned char* bp = st + fb + (((c >> 1) * PW + kk * 16 + 2 * (c & 1)) * 32) + wj * (2 * PW * 32);
+                const u32x2 b0 = lds_read_tr16(bp);
+                const u32x2 b1 = lds_read_tr16(bp + 4 * 32);
+                const u32x4 bv = {b0[0], b0[1], b1[0], b1[1]};
+                acc[c] = mfma_32x32x16_bf16(av, bv, acc[c]);
+            }
+        }
+    };
+
+    if (c_begin < c_end) issue(c_begin, 0);
+    __syncthreads();
+    for (int ch = c_begin; ch < c_end; ++ch) {
+        const int buf = (ch - c_begin) & 1;
+        if (ch + 1 < c_end) issue(ch + 1, buf ^ 1);
+        compute(buf);
+        __syncthreads();
+    }
+
+    // partial slab rows = co, columns = tap*16 + ch = (kernel row)*64 + (c&1)*32 + lane column
+    DPC_UNROLL
+    for (int c = 0; c < 4; ++c) {
+        const int col = (2 * wj + (c >> 1)) * 64 + (c & 1) * 32 + l31;
+        DPC_UNROLL
+        for (int r = 0; r < 16; ++r) {
+            const int co = tile_m * 64 + wi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+            p.part[((long long)ks * p.Co + co) * 256 + col] = acc[c][r];
+        }
+    }
+}
+
+// returns 1 when the shape is not served; with part == NULL only *nsplit is set
+int dpc_wgrad_stem_try(const dpc_conv_desc* d, const void* src, const void* dy, int dy_ld, float* part, int32_t* nsplit,
+                       hipStream_t stream) {
+    static const int on = getenv("DPC_WGRAD_STEM") ? atoi(getenv("DPC_WGRAD_STEM")) : 1;
+    if (!on || d->dtype_in != DPC_BF16 || d->mode != 0) return 1;
+    if (d->KT != 1 || d->KH != 4 || d->KW != 4 || d->st != 1 || d->sh != 1 || d->sw != 1 || d->pt != 0) return 1;
+    if (d->Ci != 16 || d->src_ld != 16 || d->Co % 64 || dy_ld % 8 || dy_ld < d->Co) return 1;
+    if (d->RT != d->ST || d->RH != d->SH || d->RW != d->SW || d->RW < 48) return 1;  // narrow images: mostly padding, generic kernel
+    const long long M = (long long)d->N * d->RT * d->RH * d->RW;
+    const long long sb = M * 32, db = M * dy_ld * 2;
+    WgradStemParams p;
+    p.Co = d->Co; p.dy_ld = dy_ld; p.H = d->RH; p.W = d->RW; p.NF = d->N * d->RT;
+    p.nseg = (d->RW + 63) / 64; p.ph = d->ph; p.pw = d->pw;
+    p.cpf = d->RH * p.nseg;
+    p.d_cpf = make_fastdiv((uint32_t)p.cpf); p.d_nseg = make_fastdiv((uint32_t)p.nseg);
+    p.ntm = d->Co / 64;
+    p.src_bytes = sb; p.dy_bytes = db;
+    const int nchunks = p.NF * p.cpf;
+    int want = 1024 / p.ntm;
+    if (want > nchunks / 16) want = nchunks / 16;
+    if (want < 1) want = 1;
+    p.kcps = (nchunks + want - 1) / want;
+    p.nks = (nchunks + p.kcps - 1) / p.kcps;
+    if ((long long)(p.kcps + 2 * p.nseg * 4) * 64 * dy_ld * 2 >= (1ll << 31)) return 1;  // a workgroup's window must stay 32-bit addressable
+    if (nsplit) *nsplit = p.nks;
+    if (!part) return DPC_OK;
+    if (!src || !dy) return DPC_ERR_ARG;
+    if (((uintptr_t)src % 16) || ((uintptr_t)dy % 16)) return DPC_ERR_UNSUPPORTED;
+    p.src = src; p.dy = dy; p.part = part;
+    DPC_LAUNCH(wgrad_stem_kernel, dim3((unsigned)(p.ntm * p.nks)), dim3(256), stream, p);
+    return dpc_launch_status();
+}

@@ -68,6 +68,8 @@ def test_conv_dgrad(k, dtype, shape):
     (3, 64, 64, 1, 8, 32, (1, 3, 3), (1, 1, 1), (0, 1, 1)),     # staged-patch kernel (bf16), W = 32, 2 rows per chunk
     (2, 128, 64, 2, 8, 16, (1, 3, 3), (1, 1, 1), (0, 1, 1)),    # staged-patch kernel, W = 16, two ci tiles
     (2, 64, 64, 2, 7, 7, (1, 3, 3), (1, 1, 1), (0, 1, 1)),      # staged-patch kernel, 7x7 image padded to width 8
+    (1, 16, 64, 1, 2, 64, (1, 3, 3), (1, 1, 1), (0, 1, 1)),     # rows longer than an f32 chunk (32 positions): general kernel
+    (1, 16, 72, 1, 1, 128, (1, 1, 1), (1, 1, 1), (0, 0, 0)),    # rows longer than a bf16 chunk too
     (1, 64, 128, 2, 14, 14, (3, 3, 3), (1, 1, 1), (1, 1, 1)),   # 14x14 -> width 16, ragged last chunk of a plane
     (1, 64, 64, 1, 5, 56, (1, 3, 3), (1, 1, 1), (0, 1, 1)),     # width 56 -> 64: one image row per chunk
 ])
@@ -84,6 +86,7 @@ def test_gemm_nt(k, dtype, mnk):
 @pytest.mark.parametrize("dtype", [F32, BF16])
 def test_stem_s2d(k, dtype):
     kc.case_stem(k, dtype, 2, 2, 16, 20)
+    kc.case_stem(k, dtype, 1, 2, 6, 100)   # 50 columns after space-to-depth: staged-patch weight gradient (bf16), ragged row segment
 
 
 @pytest.mark.parametrize("dtype", [F32, BF16])

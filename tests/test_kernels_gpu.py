@@ -76,6 +76,8 @@ def test_gemm_nt(k, dtype, mnk):
 def test_stem_s2d(k, dtype):
     kc.case_stem(k, dtype, 4, 5, 64, 64)
     kc.case_stem(k, dtype, 2, 2, 16, 20)
+    kc.case_stem(k, dtype, 3, 2, 128, 128)  # the real stem geometry: staged-patch weight gradient (bf16)
+    kc.case_stem(k, dtype, 1, 2, 32, 224)   # two 64-column segments per row
 
 
 @pytest.mark.parametrize("dtype", [F32, BF16])
