@@ -306,13 +306,16 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(HaloParams p) {
 #ifndef HALO_WS_D
 #define HALO_WS_D 3
 #endif
-template <bool HAS_ADD>
+// UPP = 8: 3x3 taps over 128-byte positions (one tap = one K chunk).  UPP = 2: the space-to-depth stem, 4x4 taps over
+// 32-byte positions (one K chunk = the four kw taps of a kernel row = four neighbouring positions).
+template <bool HAS_ADD, int UPP>
 __global__ __launch_bounds__(512, 2) void conv_halo_ws_kernel(HaloParams p) {
     typedef bf16_t T;
     typedef bf16_t TO;
-    constexpr int KH = 3, NCH = 3, NTAPS = 9, CBP = 144, SPP = 9, KKSTEP = 32;
+    constexpr int KH = UPP == 8 ? 3 : 4, NCH = UPP == 8 ? 3 : 1, NTAPS = KH * NCH;
+    constexpr int SPP = UPP + 1, CBP = SPP * 16, KKSTEP = UPP == 8 ? 32 : CBP;
     constexpr int BM = 128, BN = 64, EPO = 8, UPR = BN / EPO;
-    constexpr int LIT = 8;                        // DMA pieces per helper wave and patch: 8 x 256 lanes x 16 B = 32 KB >= 227 positions x 144 B
+    constexpr int LIT = UPP == 8 ? 8 : 3;         // DMA pieces per helper wave and patch: LIT x 256 lanes x 16 B >= positions x (UPP+1) slots
     constexpr int PATCH = LIT * 256 * 16;
     constexpr int STG = BM * BN * 2;
     constexpr int NPB = 3;
@@ -421,7 +424,7 @@ __global__ __launch_bounds__(512, 2) void conv_halo_ws_kernel(HaloParams p) {
             const int hpos = slot / SPP, cu = slot - hpos * SPP;
             const unsigned hr = fdiv((unsigned)hpos, p.d_hwd);
             const int hc = hpos - (int)hr * p.HWd;
-            const bool ok = cu < 8 && hpos < npos;
+            const bool ok = cu < UPP && hpos < npos;
             hrc[it] = ok ? (((int)hr << 16) | hc) : (0x4000 << 16);
             rel[it] = (unsigned)((((int)hr * p.W + hc) * p.C + cu * 8) * 2);
         }
@@ -580,8 +583,8 @@ static bool halo_plan(const dpc_conv_desc* d, HaloParams* p) {
     static const int ws_on = getenv("DPC_HALO_WS") ? atoi(getenv("DPC_HALO_WS")) : 1;
     const long long sbytes = (long long)p->NF * d->RH * d->RW * d->Ci * esz;
     p->src_bytes = sbytes < (1ll << 31) ? (unsigned)sbytes : 0u;
-    p->ws = ws_on && k33 && d->dtype_in == DPC_BF16 && p->HR * p->HWd * 9 <= 8 * 256 && p->src_bytes > 0 && d->ldo % 8 == 0 &&
-            d->Co % 8 == 0;
+    p->ws = ws_on && d->dtype_in == DPC_BF16 && p->src_bytes > 0 && d->ldo % 8 == 0 && d->Co % 8 == 0 &&
+            ((k33 && p->HR * p->HWd * 9 <= 8 * 256) || (k44 && p->HR * p->HWd * 3 <= 3 * 256));
     static const int ws_gm = getenv("DPC_HALO_WS_GM") ? atoi(getenv("DPC_HALO_WS_GM")) : 256;  // test tiers shrink it
     if (p->ws) p->gm = p->ntm < ws_gm ? p->ntm : ws_gm;  // one resident workgroup per CU
     p->d_tpf = make_fastdiv(p->tiles_per_frame);
@@ -605,11 +608,13 @@ int dpc_conv_halo_try(const dpc_conv_desc* d, const void* src, const void* wgt, 
     const int epo = d->dtype_out == DPC_BF16 ? 8 : 4;
     p.vec_out = (d->Co % epo == 0 && d->ldo % epo == 0 && ((uintptr_t)out % 16 == 0) && ((uintptr_t)addend % 16 == 0)) ? 1 : 0;
     dim3 grid((unsigned)p.gm), block(256);
-    if (p.ws && p.vec_out && ((uintptr_t)src % 16 == 0)) {
-        if (addend) {
-            DPC_LAUNCH((conv_halo_ws_kernel<true>), grid, dim3(512), stream, p);
+    if (p.ws && p.vec_out && ((uintptr_t)src % 16 == 0) && !(d->KH == 4 && addend)) {
+        if (d->KH == 4) {
+            DPC_LAUNCH((conv_halo_ws_kernel<false, 2>), grid, dim3(512), stream, p);
+        } else if (addend) {
+            DPC_LAUNCH((conv_halo_ws_kernel<true, 8>), grid, dim3(512), stream, p);
         } else {
-            DPC_LAUNCH((conv_halo_ws_kernel<false>), grid, dim3(512), stream, p);
+            DPC_LAUNCH((conv_halo_ws_kernel<false, 8>), grid, dim3(512), stream, p);
         }
         return dpc_launch_status();
     }

@@ -24,6 +24,8 @@ SHAPES = {
     "l2k": (1707, 128, 128, 3, 16, 16, (3, 3, 3), (1, 1, 1), (1, 1, 1)),   # l2 geometry with a long reduction
     "l3k": (1024, 256, 256, 3, 8, 8, (1, 3, 3), (1, 1, 1), (0, 1, 1)),      # l3 geometry with a short one
     "l2c": (5120, 256, 128, 1, 16, 16, (1, 3, 3), (1, 1, 1), (0, 1, 1)),    # l2 with Ci=256
+    "gru": (896, 256, 768, 1, 4, 4, (1, 1, 1), (1, 1, 1), (0, 0, 0)),         # ConvGRU gate GEMMs batched over 7 steps (weight gradient)
+    "gru1": (128, 256, 768, 1, 4, 4, (1, 1, 1), (1, 1, 1), (0, 0, 0)),        # one step (forward / input gradient)
     "l4": (1024, 256, 256, 2, 4, 4, (3, 3, 3), (1, 1, 1), (1, 1, 1)),
 }
 
