@@ -153,9 +153,15 @@ def case_stem(k: K, dtype, BN, T, H, W, Co=64, seed=4):
     k.call("dpc_pack_stem_weight", L._p(k.t(w)), L._p(wp), L.dtype_code(dtype), Co)
     d = conv_desc(dtype, dtype, 0, BN, (T, H // 2, W // 2), (T, H // 2, W // 2), 16, 16, Co, 256, Co, (1, 4, 4), (1, 1, 1), (0, 2, 2))
     out = k.empty(BN, T, H // 2, W // 2, Co, dtype=dtype)
-    k.call("dpc_conv_igemm", C.byref(d), L._p(xs), L._p(wp), L._p(out), None, None)
+    rows = k.lib.call("dpc_conv_stats_rows", C.byref(d))
+    stats = k.zeros(rows, 2, Co)
+    k.call("dpc_conv_igemm", C.byref(d), L._p(xs), L._p(wp), L._p(out), None, L._p(stats))
     k.sync()
     assert relerr(out, cl(y)) < tol(dtype)
+    o = out.float().cpu().reshape(-1, Co).double()  # batch-norm partial sums are those of the STORED values
+    st = stats.cpu().double()
+    assert (st[:, 0].sum(0) - o.sum(0)).abs().max().item() < 1e-3 * max(1.0, o.abs().sum(0).max().item())
+    assert (st[:, 1].sum(0) - (o * o).sum(0)).abs().max().item() < 1e-4 * (o * o).sum(0).max().item()
     gy = q(torch.randn(y.shape, generator=g), dtype)
     gw = torch.autograd.grad(y, wq, gy.double())[0]
     ns = C.c_int32(0)

@@ -86,6 +86,7 @@ def test_gemm_nt(k, dtype, mnk):
 @pytest.mark.parametrize("dtype", [F32, BF16])
 def test_stem_s2d(k, dtype):
     kc.case_stem(k, dtype, 2, 2, 16, 20)
+    kc.case_stem(k, dtype, 2, 1, 16, 64)   # every tile inside the image: partial sums taken by the compute waves (bf16)
     kc.case_stem(k, dtype, 1, 2, 6, 100)   # 50 columns after space-to-depth: staged-patch weight gradient (bf16), ragged row segment
 
 
