@@ -308,14 +308,18 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(HaloParams p) {
 #endif
 // UPP = 8: 3x3 taps over 128-byte positions (one tap = one K chunk).  UPP = 2: the space-to-depth stem, 4x4 taps over
 // 32-byte positions (one K chunk = the four kw taps of a kernel row = four neighbouring positions).
-template <bool HAS_ADD, int UPP>
+// BM = output positions per tile: 128, or 256 for the stem (its MFMA phase is only 16 steps, so the fixed cost of a
+// tile -- two workgroup barriers, staging, address arithmetic: ~0.5 us -- was 40 % of its 1.35 us tile period).
+template <bool HAS_ADD, int UPP, int BM>
 __global__ __launch_bounds__(512, 2) void conv_halo_ws_kernel(HaloParams p) {
     typedef bf16_t T;
     typedef bf16_t TO;
     constexpr int KH = UPP == 8 ? 3 : 4, NCH = UPP == 8 ? 3 : 1, NTAPS = KH * NCH;
     constexpr int SPP = UPP + 1, CBP = SPP * 16, KKSTEP = UPP == 8 ? 32 : CBP;
-    constexpr int BM = 128, BN = 64, EPO = 8, UPR = BN / EPO;
-    constexpr int LIT = UPP == 8 ? 8 : 3;         // DMA pieces per helper wave and patch: LIT x 256 lanes x 16 B >= positions x (UPP+1) slots
+    constexpr int BN = 64, EPO = 8, UPR = BN / EPO;
+    constexpr int MI = BM / 64;                   // 32-row accumulator blocks per compute wave
+    constexpr int NQ = BM / 32;                   // output units per helper lane and tile
+    constexpr int LIT = UPP == 8 ? 8 : (BM == 128 ? 3 : 5);       // DMA pieces per helper wave and patch: LIT x 256 lanes x 16 B >= positions x (UPP+1) slots
     constexpr int PATCH = LIT * 256 * 16;
     constexpr int STG = BM * BN * 2;
     constexpr int NPB = 3;
@@ -356,18 +360,18 @@ __global__ __launch_bounds__(512, 2) void conv_halo_ws_kernel(HaloParams p) {
                 for (int kk = 0; kk < 4; ++kk) fbr[tap][kk] = *(const u32x4*)(wp ? wp + (long long)tapw * 128 + kk * 32 : zero);
             }
         }
-        int frag_a[2];
+        int frag_a[MI];
         DPC_UNROLL
-        for (int i = 0; i < 2; ++i) {
-            const int row = wm * 64 + i * 32 + l31;
+        for (int i = 0; i < MI; ++i) {
+            const int row = wm * (BM / 2) + i * 32 + l31;
             const int r = row >> p.lTW, c = row & (p.TW - 1);
             frag_a[i] = (r * p.HWd + c) * CBP + lhi * 16;
         }
         const int rowpitch = p.HWd * CBP;
         for (int j = 0; j < ntiles; ++j) {
-            f32x16 acc[2];
+            f32x16 acc[MI];
             DPC_UNROLL
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < MI; ++i)
                 DPC_UNROLL
                 for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
             barrier_lds_only();  // B1(j)
@@ -375,34 +379,35 @@ __global__ __launch_bounds__(512, 2) void conv_halo_ws_kernel(HaloParams p) {
             // 36 steps of {2 ds_read_b128, 2 MFMA}; fragments three steps ahead in a ring of four register sets (two: +3 %; four: no further gain),
             // the constant part of every address in the instruction's offset field (hand-counted waits, dpc_rt.h)
             constexpr int S = KH * NCH * 4, D = HALO_WS_D, R = HALO_WS_D + 1;
-            u32x4 ring[R][2];
-            const unsigned char* rowp[KH][2];
+            u32x4 ring[R][MI];
+            const unsigned char* rowp[KH][MI];
             DPC_UNROLL
             for (int kh = 0; kh < KH; ++kh)
                 DPC_UNROLL
-                for (int i = 0; i < 2; ++i) rowp[kh][i] = patch + frag_a[i] + kh * rowpitch;
+                for (int i = 0; i < MI; ++i) rowp[kh][i] = patch + frag_a[i] + kh * rowpitch;
             auto fetch = [&](auto sc) {
                 constexpr int s = decltype(sc)::value;
                 constexpr int kh = s / (NCH * 4), ch = (s / 4) % NCH, kk = s % 4;
                 DPC_UNROLL
-                for (int i = 0; i < 2; ++i) lds_read_b128_async_off<ch * CBP + kk * KKSTEP>(ring[s % R][i], rowp[kh][i]);
+                for (int i = 0; i < MI; ++i) lds_read_b128_async_off<ch * CBP + kk * KKSTEP>(ring[s % R][i], rowp[kh][i]);
             };
             static_for<D>(fetch);
             static_for<S>([&](auto sc) {
                 constexpr int s = decltype(sc)::value;
                 if constexpr (s + D < S) fetch(std::integral_constant<int, s + D>{});
                 constexpr int ahead = (S - 1 - s) < D ? (S - 1 - s) : D;
-                lds_wait_tie<2 * ahead>(ring[s % R][0], ring[s % R][1]);
                 DPC_UNROLL
-                for (int i = 0; i < 2; ++i) acc[i] = mfma_32x32x16_bf16(ring[s % R][i], fbr[s / 4][s % 4], acc[i]);
+                for (int i = 0; i < MI; i += 2) lds_wait_tie<MI * ahead>(ring[s % R][i], ring[s % R][i + 1]);
+                DPC_UNROLL
+                for (int i = 0; i < MI; ++i) acc[i] = mfma_32x32x16_bf16(ring[s % R][i], fbr[s / 4][s % 4], acc[i]);
                 sched_fence();
             });
             TO* tile = (TO*)(lds + NPB * PATCH + (j & 1) * STG);
             DPC_UNROLL
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < MI; ++i)
                 DPC_UNROLL
                 for (int r = 0; r < 16; ++r) {
-                    const int row_l = wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                    const int row_l = wm * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
                     tile[row_l * BN + wn * 32 + l31] = f32_to_bf16(acc[i][r]);
                 }
             barrier_lds_only();  // B2(j)
@@ -449,38 +454,38 @@ __global__ __launch_bounds__(512, 2) void conv_halo_ws_kernel(HaloParams p) {
         // The residual addend of tile j is requested one interval before it is consumed: with the loads issued
         // inside the epilogue only 4 x 16 B per lane were in flight and the extra 0.67 GB of an input-gradient
         // with residual cost +270 us (the kernel then moves 2 GB and is HBM-bound).
-        u32x4 av[4];
+        u32x4 av[NQ];
         DPC_UNROLL
-        for (int q = 0; q < 4; ++q) av[q] = u32x4{0u, 0u, 0u, 0u};
-        auto tile_rows = [&](int j, int (&rows)[4]) {
+        for (int q = 0; q < NQ; ++q) av[q] = u32x4{0u, 0u, 0u, 0u};
+        auto tile_rows = [&](int j, int (&rows)[NQ]) {
             int frame, h0, w0;
             tile_origin(m_prog + j * p.gm, frame, h0, w0);
             DPC_UNROLL
-            for (int q = 0; q < 4; ++q) {
+            for (int q = 0; q < NQ; ++q) {
                 const int row_l = rbase + 32 * q;
                 const int h = h0 + (row_l >> p.lTW), w = w0 + (row_l & (p.TW - 1));
                 const bool ok = h < p.H && w < p.W && col0 < p.Co;
                 rows[q] = ok ? (frame * p.H + h) * p.W + w : -1;
             }
         };
-        auto fetch_addend = [&](int j, u32x4 (&dst)[4]) {
-            int rows[4];
+        auto fetch_addend = [&](int j, u32x4 (&dst)[NQ]) {
+            int rows[NQ];
             tile_rows(j, rows);
             DPC_UNROLL
-            for (int q = 0; q < 4; ++q) {
+            for (int q = 0; q < NQ; ++q) {
                 const char* a = (const char*)p.addend + ((long long)rows[q] * p.ldo + col0) * 2;
                 dst[q] = *(const u32x4*)(rows[q] >= 0 ? a : zero);
             }
         };
-        auto epilogue = [&](int j, const u32x4 (&add)[4]) {
-            int rows[4];
+        auto epilogue = [&](int j, const u32x4 (&add)[NQ]) {
+            int rows[NQ];
             tile_rows(j, rows);
             const unsigned char* stg = lds + NPB * PATCH + (j & 1) * STG;
-            u32x4 ov[4];
+            u32x4 ov[NQ];
             DPC_UNROLL
-            for (int q = 0; q < 4; ++q) ov[q] = *(const u32x4*)(stg + ((rbase + 32 * q) * BN + col0) * 2);
+            for (int q = 0; q < NQ; ++q) ov[q] = *(const u32x4*)(stg + ((rbase + 32 * q) * BN + col0) * 2);
             DPC_UNROLL
-            for (int q = 0; q < 4; ++q) {
+            for (int q = 0; q < NQ; ++q) {
                 if (rows[q] >= 0) {
                     u32x4 o = ov[q];
                     if (HAS_ADD) {
@@ -511,13 +516,13 @@ __global__ __launch_bounds__(512, 2) void conv_halo_ws_kernel(HaloParams p) {
             }
             barrier_lds_only();  // B1(j)
             if (HAS_ADD) {
-                u32x4 avn[4];
+                u32x4 avn[NQ];
                 DPC_UNROLL
-                for (int q = 0; q < 4; ++q) avn[q] = av[q];
+                for (int q = 0; q < NQ; ++q) avn[q] = av[q];
                 if (j < ntiles && j >= 1) fetch_addend(j, avn);
                 if (j >= 1) epilogue(j - 1, av);
                 DPC_UNROLL
-                for (int q = 0; q < 4; ++q) av[q] = avn[q];
+                for (int q = 0; q < NQ; ++q) av[q] = avn[q];
             } else if (j >= 1) {
                 epilogue(j - 1, av);
             }
@@ -551,7 +556,7 @@ __global__ __launch_bounds__(512, 2) void conv_halo_ws_kernel(HaloParams p) {
 }
 
 // ---------------------------------------------------------------- host side
-static bool halo_plan(const dpc_conv_desc* d, HaloParams* p) {
+static bool halo_plan(const dpc_conv_desc* d, HaloParams* p, bool allow_ws = true) {
     if (d->KT != 1 || d->st != 1 || d->sh != 1 || d->sw != 1 || d->pt != 0) return false;
     if (d->RT != d->ST || d->RH != d->SH || d->RW != d->SW) return false;
     if (d->src_ld != d->Ci || d->Co > 64) return false;
@@ -564,10 +569,13 @@ static bool halo_plan(const dpc_conv_desc* d, HaloParams* p) {
     while (tw > d->RW && tw > 4) tw >>= 1;
     p->TW = tw;
     p->lTW = ilog2_exact(tw);
-    p->TR = 128 / tw;
+    static const int ws_on = getenv("DPC_HALO_WS") ? atoi(getenv("DPC_HALO_WS")) : 1;
+    const bool ws_ok = allow_ws && ws_on && d->dtype_in == DPC_BF16 && d->ldo % 8 == 0 && d->Co % 8 == 0;
+    const int bm = (ws_ok && k44) ? 256 : 128;  // the role-specialised stem variant works on 256-position tiles
+    p->TR = bm / tw;
     p->HR = p->TR + d->KH - 1;
     p->HWd = p->TW + d->KW - 1;
-    if (p->HR * p->HWd > (k33 ? 228 : 252)) return false;
+    if (bm == 128 && p->HR * p->HWd > (k33 ? 228 : 252)) return false;
     p->NF = d->N * d->RT;
     p->H = d->RH; p->W = d->RW; p->C = d->Ci; p->Co = d->Co; p->ldw = d->ldw; p->ldo = d->ldo;
     p->flip = d->mode == 1;
@@ -580,11 +588,10 @@ static bool halo_plan(const dpc_conv_desc* d, HaloParams* p) {
     if (ntm >= (1ll << 30) || (long long)p->NF * d->RH * d->RW * d->Ci >= (1ll << 31)) return false;  // 32-bit element offsets
     p->ntm = (int)ntm;
     p->gm = p->ntm < 1024 ? p->ntm : 1024;  // persistent workgroups: B is loaded once per workgroup
-    static const int ws_on = getenv("DPC_HALO_WS") ? atoi(getenv("DPC_HALO_WS")) : 1;
     const long long sbytes = (long long)p->NF * d->RH * d->RW * d->Ci * esz;
     p->src_bytes = sbytes < (1ll << 31) ? (unsigned)sbytes : 0u;
-    p->ws = ws_on && d->dtype_in == DPC_BF16 && p->src_bytes > 0 && d->ldo % 8 == 0 && d->Co % 8 == 0 &&
-            ((k33 && p->HR * p->HWd * 9 <= 8 * 256) || (k44 && p->HR * p->HWd * 3 <= 3 * 256));
+    p->ws = ws_ok && p->src_bytes > 0 && ((k33 && p->HR * p->HWd * 9 <= 8 * 256) || (k44 && p->HR * p->HWd * 3 <= 5 * 256));
+    if (bm == 256 && !p->ws) return halo_plan(d, p, false);
     static const int ws_gm = getenv("DPC_HALO_WS_GM") ? atoi(getenv("DPC_HALO_WS_GM")) : 256;  // test tiers shrink it
     if (p->ws) p->gm = p->ntm < ws_gm ? p->ntm : ws_gm;  // one resident workgroup per CU
     p->d_tpf = make_fastdiv(p->tiles_per_frame);
@@ -607,14 +614,22 @@ int dpc_conv_halo_try(const dpc_conv_desc* d, const void* src, const void* wgt, 
     p.src = src; p.wgt = wgt; p.out = out; p.addend = addend; p.stats = stats;
     const int epo = d->dtype_out == DPC_BF16 ? 8 : 4;
     p.vec_out = (d->Co % epo == 0 && d->ldo % epo == 0 && ((uintptr_t)out % 16 == 0) && ((uintptr_t)addend % 16 == 0)) ? 1 : 0;
+    const bool ws_go = p.ws && p.vec_out && ((uintptr_t)src % 16 == 0) && !(d->KH == 4 && addend);
+    if (p.ws && !ws_go) {  // the specialised kernel declined at launch: generic patch kernel, same number of stats rows as promised
+        const int promised = p.gm, vo = p.vec_out;
+        if (!halo_plan(d, &p, false)) return 1;
+        p.src = src; p.wgt = wgt; p.out = out; p.addend = addend; p.stats = stats;
+        p.vec_out = vo;
+        if (p.gm > promised) p.gm = promised;
+    }
     dim3 grid((unsigned)p.gm), block(256);
-    if (p.ws && p.vec_out && ((uintptr_t)src % 16 == 0) && !(d->KH == 4 && addend)) {
+    if (ws_go) {
         if (d->KH == 4) {
-            DPC_LAUNCH((conv_halo_ws_kernel<false, 2>), grid, dim3(512), stream, p);
+            DPC_LAUNCH((conv_halo_ws_kernel<false, 2, 256>), grid, dim3(512), stream, p);
         } else if (addend) {
-            DPC_LAUNCH((conv_halo_ws_kernel<true, 8>), grid, dim3(512), stream, p);
+            DPC_LAUNCH((conv_halo_ws_kernel<true, 8, 128>), grid, dim3(512), stream, p);
         } else {
-            DPC_LAUNCH((conv_halo_ws_kernel<false, 8>), grid, dim3(512), stream, p);
+            DPC_LAUNCH((conv_halo_ws_kernel<false, 8, 128>), grid, dim3(512), stream, p);
         }
         return dpc_launch_status();
     }
