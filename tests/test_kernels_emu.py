@@ -87,6 +87,7 @@ def test_gemm_nt(k, dtype, mnk):
 def test_stem_s2d(k, dtype):
     kc.case_stem(k, dtype, 2, 2, 16, 20)
     kc.case_stem(k, dtype, 2, 1, 16, 64)   # every tile inside the image: partial sums taken by the compute waves (bf16)
+    kc.case_stem(k, dtype, 1, 1, 4, 168)   # 84 columns: two 64-position row segments in the staged-patch weight gradient
     kc.case_stem(k, dtype, 1, 2, 6, 100)   # 50 columns after space-to-depth: staged-patch weight gradient (bf16), ragged row segment
 
 
