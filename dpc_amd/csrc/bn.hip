@@ -340,18 +340,19 @@ extern "C" int dpc_bn_bwd_apply(const void* dy, const void* y, const uint8_t* ma
     const int E = dtype == DPC_BF16 ? 8 : 4;
     if (C % E) return DPC_ERR_UNSUPPORTED;
     const long long units = rows * C / E;
+    // 2048 workgroups = the 8 resident per CU: each streams one long contiguous span (5.5 -> 5.8 TB/s, with dz 5.35 -> 6.0)
     const bool fixed = (256 * E) % C == 0;
     if (dtype == DPC_F32) {
         if (fixed) {
-            if (bn_streaming(units)) { DPC_LAUNCH((bn_bwd_apply_kernel<float, true, true>), dim3(grid_for(units)), dim3(256), stream, (const float*)dy, (const float*)y, mask, (const float*)x, units, C, mean, invstd, gamma, coef, relu, (float*)dx, (float*)dz); } else { DPC_LAUNCH((bn_bwd_apply_kernel<float, true, false>), dim3(grid_for(units)), dim3(256), stream, (const float*)dy, (const float*)y, mask, (const float*)x, units, C, mean, invstd, gamma, coef, relu, (float*)dx, (float*)dz); }
+            if (bn_streaming(units)) { DPC_LAUNCH((bn_bwd_apply_kernel<float, true, true>), dim3(grid_for(units, 256, 2048)), dim3(256), stream, (const float*)dy, (const float*)y, mask, (const float*)x, units, C, mean, invstd, gamma, coef, relu, (float*)dx, (float*)dz); } else { DPC_LAUNCH((bn_bwd_apply_kernel<float, true, false>), dim3(grid_for(units, 256, 2048)), dim3(256), stream, (const float*)dy, (const float*)y, mask, (const float*)x, units, C, mean, invstd, gamma, coef, relu, (float*)dx, (float*)dz); }
         } else {
-            if (bn_streaming(units)) { DPC_LAUNCH((bn_bwd_apply_kernel<float, false, true>), dim3(grid_for(units)), dim3(256), stream, (const float*)dy, (const float*)y, mask, (const float*)x, units, C, mean, invstd, gamma, coef, relu, (float*)dx, (float*)dz); } else { DPC_LAUNCH((bn_bwd_apply_kernel<float, false, false>), dim3(grid_for(units)), dim3(256), stream, (const float*)dy, (const float*)y, mask, (const float*)x, units, C, mean, invstd, gamma, coef, relu, (float*)dx, (float*)dz); }
+            if (bn_streaming(units)) { DPC_LAUNCH((bn_bwd_apply_kernel<float, false, true>), dim3(grid_for(units, 256, 2048)), dim3(256), stream, (const float*)dy, (const float*)y, mask, (const float*)x, units, C, mean, invstd, gamma, coef, relu, (float*)dx, (float*)dz); } else { DPC_LAUNCH((bn_bwd_apply_kernel<float, false, false>), dim3(grid_for(units, 256, 2048)), dim3(256), stream, (const float*)dy, (const float*)y, mask, (const float*)x, units, C, mean, invstd, gamma, coef, relu, (float*)dx, (float*)dz); }
         }
     } else if (dtype == DPC_BF16) {
         if (fixed) {
-            if (bn_streaming(units)) { DPC_LAUNCH((bn_bwd_apply_kernel<bf16_t, true, true>), dim3(grid_for(units)), dim3(256), stream, (const bf16_t*)dy, (const bf16_t*)y, mask, (const bf16_t*)x, units, C, mean, invstd, gamma, coef, relu, (bf16_t*)dx, (bf16_t*)dz); } else { DPC_LAUNCH((bn_bwd_apply_kernel<bf16_t, true, false>), dim3(grid_for(units)), dim3(256), stream, (const bf16_t*)dy, (const bf16_t*)y, mask, (const bf16_t*)x, units, C, mean, invstd, gamma, coef, relu, (bf16_t*)dx, (bf16_t*)dz); }
+            if (bn_streaming(units)) { DPC_LAUNCH((bn_bwd_apply_kernel<bf16_t, true, true>), dim3(grid_for(units, 256, 2048)), dim3(256), stream, (const bf16_t*)dy, (const bf16_t*)y, mask, (const bf16_t*)x, units, C, mean, invstd, gamma, coef, relu, (bf16_t*)dx, (bf16_t*)dz); } else { DPC_LAUNCH((bn_bwd_apply_kernel<bf16_t, true, false>), dim3(grid_for(units, 256, 2048)), dim3(256), stream, (const bf16_t*)dy, (const bf16_t*)y, mask, (const bf16_t*)x, units, C, mean, invstd, gamma, coef, relu, (bf16_t*)dx, (bf16_t*)dz); }
         } else {
-            if (bn_streaming(units)) { DPC_LAUNCH((bn_bwd_apply_kernel<bf16_t, false, true>), dim3(grid_for(units)), dim3(256), stream, (const bf16_t*)dy, (const bf16_t*)y, mask, (const bf16_t*)x, units, C, mean, invstd, gamma, coef, relu, (bf16_t*)dx, (bf16_t*)dz); } else { DPC_LAUNCH((bn_bwd_apply_kernel<bf16_t, false, false>), dim3(grid_for(units)), dim3(256), stream, (const bf16_t*)dy, (const bf16_t*)y, mask, (const bf16_t*)x, units, C, mean, invstd, gamma, coef, relu, (bf16_t*)dx, (bf16_t*)dz); }
+            if (bn_streaming(units)) { DPC_LAUNCH((bn_bwd_apply_kernel<bf16_t, false, true>), dim3(grid_for(units, 256, 2048)), dim3(256), stream, (const bf16_t*)dy, (const bf16_t*)y, mask, (const bf16_t*)x, units, C, mean, invstd, gamma, coef, relu, (bf16_t*)dx, (bf16_t*)dz); } else { DPC_LAUNCH((bn_bwd_apply_kernel<bf16_t, false, false>), dim3(grid_for(units, 256, 2048)), dim3(256), stream, (const bf16_t*)dy, (const bf16_t*)y, mask, (const bf16_t*)x, units, C, mean, invstd, gamma, coef, relu, (bf16_t*)dx, (bf16_t*)dz); }
         }
     } else {
         return DPC_ERR_ARG;
