@@ -174,6 +174,57 @@ def golden_train():
     save("train.npz", **out)
 
 
+def golden_eval_p5():
+    """cfg5's combination (resnet34 + pred_step 5) at a CPU-sized image/batch, eval mode (own file: the round-1
+    fixtures stay byte-identical)."""
+    out = {}
+    m, _ = build_ref("resnet34", 64, 5)
+    m.eval()
+    x = O.make_input_pcg(2, 8, 5, 64)
+    with torch.no_grad():
+        score, mask = m(x)
+    out["score_r34_64_b2_p5"] = score.numpy().astype(np.float32)
+    flat = score.view(2 * 5 * 4, -1)
+    tgt = (mask.contiguous() == 1).view(flat.shape).to(int).argmax(dim=1)
+    loss = nn.CrossEntropyLoss()(flat, tgt)
+    t1, t3, t5 = ref_utils.calc_topk_accuracy(flat, tgt, (1, 3, 5))
+    out["evalloss_r34_64_b2_p5"] = np.array([loss.item(), t1.item(), t3.item(), t5.item()])
+    save("eval_scores_p5.npz", **out)
+
+
+# ---------------------------------------------------------------- bf16 anchor (VERDICT r1 item 1c)
+def golden_anchor16():
+    """fp32 reference run at r18 / 128^2 / B=16 -- a batch at which the engine's throughput (bf16) mode selects
+    every specialised kernel -- so the bf16 path is anchored to the reference instead of to itself."""
+    out = {}
+    net, size, B = "resnet18", 128, 16
+    x = O.make_input_pcg(B, 8, 5, size)
+    m, _ = build_ref(net, size)
+    m.train()
+    m.agg.dropout_layer.p = 0.0
+    score, mask = m(x)
+    R = B * 3 * 16
+    flat = score.view(R, -1)
+    tgt = (mask.contiguous() == 1).view(flat.shape).to(int).argmax(dim=1)
+    loss = nn.CrossEntropyLoss()(flat, tgt)
+    t1, t3, t5 = ref_utils.calc_topk_accuracy(flat, tgt, (1, 3, 5))
+    loss.backward()
+    out["score_stride"] = np.array(37)
+    out["score_sub"] = score.detach().flatten()[::37].numpy().copy()
+    out["score_norm"] = np.array(score.detach().norm().item())
+    out["score_diag"] = flat.detach().diagonal().numpy().copy()
+    out["loss_topk"] = np.array([loss.item(), t1.item(), t3.item(), t5.item()])
+    names = [k for k, _ in m.named_parameters()]
+    out["param_names"] = np.array(names)
+    out["grad_norm"] = np.array([p.grad.norm().item() for _, p in m.named_parameters()])
+    for k, p in m.named_parameters():
+        g = p.grad.flatten()
+        stride = max(1, g.numel() // 1024)
+        out["grad_sub::" + k] = g[::stride].numpy().copy()
+        out["grad_substride::" + k] = np.array(stride)
+    save("anchor_r18_128_b16.npz", **out)
+
+
 # ---------------------------------------------------------------- G4 per-op fixtures
 def golden_ops():
     out = {}
@@ -233,7 +284,7 @@ def golden_ops():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["mask", "ops", "eval", "train"]
+    which = sys.argv[1:] or ["mask", "ops", "eval", "eval_p5", "train", "anchor"]
     if "mask" in which:
         golden_mask()
     if "ops" in which:
@@ -242,3 +293,7 @@ if __name__ == "__main__":
         golden_eval_scores()
     if "train" in which:
         golden_train()
+    if "eval_p5" in which:
+        golden_eval_p5()
+    if "anchor" in which:
+        golden_anchor16()

@@ -21,27 +21,32 @@ def gold(golden_dir, name):
     return np.load(os.path.join(golden_dir, name), allow_pickle=False)
 
 
-def engine(net, size, B, dtype=torch.float32):
-    eng = DPCEngine(net, size, 8, 5, 3, B, DEV, dtype)
+def engine(net, size, B, dtype=torch.float32, P=3):
+    eng = DPCEngine(net, size, 8, 5, P, B, DEV, dtype)
     assert eng.lib.kind == "hip" and eng.lib.path.endswith("libdpc_hip.so")
     eng.load_params(O.make_params_pcg(net))
     return eng
 
 
-@pytest.mark.parametrize("tag,net,size,B", [("r18_64_b2", "resnet18", 64, 2), ("r34_64_b2", "resnet34", 64, 2),
-                                            ("r18_128_b4", "resnet18", 128, 4)])
-def test_eval_score_vs_reference(golden_dir, tag, net, size, B):
-    g = gold(golden_dir, "eval_scores.npz")
-    eng = engine(net, size, B)
+@pytest.mark.parametrize("tag,net,size,B,P", [("r18_64_b2", "resnet18", 64, 2, 3), ("r34_64_b2", "resnet34", 64, 2, 3),
+                                              ("r18_128_b4", "resnet18", 128, 4, 3),
+                                              ("r34_64_b2_p5", "resnet34", 64, 2, 5)])  # cfg5's net + pred_step together
+def test_eval_score_vs_reference(golden_dir, tag, net, size, B, P):
+    g = gold(golden_dir, "eval_scores_p5.npz" if P == 5 else "eval_scores.npz")
+    eng = engine(net, size, B, P=P)
     x = O.make_input_pcg(B, 8, 5, size).to(DEV)
     score = eng.forward(x, train=False).cpu()
     ref = torch.from_numpy(g["score_" + tag])
+    assert score.shape == ref.shape
     assert (score - ref).abs().max().item() < TOL
     res = eng.loss_topk(False).cpu()
     loss, accs = O.loss_and_topk(ref)
     assert abs(res[0].item() - loss.item()) < TOL
     assert res[1:].tolist() == pytest.approx([a.item() for a in accs], abs=1e-6)
-    assert torch.equal(eng.get_mask().cpu(), O.mask_closed_form(B, 3, eng.SQ))
+    if P == 5:  # the reference's own CrossEntropyLoss / calc_topk_accuracy outputs (make_golden.golden_eval_p5)
+        e = g["evalloss_" + tag]
+        assert abs(res[0].item() - e[0]) < TOL and res[1:].tolist() == pytest.approx(list(e[1:]), abs=1e-6)
+    assert torch.equal(eng.get_mask().cpu(), O.mask_closed_form(B, P, eng.SQ))
 
 
 def test_train_step_vs_reference(golden_dir):
@@ -61,8 +66,8 @@ def test_train_step_vs_reference(golden_dir):
     # held to 1e-3 of max-abs.  Upstream of a ReLU whose pre-activation sits within fp32 noise of zero a
     # single mask flip changes the gradient discretely: the reference's own fp32 run deviates from an
     # fp64 run of itself by 0.5-4 % (max-abs) in layers 1-2 on this very input (DESIGN.md "ReLU-boundary
-    # flips"; scripts/diag_grads.py prints the flip census), so backbone gradients are held to 3 % in
-    # relative L2 / 1 % in norm instead of an element-wise bound.
+    # flips"; scripts/diag_grads.py prints the flip census), so backbone gradients are held to 1.5 % in
+    # relative L2 (observed <= 0.8 %) / 1 % in norm instead of an element-wise bound.
     for i, n in enumerate(names):
         gn = eng.G[n].norm().item()
         assert gn == pytest.approx(float(g["grad_norm_p0"][i]), rel=1e-2, abs=1e-6), n
@@ -74,7 +79,7 @@ def test_train_step_vs_reference(golden_dir):
             if n.startswith(("agg.", "network_pred.", "backbone.layer4")):
                 assert np.abs(mine - g[k]).max() < 1e-3 * np.abs(g[k]).max() + 1e-7, n
             else:
-                assert np.linalg.norm(mine - g[k]) < 3e-2 * np.linalg.norm(g[k]), n
+                assert np.linalg.norm(mine - g[k]) < 1.5e-2 * np.linalg.norm(g[k]), n
     eng.adam_step()
     torch.cuda.synchronize()
     for i, n in enumerate(names):
@@ -139,6 +144,85 @@ def test_bf16_mode_tracks_fp32(golden_dir):
     eng.loss_topk(True)
     eng.backward()
     assert torch.isfinite(eng.flat_g).all()
+
+
+# Tolerances of the bf16 anchor, from the errors measured on MI355X (printed by the test; round-2 run:
+# see profiles/r02_bf16_anchor.txt): bf16 keeps 8 mantissa bits, every activation is rounded once per layer.
+ANCHOR_SCORE_L2 = 0.02     # rel-L2 of the strided score subsample
+ANCHOR_GRADNORM = 0.05     # per-parameter gradient norm
+ANCHOR_GRAD_L2 = 0.10      # per-parameter rel-L2 of the strided gradient subsample (worst parameter)
+
+
+def test_bf16_anchored_to_reference(golden_dir):
+    """Throughput (bf16) mode at r18 / 128^2 / B=16 -- every specialised bf16 kernel (loader/compute implicit GEMM,
+    role-specialised patch kernel, staged-patch weight gradients) is selected at this batch -- against the fp32
+    outputs of the REFERENCE itself on the same input (tests/golden/anchor_r18_128_b16.npz, dropout p=0)."""
+    g = gold(golden_dir, "anchor_r18_128_b16.npz")
+    B = 16
+    eng = engine("resnet18", 128, B, torch.bfloat16)
+    x = O.make_input_pcg(B, 8, 5, 128).to(DEV)
+    ones = torch.ones(eng.n_steps, eng.M, eng.D, device=DEV)
+    score = eng.forward(x, train=True, dropout_masks=ones).cpu().flatten()
+    res = eng.loss_topk(True).cpu()
+    eng.backward()
+    torch.cuda.synchronize()
+    stride = int(g["score_stride"])
+    ref = torch.from_numpy(g["score_sub"])
+    e_score = ((score[::stride] - ref).norm() / ref.norm()).item()
+    e = g["loss_topk"]
+    names = [str(n) for n in g["param_names"]]
+    assert names == list(eng.G.keys())
+    rows = []
+    for i, n in enumerate(names):
+        gr = eng.G[n].cpu().flatten()
+        st = int(g["grad_substride::" + n])
+        rs = torch.from_numpy(g["grad_sub::" + n])
+        rows.append((n, abs(gr.norm().item() / max(float(g["grad_norm"][i]), 1e-12) - 1.0),
+                     ((gr[::st] - rs).norm() / rs.norm().clamp_min(1e-12)).item()))
+    worst_n = max(rows, key=lambda r: r[1])
+    worst_l = max(rows, key=lambda r: r[2])
+    print(f"bf16 anchor: score rel-L2 {e_score:.4f}; loss {res[0].item():.4f} vs {e[0]:.4f}; "
+          f"top-k {res[1:].tolist()} vs {list(e[1:])}; worst grad-norm err {worst_n[1]:.4f} ({worst_n[0]}); "
+          f"worst grad rel-L2 {worst_l[2]:.4f} ({worst_l[0]})")
+    for r in rows:
+        print(f"  {r[0]:48s} norm err {r[1]:.4f}  rel-L2 {r[2]:.4f}")
+    assert e_score < ANCHOR_SCORE_L2
+    assert abs(res[0].item() - e[0]) < 2e-2
+    assert res[1:].tolist() == pytest.approx(list(e[1:]), abs=8.0 / eng.R)  # a handful of near-tie rows may reorder
+    assert worst_n[1] < ANCHOR_GRADNORM, worst_n
+    assert worst_l[2] < ANCHOR_GRAD_L2, worst_l
+
+
+def test_cfg5_full_shape_properties():
+    """BASELINE.json configs[4] on one GPU shard: resnet34, 224^2, pred_step 5, B=64 -> R = 15 680 rows, a 983 MB f32
+    score and its gradient.  Too big for the CPU oracle: size-independent invariants (bf16 throughput mode)."""
+    B, P = 64, 5
+    eng = DPCEngine("resnet34", 224, 8, 5, P, B, DEV, torch.bfloat16)
+    eng.load_params(O.init_params_reference_style("resnet34", seed=0))
+    x = torch.randn(B, 8, 3, 5, 224, 224, device=DEV, generator=torch.Generator(DEV).manual_seed(2))
+    res0 = eng.train_step(x).cpu()
+    R = eng.R
+    assert R == 15680 and eng.SQ == 49 and torch.isfinite(res0).all()
+    assert torch.isfinite(eng.flat_g).all() and eng.flat_g.abs().max().item() > 0
+    # CE gradient rows sum to zero; the score is the Gram matrix of its operands (checked on row / column slabs)
+    for r0 in (0, 7777, R - 64):
+        ds = eng.dscore[r0:r0 + 64, :R].float()
+        assert ds.sum(1).abs().max().item() < 1e-3
+        chk = eng.pred.float().view(R, -1)[r0:r0 + 64] @ eng.feat_inf.float().view(R, -1).t()
+        assert (chk - eng.score[r0:r0 + 64]).abs().max().item() < 1e-2 * chk.abs().max().item()
+    # loss / top-k of the materialised score against torch on the device (same f32 logits)
+    tgt = torch.arange(R, device=DEV)
+    loss_t = torch.nn.functional.cross_entropy(eng.score, tgt)
+    assert abs(loss_t.item() - res0[0].item()) < 1e-3 * max(1.0, abs(loss_t.item()))
+    top5 = eng.score.topk(5, 1).indices
+    for kk, got in zip((1, 3, 5), res0[1:].tolist()):
+        assert (top5[:, :kk] == tgt[:, None]).any(1).float().mean().item() == pytest.approx(got, abs=1e-6)
+    mk = eng.get_mask().view(R, R)
+    assert torch.equal((mk == 1).sum(1), torch.ones(R, dtype=torch.long, device=DEV))
+    assert int((mk == -3).sum().item()) == B * (P * 49) * (P * 49) - B * P * P * 49
+    for _ in range(2):
+        res = eng.train_step(x).cpu()
+    assert res[0].item() < res0[0].item()
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])

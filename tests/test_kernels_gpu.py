@@ -67,7 +67,7 @@ def test_conv_wgrad(k, dtype, shape):
 
 
 @pytest.mark.parametrize("dtype", [F32, BF16])
-@pytest.mark.parametrize("mnk", [(6144, 6144, 256), (6468, 6468, 256), (2048, 768, 256), (192, 192, 256), (130, 70, 64)])
+@pytest.mark.parametrize("mnk", [(6144, 6144, 256), (6468, 6468, 256), (15680, 15680, 256), (2048, 768, 256), (192, 192, 256), (130, 70, 64)])
 def test_gemm_nt(k, dtype, mnk):
     kc.case_gemm_nt(k, dtype, *mnk)
 
@@ -119,6 +119,7 @@ def test_ce_topk(k, dtype_d):
     kc.case_ce_topk(k, 24, 24, dtype_d)
     kc.case_ce_topk(k, 1764, 1764, dtype_d)
     kc.case_ce_topk(k, 6144, 6144, dtype_d)
+    kc.case_ce_topk(k, 15680, 15680, dtype_d)  # cfg5: 983 MB of logits
 
 
 def test_adam(k):

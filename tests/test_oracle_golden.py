@@ -144,3 +144,41 @@ def test_topk_and_loss(golden_dir):
     loss, accs = O.loss_and_topk(sc)
     assert abs(loss.item() - float(g["topk::loss"])) < 1e-6
     assert [a.item() for a in accs] == pytest.approx(list(g["topk::acc"]), abs=1e-7)
+
+
+def test_eval_score_r34_pred_step5(golden_dir):
+    """cfg5's combination (resnet34 + pred_step 5): oracle vs the reference's own score / loss / top-k"""
+    g = load(golden_dir, "eval_scores_p5.npz")
+    p = O.make_params_pcg("resnet34")
+    x = O.make_input_pcg(2, 8, 5, 64)
+    with torch.no_grad():
+        score = O.dpc_forward(p, x, "resnet34", 5)
+    ref = torch.from_numpy(g["score_r34_64_b2_p5"])
+    assert score.shape == ref.shape == (2, 5, 4, 2, 5, 4)
+    assert (score - ref).abs().max().item() < TOL
+    loss, accs = O.loss_and_topk(score)
+    e = g["evalloss_r34_64_b2_p5"]
+    assert abs(loss.item() - e[0]) < TOL
+    assert [a.item() for a in accs] == pytest.approx(list(e[1:]), abs=1e-7)
+
+
+def test_anchor_r18_128_b16(golden_dir):
+    """the fixture that anchors the bf16 throughput mode (tests/test_engine_gpu.py): the oracle reproduces it in fp32"""
+    g = load(golden_dir, "anchor_r18_128_b16.npz")
+    p = O.make_params_pcg("resnet18")
+    x = O.make_input_pcg(16, 8, 5, 128)
+    loss, accs, grads, score = O.train_step_reference(p, x, "resnet18", 3, dropout_masks=None)
+    stride = int(g["score_stride"])
+    ref = torch.from_numpy(g["score_sub"])
+    assert (score.flatten()[::stride] - ref).abs().max().item() < TOL
+    assert abs(score.norm().item() / float(g["score_norm"]) - 1) < 1e-5
+    e = g["loss_topk"]
+    assert abs(loss.item() - e[0]) < TOL and accs == pytest.approx(list(e[1:]), abs=1e-7)
+    names = [str(n) for n in g["param_names"]]
+    assert names == O.unique_param_names(p)
+    for i, n in enumerate(names):
+        assert grads[n].norm().item() == pytest.approx(float(g["grad_norm"][i]), rel=5e-3, abs=1e-7), n
+        st = int(g["grad_substride::" + n])
+        rs = torch.from_numpy(g["grad_sub::" + n])
+        err = ((grads[n].flatten()[::st] - rs).norm() / rs.norm().clamp_min(1e-12)).item()
+        assert err < 2e-2, (n, err)  # same fp32 arithmetic, different summation order + ReLU-boundary flips
