@@ -40,12 +40,6 @@ class DpcError(RuntimeError):
     pass
 
 
-def _p(t):
-    """Kept for readability at call sites: tensors are passed as-is and turned into
-    raw device pointers inside Lib.call (which keeps them alive for the call)."""
-    return t
-
-
 _vp, _i32, _i64, _f32, _f64 = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_double
 _SIGS = {
     "dpc_abi_version": [],

@@ -516,10 +516,18 @@ extern "C" int dpc_conv_igemm(const dpc_conv_desc* d, const void* src, const voi
     p.vec_out = (d->Co % epo == 0 && d->ldo % epo == 0 && ((uintptr_t)out % 16 == 0) && ((uintptr_t)addend % 16 == 0)) ? 1 : 0;
     int bn;
     igemm_grid(d, p.g.M, &p.ntm, &p.ntn, &p.gm, &bn);
-    {   // dpc_conv_stats_rows() promised the specialised kernel's row count for this shape; if that kernel declined at
-        // launch time (alignment, addend+stats) keep the promise: the generic kernel is persistent over any gm
-        const int wr = dpc_conv_ws_rows(d);
-        if (wr > 0) p.gm = wr < p.ntm ? wr : p.ntm;
+    {   // dpc_conv_stats_rows() promised a row count for this shape (the patch kernel's, the loader/compute kernel's or this
+        // kernel's own).  If a specialised kernel declined at launch time (alignment, addend + stats) the promise is kept:
+        // the generic kernel is persistent over any gm, and rows it has no tile for are zero-filled, so that
+        // dpc_bn_finalize never reads partial sums another layer left in a shared statistics buffer.
+        const int promised = dpc_conv_stats_rows(d);
+        if (promised > 0 && promised != p.gm) {
+            p.gm = promised < p.ntm ? promised : p.ntm;
+            if (stats && p.gm < promised) {
+                if (hipMemsetAsync(stats + (size_t)p.gm * 2 * d->Co, 0, (size_t)(promised - p.gm) * 2 * d->Co * sizeof(float), stream) != hipSuccess)
+                    return DPC_ERR_LAUNCH;
+            }
+        }
     }
     if (d->dtype_in == DPC_F32 && d->dtype_out == DPC_F32) return launch_igemm<float, float>(p, bn, stream);
     if (d->dtype_in == DPC_BF16 && d->dtype_out == DPC_BF16) return launch_igemm<bf16_t, bf16_t>(p, bn, stream);

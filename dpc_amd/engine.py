@@ -426,6 +426,11 @@ class DPCEngine:
             self._need_wgrad(ns * M, co, kk)
         self.need_part(64 * 3 * D)  # dpc_colsum workspace
         self._need_wgrad(R, R, D)
+        prs = C.c_int32(0)  # stem backward: partial rows of the pooled reduction (sized by query, not by coincidence)
+        ps_ = self.pool_shape
+        self.lib.call("dpc_pooled_bn_bwd_reduce", None, None, None, L.dtype_code(dt), ps_[0] * ps_[1] * ps_[2] * ps_[3], widths[0],
+                      None, None, None, C.byref(prs), self.lib.stream())
+        self.need_stats(prs.value * 2 * widths[0])
         self.coef = self.empty((2, max(widths)), f32)
         self.stats = self.empty((max(self._stats_need, 1),), f32)
         self.part = self.empty((max(self._part_need, 1),), f32)

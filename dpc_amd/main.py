@@ -9,8 +9,9 @@ reference (DataParallel scatters it along dim 0), so each GPU sees batch_size / 
 are averaged with one RCCL all-reduce (dpc_amd/parallel.py).  Datasets / augmentation / tensorboard are outside this build's scope
 (SURVEY.md §2 rows 8,9,11): the input is the synthetic N(0,1) video of ``--synthetic`` batches per
 epoch with the dataset's tensor layout [B, num_seq, 3, seq_len, H, W] (dpc/dataset_3d.py:109-111).
-Checkpoints keep the reference's dictionary layout and ``module.``-prefixed keys
-(dpc/main.py:166-174, utils/utils.py:14-26) so they load in either code base.
+Checkpoints are the reference's dictionary (``module.``-prefixed state_dict incl. alias keys, torch-Adam-layout
+``optimizer``; dpc/main.py:166-174, utils/utils.py:14-26) written and read by ``dpc_amd/checkpoint.py``: a file
+written here resumes in the reference and vice versa (tests/test_checkpoint.py).
 """
 from __future__ import annotations
 
@@ -83,6 +84,7 @@ def _worker(rank: int, world: int, args, port: int):
     from .engine import DPCEngine
     from .model import DPC_RNN
     from .parallel import make_allreduce
+    from . import checkpoint as ckpt
 
     if args.model != 'dpc-rnn':
         raise ValueError('wrong model!')  # dpc/main.py:63
@@ -94,23 +96,26 @@ def _worker(rank: int, world: int, args, port: int):
     init = DPC_RNN(args.img_dim, args.num_seq, args.seq_len, args.pred_step, args.net, seed=0)  # same on every rank
     eng.load_params({k: v.detach() for k, v in init.named_parameters()})
     best_acc, iteration = 0.0, 0
-    for path, strict in ((args.resume, True), (args.pretrain, False)):
-        if path and os.path.isfile(path):
-            ck = torch.load(path, map_location='cpu')
-            sd = {k[7:] if k.startswith('module.') else k: v for k, v in ck['state_dict'].items()}
-            if not strict:  # neq_load_customized, backbone/resnet_2d3d.py:310-333: key intersection
-                sd = {k: v for k, v in sd.items() if k in eng.PRM or k.startswith('agg.cell_list.0.')}
-            eng.load_params(sd)
-            if strict:
-                args.start_epoch, iteration, best_acc = ck['epoch'], ck['iteration'], ck['best_acc']
-                st = ck.get('optimizer_flat')
-                if st is not None and not args.reset_lr:
-                    eng.flat_m.copy_(st['m']); eng.flat_v.copy_(st['v']); eng.step_count = int(st['step'])
-                m = re.search('_lr(.+?)_', path)
-                if m and rank == 0:
-                    print('resumed; old lr', m.group(1))
-        elif path and rank == 0:
-            print("[Warning] no checkpoint found at '{}'".format(path))
+    if args.resume:  # dpc/main.py:88-102: strict model load + optimizer state (unless --reset_lr)
+        if os.path.isfile(args.resume):
+            m = re.search('_lr(.+?)_', args.resume)
+            info = ckpt.resume(eng, args.resume, reset_lr=args.reset_lr)
+            args.start_epoch, iteration, best_acc = info['epoch'], info['iteration'], info['best_acc']
+            if args.reset_lr:
+                eng.lr, eng.wd = args.lr, args.wd
+                if rank == 0 and m:
+                    print('==== Change lr from %f to %f ====' % (float(m.group(1)), args.lr))
+            if rank == 0:
+                print("=> loaded resumed checkpoint '{}' (epoch {})".format(args.resume, info['epoch']))
+        elif rank == 0:
+            print("[Warning] no checkpoint found at '{}'".format(args.resume))
+    if args.pretrain:  # dpc/main.py:104-112: key intersection (neq_load_customized)
+        if os.path.isfile(args.pretrain):
+            info = ckpt.pretrain(eng, args.pretrain, log=print if rank == 0 else (lambda *a: None))
+            if rank == 0:
+                print("=> loaded pretrained checkpoint '{}' (epoch {})".format(args.pretrain, info['epoch']))
+        elif rank == 0:
+            print("=> no checkpoint found at '{}'".format(args.pretrain))
     allreduce = make_allreduce(dist, world)
     gen = torch.Generator(dev).manual_seed(1000 + rank)
     shape = (per_gpu, args.num_seq, 3, args.seq_len, args.img_dim, args.img_dim)
@@ -150,16 +155,10 @@ def _worker(rank: int, world: int, args, port: int):
                 os.makedirs(args.save_dir, exist_ok=True)
                 is_best = val_acc > best_acc
                 best_acc = max(val_acc, best_acc)
-                state = {'epoch': epoch + 1, 'net': args.net, 'best_acc': best_acc, 'iteration': iteration,
-                         'state_dict': {'module.' + k: v.cpu() for k, v in eng.state_dict().items()},
-                         'optimizer_flat': {'m': eng.flat_m.cpu(), 'v': eng.flat_v.cpu(), 'step': eng.step_count}}
                 fn = os.path.join(args.save_dir, 'epoch%s.pth.tar' % str(epoch + 1))
-                torch.save(state, fn)
-                last = os.path.join(args.save_dir, 'epoch%s.pth.tar' % str(epoch))
-                if os.path.exists(last):
-                    os.remove(last)  # keep_all=False, utils/utils.py:18-20
-                if is_best:
-                    torch.save(state, os.path.join(args.save_dir, 'model_best_epoch%s.pth.tar' % str(epoch + 1)))
+                # dpc/main.py:166-174 + utils/utils.py:14-26: same dictionary, same file rotation
+                ckpt.save_checkpoint(ckpt.build_state(eng, epoch + 1, args.net, best_acc, iteration), is_best, filename=fn,
+                                     keep_all=False)
     if rank == 0:
         print('Training from ep %d to ep %d finished' % (args.start_epoch, args.epochs))
     if dist is not None:

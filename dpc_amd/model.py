@@ -63,11 +63,23 @@ class _DPCScore(torch.autograd.Function):
         eng = model._engine
         score = eng.forward(block, train=train, dropout_masks=masks)
         ctx.model = model
+        # The engine keeps ONE set of saved activations (static schedule): the graph node is only valid until the
+        # next forward through the same engine, and for one backward.
+        model._fwd_generation += 1
+        ctx.generation = model._fwd_generation
+        ctx.used = False
         return score.clone()  # engine buffer is reused next step
 
     @staticmethod
     def backward(ctx, dscore):
         eng = ctx.model._engine
+        if ctx.generation != ctx.model._fwd_generation:
+            raise RuntimeError("dpc_amd.DPC_RNN: backward of a score whose saved activations were overwritten by a later "
+                               "forward (the engine holds one step's activations; call backward before the next forward)")
+        if ctx.used:
+            raise RuntimeError("dpc_amd.DPC_RNN: trying to backward through the graph a second time (activations are "
+                               "consumed in place by the backward kernels)")
+        ctx.used = True
         eng.backward(dscore_external=dscore)
         grads = tuple(eng.G[k].clone() for k in ctx.model._param_names)
         return (None, None, None, None) + grads
@@ -93,6 +105,7 @@ class DPC_RNN(nn.Module):
         self._engine_key = None
         self._param_names: List[str] = []
         self._forced_masks = None
+        self._fwd_generation = 0
         shapes = param_shapes(network, widths)
         init = _init_reference_style(shapes, torch.Generator().manual_seed(seed))
         for k, shp in shapes.items():

@@ -225,6 +225,37 @@ def golden_anchor16():
     save("anchor_r18_128_b16.npz", **out)
 
 
+# ---------------------------------------------------------------- checkpoint layout
+def golden_ckpt_layout():
+    """Structure (key names / order / shapes / dtypes, optimizer layout) of the dictionary the reference saves at
+    dpc/main.py:166-174, built with the reference's own model class wrapped as dpc/main.py:65,80-81 wrap it.
+    58 MB of weights are not a fixture; the layout is."""
+    import json
+    out = {}
+    for net in ("resnet18", "resnet34"):
+        m = DPC_RNN(sample_size=128, num_seq=8, seq_len=5, pred_step=3, network=net)
+        model = nn.DataParallel(m)                                                   # main.py:65
+        opt = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=1e-5)      # main.py:80-81
+        for p_ in model.parameters():
+            p_.grad = torch.zeros_like(p_)
+        opt.step()
+        state = {"epoch": 1, "net": net, "state_dict": model.state_dict(), "best_acc": 0.0,
+                 "optimizer": opt.state_dict(), "iteration": 0}                      # main.py:167-172
+        osd = state["optimizer"]
+        out[net] = {
+            "top_keys": list(state.keys()),
+            "state_dict": [[k, list(v.shape), str(v.dtype)] for k, v in state["state_dict"].items()],
+            "optimizer_param_order": [k for k, _ in model.named_parameters()],
+            "optimizer_state_keys": sorted(osd["state"][0].keys()),
+            "optimizer_state_shapes": [[list(osd["state"][i]["exp_avg"].shape), list(osd["state"][i]["step"].shape),
+                                        str(osd["state"][i]["step"].dtype)] for i in range(len(osd["state"]))],
+            "param_groups": [{k: (v if k != "params" else len(v)) for k, v in g_.items()} for g_ in osd["param_groups"]],
+        }
+    with open(os.path.join(HERE, "ckpt_layout.json"), "w") as f:
+        json.dump(out, f, indent=0, default=lambda o: list(o) if isinstance(o, tuple) else str(o))
+    print("wrote ckpt_layout.json", os.path.getsize(os.path.join(HERE, "ckpt_layout.json")) // 1024, "KiB")
+
+
 # ---------------------------------------------------------------- G4 per-op fixtures
 def golden_ops():
     out = {}
@@ -284,7 +315,7 @@ def golden_ops():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["mask", "ops", "eval", "eval_p5", "train", "anchor"]
+    which = sys.argv[1:] or ["mask", "ops", "eval", "eval_p5", "train", "anchor", "ckpt"]
     if "mask" in which:
         golden_mask()
     if "ops" in which:
@@ -295,5 +326,7 @@ if __name__ == "__main__":
         golden_train()
     if "eval_p5" in which:
         golden_eval_p5()
+    if "ckpt" in which:
+        golden_ckpt_layout()
     if "anchor" in which:
         golden_anchor16()

@@ -82,7 +82,7 @@ def case_conv_fwd(k: K, dtype, N, Ci, Co, T, H, W, ks, st, pd, seed=0):
     out = k.empty(N, To, Ho, Wo, Co, dtype=dtype)
     rows = k.lib.call("dpc_conv_stats_rows", C.byref(d))
     stats = k.zeros(rows, 2, Co)
-    k.call("dpc_conv_igemm", C.byref(d), L._p(src), L._p(wp), L._p(out), None, L._p(stats))
+    k.call("dpc_conv_igemm", C.byref(d), src, wp, out, None, stats)
     k.sync()
     assert relerr(out, cl(y)) < tol(dtype)
     o = out.float().cpu().reshape(-1, Co).double()
@@ -104,7 +104,7 @@ def case_conv_dgrad(k: K, dtype, N, Ci, Co, T, H, W, ks, st, pd, seed=1):
     add = q(torch.randn(N, T, H, W, Ci, generator=g), dtype)
     out = k.empty(N, T, H, W, Ci, dtype=dtype)
     wd = k.t(w.permute(1, 2, 3, 4, 0).reshape(Ci, taps * Co), dtype)
-    k.call("dpc_conv_igemm", C.byref(d), L._p(k.t(cl(gy), dtype)), L._p(wd), L._p(out), L._p(k.t(add, dtype)), None)
+    k.call("dpc_conv_igemm", C.byref(d), k.t(cl(gy), dtype), wd, out, k.t(add, dtype), None)
     k.sync()
     assert relerr(out, cl(gx) + add) < tol(dtype)
 
@@ -122,9 +122,9 @@ def case_conv_wgrad(k: K, dtype, N, Ci, Co, T, H, W, ks, st, pd, seed=2):
     ns = C.c_int32(0)
     k.call("dpc_conv_wgrad", C.byref(d), None, None, Co, None, C.byref(ns))
     part = k.zeros(ns.value, Co, taps * Ci)
-    k.call("dpc_conv_wgrad", C.byref(d), L._p(k.t(cl(x), dtype)), L._p(k.t(cl(gy), dtype)), Co, L._p(part), C.byref(ns))
+    k.call("dpc_conv_wgrad", C.byref(d), k.t(cl(x), dtype), k.t(cl(gy), dtype), Co, part, C.byref(ns))
     dw = k.zeros(*gw.shape)
-    k.call("dpc_reduce_unpack", L._p(part), ns.value, L._p(dw), Co, taps, Ci, Ci * taps, 1, taps, 0)
+    k.call("dpc_reduce_unpack", part, ns.value, dw, Co, taps, Ci, Ci * taps, 1, taps, 0)
     k.sync()
     assert relerr(dw, gw) < 1e-4  # f32 accumulation in both modes
 
@@ -135,7 +135,7 @@ def case_gemm_nt(k: K, dtype, M, N, Kd, seed=3):
     B = q(torch.randn(N, Kd, generator=g), dtype)
     d = conv_desc(dtype, torch.float32, 0, M, (1, 1, 1), (1, 1, 1), Kd, Kd, N, Kd, N, (1, 1, 1), (1, 1, 1), (0, 0, 0))
     out = k.empty(M, N)
-    k.call("dpc_conv_igemm", C.byref(d), L._p(k.t(A, dtype)), L._p(k.t(B, dtype)), L._p(out), None, None)
+    k.call("dpc_conv_igemm", C.byref(d), k.t(A, dtype), k.t(B, dtype), out, None, None)
     k.sync()
     assert relerr(out, A.double() @ B.double().t()) < 1e-5
 
@@ -148,14 +148,14 @@ def case_stem(k: K, dtype, BN, T, H, W, Co=64, seed=4):
     wq = q(w, dtype).double().requires_grad_()  # f64 expectation: the f32 reference's own noise exceeds 1e-4 at full size
     y = F.conv3d(q(x, dtype).double(), wq, None, (1, 2, 2), (0, 3, 3))
     xs = k.empty(BN, T, H // 2, W // 2, 16, dtype=dtype)
-    k.call("dpc_pack_input_s2d", L._p(k.t(x)), L._p(xs), L.dtype_code(dtype), BN, T, H, W)
+    k.call("dpc_pack_input_s2d", k.t(x), xs, L.dtype_code(dtype), BN, T, H, W)
     wp = k.empty(Co, 16, 16, dtype=dtype)
-    k.call("dpc_pack_stem_weight", L._p(k.t(w)), L._p(wp), L.dtype_code(dtype), Co)
+    k.call("dpc_pack_stem_weight", k.t(w), wp, L.dtype_code(dtype), Co)
     d = conv_desc(dtype, dtype, 0, BN, (T, H // 2, W // 2), (T, H // 2, W // 2), 16, 16, Co, 256, Co, (1, 4, 4), (1, 1, 1), (0, 2, 2))
     out = k.empty(BN, T, H // 2, W // 2, Co, dtype=dtype)
     rows = k.lib.call("dpc_conv_stats_rows", C.byref(d))
     stats = k.zeros(rows, 2, Co)
-    k.call("dpc_conv_igemm", C.byref(d), L._p(xs), L._p(wp), L._p(out), None, L._p(stats))
+    k.call("dpc_conv_igemm", C.byref(d), xs, wp, out, None, stats)
     k.sync()
     assert relerr(out, cl(y)) < tol(dtype)
     o = out.float().cpu().reshape(-1, Co).double()  # batch-norm partial sums are those of the STORED values
@@ -167,9 +167,9 @@ def case_stem(k: K, dtype, BN, T, H, W, Co=64, seed=4):
     ns = C.c_int32(0)
     k.call("dpc_conv_wgrad", C.byref(d), None, None, Co, None, C.byref(ns))
     part = k.zeros(ns.value, Co, 256)
-    k.call("dpc_conv_wgrad", C.byref(d), L._p(xs), L._p(k.t(cl(gy), dtype)), Co, L._p(part), C.byref(ns))
+    k.call("dpc_conv_wgrad", C.byref(d), xs, k.t(cl(gy), dtype), Co, part, C.byref(ns))
     dw = k.zeros(Co, 3, 1, 7, 7)
-    k.call("dpc_unpack_stem_wgrad", L._p(part), ns.value, L._p(dw), Co)
+    k.call("dpc_unpack_stem_wgrad", part, ns.value, dw, Co)
     k.sync()
     assert relerr(dw, gw) < 1e-4
 
@@ -208,17 +208,17 @@ def case_bn_fwd_bwd(k: K, dtype, rows, Cc, relu, res_mode, seed=5):
         parts[i, 0] = ch.sum(0)
         parts[i, 1] = (ch * ch).sum(0)
     dm, di, dsc, dsh = (k.empty(Cc) for _ in range(4))
-    k.call("dpc_bn_finalize", L._p(k.t(parts)), 3, Cc, float(rows), L._p(k.t(gamma)), L._p(k.t(beta)), 1e-5,
-           L._p(dm), L._p(di), L._p(dsc), L._p(dsh))
+    k.call("dpc_bn_finalize", k.t(parts), 3, Cc, float(rows), k.t(gamma), k.t(beta), 1e-5,
+           dm, di, dsc, dsh)
     k.sync()
     assert relerr(dm, mean.detach()) < 1e-5 and relerr(di, invstd.detach()) < 1e-4
     xk = k.t(x, dtype)
     yk = k.empty(rows, Cc, dtype=dtype)
     E = 4 if dtype == torch.float32 else 8
     mk = k.zeros(rows * Cc // E, dtype=torch.uint8)  # ReLU sign mask, one byte per 16-byte unit
-    k.call("dpc_bn_apply", L._p(xk), L._p(yk), L.dtype_code(dtype), rows, Cc, L._p(dsc), L._p(dsh),
-           L._p(None if res is None else k.t(res, dtype)), L._p(None if rs is None else k.t(rs)),
-           L._p(None if rb is None else k.t(rb)), int(relu), L._p(mk))
+    k.call("dpc_bn_apply", xk, yk, L.dtype_code(dtype), rows, Cc, dsc, dsh,
+           None if res is None else k.t(res, dtype), None if rs is None else k.t(rs),
+           None if rb is None else k.t(rb), int(relu), mk)
     k.sync()
     assert relerr(yk, y.detach()) < tol(dtype)
     bits = (yk.float().cpu().reshape(-1, E) > 0).to(torch.int32) * (1 << torch.arange(E, dtype=torch.int32))
@@ -234,14 +234,14 @@ def case_bn_fwd_bwd(k: K, dtype, rows, Cc, relu, res_mode, seed=5):
     mq = k.t((bits_of(yq, E)).to(torch.uint8))
     for ysrc, msrc in ((yq, None), (None, mq)) if relu else ((None, None),):
         bp = k.zeros(prow.value, 2, Cc)
-        k.call("dpc_bn_bwd_reduce", L._p(gyk), L._p(ysrc), L._p(msrc), L._p(xk), L.dtype_code(dtype), rows, Cc, L._p(dm), L._p(di),
-               int(relu), L._p(bp), C.byref(prow))
+        k.call("dpc_bn_bwd_reduce", gyk, ysrc, msrc, xk, L.dtype_code(dtype), rows, Cc, dm, di,
+               int(relu), bp, C.byref(prow))
         dgam, dbet, coef = k.empty(Cc), k.empty(Cc), k.empty(2, Cc)
-        k.call("dpc_bn_bwd_finalize", L._p(bp), prow.value, Cc, float(rows), L._p(dgam), L._p(dbet), L._p(coef))
+        k.call("dpc_bn_bwd_finalize", bp, prow.value, Cc, float(rows), dgam, dbet, coef)
         dx = k.empty(rows, Cc, dtype=dtype)
         dz = k.empty(rows, Cc, dtype=dtype)
-        k.call("dpc_bn_bwd_apply", L._p(gyk), L._p(ysrc), L._p(msrc), L._p(xk), L.dtype_code(dtype), rows, Cc, L._p(dm), L._p(di),
-               L._p(k.t(gamma)), L._p(coef), int(relu), L._p(dx), L._p(dz))
+        k.call("dpc_bn_bwd_apply", gyk, ysrc, msrc, xk, L.dtype_code(dtype), rows, Cc, dm, di,
+               k.t(gamma), coef, int(relu), dx, dz)
         k.sync()
         t = 2e-3 if dtype == torch.float32 else 3e-2  # relu-mask flips of y~0 elements are excluded by construction
         assert relerr(dgam, gd.grad) < t and relerr(dbet, bd.grad) < t
@@ -261,15 +261,15 @@ def case_stem_pool(k: K, dtype, NT, H, W, Cc, seed=6):
     Ho, Wo = y.shape[3:]
     yk = k.empty(NT, Ho, Wo, Cc, dtype=dtype)
     am = torch.empty(NT, Ho, Wo, Cc, dtype=torch.uint8, device=k.dev)
-    k.call("dpc_bn_relu_maxpool_fwd", L._p(k.t(x, dtype)), L.dtype_code(dtype), NT, H, W, Cc, L._p(k.t(sc)), L._p(k.t(sh)),
-           L._p(yk), L._p(am))
+    k.call("dpc_bn_relu_maxpool_fwd", k.t(x, dtype), L.dtype_code(dtype), NT, H, W, Cc, k.t(sc), k.t(sh),
+           yk, am)
     k.sync()
     yref = y.detach().squeeze(2).permute(0, 2, 3, 1)
     assert relerr(yk, yref) < tol(dtype)
     gy = q(torch.randn(NT, Ho, Wo, Cc, generator=g), dtype)
     y.backward(gy.permute(0, 3, 1, 2).unsqueeze(2))
     dz = k.empty(NT, H, W, Cc, dtype=dtype)
-    k.call("dpc_maxpool_bwd", L._p(k.t(gy, dtype)), L._p(am), L.dtype_code(dtype), NT, H, W, Cc, L._p(dz))
+    k.call("dpc_maxpool_bwd", k.t(gy, dtype), am, L.dtype_code(dtype), NT, H, W, Cc, dz)
     k.sync()
     dz_ref = a.grad.squeeze(2).permute(0, 2, 3, 1)
     assert relerr(dz, dz_ref) < tol(dtype)
@@ -317,7 +317,7 @@ def case_tpool_split(k: K, dtype, B, N, T, SQ, D, P, seed=7):
     fr = k.empty(N, B * SQ, D, dtype=dtype)
     fi = k.empty(B, P, SQ, D, dtype=dtype)
     xk = k.t(x.detach(), dtype)
-    k.call("dpc_tpool_split_fwd", L._p(xk), L.dtype_code(dtype), B, N, T, SQ, D, P, L._p(fr), L._p(fi))
+    k.call("dpc_tpool_split_fwd", xk, L.dtype_code(dtype), B, N, T, SQ, D, P, fr, fi)
     k.sync()
     assert relerr(fr, fr_ref.detach()) < tol(dtype) and relerr(fi, fi_ref.detach()) < tol(dtype)
     d_relu = torch.randn(N - P, B * SQ, D, generator=g)
@@ -325,7 +325,7 @@ def case_tpool_split(k: K, dtype, B, N, T, SQ, D, P, seed=7):
     loss = (fr_ref[: N - P] * d_relu).sum() + (fi_ref * d_inf).sum()
     gx = torch.autograd.grad(loss, x)[0]
     dx = k.empty(B * N, T, SQ, D, dtype=dtype)
-    k.call("dpc_tpool_split_bwd", L._p(xk), L._p(k.t(d_relu)), L._p(k.t(d_inf)), L.dtype_code(dtype), B, N, T, SQ, D, P, L._p(dx))
+    k.call("dpc_tpool_split_bwd", xk, k.t(d_relu), k.t(d_inf), L.dtype_code(dtype), B, N, T, SQ, D, P, dx)
     k.sync()
     assert relerr(dx, gx) < tol(dtype)
 
@@ -359,29 +359,29 @@ def case_gru_cell(k: K, dtype, M, D, seed=8):
 
     def gemm(A, Bm, Mm, Nn, Kk, out, add=None, ldo=None):
         d = conv_desc(dtype, torch.float32, 0, Mm, (1, 1, 1), (1, 1, 1), Kk, A.stride(0), Nn, Bm.stride(0), ldo or Nn, (1, 1, 1), (1, 1, 1), (0, 0, 0))
-        k.call("dpc_conv_igemm", C.byref(d), L._p(A), L._p(Bm), L._p(out), L._p(add), None)
+        k.call("dpc_conv_igemm", C.byref(d), A, Bm, out, add, None)
 
     px, ph, po = k.empty(M, 3 * D), k.empty(M, 2 * D), k.empty(M, D)
     gemm(xk, Wx, M, 3 * D, D, px)
     gemm(hk, Whur, M, 2 * D, D, ph)
     uk, rk, ok = k.empty(M, D), k.empty(M, D), k.empty(M, D)
     hr = k.empty(M, D, dtype=dtype)
-    k.call("dpc_gru_gates1", L._p(px), L._p(ph), L._p(k.t(b["u"])), L._p(k.t(b["r"])), L._p(hk), dc, M, D, L._p(uk), L._p(rk), L._p(hr))
+    k.call("dpc_gru_gates1", px, ph, k.t(b["u"]), k.t(b["r"]), hk, dc, M, D, uk, rk, hr)
     gemm(hr, Woh, M, D, D, po)
     hout = k.empty(M, D, dtype=dtype)
     dropk = k.t(drop)
-    k.call("dpc_gru_gates2", L._p(px), L._p(po), L._p(k.t(b["o"])), L._p(hk), L._p(uk), L._p(dropk), dc, M, D, L._p(ok), L._p(hout))
+    k.call("dpc_gru_gates2", px, po, k.t(b["o"]), hk, uk, dropk, dc, M, D, ok, hout)
     k.sync()
     t = 1e-4 if dtype == torch.float32 else 2e-2
     assert relerr(hout, hn.detach()) < t
     # backward
     G = k.zeros(M, 3 * D, dtype=dtype)
     dhprev = k.empty(M, D)
-    k.call("dpc_gru_bwd1", L._p(k.t(dh)), L._p(dropk), L._p(uk), L._p(ok), L._p(hk), dc, M, D, L._p(G), L._p(dhprev))
+    k.call("dpc_gru_bwd1", k.t(dh), dropk, uk, ok, hk, dc, M, D, G, dhprev)
     WohT = k.t(W["o"][:, D:].t(), dtype)  # dhr = dpo @ Wo_h : NT GEMM against Wo_h^T [D_in][D_out]
     dhr = k.empty(M, D)
     gemm(G[:, 2 * D:], WohT, M, D, D, dhr)
-    k.call("dpc_gru_bwd2", L._p(dhr), L._p(rk), L._p(hk), dc, M, D, L._p(G), L._p(dhprev))
+    k.call("dpc_gru_bwd2", dhr, rk, hk, dc, M, D, G, dhprev)
     WxT = k.t(torch.cat([W["u"][:, :D], W["r"][:, :D], W["o"][:, :D]], 0).t(), dtype)   # [D][3D]
     WhurT = k.t(torch.cat([W["u"][:, D:], W["r"][:, D:]], 0).t(), dtype)                 # [D][2D]
     dx = k.empty(M, D)
@@ -397,16 +397,16 @@ def case_gru_cell(k: K, dtype, M, D, seed=8):
         ns = C.c_int32(0)
         k.call("dpc_conv_wgrad", C.byref(d), None, None, dy_ld, None, C.byref(ns))
         part = k.zeros(ns.value, Co, Kk)
-        k.call("dpc_conv_wgrad", C.byref(d), L._p(X), L._p(dy), dy_ld, L._p(part), C.byref(ns))
+        k.call("dpc_conv_wgrad", C.byref(d), X, dy, dy_ld, part, C.byref(ns))
         out = k.zeros(Co, Kk)
-        k.call("dpc_reduce_unpack", L._p(part), ns.value, L._p(out), Co, 1, Kk, Kk, 0, 1, 0)
+        k.call("dpc_reduce_unpack", part, ns.value, out, Co, 1, Kk, Kk, 0, 1, 0)
         return out
     dWx = wgrad(G, 3 * D, 3 * D, xk, D)
     dWh = wgrad(G, 3 * D, 2 * D, hk, D)
     dWo = wgrad(G[:, 2 * D:], 3 * D, D, hr, D)
     db = k.empty(3 * D)
     ws = k.empty(64 * 3 * D)
-    k.call("dpc_colsum", L._p(G), dc, 3 * D, M, 3 * D, L._p(db), 0, ws, ws.numel())
+    k.call("dpc_colsum", G, dc, 3 * D, M, 3 * D, db, 0, ws, ws.numel())
     k.sync()
     ref_dWx = torch.cat([Wd["u"].grad[:, :D], Wd["r"].grad[:, :D], Wd["o"].grad[:, :D]], 0)
     ref_dWh = torch.cat([Wd["u"].grad[:, D:], Wd["r"].grad[:, D:]], 0)
@@ -422,7 +422,7 @@ def case_bias_act_rows(k: K, dtype, B, P, SQ, D, seed=9):
     pred = k.zeros(B, P, SQ, D, dtype=dtype)
     y2 = k.empty(M, D, dtype=dtype)
     p = 1 % P
-    k.call("dpc_bias_act", L._p(k.t(x)), L._p(k.t(bias)), M, D, 0, L._p(pred), L.dtype_code(dtype), P, p, SQ, L._p(y2), L.dtype_code(dtype))
+    k.call("dpc_bias_act", k.t(x), k.t(bias), M, D, 0, pred, L.dtype_code(dtype), P, p, SQ, y2, L.dtype_code(dtype))
     k.sync()
     ref = (x + bias).view(B, SQ, D)
     assert relerr(pred[:, p], ref) < tol(dtype) and relerr(y2, F.relu(x + bias)) < tol(dtype)
@@ -431,10 +431,10 @@ def case_bias_act_rows(k: K, dtype, B, P, SQ, D, seed=9):
     src = torch.randn(B, P, SQ, D, generator=g)
     add = torch.randn(M, D, generator=g)
     dst = k.empty(M, D)
-    k.call("dpc_gather_rows", L._p(k.t(src)), B, P, p, SQ, D, L._p(dst), L._p(k.t(add)))
+    k.call("dpc_gather_rows", k.t(src), B, P, p, SQ, D, dst, k.t(add))
     dy = torch.randn(M, D, generator=g)
     out = k.empty(M, D, dtype=dtype)
-    k.call("dpc_relu_bwd", L._p(k.t(dy)), L._p(y2), L.dtype_code(dtype), L._p(k.t(add)), M * D, L._p(out), L.dtype_code(dtype))
+    k.call("dpc_relu_bwd", k.t(dy), y2, L.dtype_code(dtype), k.t(add), M * D, out, L.dtype_code(dtype))
     k.sync()
     assert relerr(dst, src[:, p].reshape(M, D) + add) < 1e-6
     assert relerr(out, dy * (y2.float().cpu() > 0) + add) < tol(dtype)
@@ -444,7 +444,7 @@ def case_bias_act_rows(k: K, dtype, B, P, SQ, D, seed=9):
 def case_mask(k: K, B, P, SQ):
     from oracle import dpc_oracle as O
     m = torch.empty(B, P, SQ, B, P, SQ, dtype=torch.int8, device=k.dev)
-    k.call("dpc_mask_gen", L._p(m), B, P, SQ)
+    k.call("dpc_mask_gen", m, B, P, SQ)
     k.sync()
     assert torch.equal(m.cpu(), O.mask_closed_form(B, P, SQ))  # bit exact
 
@@ -464,7 +464,7 @@ def case_ce_topk(k: K, rows, cols, dtype_d, seed=10):
     ld_d = (cols + 7) // 8 * 8
     ws, res = k.empty(rows, 2), k.empty(4)
     ds = k.empty(rows, ld_d, dtype=dtype_d)
-    k.call("dpc_ce_topk", L._p(k.t(s)), rows, cols, cols, L._p(ws), L._p(res), L._p(ds), L.dtype_code(dtype_d), ld_d)
+    k.call("dpc_ce_topk", k.t(s), rows, cols, cols, ws, res, ds, L.dtype_code(dtype_d), ld_d)
     k.sync()
     r = res.cpu()
     assert abs(r[0].item() - loss.item()) < 1e-5 * max(1.0, abs(loss.item()))
@@ -483,7 +483,7 @@ def case_adam(k: K, n, seed=11):
     v = torch.rand(n, generator=g) * 1e-4
     pk, mk, vk = k.t(p.clone()), k.t(m.clone()), k.t(v.clone())
     step = 3
-    k.call("dpc_adam", L._p(pk), L._p(k.t(gr)), L._p(mk), L._p(vk), n, 1e-3, 0.9, 0.999, 1e-8, 1e-5,
+    k.call("dpc_adam", pk, k.t(gr), mk, vk, n, 1e-3, 0.9, 0.999, 1e-8, 1e-5,
            1 - 0.9 ** step, 1 - 0.999 ** step, 1.0)
     k.sync()
     O.adam_step(p, gr, m, v, step)
@@ -495,6 +495,6 @@ def case_transpose(k: K, rows, cols, seed=12):
     a = torch.randn(rows, cols, generator=g)
     ld = (rows + 7) // 8 * 8
     o = k.zeros(cols, ld, dtype=torch.bfloat16)
-    k.call("dpc_transpose2d", L._p(k.t(a)), 0, cols, L._p(o), 1, ld, rows, cols)
+    k.call("dpc_transpose2d", k.t(a), 0, cols, o, 1, ld, rows, cols)
     k.sync()
     assert torch.equal(o[:, :rows].cpu(), a.t().bfloat16())
