@@ -4,6 +4,7 @@
 // kernels consume their f32 outputs.  Rows are (b, s) positions, M = B*SQ, D channels.
 #include "dpc_rt.h"
 #include "../../include/dpc_hip.h"
+#include "philox.h"
 
 static inline unsigned grid_for(long long n, int block = 256, int cap = 8192) {
     long long g = (n + block - 1) / block;
@@ -278,5 +279,33 @@ extern "C" int dpc_gather_rows(const float* src, int32_t B, int32_t P, int32_t p
     hipStream_t stream = (hipStream_t)stream_;
     if (!src || !dst || B <= 0 || P <= 0 || p < 0 || p >= P || SQ <= 0 || D <= 0) return DPC_ERR_ARG;
     DPC_LAUNCH(gather_rows_kernel, dim3(grid_for((long long)B * SQ * D)), dim3(256), stream, src, B, P, p, SQ, D, dst, add);
+    return dpc_launch_status();
+}
+
+
+// ---------------------------------------------------------------- dropout keep masks (convrnn.py:78), Philox4x32-10
+// mask[i] = 1/(1-p) with probability 1-p, else 0, for i in [0, n) -- the masks of ALL recurrence steps of one optimizer
+// step in one launch.  The optimizer-step counter is read from device memory so a captured hipGraph draws fresh masks on
+// every replay (dpc_step_advance moves it).
+__global__ void dropout_mask_kernel(float* mask, long long n4, long long n, unsigned long long seed, const int32_t* step_dev,
+                                    uint32_t thresh24, float inv_keep) {
+    const uint32_t step = (uint32_t)step_dev[0];
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+        float k[4];
+        dropout_keep4(seed, step, (uint32_t)i, thresh24, inv_keep, k);
+        if (i * 4 + 4 <= n) {
+            ((f32x4*)mask)[i] = f32x4{k[0], k[1], k[2], k[3]};
+        } else {
+            for (long long e = i * 4; e < n; ++e) mask[e] = k[e - i * 4];
+        }
+    }
+}
+
+extern "C" int dpc_dropout_mask(float* mask, int64_t n, float p, uint64_t seed, const int32_t* step_dev, dpc_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!mask || n <= 0 || !step_dev || !(p >= 0.f) || !(p < 1.f) || n >= (1ll << 33)) return DPC_ERR_ARG;
+    const long long n4 = (n + 3) / 4;
+    DPC_LAUNCH(dropout_mask_kernel, dim3(grid_for(n4)), dim3(256), stream, mask, n4, (long long)n, (unsigned long long)seed, step_dev,
+               dropout_thresh24(p), 1.f / (1.f - p));
     return dpc_launch_status();
 }

@@ -158,6 +158,68 @@ __global__ void adam_kernel(float* p, const float* g, float* m, float* v, long l
     }
 }
 
+// ---- graph-capturable optimizer step: the step counter and Adam's bias corrections live in device memory, so a captured
+// hipGraph of the whole train step advances them on every replay (host scalars would be frozen at capture time)
+__global__ void step_advance_kernel(int32_t* step, float* bc, double b1, double b2) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        const int t = step[0] + 1;
+        step[0] = t;
+        bc[0] = (float)(1.0 - pow(b1, (double)t));
+        bc[1] = (float)(1.0 - pow(b2, (double)t));
+    }
+}
+
+extern "C" int dpc_step_advance(int32_t* step_dev, float* bias_corr_dev, double beta1, double beta2, dpc_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!step_dev || !bias_corr_dev) return DPC_ERR_ARG;
+    DPC_LAUNCH(step_advance_kernel, dim3(1), dim3(64), stream, step_dev, bias_corr_dev, beta1, beta2);
+    return dpc_launch_status();
+}
+
+__global__ void adam_dev_kernel(float* p, const float* g, float* m, float* v, long long n4, long long n, float lr, float b1,
+                                float b2, float omb1, float omb2, float eps, float wd, const float* bc, float gscale) {
+    const float step = lr / bc[0];
+    const float isb2 = 1.f / sqrtf(bc[1]);
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+        const long long base = i * 4;
+        if (base + 4 <= n) {
+            f32x4 pv = ((f32x4*)p)[i], gv = ((const f32x4*)g)[i], mv = ((f32x4*)m)[i], vv = ((f32x4*)v)[i];
+            DPC_UNROLL
+            for (int e = 0; e < 4; ++e) {
+                const float gg = gv[e] * gscale + wd * pv[e];
+                mv[e] = b1 * mv[e] + omb1 * gg;
+                vv[e] = b2 * vv[e] + omb2 * gg * gg;
+                pv[e] -= step * mv[e] / (sqrtf(vv[e]) * isb2 + eps);
+            }
+            ((f32x4*)p)[i] = pv; ((f32x4*)m)[i] = mv; ((f32x4*)v)[i] = vv;
+        } else {
+            for (long long k = base; k < n; ++k) {
+                const float gg = g[k] * gscale + wd * p[k];
+                m[k] = b1 * m[k] + omb1 * gg;
+                v[k] = b2 * v[k] + omb2 * gg * gg;
+                p[k] -= step * m[k] / (sqrtf(v[k]) * isb2 + eps);
+            }
+        }
+    }
+}
+
+// betas arrive as doubles: 1 - beta2 is formed in double like torch does (1 - 0.999f would be off by 1.3e-5 relative)
+extern "C" int dpc_adam_dev(float* p, const float* g, float* m, float* v, int64_t n, float lr, double beta1, double beta2,
+                            float eps, float wd, const float* bias_corr_dev, float grad_scale, dpc_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!p || !g || !m || !v || n <= 0 || !bias_corr_dev) return DPC_ERR_ARG;
+    const long long n4 = (n + 3) / 4;
+    DPC_LAUNCH(adam_dev_kernel, dim3(grid_for(n4)), dim3(256), stream, p, g, m, v, n4, (long long)n, lr, (float)beta1, (float)beta2, (float)(1.0 - beta1), (float)(1.0 - beta2), eps, wd, bias_corr_dev, grad_scale);
+    return dpc_launch_status();
+}
+
+extern "C" int dpc_fill_zero(void* ptr, int64_t bytes, dpc_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!ptr || bytes < 0) return DPC_ERR_ARG;
+    if (bytes == 0) return DPC_OK;
+    return hipMemsetAsync(ptr, 0, (size_t)bytes, stream) == hipSuccess ? DPC_OK : DPC_ERR_LAUNCH;
+}
+
 extern "C" int dpc_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
                         float eps, float wd, float bias_corr1, float bias_corr2, float grad_scale, dpc_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;

@@ -252,3 +252,25 @@ extern "C" int dpc_axpy_f32(const float* x, float* y, int64_t n, dpc_stream_t st
     DPC_LAUNCH(axpy_kernel, dim3(grid_for(n)), dim3(256), stream, x, y, (long long)n);
     return dpc_launch_status();
 }
+
+
+// dst[r][c] = src[r][c] for an f32 [rows][cols] window (leading dimensions in elements): scatters the batched ConvGRU
+// weight-gradient GEMM results into the reference's [D][2D] gate parameters (x half | h half)
+__global__ void copy2d_f32_kernel(const float* src, long long src_ld, float* dst, long long dst_ld, int rows, int cols) {
+    const long long n = (long long)rows * cols;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const long long r = i / cols, c = i % cols;
+        dst[r * dst_ld + c] = src[r * src_ld + c];
+    }
+}
+
+extern "C" int dpc_copy2d_f32(const float* src, int64_t src_ld, float* dst, int64_t dst_ld, int32_t rows, int32_t cols,
+                              dpc_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!src || !dst || rows <= 0 || cols <= 0 || src_ld < cols || dst_ld < cols) return DPC_ERR_ARG;
+    const long long n = (long long)rows * cols;
+    long long g = (n + 255) / 256;
+    if (g > 2048) g = 2048;
+    DPC_LAUNCH(copy2d_f32_kernel, dim3((unsigned)g), dim3(256), stream, src, (long long)src_ld, dst, (long long)dst_ld, rows, cols);
+    return dpc_launch_status();
+}

@@ -23,6 +23,7 @@ per optimizer step.
 """
 from __future__ import annotations
 
+import contextlib
 import ctypes as C
 import math
 from typing import Dict, List, Optional, Sequence, Tuple
@@ -78,11 +79,12 @@ def param_shapes(network: str, widths: Sequence[int] = LAYER_WIDTH) -> "Dict[str
 class KernelTimer:
     """HIP-event timing of selected C-ABI entry points on the launch stream (bench.py roofline leg).
     Every timed launch is bracketed by two events recorded on torch's current stream -- the stream the
-    kernel is launched on -- and tagged with its algorithmic FLOPs / bytes."""
+    kernel is launched on -- and tagged with its algorithmic FLOPs / bytes.  Launches made inside
+    ``with eng.tag("score")`` are additionally summed under ``tag:score``."""
 
     def __init__(self, names):
         self.names = set(names)
-        self.records = []  # (name, start_event, end_event, flops, bytes)
+        self.records = []  # (name, tag, start_event, end_event, flops, bytes)
         self.enabled = True
 
     def timed(self, eng, name, args):
@@ -93,23 +95,53 @@ class KernelTimer:
         rc = eng.lib.call(name, *args, eng.lib.stream())
         b.record()
         fl, by = algorithmic_cost(name, args)
-        self.records.append((name, a, b, fl, by))
+        self.records.append((name, eng._tag, a, b, fl, by))
         return rc
 
     def summary(self):
         torch.cuda.synchronize()
         out = {}
-        for name, a, b, fl, by in self.records:
-            d = out.setdefault(name, {"launches": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0})
-            d["launches"] += 1
-            d["ms"] += a.elapsed_time(b)
-            d["flops"] += fl
-            d["bytes"] += by
+        for name, tag, a, b, fl, by in self.records:
+            ms = a.elapsed_time(b)
+            for key in (name,) + ((f"tag:{tag}",) if tag else ()):
+                d = out.setdefault(key, {"launches": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0})
+                d["launches"] += 1
+                d["ms"] += ms
+                d["flops"] += fl
+                d["bytes"] += by
         return out
+
+
+HBM_FAMILY = ("dpc_bn_apply", "dpc_bn_bwd_reduce", "dpc_bn_bwd_apply", "dpc_bn_relu_maxpool_fwd", "dpc_pool_bn_bwd_apply",
+              "dpc_pooled_bn_bwd_reduce", "dpc_pack_input_s2d")
+
+
+def _esz(dc):
+    return 2 if dc == L.BF16 else 4
 
 
 def algorithmic_cost(name, args):
     """algorithmic FLOPs and HBM bytes (operands read once + output written once) of one launch"""
+    if name == "dpc_bn_apply":          # x, y, dtype, rows, C, scale, shift, res, rscale, rshift, relu, mask
+        n = args[3] * args[4] * _esz(args[2])
+        return 0.0, float(n * (2 + (args[7] is not None)) + (n // 16 if args[11] is not None else 0))
+    if name == "dpc_bn_bwd_reduce":     # dy, y, mask, x, dtype, rows, C, ...
+        n = args[5] * args[6] * _esz(args[4])
+        return 0.0, float(2 * n + (n // 16 if args[2] is not None else (n if args[1] is not None else 0)))
+    if name == "dpc_bn_bwd_apply":      # dy, y, mask, x, dtype, rows, C, mean, invstd, gamma, coef, relu, dx, dz
+        n = args[5] * args[6] * _esz(args[4])
+        return 0.0, float(3 * n + (n if args[13] is not None else 0) + (n // 16 if args[2] is not None else (n if args[1] is not None else 0)))
+    if name == "dpc_bn_relu_maxpool_fwd":   # raw, dtype, NT, H, W, C, scale, shift, pooled, arg
+        e, NT, H, W, Cc = _esz(args[1]), args[2], args[3], args[4], args[5]
+        return 0.0, float(NT * H * W * Cc * e + NT * ((H - 1) // 2 + 1) * ((W - 1) // 2 + 1) * Cc * (e + 1))
+    if name == "dpc_pool_bn_bwd_apply":     # dy, arg, x, dtype, NT, H, W, C, ..., dx
+        e, NT, H, W, Cc = _esz(args[3]), args[4], args[5], args[6], args[7]
+        return 0.0, float(2 * NT * H * W * Cc * e + NT * ((H - 1) // 2 + 1) * ((W - 1) // 2 + 1) * Cc * (e + 1))
+    if name == "dpc_pooled_bn_bwd_reduce":  # dy, arg, ypool, dtype, rows, C
+        return 0.0, float(args[4] * args[5] * (2 * _esz(args[3]) + 1))
+    if name == "dpc_pack_input_s2d":        # block, x_s2d, dtype, BN, SL, H, W
+        px = args[3] * args[4] * args[5] * args[6]
+        return 0.0, float(px * 3 * 4 + px * 4 * _esz(args[2]))
     if name not in ("dpc_conv_igemm", "dpc_conv_wgrad"):
         return 0.0, 0.0
     d = args[0]._obj
@@ -296,7 +328,7 @@ class DPCEngine:
     def __init__(self, network: str = "resnet18", sample_size: int = 128, num_seq: int = 8, seq_len: int = 5,
                  pred_step: int = 3, batch: int = 4, device="cuda", compute_dtype=torch.float32,
                  widths: Sequence[int] = LAYER_WIDTH, lib: Optional[L.Lib] = None,
-                 lr: float = 1e-3, wd: float = 1e-5, dropout: float = 0.1):
+                 lr: float = 1e-3, wd: float = 1e-5, dropout: float = 0.1, seed: int = 233):
         self.device = torch.device(device)
         self.lib = L.lib_for(self.device, lib)  # raises unless HIP device (or an explicit simulator handle in tests)
         self.cdtype = compute_dtype
@@ -312,8 +344,11 @@ class DPCEngine:
         self._stats_need = 0
         self._part_need = 0
         self._scratch: Dict[Tuple[int, ...], List[torch.Tensor]] = {}
-        self.step_count = 0
+        self._step_count = 0
+        self.seed = int(seed)  # dropout stream (the reference seeds the device generator with 233, dpc/model_3d.py:18); per rank
+        self.score_mode = "materialised"
         self.timer: Optional["KernelTimer"] = None
+        self._tag: Optional[str] = None
 
         # ---- flat f32 arenas: parameters, gradients, Adam moments
         self.shapes = param_shapes(network, widths)
@@ -376,11 +411,15 @@ class DPCEngine:
         ns = self.n_steps
         self.X_all = self.feat_relu[:ns]              # GRU inputs x_t (agg: feat_relu[t]; predict: relu(p_t) overwrites
                                                       # the slots of the last P blocks, whose ReLU'd features are unused)
-        self.H_all = self.empty((ns + 1, M, D), dt)   # h_0 = 0, h_t after dropout
+        self.H_all = torch.zeros((ns + 1, M, D), dtype=dt, device=self.device)   # h_0 = 0 (never written), h_t after dropout
         self.HR_all = self.empty((ns, M, D), dt)
         self.G_all = self.empty((ns, M, 3 * D), dt)   # [dpu | dpr | dpo] per step
         self.U_all, self.R_all, self.O_all = (self.empty((ns, M, D), f32) for _ in range(3))
         self.drop_all: Optional[torch.Tensor] = None
+        self.drop_buf = self.empty((ns, M, D), f32)   # train-mode keep masks of one step (Philox, dpc_dropout_mask)
+        # optimizer-step counter and Adam bias corrections in device memory: a captured hipGraph advances them on replay
+        self.dev_step = torch.zeros(1, dtype=torch.int32, device=self.device)
+        self.dev_bc = torch.ones(2, dtype=f32, device=self.device)
         self.px = self.empty((ns, M, 3 * D), f32)
         self.ph = self.empty((M, 2 * D), f32)
         self.po = self.empty((M, D), f32)
@@ -459,6 +498,15 @@ class DPCEngine:
             return tm.timed(self, name, args)
         return self.lib.call(name, *args, self.lib.stream())
 
+    @contextlib.contextmanager
+    def tag(self, name: str):
+        """labels the launches made inside the block for KernelTimer (bench.py: score-GEMM roofline)"""
+        prev, self._tag = self._tag, name
+        try:
+            yield
+        finally:
+            self._tag = prev
+
     def scratch(self, shape, exclude):
         """gradient scratch of a given activation shape; at most 3 live per shape by construction"""
         pool = self._scratch.setdefault(tuple(shape), [])
@@ -505,7 +553,7 @@ class DPCEngine:
         return sd
 
     def pack_weights(self):
-        if self.packed_for_step == self.step_count:
+        if self.packed_for_step == self._step_count:
             return
         dc = L.dtype_code(self.cdtype)
         for u in self.units:
@@ -523,7 +571,7 @@ class DPCEngine:
         for src, dst, r, c in ((self.Wx, self.WxT, 3 * D, D), (self.Whur, self.WhurT, 2 * D, D), (self.Woh, self.WohT, D, D),
                                (self.W1, self.W1T, D, D), (self.W2, self.W2T, D, D)):
             self.call("dpc_transpose2d", src, dc, c, dst, dc, r, r, c)
-        self.packed_for_step = self.step_count
+        self.packed_for_step = self._step_count
 
     # ------------------------------------------------------------------ forward
     def forward(self, block: torch.Tensor, train: bool = False, dropout_masks: Optional[torch.Tensor] = None):
@@ -551,14 +599,13 @@ class DPCEngine:
         # dropout masks on the carried hidden state (backbone/convrnn.py:78)
         if dropout_masks is not None:
             self.drop_all = dropout_masks.to(self.device, torch.float32).contiguous()
-        elif train and self.p_drop > 0:
-            keep = 1.0 - self.p_drop
-            self.drop_all = (torch.rand((self.n_steps, M, D), device=self.device) < keep).to(torch.float32) / keep
+        elif train and self.p_drop > 0:  # drawn in one launch, keyed on (seed, optimizer step): graph-replay safe
+            self.call("dpc_dropout_mask", self.drop_buf, self.drop_buf.numel(), float(self.p_drop), self.seed, self.dev_step)
+            self.drop_all = self.drop_buf
         else:
             self.drop_all = None
         # aggregate: x-side gate pre-activations of all n_agg steps in one GEMM
         na = self.n_agg
-        self.H_all[0].zero_()
         self.gemm(self.X_all, self.Wx, self.px, na * M, 3 * D, D)
         step = 0
         for t in range(na):
@@ -577,7 +624,8 @@ class DPCEngine:
                 step += 1
         # score (dpc/model_3d.py:79-84): pred [R][D] x feat_inf [R][D]^T
         R = self.R
-        self.gemm(self.pred, self.feat_inf, self.score, R, R, D)
+        with self.tag("score"):
+            self.gemm(self.pred, self.feat_inf, self.score, R, R, D)
         return self.score.view(B, P, SQ, B, P, SQ)
 
     def _gru_step(self, s: int, px_ready: bool):
@@ -621,17 +669,18 @@ class DPCEngine:
             src = dscore_external.reshape(R, R).to(torch.float32).contiguous()
             if self.ld_d != R:
                 self.dscore.zero_()
-            self.dscore[:, :R].copy_(src)
+            self.dscore[:, :R].copy_(src)  # module-boundary path only (torch hands over an arbitrary d/dscore)
         # score = pred @ finf^T  ->  d_pred = dS @ finf ; d_finf = dS^T @ pred
         self.call("dpc_transpose2d", self.feat_inf, dc, D, self.finfT, dc, self.ld_d, R, D)
         if self.ld_d != R:
             self.finfT[:, R:].zero_()
-        self.gemm(self.dscore, self.finfT, self.d_pred, R, D, self.ld_d, lda=self.ld_d, ldb=self.ld_d)
-        self.gemm_tn(self.dscore, self.ld_d, self.pred, D, self.d_finf, R, R, D)
+        with self.tag("score"):
+            self.gemm(self.dscore, self.finfT, self.d_pred, R, D, self.ld_d, lda=self.ld_d, ldb=self.ld_d)
+            self.gemm_tn(self.dscore, self.ld_d, self.pred, D, self.d_finf, R, R, D)
         # ---- predict loop + aggregation, reversed
         ns, na = self.n_steps, self.n_agg
         dh = self.tmp_f[0]       # grad w.r.t. the current hidden state (f32)
-        dh.zero_()
+        self.call("dpc_fill_zero", dh, dh.numel() * 4)
         dxn = self.tmp_f[1]      # grad w.r.t. x of the GRU step that consumed relu(p_i)
         step = ns
         for i in reversed(range(P)):
@@ -659,10 +708,10 @@ class DPCEngine:
         self.gemm_tn(self.G_all[:, :, 2 * D:], 3 * D, self.HR_all, D, self.dWo, ns * M, D, D)
         self.call("dpc_colsum", self.G_all, dc, 3 * D, ns * M, 3 * D, self.db, 0, self.part, self.part.numel())
         for i, (g, n) in enumerate((("u", "update_gate"), ("r", "reset_gate"), ("o", "out_gate"))):
-            w = Gm[f"agg.ConvGRUCell_00.{n}.weight"].view(D, 2 * D)
-            w[:, :D].copy_(self.dWx[i * D:(i + 1) * D])
-            w[:, D:].copy_(self.dWh[i * D:(i + 1) * D] if g != "o" else self.dWo)
-            Gm[f"agg.ConvGRUCell_00.{n}.bias"].copy_(self.db[i * D:(i + 1) * D])
+            w = Gm[f"agg.ConvGRUCell_00.{n}.weight"].view(D, 2 * D)   # [D][x half | h half]
+            self.call("dpc_copy2d_f32", self.dWx[i * D:(i + 1) * D], D, w, 2 * D, D, D)
+            self.call("dpc_copy2d_f32", self.dWh[i * D:(i + 1) * D] if g != "o" else self.dWo, D, w[:, D:], 2 * D, D, D)
+            self.call("dpc_copy2d_f32", self.db[i * D:(i + 1) * D], D, Gm[f"agg.ConvGRUCell_00.{n}.bias"], D, 1, D)
         self.gemm_tn(self.dP1, D, self.Hpred, D, Gm["network_pred.0.weight"].view(D, D), P * M, D, D)
         self.gemm_tn(self.dP2, D, self.P1_all, D, Gm["network_pred.2.weight"].view(D, D), P * M, D, D)
         self.call("dpc_colsum", self.dP1, dc, D, P * M, D, Gm["network_pred.0.bias"], 0, self.part, self.part.numel())
@@ -703,11 +752,86 @@ class DPCEngine:
         self.gemm(self.G_all[s], self.WhurT, dh, M, D, 2 * D, lda=3 * D, addend=dhprev)
 
     # ------------------------------------------------------------------ optimizer / full step
+    @property
+    def step_count(self) -> int:
+        """completed optimizer steps (host mirror of dev_step)"""
+        return self._step_count
+
+    @step_count.setter
+    def step_count(self, t: int):  # checkpoint resume: host value -> device counter
+        self._step_count = int(t)
+        self.dev_step.fill_(int(t))
+
     def adam_step(self, grad_scale: float = 1.0):
-        self.step_count += 1
-        t = self.step_count
-        self.call("dpc_adam", self.flat_p, self.flat_g, self.flat_m, self.flat_v, self.numel, self.lr, 0.9, 0.999, 1e-8,
-                  self.wd, 1.0 - 0.9 ** t, 1.0 - 0.999 ** t, grad_scale)
+        self._step_count += 1
+        self.call("dpc_step_advance", self.dev_step, self.dev_bc, 0.9, 0.999)
+        self.call("dpc_adam_dev", self.flat_p, self.flat_g, self.flat_m, self.flat_v, self.numel, self.lr, 0.9, 0.999, 1e-8,
+                  self.wd, self.dev_bc, grad_scale)
+
+    def capture_train_step(self, block: torch.Tensor, allreduce=None, warmup: int = 2):
+        """Captures the whole train step on `block` (a static device buffer: refill it in place between replays) into
+        hipGraphs and returns ``replay() -> device f32[4]``.  One graph without data parallelism; with the two-bucket
+        gradient exchange the capture is cut where the backward hands the gradient tail to RCCL, so the replay is
+        graph A (forward, loss, backward down to layer2) -> all-reduce(tail) asynchronously -> graph B (layer1 + stem
+        backward) -> all-reduce(head) + join -> graph C (Adam).  Dropout masks and Adam's bias corrections are keyed on
+        the device-side step counter, so every replay is a new optimizer step."""
+        if self.device.type != "cuda":
+            raise L.DpcError("hipGraph capture needs the HIP device")
+        cur = torch.cuda.current_stream(self.device)
+        side = torch.cuda.Stream(self.device)
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):  # eager warm-up: lazy buffers, RCCL communicator
+            for _ in range(warmup):
+                self.train_step(block, allreduce=allreduce)
+        cur.wait_stream(side)
+        torch.cuda.synchronize(self.device)
+        two_bucket = allreduce is not None and hasattr(allreduce, "start")
+        pool = torch.cuda.graph_pool_handle()
+        graphs: List[torch.cuda.CUDAGraph] = []
+        state = {}
+
+        def begin():
+            state["g"] = torch.cuda.CUDAGraph()
+            state["g"].capture_begin(pool=pool)
+
+        def cut(*_):
+            state["g"].capture_end()
+            graphs.append(state["g"])
+            begin()
+
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            begin()
+            self.packed_for_step = -1
+            self.forward(block, train=True)
+            self.loss_topk(with_grad=True)
+            self.backward(on_tail_ready=cut if two_bucket else None)
+            if allreduce is not None:
+                cut()
+            host_steps = self._step_count
+            self.adam_step()
+            self._step_count = host_steps  # capture executes nothing
+            state["g"].capture_end()
+            graphs.append(state["g"])
+        cur.wait_stream(side)
+        tail, head = self.flat_g[self.grad_split:], self.flat_g[:self.grad_split]
+
+        def replay():
+            graphs[0].replay()
+            if two_bucket:
+                allreduce.start(tail)
+                graphs[1].replay()
+                allreduce.finish(head)
+                graphs[2].replay()
+            elif allreduce is not None:
+                allreduce(self.flat_g)
+                graphs[1].replay()
+            self._step_count += 1
+            self.packed_for_step = -1
+            return self.result
+
+        replay.graphs = graphs
+        return replay
 
     def train_step(self, block: torch.Tensor, dropout_masks: Optional[torch.Tensor] = None, allreduce=None) -> torch.Tensor:
         """forward + CE/top-k + backward (+ gradient all-reduce) + Adam.  Returns device f32[4] = loss, top1, top3, top5."""

@@ -89,7 +89,7 @@ class DPC_RNN(nn.Module):
     """DPC with RNN (dpc/model_3d.py:14)"""
 
     def __init__(self, sample_size, num_seq=8, seq_len=5, pred_step=3, network="resnet50",
-                 compute_dtype=torch.float32, widths=LAYER_WIDTH, seed: int = 0):
+                 compute_dtype=torch.float32, widths=LAYER_WIDTH, seed: int = 0, _simulator: Optional[L.Lib] = None):
         super().__init__()
         if network not in LAYER_PLAN:
             raise IOError("model type is wrong")  # select_backbone.py:19 (resnet50+ are outside this build's scope)
@@ -106,6 +106,7 @@ class DPC_RNN(nn.Module):
         self._param_names: List[str] = []
         self._forced_masks = None
         self._fwd_generation = 0
+        self._simulator = _simulator  # tests only: the host-side SIMT simulator handle (CPU tier); never set by the product
         shapes = param_shapes(network, widths)
         init = _init_reference_style(shapes, torch.Generator().manual_seed(seed))
         for k, shp in shapes.items():
@@ -123,7 +124,7 @@ class DPC_RNN(nn.Module):
         if self._engine is not None and self._engine_key == key and first.data_ptr() == self._engine.PRM[self._param_names[0]].data_ptr():
             return
         eng = DPCEngine(self.network, self.sample_size, self.num_seq, self.seq_len, self.pred_step, B, dev,
-                        self.compute_dtype, self.widths)
+                        self.compute_dtype, self.widths, lib=self._simulator)
         named = {k: v for k, v in self.named_parameters()}
         eng.load_params({k: named[k].detach() for k in self._param_names})
         for k in self._param_names:
@@ -133,7 +134,7 @@ class DPC_RNN(nn.Module):
 
     def forward(self, block):
         # block: [B, N, C, SL, H, W] (dpc/model_3d.py:47-49)
-        if block.device.type != "cuda":
+        if block.device.type != "cuda" and self._simulator is None:
             raise L.DpcError("dpc_amd.DPC_RNN runs on MI355X only: move the module and the input to a cuda (HIP) device")
         self._ensure_engine(block)
         self._engine.packed_for_step = -1  # parameters may have been changed by an external optimizer

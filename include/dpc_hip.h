@@ -193,6 +193,22 @@ int dpc_ce_topk(const float* score, int32_t rows, int32_t cols, int32_t ld, floa
 int dpc_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
              float wd, float bias_corr1, float bias_corr2, float grad_scale, dpc_stream_t stream);
 
+/* graph-capturable optimizer step (the whole train step is replayed as ONE hipGraph, dpc_amd/engine.py): the step
+ * counter t and Adam's bias corrections 1-beta^t live in device memory.  step_advance: t += 1, bc = {1-b1^t, 1-b2^t}.
+ * adam_dev == dpc_adam with the two corrections read from bias_corr_dev[0..1]. */
+int dpc_step_advance(int32_t* step_dev, float* bias_corr_dev, double beta1, double beta2, dpc_stream_t stream);
+int dpc_adam_dev(float* p, const float* g, float* m, float* v, int64_t n, float lr, double beta1, double beta2, float eps,
+                 float wd, const float* bias_corr_dev, float grad_scale, dpc_stream_t stream);
+/* f32 [rows][cols] window copy between two leading dimensions (ConvGRU gate-gradient scatter) */
+int dpc_copy2d_f32(const float* src, int64_t src_ld, float* dst, int64_t dst_ld, int32_t rows, int32_t cols, dpc_stream_t stream);
+/* asynchronous zero fill on the stream (hipMemsetAsync) */
+int dpc_fill_zero(void* ptr, int64_t bytes, dpc_stream_t stream);
+
+/* ---- ConvGRU dropout (nn.Dropout(p=0.1) on the carried hidden state, backbone/convrnn.py:39,59,78) ---------------
+ * mask[i] = 1/(1-p) w.p. 1-p else 0: Philox4x32-10, key = seed, counter = (i/4, step_dev[0], 0, 0), word i%4,
+ * keep iff (word >> 8) >= round(p * 2^24).  One launch draws the masks of all recurrence steps of one train step. */
+int dpc_dropout_mask(float* mask, int64_t n, float p, uint64_t seed, const int32_t* step_dev, dpc_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -498,3 +498,68 @@ def case_transpose(k: K, rows, cols, seed=12):
     k.call("dpc_transpose2d", k.t(a), 0, cols, o, 1, ld, rows, cols)
     k.sync()
     assert torch.equal(o[:, :rows].cpu(), a.t().bfloat16())
+
+
+# ---------------------------------------------------------------- dropout masks (Philox4x32-10) / device-side Adam step
+def philox4x32_10_np(ctr, key):
+    """numpy Philox4x32-10 (Salmon et al., SC'11): ctr [n,4] uint32, key [2] uint32 -> [n,4] uint32.
+    Pinned by the Random123 known-answer vectors in tests/test_kernels_emu.py::test_philox_known_answers."""
+    import numpy as np
+    c = [ctr[:, i].astype(np.uint64) for i in range(4)]
+    k0, k1 = np.uint64(key[0]), np.uint64(key[1])
+    M0, M1, W0, W1, MASK = np.uint64(0xD2511F53), np.uint64(0xCD9E8D57), np.uint64(0x9E3779B9), np.uint64(0xBB67AE85), np.uint64(0xFFFFFFFF)
+    for _ in range(10):
+        p0, p1 = M0 * c[0], M1 * c[2]
+        c = [(p1 >> np.uint64(32)) ^ c[1] ^ k0, p1 & MASK, (p0 >> np.uint64(32)) ^ c[3] ^ k1, p0 & MASK]
+        k0, k1 = (k0 + W0) & MASK, (k1 + W1) & MASK
+    return np.stack(c, 1).astype(np.uint32)
+
+
+def dropout_mask_np(n, p, seed, step):
+    import numpy as np
+    nb = (n + 3) // 4
+    ctr = np.zeros((nb, 4), np.uint32)
+    ctr[:, 0] = np.arange(nb, dtype=np.uint32)
+    ctr[:, 1] = step
+    r = philox4x32_10_np(ctr, (seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF)).reshape(-1)[:n]
+    thresh = int(p * 16777216.0 + 0.5)
+    return ((r >> 8) >= thresh).astype(np.float32) / np.float32(1.0 - p)
+
+
+def case_dropout_mask(k: K, n, p=0.1, seed=233, step=5):
+    import numpy as np
+    st = torch.tensor([step], dtype=torch.int32, device=k.dev)
+    m = k.empty(n)
+    k.call("dpc_dropout_mask", m, n, p, seed, st)
+    k.sync()
+    ref = dropout_mask_np(n, p, seed, step)
+    assert np.array_equal(m.cpu().numpy(), ref)  # bit-exact
+    if n >= 100000:
+        assert abs(float((ref > 0).mean()) - (1 - p)) < 4 * (p * (1 - p) / n) ** 0.5
+        other = dropout_mask_np(n, p, seed, step + 1)
+        assert 0.15 < float((other != ref).mean()) < 0.21  # a new optimizer step draws new masks (2p(1-p) = 0.18)
+
+
+def case_adam_dev(k: K, n, seed=13):
+    from oracle import dpc_oracle as O
+    g = torch.Generator().manual_seed(seed)
+    p = torch.randn(n, generator=g)
+    m = torch.zeros(n)
+    v = torch.zeros(n)
+    pk, mk, vk = k.t(p.clone()), k.t(m.clone()), k.t(v.clone())
+    st = torch.zeros(1, dtype=torch.int32, device=k.dev)
+    bc = k.empty(2)
+    for step in (1, 2, 3):
+        gr = torch.randn(n, generator=g) * 0.01
+        k.call("dpc_step_advance", st, bc, 0.9, 0.999)
+        k.call("dpc_adam_dev", pk, k.t(gr), mk, vk, n, 1e-3, 0.9, 0.999, 1e-8, 1e-5, bc, 1.0)
+        k.sync()
+        O.adam_step(p, gr, m, v, step)
+        assert int(st.item()) == step
+        assert bc.cpu().tolist() == pytest_approx([1 - 0.9 ** step, 1 - 0.999 ** step])
+    assert (pk.cpu() - p).abs().max().item() < 2e-6 and relerr(mk, m) < 1e-5 and relerr(vk, v) < 1e-5
+
+
+def pytest_approx(v):
+    import pytest
+    return pytest.approx(v, rel=1e-6)

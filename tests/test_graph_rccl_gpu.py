@@ -1,0 +1,116 @@
+"""GPU tier: hipGraph replay of the whole train step == the same steps launched kernel by kernel; the gradient
+exchange over RCCL with one rank (the driver's 1-GPU box) and -- when the node has >= 2 devices -- two ranks."""
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+from dpc_amd.engine import DPCEngine
+from oracle import dpc_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _eng(dtype, B=4, seed=233):
+    eng = DPCEngine("resnet18", 64, 8, 5, 3, B, DEV, dtype, seed=seed)
+    eng.load_params(O.init_params_reference_style("resnet18", seed=0))
+    return eng
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_graph_replay_equals_eager(dtype):
+    x = torch.randn(4, 8, 3, 5, 64, 64, device=DEV, generator=torch.Generator(DEV).manual_seed(1))
+    a, b = _eng(dtype), _eng(dtype)
+    for _ in range(5):
+        ra = a.train_step(x).clone()
+    replay = b.capture_train_step(x, warmup=2)  # 2 real warm-up steps, then every replay is one more step
+    assert len(replay.graphs) == 1
+    for _ in range(3):
+        rb = replay().clone()
+    torch.cuda.synchronize()
+    assert a.step_count == b.step_count == 5 and int(b.dev_step.item()) == 5
+    assert torch.equal(a.flat_p, b.flat_p)  # deterministic kernels, same dropout stream (seed, step)
+    assert torch.equal(ra, rb)
+    # dropout masks change from step to step inside the graph (keyed on the device-side counter)
+    m5 = b.drop_buf.clone()
+    replay()
+    assert not torch.equal(m5, b.drop_buf) and abs(b.drop_buf.ne(0).float().mean().item() - 0.9) < 0.01
+    # a refilled input buffer is picked up by the replay
+    x.copy_(torch.randn(x.shape, device=DEV, generator=torch.Generator(DEV).manual_seed(2)))
+    r7 = replay().clone()
+    assert not torch.equal(r7, rb)
+
+
+_RANK_SCRIPT = r"""
+import os, sys, torch
+import torch.distributed as dist
+sys.path.insert(0, {root!r})
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+torch.cuda.set_device(rank)
+dev = torch.device("cuda", rank)
+dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+from dpc_amd.engine import DPCEngine
+from dpc_amd.parallel import make_allreduce, shard_of
+from oracle import dpc_oracle as O
+B = 2
+eng = DPCEngine("resnet18", 64, 8, 5, 3, B, dev, torch.float32, seed=233 + rank)
+eng.load_params(O.make_params_pcg("resnet18"))
+xg = O.make_input_pcg(B * world, 8, 5, 64)
+x = xg[shard_of(B * world, world, rank)].contiguous().to(dev)
+ones = torch.ones(eng.n_steps, eng.M, eng.D, device=dev)
+ar = make_allreduce(dist, world, force=True)
+eng.forward(x, train=True, dropout_masks=ones)
+res = eng.loss_topk(True).clone()
+local_tail = []
+def on_tail(tail):
+    local_tail.append(tail.clone())
+    ar.start(tail)
+eng.backward(on_tail_ready=on_tail)
+local = torch.cat([eng.flat_g[:eng.grad_split].clone(), local_tail[0]])
+ar.finish(eng.flat_g[:eng.grad_split])
+eng.adam_step()
+# then the captured three-graph replay of the same exchange (graph A | all-reduce tail | graph B | all-reduce head | Adam)
+replay = eng.capture_train_step(x, allreduce=ar, warmup=1)
+r2 = replay().clone()
+torch.cuda.synchronize()
+torch.save({{"local": local.cpu(), "avg": None, "params": eng.flat_p.cpu(), "res": res.cpu(), "r2": r2.cpu(),
+            "ngraphs": len(replay.graphs), "steps": eng.step_count}}, os.path.join({out!r}, f"rank{{rank}}.pt"))
+dist.barrier()
+dist.destroy_process_group()
+"""
+
+
+def _run_ranks(world, tmp_path):
+    script = tmp_path / "rank.py"
+    script.write_text(_RANK_SCRIPT.format(root=ROOT, out=str(tmp_path)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
+                        "--master-addr", "127.0.0.1", "--master-port", str(29700 + os.getpid() % 200), str(script)],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-4000:]
+    return [torch.load(tmp_path / f"rank{i}.pt") for i in range(world)]
+
+
+def test_rccl_single_rank_exchange_and_graph_cut(tmp_path):
+    """the RCCL path with world_size 1 (all a 1-GPU box can run): two-bucket exchange + three-graph replay"""
+    (r,) = _run_ranks(1, tmp_path)
+    assert r["ngraphs"] == 3 and r["steps"] == 3 and torch.isfinite(r["r2"]).all()
+    assert r["r2"][0].item() < r["res"][0].item() + 0.5
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two MI355X on the node")
+def test_rccl_two_rank_data_parallel(tmp_path):
+    """as tests/test_parallel_gloo.py, over RCCL/xGMI: identical parameters on both ranks after the averaged step, local
+    gradients differ (per-rank shards, negatives and BN statistics, dpc/main.py:180,211-213)"""
+    r = _run_ranks(2, tmp_path)
+    assert torch.equal(r[0]["params"], r[1]["params"])
+    assert not torch.equal(r[0]["local"], r[1]["local"])
+    p = O.make_params_pcg("resnet18")
+    xg = O.make_input_pcg(4, 8, 5, 64)
+    for i in range(2):
+        loss, accs, grads, _ = O.train_step_reference(p, xg[2 * i:2 * i + 2], "resnet18", 3, None)
+        assert abs(r[i]["res"][0].item() - loss.item()) < 1e-3

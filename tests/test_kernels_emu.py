@@ -138,3 +138,23 @@ def test_adam(k):
 
 def test_transpose(k):
     kc.case_transpose(k, 70, 45)
+
+
+def test_philox_known_answers():
+    """Random123 kat_vectors for philox4x32-10 pin the numpy generator the dropout-mask cases compare against"""
+    import numpy as np
+    kat = [((0, 0, 0, 0), (0, 0), (0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8)),
+           ((0xffffffff,) * 4, (0xffffffff,) * 2, (0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd)),
+           ((0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344), (0xa4093822, 0x299f31d0), (0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1))]
+    for ctr, key, exp in kat:
+        got = kc.philox4x32_10_np(np.array([ctr], np.uint32), key)[0]
+        assert tuple(int(v) for v in got) == exp
+
+
+def test_dropout_mask(k):
+    kc.case_dropout_mask(k, 1027, 0.1, 233, 0)
+    kc.case_dropout_mask(k, 7 * 8 * 32, 0.1, (5 << 32) | 77, 12)
+
+
+def test_adam_dev(k):
+    kc.case_adam_dev(k, 1027)

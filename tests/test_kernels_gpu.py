@@ -129,3 +129,13 @@ def test_adam(k):
 
 def test_transpose(k):
     kc.case_transpose(k, 6468, 256)
+
+
+def test_dropout_mask(k):
+    kc.case_dropout_mask(k, 1027, 0.1, 233, 0)
+    kc.case_dropout_mask(k, 7 * 2048 * 256, 0.1, (5 << 32) | 77, 12)  # cfg2: masks of all 7 recurrence steps
+
+
+def test_adam_dev(k):
+    kc.case_adam_dev(k, 1027)
+    kc.case_adam_dev(k, 14583104)

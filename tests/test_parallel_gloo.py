@@ -77,3 +77,52 @@ def test_two_rank_data_parallel(tmp_path):
             o, n = r[i]["offsets"][k]
             mine = r[i]["local_grad"][o:o + n].view(g.shape)
             assert (mine - g).abs().max().item() < 2e-3 * max(g.abs().max().item(), 1e-6), k
+
+
+# ---------------------------------------------------------------- the drop-in module under DistributedDataParallel
+def _ddp_rank_main(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from dpc_amd import _lib as L
+    from dpc_amd.model import DPC_RNN
+    from dpc_amd.parallel import shard_of
+    from oracle import dpc_oracle as O
+    model = DPC_RNN(sample_size=SIZE, num_seq=8, seq_len=5, pred_step=3, network="resnet18", widths=WIDTHS,
+                    _simulator=L.load_emulator())
+    model.load_state_dict(O.make_params_pcg("resnet18", WIDTHS), strict=True)
+    model.eval()  # dropout off (BN stays batch-stat); the reference's loop lines follow (dpc/main.py:198-231)
+    ddp = torch.nn.parallel.DistributedDataParallel(model)
+    x = O.make_input_pcg(BPER * world, 8, 5, SIZE)[shard_of(BPER * world, world, rank)].contiguous()
+    score_, mask_ = ddp(x)
+    B, NP, SQ, B2, NS, _ = mask_.size()
+    target = (mask_ == 1).view(B * NP * SQ, B2 * NS * SQ).to(int).argmax(dim=1)
+    loss = torch.nn.CrossEntropyLoss()(score_.view(B * NP * SQ, B2 * NS * SQ), target)
+    loss.backward()
+    grads = {k: p.grad.clone() for k, p in model.named_parameters()}
+    torch.save({"grads": grads, "loss": loss.detach()}, os.path.join(out_dir, f"ddp{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_module_under_ddp(tmp_path):
+    """SURVEY section 8b "Callers": DPC_RNN must work under one-process-per-GPU DDP.  DDP averages what the module's
+    autograd node hands back: every rank ends with the mean of the per-shard reference gradients."""
+    subprocess.run(["make", "-s", "-j8", "emu"], cwd=ROOT, check=True)
+    world, port = 2, 29900 + os.getpid() % 300
+    mp.spawn(_ddp_rank_main, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    r = [torch.load(tmp_path / f"ddp{i}.pt") for i in range(world)]
+    from oracle import dpc_oracle as O
+    p = O.make_params_pcg("resnet18", WIDTHS)
+    xg = O.make_input_pcg(BPER * world, 8, 5, SIZE)
+    ref = []
+    for i in range(world):
+        loss, accs, grads, _ = O.train_step_reference(p, xg[i * BPER:(i + 1) * BPER], "resnet18", 3, None)
+        assert abs(r[i]["loss"].item() - loss.item()) < 1e-4
+        ref.append(grads)
+    for k in ref[0]:
+        mean = 0.5 * (ref[0][k] + ref[1][k])
+        assert torch.equal(r[0]["grads"][k], r[1]["grads"][k]), k
+        assert (r[0]["grads"][k] - mean).abs().max().item() < 2e-3 * max(mean.abs().max().item(), 1e-6), k
