@@ -139,8 +139,16 @@ def main():
     g = torch.Generator(dev).manual_seed(1234 + rank)
     block = torch.randn(batch, 8, 3, 5, img, img, device=dev, generator=g)
     allreduce = make_allreduce(dist, world, force=dist is not None)
-    use_graph = not args.no_graph and hasattr(eng, "capture_train_step")
-    step_fn = eng.capture_train_step(block, allreduce=allreduce) if use_graph else (lambda: eng.train_step(block, allreduce=allreduce))
+    use_graph, graph_note = not args.no_graph, ""
+    step_fn = None
+    if use_graph:
+        try:
+            step_fn = eng.capture_train_step(block, allreduce=allreduce)
+        except Exception as e:  # report it, never hide it: the line says which launch mode was timed
+            use_graph, graph_note = False, f" (hipGraph capture failed: {type(e).__name__}: {str(e)[:120]})"
+            torch.cuda.synchronize()
+    if step_fn is None:
+        step_fn = lambda: eng.train_step(block, allreduce=allreduce)  # noqa: E731
 
     def sync():
         if dist is not None:
@@ -182,7 +190,7 @@ def main():
             "config": {"workload": f"{args.config}: {net} 2d3d, img_dim {img}, seq_len 5, num_seq 8, pred_step {P}, "
                                    f"batch {batch}/GPU, full train step (fwd+CE/top-k+bwd+all-reduce+Adam)",
                        "global_batch": batch * world, "parallelism": f"dp{world}", "init": "reference init, random",
-                       "launch": "hipGraph replay" if use_graph else "kernel by kernel"},
+                       "launch": "hipGraph replay" if use_graph else "kernel by kernel" + graph_note},
             "final_loss": round(loss[0], 4),
         }
         if timer is not None:
