@@ -92,7 +92,8 @@ def _worker(rank: int, world: int, args, port: int):
         raise ValueError('batch_size must be divisible by the number of GPUs (drop_last semantics, dpc/main.py:313)')
     per_gpu = args.batch_size // world
     cdt = torch.bfloat16 if args.dtype == 'bf16' else torch.float32
-    eng = DPCEngine(args.net, args.img_dim, args.num_seq, args.seq_len, args.pred_step, per_gpu, dev, cdt, lr=args.lr, wd=args.wd)
+    eng = DPCEngine(args.net, args.img_dim, args.num_seq, args.seq_len, args.pred_step, per_gpu, dev, cdt, lr=args.lr, wd=args.wd,
+                    seed=233 + rank)  # dropout stream: the reference seeds 233 (dpc/model_3d.py:18); independent per replica
     init = DPC_RNN(args.img_dim, args.num_seq, args.seq_len, args.pred_step, args.net, seed=0)  # same on every rank
     eng.load_params({k: v.detach() for k, v in init.named_parameters()})
     best_acc, iteration = 0.0, 0
