@@ -146,11 +146,14 @@ def test_bf16_mode_tracks_fp32(golden_dir):
     assert torch.isfinite(eng.flat_g).all()
 
 
-# Tolerances of the bf16 anchor, from the errors measured on MI355X (printed by the test; round-2 run:
-# see profiles/r02_bf16_anchor.txt): bf16 keeps 8 mantissa bits, every activation is rounded once per layer.
-ANCHOR_SCORE_L2 = 0.02     # rel-L2 of the strided score subsample
-ANCHOR_GRADNORM = 0.05     # per-parameter gradient norm
-ANCHOR_GRAD_L2 = 0.10      # per-parameter rel-L2 of the strided gradient subsample (worst parameter)
+# Tolerances of the bf16 anchor are MULTIPLES OF THE MEASURED bf16 NOISE, not guesses: the fixture holds, next to the
+# fp32 outputs of the reference, the deviation the reference ITSELF shows when every module output (and the gradient
+# flowing back through it) is rounded to bf16 by hooks (make_golden.golden_anchor16: score rel-L2 4.4 %, gradient rel-L2
+# 5 % at the head ... 37-42 % in layer1 -- bf16 noise is decorrelated by the ReLU masks of 17 layers -- gradient norms
+# <= 8 %).  A correct bf16 implementation lands at that level (round-2 run on MI355X: score 4.8 %, head 6 %, layer1
+# 31-46 %); a wrong kernel is O(1) on the score and > 100 % on gradients.
+ANCHOR_NOISE_FACTOR = 2.0  # the hooks round at module boundaries; the engine also rounds pooled features, predictions and d/dscore
+ANCHOR_GRADNORM = 0.15
 
 
 def test_bf16_anchored_to_reference(golden_dir):
@@ -178,19 +181,17 @@ def test_bf16_anchored_to_reference(golden_dir):
         st = int(g["grad_substride::" + n])
         rs = torch.from_numpy(g["grad_sub::" + n])
         rows.append((n, abs(gr.norm().item() / max(float(g["grad_norm"][i]), 1e-12) - 1.0),
-                     ((gr[::st] - rs).norm() / rs.norm().clamp_min(1e-12)).item()))
-    worst_n = max(rows, key=lambda r: r[1])
-    worst_l = max(rows, key=lambda r: r[2])
-    print(f"bf16 anchor: score rel-L2 {e_score:.4f}; loss {res[0].item():.4f} vs {e[0]:.4f}; "
-          f"top-k {res[1:].tolist()} vs {list(e[1:])}; worst grad-norm err {worst_n[1]:.4f} ({worst_n[0]}); "
-          f"worst grad rel-L2 {worst_l[2]:.4f} ({worst_l[0]})")
+                     ((gr[::st] - rs).norm() / rs.norm().clamp_min(1e-12)).item(), float(g["noise_grad_l2"][i])))
+    print(f"bf16 anchor: score rel-L2 {e_score:.4f} (bf16 noise of the reference {float(g['noise_score_l2']):.4f}); "
+          f"loss {res[0].item():.4f} vs {e[0]:.4f}; top-k {res[1:].tolist()} vs {list(e[1:])}")
     for r in rows:
-        print(f"  {r[0]:48s} norm err {r[1]:.4f}  rel-L2 {r[2]:.4f}")
-    assert e_score < ANCHOR_SCORE_L2
-    assert abs(res[0].item() - e[0]) < 2e-2
+        print(f"  {r[0]:48s} norm err {r[1]:.4f}  rel-L2 {r[2]:.4f}  (noise {r[3]:.4f})")
+    assert e_score < ANCHOR_NOISE_FACTOR * float(g["noise_score_l2"])
+    assert abs(res[0].item() - e[0]) < max(0.1, 10 * float(g["noise_loss"]))
     assert res[1:].tolist() == pytest.approx(list(e[1:]), abs=8.0 / eng.R)  # a handful of near-tie rows may reorder
-    assert worst_n[1] < ANCHOR_GRADNORM, worst_n
-    assert worst_l[2] < ANCHOR_GRAD_L2, worst_l
+    for n, e_norm, e_l2, noise in rows:
+        assert e_norm < ANCHOR_GRADNORM, (n, e_norm)
+        assert e_l2 < ANCHOR_NOISE_FACTOR * noise + 0.02, (n, e_l2, noise)
 
 
 def test_cfg5_full_shape_properties():
