@@ -36,6 +36,15 @@ class ConvDesc(C.Structure):
         "Co", "ldw", "ldo", "KT", "KH", "KW", "st", "sh", "sw", "pt", "ph", "pw")]
 
 
+class GruChainDesc(C.Structure):
+    """struct dpc_gru_chain_desc (include/dpc_hip.h)"""
+    _fields_ = ([(n, C.c_int32) for n in ("dtype", "M", "D", "SQ", "P", "n_agg", "n_steps", "reserved")] +
+                [("p_drop", C.c_float), ("reserved2", C.c_uint32), ("seed", C.c_uint64)] +
+                [(n, C.c_void_p) for n in ("step_dev", "drop_masks", "packed", "bias_u", "bias_r", "bias_o", "bias_1", "bias_2",
+                                           "X_all", "H_all", "HR_all", "U_all", "R_all", "O_all", "P1_all", "pred",
+                                           "d_pred", "G_all", "dP1", "dP2", "d_x", "ws")])
+
+
 class DpcError(RuntimeError):
     pass
 
@@ -61,26 +70,19 @@ _SIGS = {
     "dpc_maxpool_bwd": [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp],
     "dpc_tpool_split_fwd": [_vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp],
     "dpc_tpool_split_bwd": [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp],
-    "dpc_gru_gates1": [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp],
-    "dpc_gru_gates2": [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp],
-    "dpc_gru_bwd1": [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp],
-    "dpc_gru_bwd2": [_vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp],
-    "dpc_bias_act": [_vp, _vp, _i32, _i32, _i32, _vp, _i32, _i32, _i32, _i32, _vp, _i32, _vp],
-    "dpc_relu_bwd": [_vp, _vp, _i32, _vp, _i64, _vp, _i32, _vp],
     "dpc_colsum": [_vp, _i32, _i32, _i32, _i32, _vp, _i32, _vp, _i64, _vp],
     "dpc_pool_bn_bwd_reduce": [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, C.POINTER(_i32), _vp],
     "dpc_pooled_bn_bwd_reduce": [_vp, _vp, _vp, _i32, _i64, _i32, _vp, _vp, _vp, C.POINTER(_i32), _vp],
     "dpc_pool_bn_bwd_apply": [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp],
-    "dpc_gather_rows": [_vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp],
-    "dpc_convert": [_vp, _i32, _vp, _i32, _i64, _vp],
-    "dpc_axpy_f32": [_vp, _vp, _i64, _vp],
     "dpc_mask_gen": [_vp, _i32, _i32, _i32, _vp],
     "dpc_ce_topk": [_vp, _i32, _i32, _i32, _vp, _vp, _vp, _i32, _i32, _vp],
     "dpc_step_advance": [_vp, _vp, _f64, _f64, _vp],
     "dpc_adam_dev": [_vp, _vp, _vp, _vp, _i64, _f32, _f64, _f64, _f32, _f32, _vp, _f32, _vp],
     "dpc_copy2d_f32": [_vp, _i64, _vp, _i64, _i32, _i32, _vp],
-    "dpc_fill_zero": [_vp, _i64, _vp],
     "dpc_dropout_mask": [_vp, _i64, _f32, C.c_uint64, _vp, _vp],
+    "dpc_gru_pack": [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp],
+    "dpc_gru_chain_fwd": [C.POINTER(GruChainDesc), _vp],
+    "dpc_gru_chain_bwd": [C.POINTER(GruChainDesc), _vp],
     "dpc_adam": [_vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _f32, _f32, _f32, _f32, _vp],
 }
 

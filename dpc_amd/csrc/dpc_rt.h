@@ -12,12 +12,18 @@
 #include "simt_emu.h"
 #define DPC_LAUNCH(kernel, grid, block, stream, ...) \
     simt::launch((grid), (block), [=]() { (kernel)(__VA_ARGS__); })
+#define DPC_LAUNCH_DYN(kernel, grid, block, lds, stream, ...) \
+    simt::launch_dyn((grid), (block), (lds), [=]() { (kernel)(__VA_ARGS__); })
+#define DPC_DYN_SMEM(name) unsigned char* name = simt::dyn_smem
 #define DPC_UNROLL
 #define DPC_NOUNROLL
 #else
 #include <hip/hip_runtime.h>
 #define DPC_LAUNCH(kernel, grid, block, stream, ...) \
     hipLaunchKernelGGL(kernel, (grid), (block), 0, (stream), __VA_ARGS__)
+#define DPC_LAUNCH_DYN(kernel, grid, block, lds, stream, ...) \
+    hipLaunchKernelGGL(kernel, (grid), (block), (lds), (stream), __VA_ARGS__)
+#define DPC_DYN_SMEM(name) extern __shared__ __attribute__((aligned(16))) unsigned char name[]
 #define DPC_UNROLL _Pragma("unroll")
 #define DPC_NOUNROLL _Pragma("unroll 1")
 #endif

@@ -97,6 +97,7 @@ struct ChainP {
     void* G_all;          // [n_steps][M][3D]  pre-activation gradients [u | r | o]
     void *dP1, *dP2;      // [P][M][D]
     float* d_x;           // [n_agg][M][D] f32: gradient w.r.t. the aggregation inputs
+    float* ws;            // [2][M][D] f32 scratch: dh, dx of a prediction-feeding step
 };
 
 constexpr int TM = 32;          // rows per workgroup
@@ -138,40 +139,53 @@ template <class T> __device__ __forceinline__ void zero_tile(unsigned char* tile
 // acc[b][t] += A(tile rows, K = ks_n unit steps starting at the tile's unit 0) x B_b(tile t of the wave)^T
 // Bp[b][t]: fragment base of packed matrix b, tile t, ALREADY advanced to the first K step of this call.
 // The B fragments are fetched four K steps ahead of their MFMAs (register ring with compile-time slots).
-template <class T, int NB>
-__device__ __forceinline__ void gemm_acc(f32x16 (&acc)[NB][2], int ntw, const unsigned char* tile, int ks_n, const u32x4* const (&Bp)[NB][2],
-                                         int lane) {
+// NT = number of 32-column tiles this wave owns (compile time: branches around MFMAs cost registers).
+template <class T, int NB, int NT>
+__device__ __forceinline__ void gemm_acc(f32x16 (&acc)[NB][2], const unsigned char* tile, int ks_n, const u32x4* const (&Bp)[NB][2], int lane) {
+    if constexpr (NT == 0) return;
     const int row = lane & 31, kg = lane >> 5;
-    u32x4 ring[4][NB][2];
-    DPC_UNROLL
-    for (int j = 0; j < 4; ++j)
-        if (j < ks_n) {
+    constexpr int NTT = NT > 0 ? NT : 1;
+    auto a_frag = [&](int ks) -> u32x4 {
+        const int unit = ks * 2 + kg;
+        return *(const u32x4*)(tile + (unit >> 3) * CHUNK + lds_unit_off(row, unit & 7));
+    };
+    if ((ks_n & 3) == 0 && ks_n >= 4) {
+        // software pipeline without a single conditional MFMA (a branch around an MFMA doubles its accumulator registers)
+        u32x4 ring[4][NB][NTT];
+        DPC_UNROLL
+        for (int j = 0; j < 4; ++j)
             DPC_UNROLL
-            for (int b = 0; b < NB; ++b) {
-                if (ntw > 0) ring[j][b][0] = Bp[b][0][j * 64 + lane];
-                if (ntw > 1) ring[j][b][1] = Bp[b][1][j * 64 + lane];
+            for (int b = 0; b < NB; ++b)
+                DPC_UNROLL
+                for (int t = 0; t < NT; ++t) ring[j][b][t] = Bp[b][t][j * 64 + lane];
+        for (int ks0 = 0; ks0 < ks_n - 4; ks0 += 4) {
+            DPC_UNROLL
+            for (int j = 0; j < 4; ++j) {
+                const u32x4 a = a_frag(ks0 + j);
+                DPC_UNROLL
+                for (int b = 0; b < NB; ++b)
+                    DPC_UNROLL
+                    for (int t = 0; t < NT; ++t) {
+                        acc[b][t] = mfma_unit<T>(a, ring[j][b][t], acc[b][t]);
+                        ring[j][b][t] = Bp[b][t][(ks0 + j + 4) * 64 + lane];
+                    }
             }
         }
-    for (int ks0 = 0; ks0 < ks_n; ks0 += 4) {
         DPC_UNROLL
         for (int j = 0; j < 4; ++j) {
-            const int ks = ks0 + j;
-            if (ks < ks_n) {
-                const int unit = ks * 2 + kg;
-                const u32x4 a = *(const u32x4*)(tile + (unit >> 3) * CHUNK + lds_unit_off(row, unit & 7));
+            const u32x4 a = a_frag(ks_n - 4 + j);
+            DPC_UNROLL
+            for (int b = 0; b < NB; ++b)
                 DPC_UNROLL
-                for (int b = 0; b < NB; ++b) {
-                    if (ntw > 0) acc[b][0] = mfma_unit<T>(a, ring[j][b][0], acc[b][0]);
-                    if (ntw > 1) acc[b][1] = mfma_unit<T>(a, ring[j][b][1], acc[b][1]);
-                }
-                if (ks + 4 < ks_n) {
-                    DPC_UNROLL
-                    for (int b = 0; b < NB; ++b) {
-                        if (ntw > 0) ring[j][b][0] = Bp[b][0][(ks + 4) * 64 + lane];
-                        if (ntw > 1) ring[j][b][1] = Bp[b][1][(ks + 4) * 64 + lane];
-                    }
-                }
-            }
+                for (int t = 0; t < NT; ++t) acc[b][t] = mfma_unit<T>(a, ring[j][b][t], acc[b][t]);
+        }
+    } else {  // narrow test networks (D = 32 in bf16: two K steps)
+        for (int ks = 0; ks < ks_n; ++ks) {
+            const u32x4 a = a_frag(ks);
+            DPC_UNROLL
+            for (int b = 0; b < NB; ++b)
+                DPC_UNROLL
+                for (int t = 0; t < NT; ++t) acc[b][t] = mfma_unit<T>(a, Bp[b][t][ks * 64 + lane], acc[b][t]);
         }
     }
 }
@@ -188,47 +202,84 @@ template <int NB> __device__ __forceinline__ void zero_acc(f32x16 (&acc)[NB][2])
 // fragment base (in 16-byte units) of packed matrix `mat`, the wave's t-th tile, K step `ks_begin`; KS = K steps of the matrix
 template <class T>
 __device__ __forceinline__ const u32x4* frag(const ChainP& p, int mat, int tile, int KS, int ks_begin) {
-    constexpr int E = Elt<T>::PER16;
     return (const u32x4*)((const T*)p.packed + mat_off(mat, p.D)) + ((long long)tile * KS + ks_begin) * 64;
-    (void)E;
 }
 
-// keep-mask bytes of step s for the workgroup's rows -> LDS (Philox mode); element (row, col) at [row * D + col]
-__device__ __forceinline__ void gen_mask_tile(uint8_t* mt, const ChainP& p, int s, int m0) {
-    const uint32_t step = (uint32_t)p.step_dev[0];
-    const int D4 = p.D / 4;
-    for (int q = threadIdx.x; q < TM * D4; q += blockDim.x) {
-        const int row = q / D4, c4 = q - row * D4;
-        float k[4] = {0.f, 0.f, 0.f, 0.f};
-        if (m0 + row < p.M) {
-            const long long idx = ((long long)s * p.M + (m0 + row)) * p.D + c4 * 4;  // element index in [n_steps][M][D], multiple of 4
-            dropout_keep4(p.seed, step, (uint32_t)(idx >> 2), p.thresh24, 1.f, k);
-        }
+// ---- accumulators (MFMA C layout: lane = column, 16 rows) <-> row-major f32 staging tile in LDS.
+// Everything element-wise (gates, dropout, ReLU masks, the global loads / stores of the saved tensors) runs on the
+// row-major side: a thread owns 4 consecutive columns of a row (one 16-byte access, one Philox block), the loops stay
+// rolled-up small and no 64-bit per-element address lives in a register next to the accumulators.
+constexpr int SPAD = 8;  // floats of row padding: rows 4 apart (the two half-waves of a C-layout store) land 32 banks apart
+template <int NT>
+__device__ __forceinline__ void stage_put(float* stage, int D, const f32x16 (&acc)[2], int wave, int lane) {
+    const int ld = D + SPAD;
+    DPC_UNROLL
+    for (int t = 0; t < NT; ++t) {
+        float* base = stage + (4 * (lane >> 5)) * ld + (wave + 4 * t) * 32 + (lane & 31);
         DPC_UNROLL
-        for (int e = 0; e < 4; ++e) mt[row * p.D + c4 * 4 + e] = k[e] != 0.f ? 1 : 0;
+        for (int r = 0; r < 16; ++r) base[((r & 3) + 8 * (r >> 2)) * ld] = acc[t][r];
     }
 }
-__device__ __forceinline__ float mask_at(const ChainP& p, const uint8_t* mt, int s, int grow, int row, int col) {
-    if (p.drop) return p.drop[((long long)s * p.M + grow) * p.D + col];
-    if (p.step_dev) return mt[row * p.D + col] ? p.inv_keep : 0.f;
-    return 1.f;
+// row-major iteration over the thread's 4-column groups (rolled: the state a thread carries from one pass to the next --
+// u, dh, dx -- lives in memory the same thread wrote, never in per-iteration registers next to the accumulators)
+#define RM_FOR(D_)                                                                      \
+    DPC_NOUNROLL                                                                        \
+    for (int q_ = (int)threadIdx.x; q_ < TM * ((D_) / 4); q_ += 256)                    \
+        if (const int row = q_ / ((D_) / 4), col = (q_ % ((D_) / 4)) * 4; true)
+
+__device__ __forceinline__ f32x4 ld4(const float* p) { return *(const f32x4*)p; }
+__device__ __forceinline__ void st4(float* p, const f32x4& v) { *(f32x4*)p = v; }
+template <class T> __device__ __forceinline__ f32x4 ldT4(const T* p);
+template <> __device__ __forceinline__ f32x4 ldT4<float>(const float* p) { return *(const f32x4*)p; }
+template <> __device__ __forceinline__ f32x4 ldT4<bf16_t>(const bf16_t* p) {
+    const u32x2 w = *(const u32x2*)p;
+    f32x4 v = {bf16_to_f32((bf16_t)(w[0] & 0xffffu)), bf16_to_f32((bf16_t)(w[0] >> 16)), bf16_to_f32((bf16_t)(w[1] & 0xffffu)),
+               bf16_to_f32((bf16_t)(w[1] >> 16))};
+    return v;
+}
+template <class T> __device__ __forceinline__ void stT4(T* p, const f32x4& v);
+template <> __device__ __forceinline__ void stT4<float>(float* p, const f32x4& v) { *(f32x4*)p = v; }
+template <> __device__ __forceinline__ void stT4<bf16_t>(bf16_t* p, const f32x4& v) {
+    u32x2 w = {bf16x2_pack(v[0], v[1]), bf16x2_pack(v[2], v[3])};
+    *(u32x2*)p = w;
+}
+// round a value the way it is stored (so that what the next GEMM reads and what the math keeps agree)
+template <class T> __device__ __forceinline__ f32x4 roundT4(const f32x4& v);
+template <> __device__ __forceinline__ f32x4 roundT4<float>(const f32x4& v) { return v; }
+template <> __device__ __forceinline__ f32x4 roundT4<bf16_t>(const f32x4& v) {
+    f32x4 o;
+    DPC_UNROLL
+    for (int e = 0; e < 4; ++e) o[e] = bf16_to_f32(f32_to_bf16(v[e]));
+    return o;
+}
+template <class T> __device__ __forceinline__ T* tile_ptr(unsigned char* tile, int row, int col) { return (T*)(tile + TileIO<T>::elem_addr(row, col)); }
+
+// pre-scaled keep mask of elements (s, grow, col..col+3)
+__device__ __forceinline__ f32x4 mask4(const ChainP& p, int s, int grow, int col) {
+    const long long idx = ((long long)s * p.M + grow) * p.D + col;
+    if (p.drop) return ld4(p.drop + idx);
+    f32x4 k = {1.f, 1.f, 1.f, 1.f};
+    if (p.step_dev) {
+        float kk[4];
+        dropout_keep4(p.seed, (uint32_t)p.step_dev[0], (uint32_t)(idx >> 2), p.thresh24, p.inv_keep, kk);
+        k = f32x4{kk[0], kk[1], kk[2], kk[3]};
+    }
+    return k;
 }
 
 // ---------------------------------------------------------------- forward chain
-template <class T>
-__global__ __launch_bounds__(256) void gru_chain_fwd_kernel(ChainP p) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+template <class T, int NT>
+__device__ __forceinline__ void gru_chain_fwd_body(const ChainP& p, unsigned char* smem) {
     constexpr int E = Elt<T>::PER16;
     const int D = p.D, M = p.M;
     const int tile_bytes = (D * (16 / E) + 127) / 128 * CHUNK;
     unsigned char* tx = smem;
     unsigned char* th = smem + tile_bytes;
     unsigned char* thr = smem + 2 * tile_bytes;
-    uint8_t* mt = smem + 3 * tile_bytes;
+    float* stage = (float*)(smem + 3 * tile_bytes);
+    const int ld = D + SPAD;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int m0 = blockIdx.x * TM;
-    const int ntiles = D / 32;
-    const int ntw = wave < ntiles ? (wave + 4 < ntiles ? 2 : 1) : 0;
     const int KSD = D / (2 * E);  // K steps over D input channels
     const long long MD = (long long)M * D;
     T* X_all = (T*)p.X_all;
@@ -240,71 +291,80 @@ __global__ __launch_bounds__(256) void gru_chain_fwd_kernel(ChainP p) {
     load_tile<T>(th, H_all, m0, M, D);  // h_0
     for (int s = 0; s < p.n_steps; ++s) {
         if (s < p.n_agg) load_tile<T>(tx, X_all + (long long)s * MD, m0, M, D);
-        if (!p.drop && p.step_dev) gen_mask_tile(mt, p, s, m0);
         __syncthreads();
         // ---- [u | r] = [x | h] @ [Wu ; Wr]^T, o_x = x @ Wo_x^T
-        f32x16 aur[2][2], ao[1][2];
-        zero_acc<2>(aur);
-        zero_acc<1>(ao);
+        f32x16 a3[3][2];
+        zero_acc<3>(a3);
         {
             const u32x4* const Bx[3][2] = {{frag<T>(p, M_WU, wave, 2 * KSD, 0), frag<T>(p, M_WU, wave + 4, 2 * KSD, 0)},
                                            {frag<T>(p, M_WR, wave, 2 * KSD, 0), frag<T>(p, M_WR, wave + 4, 2 * KSD, 0)},
                                            {frag<T>(p, M_WOX, wave, KSD, 0), frag<T>(p, M_WOX, wave + 4, KSD, 0)}};
-            f32x16 a3[3][2];
-            zero_acc<3>(a3);
-            gemm_acc<T, 3>(a3, ntw, tx, KSD, Bx, lane);
-            DPC_UNROLL
-            for (int t = 0; t < 2; ++t) { aur[0][t] = a3[0][t]; aur[1][t] = a3[1][t]; ao[0][t] = a3[2][t]; }
+            gemm_acc<T, 3, NT>(a3, tx, KSD, Bx, lane);
+        }
+        f32x16 aur[2][2];
+        DPC_UNROLL
+        for (int t = 0; t < 2; ++t) { aur[0][t] = a3[0][t]; aur[1][t] = a3[1][t]; }
+        {
             const u32x4* const Bh[2][2] = {{frag<T>(p, M_WU, wave, 2 * KSD, KSD), frag<T>(p, M_WU, wave + 4, 2 * KSD, KSD)},
                                            {frag<T>(p, M_WR, wave, 2 * KSD, KSD), frag<T>(p, M_WR, wave + 4, 2 * KSD, KSD)}};
-            gemm_acc<T, 2>(aur, ntw, th, KSD, Bh, lane);
+            gemm_acc<T, 2, NT>(aur, th, KSD, Bh, lane);
         }
-        // ---- gates 1: u, r, h*r
-        float uu[2][16];
-        for (int t = 0; t < ntw; ++t) {
-            const int col = (wave + 4 * t) * 32 + (lane & 31);
-            const float bu = p.bu[col], br = p.br[col];
+        // ---- r = sigmoid(.), h*r (the operand of the next product)
+        stage_put<NT>(stage, D, aur[1], wave, lane);
+        __syncthreads();
+        RM_FOR(D) {
+            const int grow = m0 + row;
+            const f32x4 pre = ld4(stage + row * ld + col), b = ld4(p.br + col);
+            const f32x4 h = ldT4<T>(tile_ptr<T>(th, row, col));
+            f32x4 rr, hr;
             DPC_UNROLL
-            for (int r = 0; r < 16; ++r) {
-                const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                const float u = sigm(aur[0][t][r] + bu), rr = sigm(aur[1][t][r] + br);
-                const float h = TileIO<T>::get(th, row, col);
-                const T hr = Elt<T>::from_f32(h * rr);
-                uu[t][r] = u;
-                *(T*)(thr + TileIO<T>::elem_addr(row, col)) = hr;
-                if (m0 + row < M) {
-                    const long long o = (long long)s * MD + (long long)(m0 + row) * D + col;
-                    p.U_all[o] = u;
-                    p.R_all[o] = rr;
-                    HR_all[o] = hr;
-                }
+            for (int e = 0; e < 4; ++e) { rr[e] = sigm(pre[e] + b[e]); hr[e] = h[e] * rr[e]; }
+            stT4<T>(tile_ptr<T>(thr, row, col), hr);
+            if (grow < M) {
+                const long long o = (long long)s * MD + (long long)grow * D + col;
+                st4(p.R_all + o, rr);
+                stT4<T>(HR_all + o, hr);
             }
         }
         __syncthreads();
+        // ---- u = sigmoid(.) (kept in registers for the state update)
+        stage_put<NT>(stage, D, aur[0], wave, lane);
+        __syncthreads();
+        RM_FOR(D) {
+            const f32x4 pre = ld4(stage + row * ld + col), b = ld4(p.bu + col);
+            f32x4 u;
+            DPC_UNROLL
+            for (int e = 0; e < 4; ++e) u[e] = sigm(pre[e] + b[e]);
+            if (m0 + row < M) st4(p.U_all + (long long)s * MD + (long long)(m0 + row) * D + col, u);  // re-read by this thread below
+        }
         // ---- o = tanh(o_x + (h*r) @ Wo_h^T + bo); h' = (h (1-u) + o u) * drop
+        f32x16 ao[1][2];
+        DPC_UNROLL
+        for (int t = 0; t < 2; ++t) ao[0][t] = a3[2][t];
         {
             const u32x4* const Bo[1][2] = {{frag<T>(p, M_WOH, wave, KSD, 0), frag<T>(p, M_WOH, wave + 4, KSD, 0)}};
-            gemm_acc<T, 1>(ao, ntw, thr, KSD, Bo, lane);
+            gemm_acc<T, 1, NT>(ao, thr, KSD, Bo, lane);
         }
-        for (int t = 0; t < ntw; ++t) {
-            const int col = (wave + 4 * t) * 32 + (lane & 31);
-            const float bo = p.bo[col];
+        __syncthreads();  // every thread has read its u pre-activations
+        stage_put<NT>(stage, D, ao[0], wave, lane);
+        __syncthreads();
+        RM_FOR(D) {
+            const int grow = m0 + row;
+            const f32x4 pre = ld4(stage + row * ld + col), b = ld4(p.bo + col);
+            const f32x4 h = ldT4<T>(tile_ptr<T>(th, row, col));
+            f32x4 o, hn = {0.f, 0.f, 0.f, 0.f};
             DPC_UNROLL
-            for (int r = 0; r < 16; ++r) {
-                const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                const int grow = m0 + row;
-                const float o = tanhf(ao[0][t][r] + bo);
-                const float h = TileIO<T>::get(th, row, col);
-                const float u = uu[t][r];
-                float hn = h * (1.f - u) + o * u;
-                if (grow < M) hn *= mask_at(p, mt, s, grow, row, col);
-                const T hq = Elt<T>::from_f32(hn);
-                *(T*)(th + TileIO<T>::elem_addr(row, col)) = hq;
-                if (grow < M) {
-                    const long long oidx = (long long)s * MD + (long long)grow * D + col;
-                    p.O_all[oidx] = o;
-                    H_all[oidx + MD] = hq;
-                }
+            for (int e = 0; e < 4; ++e) o[e] = tanhf(pre[e] + b[e]);
+            if (grow < M) {
+                const f32x4 u = ld4(p.U_all + (long long)s * MD + (long long)grow * D + col), k = mask4(p, s, grow, col);
+                DPC_UNROLL
+                for (int e = 0; e < 4; ++e) hn[e] = (h[e] * (1.f - u[e]) + o[e] * u[e]) * k[e];
+            }
+            stT4<T>(tile_ptr<T>(th, row, col), hn);
+            if (grow < M) {
+                const long long oidx = (long long)s * MD + (long long)grow * D + col;
+                st4(p.O_all + oidx, o);
+                stT4<T>(H_all + oidx + MD, hn);
             }
         }
         __syncthreads();
@@ -313,221 +373,265 @@ __global__ __launch_bounds__(256) void gru_chain_fwd_kernel(ChainP p) {
         if (i >= 0 && i < p.P) {
             f32x16 a1[1][2];
             zero_acc<1>(a1);
-            const u32x4* const B1[1][2] = {{frag<T>(p, M_W1, wave, KSD, 0), frag<T>(p, M_W1, wave + 4, KSD, 0)}};
-            gemm_acc<T, 1>(a1, ntw, th, KSD, B1, lane);
-            for (int t = 0; t < ntw; ++t) {
-                const int col = (wave + 4 * t) * 32 + (lane & 31);
-                const float b1 = p.b1[col];
+            {
+                const u32x4* const B1[1][2] = {{frag<T>(p, M_W1, wave, KSD, 0), frag<T>(p, M_W1, wave + 4, KSD, 0)}};
+                gemm_acc<T, 1, NT>(a1, th, KSD, B1, lane);
+            }
+            stage_put<NT>(stage, D, a1[0], wave, lane);
+            __syncthreads();
+            RM_FOR(D) {
+                const f32x4 pre = ld4(stage + row * ld + col), b = ld4(p.b1 + col);
+                f32x4 v;
                 DPC_UNROLL
-                for (int r = 0; r < 16; ++r) {
-                    const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                    float v = a1[0][t][r] + b1;
-                    v = v > 0.f ? v : 0.f;
-                    const T q = Elt<T>::from_f32(v);
-                    *(T*)(thr + TileIO<T>::elem_addr(row, col)) = q;
-                    if (m0 + row < M) P1_all[(long long)i * MD + (long long)(m0 + row) * D + col] = q;
-                }
+                for (int e = 0; e < 4; ++e) { v[e] = pre[e] + b[e]; v[e] = v[e] > 0.f ? v[e] : 0.f; }
+                stT4<T>(tile_ptr<T>(thr, row, col), v);
+                if (m0 + row < M) stT4<T>(P1_all + (long long)i * MD + (long long)(m0 + row) * D + col, v);
             }
             __syncthreads();
             zero_acc<1>(a1);
-            const u32x4* const B2[1][2] = {{frag<T>(p, M_W2, wave, KSD, 0), frag<T>(p, M_W2, wave + 4, KSD, 0)}};
-            gemm_acc<T, 1>(a1, ntw, thr, KSD, B2, lane);
-            for (int t = 0; t < ntw; ++t) {
-                const int col = (wave + 4 * t) * 32 + (lane & 31);
-                const float b2 = p.b2[col];
+            {
+                const u32x4* const B2[1][2] = {{frag<T>(p, M_W2, wave, KSD, 0), frag<T>(p, M_W2, wave + 4, KSD, 0)}};
+                gemm_acc<T, 1, NT>(a1, thr, KSD, B2, lane);
+            }
+            stage_put<NT>(stage, D, a1[0], wave, lane);
+            __syncthreads();
+            RM_FOR(D) {
+                const int grow = m0 + row;
+                const f32x4 pre = ld4(stage + row * ld + col), b = ld4(p.b2 + col);
+                f32x4 v, xr;
                 DPC_UNROLL
-                for (int r = 0; r < 16; ++r) {
-                    const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                    const int grow = m0 + row;
-                    const float v = a1[0][t][r] + b2;
-                    const T xq = Elt<T>::from_f32(v > 0.f ? v : 0.f);
-                    if (i < p.P - 1) *(T*)(tx + TileIO<T>::elem_addr(row, col)) = xq;
-                    if (grow < M) {
-                        const int b = grow / p.SQ, sq = grow - b * p.SQ;
-                        pred[((long long)(b * p.P + i) * p.SQ + sq) * D + col] = Elt<T>::from_f32(v);
-                        if (i < p.P - 1) X_all[(long long)(s + 1) * MD + (long long)grow * D + col] = xq;
-                    }
+                for (int e = 0; e < 4; ++e) { v[e] = pre[e] + b[e]; xr[e] = v[e] > 0.f ? v[e] : 0.f; }
+                if (i < p.P - 1) stT4<T>(tile_ptr<T>(tx, row, col), xr);
+                if (grow < M) {
+                    const int b_ = grow / p.SQ, sq = grow - b_ * p.SQ;
+                    stT4<T>(pred + ((long long)(b_ * p.P + i) * p.SQ + sq) * D + col, v);
+                    if (i < p.P - 1) stT4<T>(X_all + (long long)(s + 1) * MD + (long long)grow * D + col, xr);
                 }
             }
-            // the next iteration's barrier orders these LDS writes before the reads
+            __syncthreads();
         }
     }
 }
 
 // ---------------------------------------------------------------- backward chain
-// One GRU step s, reversed (the arithmetic of the former dpc_gru_bwd1/2 kernels + their three GEMMs):
+// One GRU step s, reversed (the arithmetic of round 1's dpc_gru_bwd1/2 kernels and their three GEMMs):
 //   dhn = dh*drop; G_u = dhn (o-h) u (1-u); G_o = dhn u (1-o^2); dhprev = dhn (1-u)
 //   dhr = G_o @ Wo_h;  G_r = dhr h r (1-r);  dhprev += dhr r
 //   dx = [G_u|G_r|G_o] @ [Wu_x;Wr_x;Wo_x];  dh <- dhprev + [G_u|G_r] @ [Wu_h;Wr_h]
-template <class T>
-__device__ __forceinline__ void gru_step_bwd(const ChainP& p, int s, int m0, int ntw, int wave, int lane, unsigned char* tu, unsigned char* tr,
-                                             unsigned char* to, uint8_t* mt, f32x16 (&dh)[1][2], f32x16 (&dx)[1][2]) {
+// dh lives in p.ws[0] (f32 [M][D]), the dx of a step that feeds a prediction in p.ws[1]: thread-private state (every element
+// is read and written by the same thread in every pass), kept in L2-resident memory instead of registers.
+template <class T, int NT>
+__device__ __forceinline__ void gru_step_bwd(const ChainP& p, int s, int m0, int wave, int lane, unsigned char* tu, unsigned char* tr,
+                                             unsigned char* to, float* stage, float* dx_out) {
     constexpr int E = Elt<T>::PER16;
     const int D = p.D, M = p.M;
+    const int ld = D + SPAD;
     const int KSD = D / (2 * E);
     const long long MD = (long long)M * D;
     const T* H_all = (const T*)p.H_all;
     T* G_all = (T*)p.G_all;
-    if (!p.drop && p.step_dev) {
-        gen_mask_tile(mt, p, s, m0);
-        __syncthreads();
-    }
-    float dhprev[2][16];
-    for (int t = 0; t < ntw; ++t) {
-        const int col = (wave + 4 * t) * 32 + (lane & 31);
-        DPC_UNROLL
-        for (int r = 0; r < 16; ++r) {
-            const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-            const int grow = m0 + row;
-            float gu = 0.f, go = 0.f, dp = 0.f;
-            if (grow < M) {
-                const long long o = (long long)s * MD + (long long)grow * D + col;
-                const float dhn = dh[0][t][r] * mask_at(p, mt, s, grow, row, col);
-                const float u = p.U_all[o], oo = p.O_all[o], h = Elt<T>::to_f32(H_all[o]);
-                gu = dhn * (oo - h) * u * (1.f - u);
-                go = dhn * u * (1.f - oo * oo);
-                dp = dhn * (1.f - u);
-                G_all[((long long)s * M + grow) * 3 * D + col] = Elt<T>::from_f32(gu);
-                G_all[((long long)s * M + grow) * 3 * D + 2 * D + col] = Elt<T>::from_f32(go);
+    float* dh_ws = p.ws;
+    RM_FOR(D) {
+        const int grow = m0 + row;
+        f32x4 gu = {0.f, 0.f, 0.f, 0.f}, go = gu;
+        if (grow < M) {
+            const long long o2 = (long long)grow * D + col, o = (long long)s * MD + o2;
+            const f32x4 k = mask4(p, s, grow, col), dh = ld4(dh_ws + o2);
+            const f32x4 u = ld4(p.U_all + o), oo = ld4(p.O_all + o), h = ldT4<T>(H_all + o);
+            f32x4 dp;
+            DPC_UNROLL
+            for (int e = 0; e < 4; ++e) {
+                const float dhn = dh[e] * k[e];
+                gu[e] = dhn * (oo[e] - h[e]) * u[e] * (1.f - u[e]);
+                go[e] = dhn * u[e] * (1.f - oo[e] * oo[e]);
+                dp[e] = dhn * (1.f - u[e]);
             }
-            dhprev[t][r] = dp;
-            TileIO<T>::put(tu, row, col, gu);
-            TileIO<T>::put(to, row, col, go);
+            st4(dh_ws + o2, dp);
+            T* g = G_all + ((long long)s * M + grow) * 3 * D + col;
+            stT4<T>(g, gu);
+            stT4<T>(g + 2 * D, go);
         }
+        stT4<T>(tile_ptr<T>(tu, row, col), gu);
+        stT4<T>(tile_ptr<T>(to, row, col), go);
     }
     __syncthreads();
-    f32x16 dhr[1][2];
-    zero_acc<1>(dhr);
+    f32x16 acc[1][2];
+    zero_acc<1>(acc);
     {
         const u32x4* const B[1][2] = {{frag<T>(p, M_WOHT, wave, KSD, 0), frag<T>(p, M_WOHT, wave + 4, KSD, 0)}};
-        gemm_acc<T, 1>(dhr, ntw, to, KSD, B, lane);
+        gemm_acc<T, 1, NT>(acc, to, KSD, B, lane);
     }
-    for (int t = 0; t < ntw; ++t) {
-        const int col = (wave + 4 * t) * 32 + (lane & 31);
-        DPC_UNROLL
-        for (int r = 0; r < 16; ++r) {
-            const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-            const int grow = m0 + row;
-            float gr = 0.f;
-            if (grow < M) {
-                const long long o = (long long)s * MD + (long long)grow * D + col;
-                const float g = dhr[0][t][r], rr = p.R_all[o], h = Elt<T>::to_f32(H_all[o]);
-                gr = g * h * rr * (1.f - rr);
-                dhprev[t][r] += g * rr;
-                G_all[((long long)s * M + grow) * 3 * D + D + col] = Elt<T>::from_f32(gr);
+    stage_put<NT>(stage, D, acc[0], wave, lane);
+    __syncthreads();
+    RM_FOR(D) {
+        const int grow = m0 + row;
+        f32x4 gr = {0.f, 0.f, 0.f, 0.f};
+        if (grow < M) {
+            const long long o2 = (long long)grow * D + col, o = (long long)s * MD + o2;
+            const f32x4 g = ld4(stage + row * ld + col), rr = ld4(p.R_all + o), h = ldT4<T>(H_all + o);
+            f32x4 dp = ld4(dh_ws + o2);
+            DPC_UNROLL
+            for (int e = 0; e < 4; ++e) {
+                gr[e] = g[e] * h[e] * rr[e] * (1.f - rr[e]);
+                dp[e] += g[e] * rr[e];
             }
-            TileIO<T>::put(tr, row, col, gr);
+            st4(dh_ws + o2, dp);
+            stT4<T>(G_all + ((long long)s * M + grow) * 3 * D + D + col, gr);
         }
+        stT4<T>(tile_ptr<T>(tr, row, col), gr);
     }
     __syncthreads();
-    zero_acc<1>(dx);
-    DPC_UNROLL
-    for (int t = 0; t < 2; ++t)
-        DPC_UNROLL
-        for (int r = 0; r < 16; ++r) dh[0][t][r] = dhprev[t][r];
+    // dx
+    zero_acc<1>(acc);
     {
-        const u32x4* const Bx0[1][2] = {{frag<T>(p, M_WUXT, wave, KSD, 0), frag<T>(p, M_WUXT, wave + 4, KSD, 0)}};
-        const u32x4* const Bx1[1][2] = {{frag<T>(p, M_WRXT, wave, KSD, 0), frag<T>(p, M_WRXT, wave + 4, KSD, 0)}};
-        const u32x4* const Bx2[1][2] = {{frag<T>(p, M_WOXT, wave, KSD, 0), frag<T>(p, M_WOXT, wave + 4, KSD, 0)}};
-        const u32x4* const Bh0[1][2] = {{frag<T>(p, M_WUHT, wave, KSD, 0), frag<T>(p, M_WUHT, wave + 4, KSD, 0)}};
-        const u32x4* const Bh1[1][2] = {{frag<T>(p, M_WRHT, wave, KSD, 0), frag<T>(p, M_WRHT, wave + 4, KSD, 0)}};
-        gemm_acc<T, 1>(dx, ntw, tu, KSD, Bx0, lane);
-        gemm_acc<T, 1>(dh, ntw, tu, KSD, Bh0, lane);
-        gemm_acc<T, 1>(dx, ntw, tr, KSD, Bx1, lane);
-        gemm_acc<T, 1>(dh, ntw, tr, KSD, Bh1, lane);
-        gemm_acc<T, 1>(dx, ntw, to, KSD, Bx2, lane);
+        const u32x4* const B0[1][2] = {{frag<T>(p, M_WUXT, wave, KSD, 0), frag<T>(p, M_WUXT, wave + 4, KSD, 0)}};
+        const u32x4* const B1[1][2] = {{frag<T>(p, M_WRXT, wave, KSD, 0), frag<T>(p, M_WRXT, wave + 4, KSD, 0)}};
+        const u32x4* const B2[1][2] = {{frag<T>(p, M_WOXT, wave, KSD, 0), frag<T>(p, M_WOXT, wave + 4, KSD, 0)}};
+        gemm_acc<T, 1, NT>(acc, tu, KSD, B0, lane);
+        gemm_acc<T, 1, NT>(acc, tr, KSD, B1, lane);
+        gemm_acc<T, 1, NT>(acc, to, KSD, B2, lane);
     }
-    __syncthreads();  // the three tiles are free again
+    stage_put<NT>(stage, D, acc[0], wave, lane);
+    __syncthreads();
+    RM_FOR(D) {
+        if (m0 + row < M) st4(dx_out + (long long)(m0 + row) * D + col, ld4(stage + row * ld + col));
+    }
+    __syncthreads();
+    // dh
+    zero_acc<1>(acc);
+    {
+        const u32x4* const B0[1][2] = {{frag<T>(p, M_WUHT, wave, KSD, 0), frag<T>(p, M_WUHT, wave + 4, KSD, 0)}};
+        const u32x4* const B1[1][2] = {{frag<T>(p, M_WRHT, wave, KSD, 0), frag<T>(p, M_WRHT, wave + 4, KSD, 0)}};
+        gemm_acc<T, 1, NT>(acc, tu, KSD, B0, lane);
+        gemm_acc<T, 1, NT>(acc, tr, KSD, B1, lane);
+    }
+    stage_put<NT>(stage, D, acc[0], wave, lane);
+    __syncthreads();
+    RM_FOR(D) {
+        if (m0 + row < M) {
+            const long long o2 = (long long)(m0 + row) * D + col;
+            const f32x4 g = ld4(stage + row * ld + col);
+            f32x4 dp = ld4(dh_ws + o2);
+            DPC_UNROLL
+            for (int e = 0; e < 4; ++e) dp[e] += g[e];
+            st4(dh_ws + o2, dp);
+        }
+    }
+    __syncthreads();  // tiles and staging are free again
 }
 
-template <class T>
-__global__ __launch_bounds__(256) void gru_chain_bwd_kernel(ChainP p) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+template <class T, int NT>
+__device__ __forceinline__ void gru_chain_bwd_body(const ChainP& p, unsigned char* smem) {
     constexpr int E = Elt<T>::PER16;
     const int D = p.D, M = p.M;
     const int tile_bytes = (D * (16 / E) + 127) / 128 * CHUNK;
     unsigned char* tu = smem;
     unsigned char* tr = smem + tile_bytes;
     unsigned char* to = smem + 2 * tile_bytes;
-    uint8_t* mt = smem + 3 * tile_bytes;
+    float* stage = (float*)(smem + 3 * tile_bytes);
+    const int ld = D + SPAD;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int m0 = blockIdx.x * TM;
-    const int ntiles = D / 32;
-    const int ntw = wave < ntiles ? (wave + 4 < ntiles ? 2 : 1) : 0;
     const int KSD = D / (2 * E);
     const long long MD = (long long)M * D;
     const T* X_all = (const T*)p.X_all;
     const T* P1_all = (const T*)p.P1_all;
     T* dP1 = (T*)p.dP1;
     T* dP2 = (T*)p.dP2;
-    f32x16 dh[1][2], dx[1][2];
-    zero_acc<1>(dh);
-    zero_acc<1>(dx);
+    float* dh_ws = p.ws;
+    float* dxn_ws = p.ws + MD;
+    RM_FOR(D) {
+        if (m0 + row < M) st4(dh_ws + (long long)(m0 + row) * D + col, f32x4{0.f, 0.f, 0.f, 0.f});
+    }
     int step = p.n_steps;
     for (int i = p.P - 1; i >= 0; --i) {
         // p_i = W2 relu(W1 h + b1) + b2 feeds the score (row-mapped) and, for i < P-1, GRU step `step` through relu
         const bool feeds = i < p.P - 1;
         if (feeds) {
             --step;
-            gru_step_bwd<T>(p, step, m0, ntw, wave, lane, tu, tr, to, mt, dh, dx);
+            gru_step_bwd<T, NT>(p, step, m0, wave, lane, tu, tr, to, stage, dxn_ws);
         }
-        for (int t = 0; t < ntw; ++t) {
-            const int col = (wave + 4 * t) * 32 + (lane & 31);
-            DPC_UNROLL
-            for (int r = 0; r < 16; ++r) {
-                const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                const int grow = m0 + row;
-                float g = 0.f;
-                if (grow < M) {
-                    const int b = grow / p.SQ, sq = grow - b * p.SQ;
-                    g = p.d_pred[((long long)(b * p.P + i) * p.SQ + sq) * D + col];
-                    if (feeds && Elt<T>::to_f32(X_all[(long long)step * MD + (long long)grow * D + col]) > 0.f) g += dx[0][t][r];
-                    dP2[(long long)i * MD + (long long)grow * D + col] = Elt<T>::from_f32(g);
+        RM_FOR(D) {
+            const int grow = m0 + row;
+            f32x4 g = {0.f, 0.f, 0.f, 0.f};
+            if (grow < M) {
+                const int b_ = grow / p.SQ, sq = grow - b_ * p.SQ;
+                g = ld4(p.d_pred + ((long long)(b_ * p.P + i) * p.SQ + sq) * D + col);
+                if (feeds) {
+                    const f32x4 xr = ldT4<T>(X_all + (long long)step * MD + (long long)grow * D + col);
+                    const f32x4 dx = ld4(dxn_ws + (long long)grow * D + col);
+                    DPC_UNROLL
+                    for (int e = 0; e < 4; ++e) g[e] += xr[e] > 0.f ? dx[e] : 0.f;
                 }
-                TileIO<T>::put(tu, row, col, g);
+                stT4<T>(dP2 + (long long)i * MD + (long long)grow * D + col, g);
             }
+            stT4<T>(tile_ptr<T>(tu, row, col), g);
         }
         __syncthreads();
-        f32x16 g1[1][2];
-        zero_acc<1>(g1);
+        f32x16 acc[1][2];
+        zero_acc<1>(acc);
         {
             const u32x4* const B[1][2] = {{frag<T>(p, M_W2T, wave, KSD, 0), frag<T>(p, M_W2T, wave + 4, KSD, 0)}};
-            gemm_acc<T, 1>(g1, ntw, tu, KSD, B, lane);
+            gemm_acc<T, 1, NT>(acc, tu, KSD, B, lane);
         }
-        for (int t = 0; t < ntw; ++t) {
-            const int col = (wave + 4 * t) * 32 + (lane & 31);
-            DPC_UNROLL
-            for (int r = 0; r < 16; ++r) {
-                const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                const int grow = m0 + row;
-                float g = 0.f;
-                if (grow < M) {
-                    const long long o = (long long)i * MD + (long long)grow * D + col;
-                    g = Elt<T>::to_f32(P1_all[o]) > 0.f ? g1[0][t][r] : 0.f;
-                    dP1[o] = Elt<T>::from_f32(g);
-                }
-                TileIO<T>::put(tr, row, col, g);
+        stage_put<NT>(stage, D, acc[0], wave, lane);
+        __syncthreads();
+        RM_FOR(D) {
+            const int grow = m0 + row;
+            f32x4 g = {0.f, 0.f, 0.f, 0.f};
+            if (grow < M) {
+                const long long o = (long long)i * MD + (long long)grow * D + col;
+                const f32x4 g1 = ld4(stage + row * ld + col), p1 = ldT4<T>(P1_all + o);
+                DPC_UNROLL
+                for (int e = 0; e < 4; ++e) g[e] = p1[e] > 0.f ? g1[e] : 0.f;
+                stT4<T>(dP1 + o, g);
             }
+            stT4<T>(tile_ptr<T>(tr, row, col), g);
         }
         __syncthreads();
+        zero_acc<1>(acc);
         {
             const u32x4* const B[1][2] = {{frag<T>(p, M_W1T, wave, KSD, 0), frag<T>(p, M_W1T, wave + 4, KSD, 0)}};
-            gemm_acc<T, 1>(dh, ntw, tr, KSD, B, lane);  // dh += dP1 @ W1
+            gemm_acc<T, 1, NT>(acc, tr, KSD, B, lane);  // dP1 @ W1
+        }
+        stage_put<NT>(stage, D, acc[0], wave, lane);
+        __syncthreads();
+        RM_FOR(D) {
+            if (m0 + row < M) {
+                const long long o2 = (long long)(m0 + row) * D + col;
+                const f32x4 g = ld4(stage + row * ld + col);
+                f32x4 dh = ld4(dh_ws + o2);
+                DPC_UNROLL
+                for (int e = 0; e < 4; ++e) dh[e] += g[e];
+                st4(dh_ws + o2, dh);
+            }
         }
         __syncthreads();
     }
     for (int t = p.n_agg - 1; t >= 0; --t) {
         --step;
-        gru_step_bwd<T>(p, step, m0, ntw, wave, lane, tu, tr, to, mt, dh, dx);
-        for (int tt = 0; tt < ntw; ++tt) {
-            const int col = (wave + 4 * tt) * 32 + (lane & 31);
-            DPC_UNROLL
-            for (int r = 0; r < 16; ++r) {
-                const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                if (m0 + row < M) p.d_x[(long long)t * MD + (long long)(m0 + row) * D + col] = dx[0][tt][r];
-            }
-        }
+        gru_step_bwd<T, NT>(p, step, m0, wave, lane, tu, tr, to, stage, p.d_x + (long long)t * MD);
     }
+}
+
+// the number of column tiles a wave owns is wave-uniform: one instantiation per count keeps every MFMA unconditional
+template <class T>
+__global__ __launch_bounds__(256) void gru_chain_fwd_kernel(ChainP p) {
+    DPC_DYN_SMEM(smem);
+    const int wave = threadIdx.x >> 6, ntiles = p.D / 32;
+    const int ntw = wave < ntiles ? (wave + 4 < ntiles ? 2 : 1) : 0;
+    if (ntw == 2) gru_chain_fwd_body<T, 2>(p, smem);
+    else if (ntw == 1) gru_chain_fwd_body<T, 1>(p, smem);
+    else gru_chain_fwd_body<T, 0>(p, smem);
+}
+template <class T>
+__global__ __launch_bounds__(256) void gru_chain_bwd_kernel(ChainP p) {
+    DPC_DYN_SMEM(smem);
+    const int wave = threadIdx.x >> 6, ntiles = p.D / 32;
+    const int ntw = wave < ntiles ? (wave + 4 < ntiles ? 2 : 1) : 0;
+    if (ntw == 2) gru_chain_bwd_body<T, 2>(p, smem);
+    else if (ntw == 1) gru_chain_bwd_body<T, 1>(p, smem);
+    else gru_chain_bwd_body<T, 0>(p, smem);
 }
 
 int chain_params(const dpc_gru_chain_desc* c, ChainP* p, bool backward) {
@@ -536,7 +640,7 @@ int chain_params(const dpc_gru_chain_desc* c, ChainP* p, bool backward) {
     if (!c->packed || !c->bias_u || !c->bias_r || !c->bias_o || !c->bias_1 || !c->bias_2 || !c->X_all || !c->H_all || !c->HR_all ||
         !c->U_all || !c->R_all || !c->O_all || !c->P1_all || !c->pred)
         return DPC_ERR_ARG;
-    if (backward && (!c->d_pred || !c->G_all || !c->dP1 || !c->dP2 || !c->d_x)) return DPC_ERR_ARG;
+    if (backward && (!c->d_pred || !c->G_all || !c->dP1 || !c->dP2 || !c->d_x || !c->ws)) return DPC_ERR_ARG;
     if (!(c->p_drop >= 0.f) || !(c->p_drop < 1.f)) return DPC_ERR_ARG;
     p->M = c->M; p->D = c->D; p->SQ = c->SQ; p->P = c->P; p->n_agg = c->n_agg; p->n_steps = c->n_steps;
     p->packed = c->packed;
@@ -549,25 +653,17 @@ int chain_params(const dpc_gru_chain_desc* c, ChainP* p, bool backward) {
     p->X_all = c->X_all; p->H_all = c->H_all; p->HR_all = c->HR_all;
     p->U_all = c->U_all; p->R_all = c->R_all; p->O_all = c->O_all;
     p->P1_all = c->P1_all; p->pred = c->pred;
-    p->d_pred = c->d_pred; p->G_all = c->G_all; p->dP1 = c->dP1; p->dP2 = c->dP2; p->d_x = c->d_x;
+    p->d_pred = c->d_pred; p->G_all = c->G_all; p->dP1 = c->dP1; p->dP2 = c->dP2; p->d_x = c->d_x; p->ws = c->ws;
     return DPC_OK;
 }
 
 size_t chain_lds(const dpc_gru_chain_desc* c) {
     const int esz = c->dtype == DPC_BF16 ? 2 : 4;
     const size_t tile = (size_t)((c->D * esz + 127) / 128) * CHUNK;
-    return 3 * tile + (size_t)TM * c->D;
+    return 3 * tile + (size_t)TM * (c->D + SPAD) * sizeof(float);
 }
 
 }  // namespace
-
-#ifdef DPC_SIMT_EMU
-#define DPC_LAUNCH_DYN(kernel, grid, block, lds, stream, ...) simt::launch_dyn((grid), (block), (lds), [=]() { (kernel)(__VA_ARGS__); })
-#else
-#define DPC_LAUNCH_DYN(kernel, grid, block, lds, stream, ...) hipLaunchKernelGGL(kernel, (grid), (block), (lds), (stream), __VA_ARGS__)
-#endif
-
-extern "C" int64_t dpc_gru_packed_elems(int32_t D) { return 16ll * D * D; }
 
 extern "C" int dpc_gru_pack(const float* w_update, const float* w_reset, const float* w_out, const float* w_pred0, const float* w_pred2,
                             int32_t D, int32_t dtype, void* packed, dpc_stream_t stream_) {

@@ -213,13 +213,6 @@ extern "C" int dpc_adam_dev(float* p, const float* g, float* m, float* v, int64_
     return dpc_launch_status();
 }
 
-extern "C" int dpc_fill_zero(void* ptr, int64_t bytes, dpc_stream_t stream_) {
-    hipStream_t stream = (hipStream_t)stream_;
-    if (!ptr || bytes < 0) return DPC_ERR_ARG;
-    if (bytes == 0) return DPC_OK;
-    return hipMemsetAsync(ptr, 0, (size_t)bytes, stream) == hipSuccess ? DPC_OK : DPC_ERR_LAUNCH;
-}
-
 extern "C" int dpc_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
                         float eps, float wd, float bias_corr1, float bias_corr2, float grad_scale, dpc_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;

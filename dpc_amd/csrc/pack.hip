@@ -218,42 +218,6 @@ extern "C" int dpc_unpack_stem_wgrad(const float* part, int32_t nsplit, float* d
     return dpc_launch_status();
 }
 
-template <class TI, class TO>
-__global__ void convert_kernel(const TI* in, TO* out, long long n) {
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
-        out[i] = Elt<TO>::from_f32(Elt<TI>::to_f32(in[i]));
-}
-
-extern "C" int dpc_convert(const void* in, int32_t dtype_in, void* out, int32_t dtype_out, int64_t n, dpc_stream_t stream_) {
-    hipStream_t stream = (hipStream_t)stream_;
-    if (!in || !out || n <= 0) return DPC_ERR_ARG;
-    dim3 grid(grid_for(n)), block(256);
-    if (dtype_in == DPC_F32 && dtype_out == DPC_BF16) {
-        DPC_LAUNCH((convert_kernel<float, bf16_t>), grid, block, stream, (const float*)in, (bf16_t*)out, (long long)n);
-    } else if (dtype_in == DPC_BF16 && dtype_out == DPC_F32) {
-        DPC_LAUNCH((convert_kernel<bf16_t, float>), grid, block, stream, (const bf16_t*)in, (float*)out, (long long)n);
-    } else if (dtype_in == DPC_F32 && dtype_out == DPC_F32) {
-        DPC_LAUNCH((convert_kernel<float, float>), grid, block, stream, (const float*)in, (float*)out, (long long)n);
-    } else if (dtype_in == DPC_BF16 && dtype_out == DPC_BF16) {
-        DPC_LAUNCH((convert_kernel<bf16_t, bf16_t>), grid, block, stream, (const bf16_t*)in, (bf16_t*)out, (long long)n);
-    } else {
-        return DPC_ERR_ARG;
-    }
-    return dpc_launch_status();
-}
-
-__global__ void axpy_kernel(const float* x, float* y, long long n) {
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) y[i] += x[i];
-}
-
-extern "C" int dpc_axpy_f32(const float* x, float* y, int64_t n, dpc_stream_t stream_) {
-    hipStream_t stream = (hipStream_t)stream_;
-    if (!x || !y || n <= 0) return DPC_ERR_ARG;
-    DPC_LAUNCH(axpy_kernel, dim3(grid_for(n)), dim3(256), stream, x, y, (long long)n);
-    return dpc_launch_status();
-}
-
-
 // dst[r][c] = src[r][c] for an f32 [rows][cols] window (leading dimensions in elements): scatters the batched ConvGRU
 // weight-gradient GEMM results into the reference's [D][2D] gate parameters (x half | h half)
 __global__ void copy2d_f32_kernel(const float* src, long long src_ld, float* dst, long long dst_ld, int rows, int cols) {

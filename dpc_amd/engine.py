@@ -416,21 +416,13 @@ class DPCEngine:
         self.G_all = self.empty((ns, M, 3 * D), dt)   # [dpu | dpr | dpo] per step
         self.U_all, self.R_all, self.O_all = (self.empty((ns, M, D), f32) for _ in range(3))
         self.drop_all: Optional[torch.Tensor] = None
-        self.drop_buf = self.empty((ns, M, D), f32)   # train-mode keep masks of one step (Philox, dpc_dropout_mask)
         # optimizer-step counter and Adam bias corrections in device memory: a captured hipGraph advances them on replay
         self.dev_step = torch.zeros(1, dtype=torch.int32, device=self.device)
         self.dev_bc = torch.ones(2, dtype=f32, device=self.device)
-        self.px = self.empty((ns, M, 3 * D), f32)
-        self.ph = self.empty((M, 2 * D), f32)
-        self.po = self.empty((M, D), f32)
-        self.p1_pre = self.empty((M, D), f32)
         self.P1_all = self.empty((P, M, D), dt)       # relu(W1 h + b1)
-        self.p2_pre = self.empty((M, D), f32)
         self.dP1 = self.empty((P, M, D), dt)          # grads at the pre-activations of network_pred
         self.dP2 = self.empty((P, M, D), dt)
         self.Hpred = self.H_all[self.n_agg:]          # hidden state each prediction was made from
-        self.tmp_f = [self.empty((M, D), f32) for _ in range(4)]
-        self.tmp_3d = self.empty((M, 3 * D), f32)
         R = B * P * SQ
         self.R = R
         self.score = self.empty((R, R), f32)
@@ -446,17 +438,13 @@ class DPCEngine:
         self.d_featrelu = self.empty((self.n_agg, M, D), f32)
         self.d_feat = self.empty(self.feat_shape + (widths[3],), dt)
         self.mask: Optional[torch.Tensor] = None
-        # packed GEMM weights (compute dtype)
-        self.Wx = self.empty((3 * D, D), dt)     # rows [Wu_x; Wr_x; Wo_x]
-        self.Whur = self.empty((2 * D, D), dt)   # rows [Wu_h; Wr_h]
-        self.Woh = self.empty((D, D), dt)
-        self.WxT = self.empty((D, 3 * D), dt)
-        self.WhurT = self.empty((D, 2 * D), dt)
-        self.WohT = self.empty((D, D), dt)
-        self.W1 = self.empty((D, D), dt)
-        self.W2 = self.empty((D, D), dt)
-        self.W1T = self.empty((D, D), dt)
-        self.W2T = self.empty((D, D), dt)
+        # the recurrence runs as two launches (dpc_gru_chain_fwd / _bwd, csrc/gru_chain.hip): fragment-major packed weights,
+        # f32 scratch of the backward kernel, and the descriptor with every (static) buffer address
+        if D % 32 or D > 256:
+            raise ValueError("feature size must be a multiple of 32, at most 256 (fused ConvGRU recurrence)")
+        self.gru_packed = self.empty((16 * D * D,), dt)
+        self.gru_ws = self.empty((2, M, D), f32)
+        self.gru_desc = L.GruChainDesc()
         self.dWx = self.empty((3 * D, D), f32)
         self.dWh = self.empty((2 * D, D), f32)
         self.dWo = self.empty((D, D), f32)
@@ -465,6 +453,16 @@ class DPCEngine:
             self._need_wgrad(ns * M, co, kk)
         self.need_part(64 * 3 * D)  # dpc_colsum workspace
         self._need_wgrad(R, R, D)
+        gd, Pm = self.gru_desc, self.PRM
+        gd.dtype, gd.M, gd.D, gd.SQ, gd.P, gd.n_agg, gd.n_steps = L.dtype_code(dt), M, D, SQ, P, self.n_agg, ns
+        gd.p_drop, gd.seed = float(self.p_drop), self.seed
+        for name, t in (("packed", self.gru_packed), ("bias_u", Pm["agg.ConvGRUCell_00.update_gate.bias"]),
+                        ("bias_r", Pm["agg.ConvGRUCell_00.reset_gate.bias"]), ("bias_o", Pm["agg.ConvGRUCell_00.out_gate.bias"]),
+                        ("bias_1", Pm["network_pred.0.bias"]), ("bias_2", Pm["network_pred.2.bias"]), ("X_all", self.X_all),
+                        ("H_all", self.H_all), ("HR_all", self.HR_all), ("U_all", self.U_all), ("R_all", self.R_all),
+                        ("O_all", self.O_all), ("P1_all", self.P1_all), ("pred", self.pred), ("d_pred", self.d_pred),
+                        ("G_all", self.G_all), ("dP1", self.dP1), ("dP2", self.dP2), ("d_x", self.d_featrelu), ("ws", self.gru_ws)):
+            setattr(gd, name, t.data_ptr())
         prs = C.c_int32(0)  # stem backward: partial rows of the pooled reduction (sized by query, not by coincidence)
         ps_ = self.pool_shape
         self.lib.call("dpc_pooled_bn_bwd_reduce", None, None, None, L.dtype_code(dt), ps_[0] * ps_[1] * ps_[2] * ps_[3], widths[0],
@@ -558,19 +556,10 @@ class DPCEngine:
         dc = L.dtype_code(self.cdtype)
         for u in self.units:
             u.pack()
-        D = self.D
-        gates = {g: self.PRM[f"agg.ConvGRUCell_00.{n}.weight"] for g, n in
-                 (("u", "update_gate"), ("r", "reset_gate"), ("o", "out_gate"))}
-        for i, g in enumerate("uro"):  # x half: columns [0,D) of [D][2D]
-            self.call("dpc_pack3d", gates[g], self.Wx[i * D:(i + 1) * D], dc, D, 1, D, 2 * D, 0, 1)
-        for i, g in enumerate("ur"):   # h half: columns [D,2D)
-            self.call("dpc_pack3d", gates[g][:, D:], self.Whur[i * D:(i + 1) * D], dc, D, 1, D, 2 * D, 0, 1)
-        self.call("dpc_pack3d", gates["o"][:, D:], self.Woh, dc, D, 1, D, 2 * D, 0, 1)
-        self.call("dpc_pack3d", self.PRM["network_pred.0.weight"], self.W1, dc, D, 1, D, D, 0, 1)
-        self.call("dpc_pack3d", self.PRM["network_pred.2.weight"], self.W2, dc, D, 1, D, D, 0, 1)
-        for src, dst, r, c in ((self.Wx, self.WxT, 3 * D, D), (self.Whur, self.WhurT, 2 * D, D), (self.Woh, self.WohT, D, D),
-                               (self.W1, self.W1T, D, D), (self.W2, self.W2T, D, D)):
-            self.call("dpc_transpose2d", src, dc, c, dst, dc, r, r, c)
+        Pm = self.PRM
+        self.call("dpc_gru_pack", Pm["agg.ConvGRUCell_00.update_gate.weight"], Pm["agg.ConvGRUCell_00.reset_gate.weight"],
+                  Pm["agg.ConvGRUCell_00.out_gate.weight"], Pm["network_pred.0.weight"], Pm["network_pred.2.weight"], self.D, dc,
+                  self.gru_packed)
         self.packed_for_step = self._step_count
 
     # ------------------------------------------------------------------ forward
@@ -599,49 +588,27 @@ class DPCEngine:
         # dropout masks on the carried hidden state (backbone/convrnn.py:78)
         if dropout_masks is not None:
             self.drop_all = dropout_masks.to(self.device, torch.float32).contiguous()
-        elif train and self.p_drop > 0:  # drawn in one launch, keyed on (seed, optimizer step): graph-replay safe
-            self.call("dpc_dropout_mask", self.drop_buf, self.drop_buf.numel(), float(self.p_drop), self.seed, self.dev_step)
-            self.drop_all = self.drop_buf
-        else:
+            if tuple(self.drop_all.shape) != (self.n_steps, M, D):
+                raise ValueError(f"dropout_masks must be [n_steps, M, D] = {(self.n_steps, M, D)}")
+        else:  # train: Philox masks are generated inside the recurrence kernel, keyed on (seed, optimizer step)
             self.drop_all = None
-        # aggregate: x-side gate pre-activations of all n_agg steps in one GEMM
-        na = self.n_agg
-        self.gemm(self.X_all, self.Wx, self.px, na * M, 3 * D, D)
-        step = 0
-        for t in range(na):
-            self._gru_step(step, px_ready=True)
-            step += 1
-        # predict (dpc/model_3d.py:65-72)
-        for i in range(P):
-            h = self.H_all[step]
-            self.gemm(h, self.W1, self.p1_pre, M, D, D)
-            self.call("dpc_bias_act", self.p1_pre, self.PRM["network_pred.0.bias"], M, D, 1, self.P1_all[i], dc, 0, 0, SQ, None, dc)
-            self.gemm(self.P1_all[i], self.W2, self.p2_pre, M, D, D)
-            y2 = self.X_all[step] if i < P - 1 else None
-            self.call("dpc_bias_act", self.p2_pre, self.PRM["network_pred.2.bias"], M, D, 0, self.pred, dc, P, i, SQ, y2, dc)
-            if i < P - 1:
-                self._gru_step(step, px_ready=False)
-                step += 1
+        # aggregate + predict (dpc/model_3d.py:62-72): the whole recurrence in one launch
+        gd = self.gru_desc
+        gd.drop_masks = self.drop_all.data_ptr() if dropout_masks is not None else None
+        gd.step_dev = self.dev_step.data_ptr() if (dropout_masks is None and train and self.p_drop > 0) else None
+        self.call("dpc_gru_chain_fwd", C.byref(gd))
         # score (dpc/model_3d.py:79-84): pred [R][D] x feat_inf [R][D]^T
         R = self.R
         with self.tag("score"):
             self.gemm(self.pred, self.feat_inf, self.score, R, R, D)
         return self.score.view(B, P, SQ, B, P, SQ)
 
-    def _gru_step(self, s: int, px_ready: bool):
-        D, M = self.D, self.M
-        dc = L.dtype_code(self.cdtype)
-        x, h = self.X_all[s], self.H_all[s]
-        if not px_ready:
-            self.gemm(x, self.Wx, self.px[s], M, 3 * D, D)
-        self.gemm(h, self.Whur, self.ph, M, 2 * D, D)
-        Pm = self.PRM
-        self.call("dpc_gru_gates1", self.px[s], self.ph, Pm["agg.ConvGRUCell_00.update_gate.bias"],
-                  Pm["agg.ConvGRUCell_00.reset_gate.bias"], h, dc, M, D, self.U_all[s], self.R_all[s], self.HR_all[s])
-        self.gemm(self.HR_all[s], self.Woh, self.po, M, D, D)
-        drop = self.drop_all[s] if self.drop_all is not None else None
-        self.call("dpc_gru_gates2", self.px[s], self.po, Pm["agg.ConvGRUCell_00.out_gate.bias"], h, self.U_all[s], drop, dc,
-                  M, D, self.O_all[s], self.H_all[s + 1])
+    def dropout_masks_of_step(self) -> torch.Tensor:
+        """[n_steps, M, D] pre-scaled keep masks the recurrence kernels generate in train mode at the CURRENT optimizer step
+        (same Philox stream, materialised by dpc_dropout_mask): diagnostics and tests."""
+        buf = self.empty((self.n_steps, self.M, self.D), torch.float32)
+        self.call("dpc_dropout_mask", buf, buf.numel(), float(self.p_drop), self.seed, self.dev_step)
+        return buf
 
     def get_mask(self) -> torch.Tensor:
         if self.mask is None:
@@ -677,30 +644,9 @@ class DPCEngine:
         with self.tag("score"):
             self.gemm(self.dscore, self.finfT, self.d_pred, R, D, self.ld_d, lda=self.ld_d, ldb=self.ld_d)
             self.gemm_tn(self.dscore, self.ld_d, self.pred, D, self.d_finf, R, R, D)
-        # ---- predict loop + aggregation, reversed
-        ns, na = self.n_steps, self.n_agg
-        dh = self.tmp_f[0]       # grad w.r.t. the current hidden state (f32)
-        self.call("dpc_fill_zero", dh, dh.numel() * 4)
-        dxn = self.tmp_f[1]      # grad w.r.t. x of the GRU step that consumed relu(p_i)
-        step = ns
-        for i in reversed(range(P)):
-            # p_i = W2 relu(W1 h + b1) + b2 ; contributes to score (row-mapped) and, for i < P-1, to GRU step `step`
-            if i < P - 1:
-                step -= 1
-                self._gru_step_backward(step, dh, dxn)            # dh <- grad wrt h_{step}; dxn <- grad wrt x_step
-                t = self.tmp_f[2]
-                self.call("dpc_relu_bwd", dxn, self.X_all[step], dc, None, M * D, t, L.F32)
-                self.call("dpc_gather_rows", self.d_pred, B, P, i, SQ, D, self.tmp_f[3], t)
-            else:
-                self.call("dpc_gather_rows", self.d_pred, B, P, i, SQ, D, self.tmp_f[3], None)
-            self.call("dpc_convert", self.tmp_f[3], L.F32, self.dP2[i], dc, M * D)
-            self.gemm(self.dP2[i], self.W2T, self.tmp_f[2], M, D, D)                       # d relu(p1)
-            self.call("dpc_relu_bwd", self.tmp_f[2], self.P1_all[i], dc, None, M * D, self.dP1[i], dc)
-            self.gemm(self.dP1[i], self.W1T, dh, M, D, D, addend=dh)                       # dh += dP1 @ W1
-        for t in reversed(range(na)):
-            step -= 1
-            self._gru_step_backward(step, dh, self.d_featrelu[t])
-        assert step == 0
+        # ---- predict loop + aggregation, reversed: one launch (G_all, dP1, dP2, d_featrelu come back)
+        ns = self.n_steps
+        self.call("dpc_gru_chain_bwd", C.byref(self.gru_desc))
         # ---- weight / bias grads of the ConvGRU and predictor, batched over all steps
         Gm = self.G
         self.gemm_tn(self.G_all, 3 * D, self.X_all, D, self.dWx, ns * M, 3 * D, D)
@@ -736,20 +682,6 @@ class DPCEngine:
         self.call("dpc_pool_bn_bwd_apply", d, self.pool_arg, u.raw, dc, st[0] * st[1], st[2], st[3], C0, u.mean, u.invstd,
                   self.PRM[u.bnname + ".weight"], self.coef, self.stem_dz)
         self.stem.wgrad(self.x_s2d, self.stem_dz)
-
-    def _gru_step_backward(self, s: int, dh: torch.Tensor, dx_out: torch.Tensor):
-        """in: dh = dL/dh_{s+1} (post-dropout state).  out: dh <- dL/dh_s, dx_out <- dL/dx_s, G_all[s] filled"""
-        D, M = self.D, self.M
-        dc = L.dtype_code(self.cdtype)
-        h = self.H_all[s]
-        drop = self.drop_all[s] if self.drop_all is not None else None
-        dhprev = self.tmp_3d.view(-1)[: M * D].view(M, D)
-        self.call("dpc_gru_bwd1", dh, drop, self.U_all[s], self.O_all[s], h, dc, M, D, self.G_all[s], dhprev)
-        dhr = self.po
-        self.gemm(self.G_all[s][:, 2 * D:], self.WohT, dhr, M, D, D, lda=3 * D)
-        self.call("dpc_gru_bwd2", dhr, self.R_all[s], h, dc, M, D, self.G_all[s], dhprev)
-        self.gemm(self.G_all[s], self.WxT, dx_out, M, D, 3 * D)
-        self.gemm(self.G_all[s], self.WhurT, dh, M, D, 2 * D, lda=3 * D, addend=dhprev)
 
     # ------------------------------------------------------------------ optimizer / full step
     @property

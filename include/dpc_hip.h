@@ -151,35 +151,10 @@ int dpc_tpool_split_fwd(const void* x, int32_t dtype, int32_t B, int32_t N, int3
 int dpc_tpool_split_bwd(const void* x, const void* d_relu, const float* d_inf, int32_t dtype, int32_t B, int32_t N,
                         int32_t T, int32_t SQ, int32_t D, int32_t P, void* dx, dpc_stream_t stream);
 
-/* ---- ConvGRU cell, kernel_size 1 (backbone/convrnn.py:24-34,76-79) ------------------
- * gates1: u=sig(px_u+ph_u+bu), r=sig(px_r+ph_r+br), hr=h*r      (px [M][3D], ph [M][2D] f32 GEMM outputs)
- * gates2: o=tanh(px_o+po+bo), hn=h*(1-u)+o*u, hout=hn*drop      (drop = pre-scaled keep mask or NULL) */
-int dpc_gru_gates1(const float* px, const float* ph, const float* bias_u, const float* bias_r, const void* h,
-                   int32_t dtype, int32_t M, int32_t D, float* u, float* r, void* hr, dpc_stream_t stream);
-int dpc_gru_gates2(const float* px, const float* po, const float* bias_o, const void* h, const float* u,
-                   const float* drop, int32_t dtype, int32_t M, int32_t D, float* o, void* hout, dpc_stream_t stream);
-/* backward halves (see DESIGN.md §ConvGRU backward):
- * bwd1: dhn=dh*drop; dpo=dhn*u*(1-o^2); dpu=dhn*(o-h)*u*(1-u); dhprev=dhn*(1-u);  G[:,0:D]=dpu, G[:,2D:3D]=dpo
- * bwd2: dr=dhr*h; G[:,D:2D]=dr*r*(1-r); dhprev+=dhr*r */
-int dpc_gru_bwd1(const float* dh, const float* drop, const float* u, const float* o, const void* h, int32_t dtype,
-                 int32_t M, int32_t D, void* G, float* dhprev, dpc_stream_t stream);
-int dpc_gru_bwd2(const float* dhr, const float* r, const void* h, int32_t dtype, int32_t M, int32_t D, void* G,
-                 float* dhprev, dpc_stream_t stream);
-
-/* ---- small fused elementwise pieces of network_pred / the predict loop (model_3d.py:36-40,66-71)
- * y[rowmap(m)][d] = act(x[m][d] + bias[d]); optional second output y2 = relu(same) (dense rows).
- * rowmap(m) = (m/SQ*P + p)*SQ + m%SQ when P>0 (writes step p of pred [B][P][SQ][D]). */
-int dpc_bias_act(const float* x, const float* bias, int32_t M, int32_t D, int32_t relu, void* y, int32_t dtype_y,
-                 int32_t P, int32_t p, int32_t SQ, void* y2, int32_t dtype_y2, dpc_stream_t stream);
-/* generic elementwise helpers on f32: out = a*(mask>0) (+ b) ; colsum of [M][D] into out[D] (+=) */
-int dpc_relu_bwd(const float* dy, const void* y, int32_t dtype_y, const float* add, int64_t n, void* out,
-                 int32_t dtype_out, dpc_stream_t stream);
+/* ---- pieces around the fused ConvGRU recurrence (dpc_gru_chain_* below) -------------------
+ * colsum of [M][D] (leading dimension ld) into out[D] (+= when accumulate): bias gradients of the ConvGRU / network_pred */
 int dpc_colsum(const void* x, int32_t dtype, int32_t ld, int32_t M, int32_t D, float* out, int32_t accumulate,
                float* ws, int64_t ws_floats /* >= 64*D */, dpc_stream_t stream);
-int dpc_gather_rows(const float* src, int32_t B, int32_t P, int32_t p, int32_t SQ, int32_t D, float* dst,
-                    const float* add, dpc_stream_t stream);
-int dpc_convert(const void* in, int32_t dtype_in, void* out, int32_t dtype_out, int64_t n, dpc_stream_t stream);
-int dpc_axpy_f32(const float* x, float* y, int64_t n, dpc_stream_t stream);
 
 /* ---- contrastive loss head (dpc/main.py:178-185,213-218; utils/utils.py:38-55) -------
  * mask: closed form of dpc/model_3d.py:86-96, int8 [B][P][SQ][B][P][SQ] contiguous.
@@ -201,13 +176,46 @@ int dpc_adam_dev(float* p, const float* g, float* m, float* v, int64_t n, float 
                  float wd, const float* bias_corr_dev, float grad_scale, dpc_stream_t stream);
 /* f32 [rows][cols] window copy between two leading dimensions (ConvGRU gate-gradient scatter) */
 int dpc_copy2d_f32(const float* src, int64_t src_ld, float* dst, int64_t dst_ld, int32_t rows, int32_t cols, dpc_stream_t stream);
-/* asynchronous zero fill on the stream (hipMemsetAsync) */
-int dpc_fill_zero(void* ptr, int64_t bytes, dpc_stream_t stream);
 
 /* ---- ConvGRU dropout (nn.Dropout(p=0.1) on the carried hidden state, backbone/convrnn.py:39,59,78) ---------------
  * mask[i] = 1/(1-p) w.p. 1-p else 0: Philox4x32-10, key = seed, counter = (i/4, step_dev[0], 0, 0), word i%4,
  * keep iff (word >> 8) >= round(p * 2^24).  One launch draws the masks of all recurrence steps of one train step. */
 int dpc_dropout_mask(float* mask, int64_t n, float p, uint64_t seed, const int32_t* step_dev, dpc_stream_t stream);
+
+/* ---- the whole ConvGRU aggregate / predict recurrence in one launch, and its backward in one more --------------
+ * (dpc/model_3d.py:62-72: agg over the first N-P blocks, then P x {network_pred, agg step}; backbone/convrnn.py:24-34,76-79;
+ *  network_pred dpc/model_3d.py:36-40).  Rows m = (b, s) of the [B*SQ][D] state are independent sequences (1x1 convolutions):
+ *  a workgroup owns 32 rows for all steps.  T = compute dtype (dtype field); all buffers are caller-owned.
+ * dpc_gru_pack repacks the five f32 parameters (gate weights [D][2D] = [x half | h half], network_pred [D][D]) into the
+ *  fragment-major operand layout both kernels stream (`packed`: 16 * D * D elements of T); call it once per optimizer step.
+ * Dropout on the carried state: drop_masks != NULL -> explicit pre-scaled keep masks [n_steps][M][D]; else step_dev != NULL ->
+ *  Philox4x32-10 keyed on (seed, step_dev[0]) generated in the kernel (the bits dpc_dropout_mask writes); else none (eval). */
+typedef struct dpc_gru_chain_desc {
+    int32_t dtype, M, D, SQ, P, n_agg, n_steps, reserved;
+    float p_drop;
+    uint32_t reserved2;
+    uint64_t seed;
+    const int32_t* step_dev;
+    const float* drop_masks;
+    const void* packed;
+    const float *bias_u, *bias_r, *bias_o, *bias_1, *bias_2;
+    void* X_all;   /* [n_steps][M][D] T   in: relu'd features of the n_agg aggregation steps; out: relu(pred_i) for the others */
+    void* H_all;   /* [n_steps+1][M][D] T  [0] = h_0 (read), [s+1] = state after step s (written) */
+    void* HR_all;  /* [n_steps][M][D] T    h * r */
+    float *U_all, *R_all, *O_all;  /* [n_steps][M][D] f32 gate activations (saved for the backward) */
+    void* P1_all;  /* [P][M][D] T          relu(W1 h + b1) */
+    void* pred;    /* [B][P][SQ][D] T      predictions, rows in the score's order */
+    /* backward only */
+    const float* d_pred;  /* [B][P][SQ][D] f32   d loss / d pred */
+    void* G_all;          /* [n_steps][M][3D] T  pre-activation gradients [u | r | o] (operands of the batched weight gradients) */
+    void *dP1, *dP2;      /* [P][M][D] T         gradients at the pre-activations of network_pred */
+    float* d_x;           /* [n_agg][M][D] f32   gradient w.r.t. the aggregation inputs */
+    float* ws;            /* [2][M][D] f32       scratch of the backward kernel */
+} dpc_gru_chain_desc;
+int dpc_gru_pack(const float* w_update, const float* w_reset, const float* w_out, const float* w_pred0, const float* w_pred2,
+                 int32_t D, int32_t dtype, void* packed, dpc_stream_t stream);
+int dpc_gru_chain_fwd(const dpc_gru_chain_desc* c, dpc_stream_t stream);
+int dpc_gru_chain_bwd(const dpc_gru_chain_desc* c, dpc_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -331,116 +331,6 @@ def case_tpool_split(k: K, dtype, B, N, T, SQ, D, P, seed=7):
 
 
 # ------------------------------------------------------------------ ConvGRU cell pieces
-def case_gru_cell(k: K, dtype, M, D, seed=8):
-    """One ConvGRUCell step (convrnn.py:24-34) + dropout on the new state (:78), forward and backward,
-    assembled from the GEMM kernel and the gate kernels exactly as the engine does."""
-    g = torch.Generator().manual_seed(seed)
-    x = q(torch.randn(M, D, generator=g), dtype)
-    h = q(torch.randn(M, D, generator=g) * 0.5, dtype)
-    W = {n: q(torch.randn(D, 2 * D, generator=g) * 0.2, dtype) for n in "uro"}
-    b = {n: torch.randn(D, generator=g) * 0.1 for n in "uro"}
-    drop = (torch.rand(M, D, generator=g) > 0.1).float() / 0.9
-    xd, hd = x.double().requires_grad_(), h.double().requires_grad_()
-    Wd = {n: W[n].double().requires_grad_() for n in "uro"}
-    bd = {n: b[n].double().requires_grad_() for n in "uro"}
-    comb = torch.cat([xd, hd], 1)
-    u = torch.sigmoid(comb @ Wd["u"].t() + bd["u"])
-    r = torch.sigmoid(comb @ Wd["r"].t() + bd["r"])
-    o = torch.tanh(torch.cat([xd, hd * r], 1) @ Wd["o"].t() + bd["o"])
-    hn = (hd * (1 - u) + o * u) * drop.double()
-    dh = torch.randn(M, D, generator=g)
-    hn.backward(dh.double())
-
-    dc = L.dtype_code(dtype)
-    Wx = k.t(torch.cat([W["u"][:, :D], W["r"][:, :D], W["o"][:, :D]], 0), dtype)     # [3D][D]
-    Whur = k.t(torch.cat([W["u"][:, D:], W["r"][:, D:]], 0), dtype)                    # [2D][D]
-    Woh = k.t(W["o"][:, D:], dtype)                                                     # [D][D]
-    xk, hk = k.t(x, dtype), k.t(h, dtype)
-
-    def gemm(A, Bm, Mm, Nn, Kk, out, add=None, ldo=None):
-        d = conv_desc(dtype, torch.float32, 0, Mm, (1, 1, 1), (1, 1, 1), Kk, A.stride(0), Nn, Bm.stride(0), ldo or Nn, (1, 1, 1), (1, 1, 1), (0, 0, 0))
-        k.call("dpc_conv_igemm", C.byref(d), A, Bm, out, add, None)
-
-    px, ph, po = k.empty(M, 3 * D), k.empty(M, 2 * D), k.empty(M, D)
-    gemm(xk, Wx, M, 3 * D, D, px)
-    gemm(hk, Whur, M, 2 * D, D, ph)
-    uk, rk, ok = k.empty(M, D), k.empty(M, D), k.empty(M, D)
-    hr = k.empty(M, D, dtype=dtype)
-    k.call("dpc_gru_gates1", px, ph, k.t(b["u"]), k.t(b["r"]), hk, dc, M, D, uk, rk, hr)
-    gemm(hr, Woh, M, D, D, po)
-    hout = k.empty(M, D, dtype=dtype)
-    dropk = k.t(drop)
-    k.call("dpc_gru_gates2", px, po, k.t(b["o"]), hk, uk, dropk, dc, M, D, ok, hout)
-    k.sync()
-    t = 1e-4 if dtype == torch.float32 else 2e-2
-    assert relerr(hout, hn.detach()) < t
-    # backward
-    G = k.zeros(M, 3 * D, dtype=dtype)
-    dhprev = k.empty(M, D)
-    k.call("dpc_gru_bwd1", k.t(dh), dropk, uk, ok, hk, dc, M, D, G, dhprev)
-    WohT = k.t(W["o"][:, D:].t(), dtype)  # dhr = dpo @ Wo_h : NT GEMM against Wo_h^T [D_in][D_out]
-    dhr = k.empty(M, D)
-    gemm(G[:, 2 * D:], WohT, M, D, D, dhr)
-    k.call("dpc_gru_bwd2", dhr, rk, hk, dc, M, D, G, dhprev)
-    WxT = k.t(torch.cat([W["u"][:, :D], W["r"][:, :D], W["o"][:, :D]], 0).t(), dtype)   # [D][3D]
-    WhurT = k.t(torch.cat([W["u"][:, D:], W["r"][:, D:]], 0).t(), dtype)                 # [D][2D]
-    dx = k.empty(M, D)
-    gemm(G, WxT, M, D, 3 * D, dx)
-    gemm(G, WhurT, M, D, 2 * D, dhprev, add=dhprev)  # in-place accumulate
-    k.sync()
-    t = 5e-4 if dtype == torch.float32 else 4e-2
-    assert relerr(dx, xd.grad) < t
-    assert relerr(dhprev, hd.grad) < t
-    # weight grads: dWx = G^T x, dWh_ur = G[:, :2D]^T h, dWo_h = G[:, 2D:]^T hr ; biases = colsum(G)
-    def wgrad(dy, dy_ld, Co, X, Kk):
-        d = conv_desc(dtype, torch.float32, 0, M, (1, 1, 1), (1, 1, 1), Kk, X.stride(0), Co, Kk, Co, (1, 1, 1), (1, 1, 1), (0, 0, 0))
-        ns = C.c_int32(0)
-        k.call("dpc_conv_wgrad", C.byref(d), None, None, dy_ld, None, C.byref(ns))
-        part = k.zeros(ns.value, Co, Kk)
-        k.call("dpc_conv_wgrad", C.byref(d), X, dy, dy_ld, part, C.byref(ns))
-        out = k.zeros(Co, Kk)
-        k.call("dpc_reduce_unpack", part, ns.value, out, Co, 1, Kk, Kk, 0, 1, 0)
-        return out
-    dWx = wgrad(G, 3 * D, 3 * D, xk, D)
-    dWh = wgrad(G, 3 * D, 2 * D, hk, D)
-    dWo = wgrad(G[:, 2 * D:], 3 * D, D, hr, D)
-    db = k.empty(3 * D)
-    ws = k.empty(64 * 3 * D)
-    k.call("dpc_colsum", G, dc, 3 * D, M, 3 * D, db, 0, ws, ws.numel())
-    k.sync()
-    ref_dWx = torch.cat([Wd["u"].grad[:, :D], Wd["r"].grad[:, :D], Wd["o"].grad[:, :D]], 0)
-    ref_dWh = torch.cat([Wd["u"].grad[:, D:], Wd["r"].grad[:, D:]], 0)
-    assert relerr(dWx, ref_dWx) < t and relerr(dWh, ref_dWh) < t and relerr(dWo, Wd["o"].grad[:, D:]) < t
-    assert relerr(db, torch.cat([bd["u"].grad, bd["r"].grad, bd["o"].grad])) < t
-
-
-def case_bias_act_rows(k: K, dtype, B, P, SQ, D, seed=9):
-    g = torch.Generator().manual_seed(seed)
-    M = B * SQ
-    x = torch.randn(M, D, generator=g)
-    bias = torch.randn(D, generator=g)
-    pred = k.zeros(B, P, SQ, D, dtype=dtype)
-    y2 = k.empty(M, D, dtype=dtype)
-    p = 1 % P
-    k.call("dpc_bias_act", k.t(x), k.t(bias), M, D, 0, pred, L.dtype_code(dtype), P, p, SQ, y2, L.dtype_code(dtype))
-    k.sync()
-    ref = (x + bias).view(B, SQ, D)
-    assert relerr(pred[:, p], ref) < tol(dtype) and relerr(y2, F.relu(x + bias)) < tol(dtype)
-    if P > 1:
-        assert pred[:, (p + 1) % P].abs().max().item() == 0
-    src = torch.randn(B, P, SQ, D, generator=g)
-    add = torch.randn(M, D, generator=g)
-    dst = k.empty(M, D)
-    k.call("dpc_gather_rows", k.t(src), B, P, p, SQ, D, dst, k.t(add))
-    dy = torch.randn(M, D, generator=g)
-    out = k.empty(M, D, dtype=dtype)
-    k.call("dpc_relu_bwd", k.t(dy), y2, L.dtype_code(dtype), k.t(add), M * D, out, L.dtype_code(dtype))
-    k.sync()
-    assert relerr(dst, src[:, p].reshape(M, D) + add) < 1e-6
-    assert relerr(out, dy * (y2.float().cpu() > 0) + add) < tol(dtype)
-
-
-# ------------------------------------------------------------------ loss head / optimizer
 def case_mask(k: K, B, P, SQ):
     from oracle import dpc_oracle as O
     m = torch.empty(B, P, SQ, B, P, SQ, dtype=torch.int8, device=k.dev)
@@ -563,3 +453,170 @@ def case_adam_dev(k: K, n, seed=13):
 def pytest_approx(v):
     import pytest
     return pytest.approx(v, rel=1e-6)
+
+
+# ---------------------------------------------------------------- fused ConvGRU recurrence (csrc/gru_chain.hip)
+def _chain_setup(k: K, dtype, B, SQ, D, P, n_agg, seed):
+    g = torch.Generator().manual_seed(seed)
+    ns, M = n_agg + P - 1, B * SQ
+    w = {n: q(torch.randn(D, 2 * D, generator=g) * (1.0 / (2 * D) ** 0.5), dtype) for n in ("update", "reset", "out")}
+    w["p0"] = q(torch.randn(D, D, generator=g) * (1.0 / D ** 0.5), dtype)
+    w["p2"] = q(torch.randn(D, D, generator=g) * (1.0 / D ** 0.5), dtype)
+    b = {n: torch.randn(D, generator=g) * 0.1 for n in ("update", "reset", "out", "p0", "p2")}
+    x = q(torch.relu(torch.randn(n_agg, M, D, generator=g)), dtype)
+    d_pred = torch.randn(B, P, SQ, D, generator=g) * 0.1
+    dev = {}
+    dev["packed"] = k.empty(16 * D * D, dtype=dtype)
+    k.call("dpc_gru_pack", k.t(w["update"]), k.t(w["reset"]), k.t(w["out"]), k.t(w["p0"]), k.t(w["p2"]), D, L.dtype_code(dtype), dev["packed"])
+    dev["bias"] = {n: k.t(v) for n, v in b.items()}
+    X_all = k.zeros(ns, M, D, dtype=dtype)
+    X_all[:n_agg] = k.t(x, dtype)
+    dev.update(X_all=X_all, H_all=k.zeros(ns + 1, M, D, dtype=dtype), HR_all=k.empty(ns, M, D, dtype=dtype),
+               U_all=k.empty(ns, M, D), R_all=k.empty(ns, M, D), O_all=k.empty(ns, M, D), P1_all=k.empty(P, M, D, dtype=dtype),
+               pred=k.empty(B, P, SQ, D, dtype=dtype), d_pred=k.t(d_pred), G_all=k.empty(ns, M, 3 * D, dtype=dtype),
+               dP1=k.empty(P, M, D, dtype=dtype), dP2=k.empty(P, M, D, dtype=dtype), d_x=k.empty(n_agg, M, D), ws=k.empty(2, M, D))
+    d = L.GruChainDesc()
+    d.dtype, d.M, d.D, d.SQ, d.P, d.n_agg, d.n_steps = L.dtype_code(dtype), M, D, SQ, P, n_agg, ns
+    d.p_drop, d.seed = 0.1, 233
+    d.packed = dev["packed"].data_ptr()
+    for f, n in (("bias_u", "update"), ("bias_r", "reset"), ("bias_o", "out"), ("bias_1", "p0"), ("bias_2", "p2")):
+        setattr(d, f, dev["bias"][n].data_ptr())
+    for f in ("X_all", "H_all", "HR_all", "U_all", "R_all", "O_all", "P1_all", "pred", "d_pred", "G_all", "dP1", "dP2", "d_x", "ws"):
+        setattr(d, f, dev[f].data_ptr())
+    return d, dev, w, b, x, d_pred
+
+
+def case_gru_chain(k: K, dtype, B, SQ, D, P, n_agg, seed=21):
+    """dpc_gru_chain_fwd/_bwd with injected dropout masks against autograd over the reference's recurrence
+    (dpc/model_3d.py:62-72 restated with 1x1 convolutions as matmuls on rows m = (b, s))."""
+    d, dev, w, b, x, d_pred = _chain_setup(k, dtype, B, SQ, D, P, n_agg, seed)
+    ns, M = n_agg + P - 1, B * SQ
+    g = torch.Generator().manual_seed(seed + 1)
+    masks = (torch.rand(ns, M, D, generator=g) > 0.1).float() / 0.9
+    mdev = k.t(masks)
+    d.drop_masks = mdev.data_ptr()
+    k.call("dpc_gru_chain_fwd", C.byref(d))
+    k.call("dpc_gru_chain_bwd", C.byref(d))
+    k.sync()
+    # ---- expectation (f64 autograd; operands quantised where the kernel stores them in `dtype`)
+    W = {n: v.double().requires_grad_() for n, v in w.items()}
+    Bs = {n: v.double().requires_grad_() for n, v in b.items()}
+    xs = x.double().requires_grad_()
+    qd = (lambda t: t) if dtype == torch.float32 else (lambda t: t + (t.detach().to(dtype).double() - t.detach()))  # straight-through rounding
+
+    def cell(xi, h):
+        c = torch.cat([xi, h], 1)
+        u = torch.sigmoid(c @ W["update"].t() + Bs["update"])
+        r = torch.sigmoid(c @ W["reset"].t() + Bs["reset"])
+        o = torch.tanh(torch.cat([xi, qd(h * r)], 1) @ W["out"].t() + Bs["out"])
+        return h * (1 - u) + o * u
+
+    h = torch.zeros(M, D, dtype=torch.float64)
+    step, preds, hs = 0, [], [h]
+    for t in range(n_agg):
+        h = qd(cell(xs[t], h) * masks[step].double())
+        hs.append(h)
+        step += 1
+    for i in range(P):
+        p1 = qd(torch.relu(h @ W["p0"].t() + Bs["p0"]))
+        p2 = p1 @ W["p2"].t() + Bs["p2"]
+        preds.append(qd(p2))
+        if i < P - 1:
+            h = qd(cell(qd(torch.relu(p2)), h) * masks[step].double())
+            hs.append(h)
+            step += 1
+    pred = torch.stack(preds, 1).view(B, SQ, P, D).permute(0, 2, 1, 3)  # rows (b, s) -> [B][P][SQ][D]
+    (pred * d_pred.double()).sum().backward()
+    t_f, t_b = (2e-5, 2e-4) if dtype == torch.float32 else (3e-2, 6e-2)
+    assert relerr(dev["pred"], pred.detach()) < t_f
+    assert relerr(dev["H_all"][1:], torch.stack(hs[1:]).detach()) < t_f
+    assert relerr(dev["d_x"], xs.grad) < t_b
+    # the saved operands give the reference's weight gradients (the engine's batched GEMMs compute exactly these products)
+    G = dev["G_all"].double().cpu().view(ns * M, 3 * D)
+    Xa = dev["X_all"].double().cpu().view(ns * M, D)
+    Ha = dev["H_all"][:ns].double().cpu().view(ns * M, D)
+    HRa = dev["HR_all"].double().cpu().view(ns * M, D)
+    gW = {"update": torch.cat([G[:, :D].t() @ Xa, G[:, :D].t() @ Ha], 1), "reset": torch.cat([G[:, D:2 * D].t() @ Xa, G[:, D:2 * D].t() @ Ha], 1),
+          "out": torch.cat([G[:, 2 * D:].t() @ Xa, G[:, 2 * D:].t() @ HRa], 1)}
+    Hp = dev["H_all"][n_agg:].double().cpu().view(P * M, D)
+    gW["p0"] = dev["dP1"].double().cpu().view(P * M, D).t() @ Hp
+    gW["p2"] = dev["dP2"].double().cpu().view(P * M, D).t() @ dev["P1_all"].double().cpu().view(P * M, D)
+    for n in gW:
+        assert relerr(gW[n], W[n].grad) < t_b, n
+    gB = {"update": G[:, :D].sum(0), "reset": G[:, D:2 * D].sum(0), "out": G[:, 2 * D:].sum(0),
+          "p0": dev["dP1"].double().cpu().view(P * M, D).sum(0), "p2": dev["dP2"].double().cpu().view(P * M, D).sum(0)}
+    for n in gB:
+        assert relerr(gB[n], Bs[n].grad) < t_b, n
+
+
+def case_gru_chain_philox(k: K, dtype, B, SQ, D, P, n_agg, seed=22):
+    """train mode: masks generated in the kernel (Philox keyed on seed + device-side step) == the masks dpc_dropout_mask
+    writes for the same (seed, step), injected explicitly: bit-identical states and gradients; eval mode = no mask."""
+    ns, M = n_agg + P - 1, B * SQ
+    step = torch.tensor([3], dtype=torch.int32, device=k.dev)
+    d1, dev1, *_ = _chain_setup(k, dtype, B, SQ, D, P, n_agg, seed)
+    d1.step_dev = step.data_ptr()
+    k.call("dpc_gru_chain_fwd", C.byref(d1))
+    k.call("dpc_gru_chain_bwd", C.byref(d1))
+    d2, dev2, *_ = _chain_setup(k, dtype, B, SQ, D, P, n_agg, seed)
+    masks = k.empty(ns, M, D)
+    k.call("dpc_dropout_mask", masks, masks.numel(), 0.1, 233, step)
+    d2.drop_masks = masks.data_ptr()
+    k.call("dpc_gru_chain_fwd", C.byref(d2))
+    k.call("dpc_gru_chain_bwd", C.byref(d2))
+    k.sync()
+    for f in ("H_all", "pred", "d_x", "G_all", "dP1"):
+        assert torch.equal(dev1[f], dev2[f]), f
+    assert 0.85 < (masks > 0).float().mean().item() < 0.95
+    d3, dev3, *_ = _chain_setup(k, dtype, B, SQ, D, P, n_agg, seed)
+    k.call("dpc_gru_chain_fwd", C.byref(d3))  # eval: neither masks nor a step counter
+    k.sync()
+    assert not torch.equal(dev3["H_all"], dev1["H_all"])
+
+
+def case_gru_chain_golden(k: K, ops):
+    """The reference's own ConvGRUCell(8, 8, 1) fixture (tests/golden/ops.npz "gru::*", forward + autograd of
+    backbone/convrnn.py:24-34) through the fused recurrence kernels: one aggregation step from the fixture's non-zero
+    h, the 8 channels zero-padded to the kernel's 32-channel granularity (padded channels stay exactly 0), and an
+    identity predictor (W1 = W2 = I, b1 = +4, b2 = -4: relu is transparent for |h| < 1) so that d_pred IS d/dh'."""
+    f32 = torch.float32
+    x, h = torch.from_numpy(ops["gru::x"]), torch.from_numpy(ops["gru::h"])      # [3, 8, 3, 3]
+    Bn, Cg, ls = x.shape[0], x.shape[1], x.shape[2]
+    D, SQ, M = 32, ls * ls, Bn * ls * ls
+    rows = lambda t: t.permute(0, 2, 3, 1).reshape(M, Cg)
+    pad = lambda t: torch.cat([t, torch.zeros(t.shape[0], D - Cg)], 1)
+    d, dev, *_ = _chain_setup(k, f32, Bn, SQ, D, 1, 1, seed=1)
+    w = {}
+    for gate in ("update", "reset", "out"):
+        wg = torch.from_numpy(ops[f"gru::w::{gate}_gate.weight"]).view(Cg, 2 * Cg)
+        full = torch.zeros(D, 2 * D)
+        full[:Cg, :Cg], full[:Cg, D:D + Cg] = wg[:, :Cg], wg[:, Cg:]
+        w[gate] = full
+    eye = torch.eye(D)
+    k.call("dpc_gru_pack", k.t(w["update"]), k.t(w["reset"]), k.t(w["out"]), k.t(eye), k.t(eye), D, L.F32, dev["packed"])
+    for f, n in (("bias_u", "update"), ("bias_r", "reset"), ("bias_o", "out")):
+        bt = k.t(torch.cat([torch.from_numpy(ops[f"gru::w::{n}_gate.bias"]), torch.zeros(D - Cg)]))
+        dev["bias"][f] = bt
+        setattr(d, f, bt.data_ptr())
+    b1, b2 = k.t(torch.full((D,), 4.0)), k.t(torch.full((D,), -4.0))
+    d.bias_1, d.bias_2 = b1.data_ptr(), b2.data_ptr()
+    dev["X_all"][0] = k.t(pad(rows(x)))
+    dev["H_all"][0] = k.t(pad(rows(h)))
+    gh = torch.from_numpy(ops["gru::gh"])
+    dev["d_pred"].copy_(k.t(pad(rows(gh)).view(Bn, SQ, 1, D).permute(0, 2, 1, 3).contiguous()))
+    k.call("dpc_gru_chain_fwd", C.byref(d))
+    k.call("dpc_gru_chain_bwd", C.byref(d))
+    k.sync()
+    hn = dev["H_all"][1].cpu()
+    assert (hn[:, :Cg] - rows(torch.from_numpy(ops["gru::hn"]))).abs().max().item() < 1e-5
+    assert hn[:, Cg:].abs().max().item() == 0
+    assert (dev["pred"].cpu().view(Bn, SQ, D).reshape(M, D) - hn).abs().max().item() < 1e-5
+    assert (dev["d_x"][0].cpu()[:, :Cg] - rows(torch.from_numpy(ops["gru::gx"]))).abs().max().item() < 1e-5
+    G = dev["G_all"][0].cpu()
+    Xr, Hr, HRr = pad(rows(x)), pad(rows(h)), dev["HR_all"][0].cpu()
+    for gi, gate in enumerate(("update", "reset", "out")):
+        Gg = G[:, gi * D:gi * D + Cg]
+        gw = torch.cat([Gg.t() @ Xr[:, :Cg], Gg.t() @ (HRr if gate == "out" else Hr)[:, :Cg]], 1)
+        ref = torch.from_numpy(ops[f"gru::gw::{gate}_gate.weight"]).view(Cg, 2 * Cg)
+        assert (gw - ref).abs().max().item() < 1e-4, gate
+        assert (Gg.sum(0) - torch.from_numpy(ops[f"gru::gw::{gate}_gate.bias"])).abs().max().item() < 1e-4, gate

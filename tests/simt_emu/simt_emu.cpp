@@ -89,6 +89,19 @@ static void prepare(Fiber& f, int idx) {
     f.st = READY;
 }
 
+unsigned char* dyn_smem = nullptr;
+
+void launch_dyn(dim3 grid, dim3 block, size_t lds_bytes, const std::function<void()>& body) {
+    if (lds_bytes > 160 * 1024) {
+        std::fprintf(stderr, "simt: %zu bytes of dynamic LDS exceed the 160 KB of a gfx950 CU\n", lds_bytes);
+        std::abort();
+    }
+    std::vector<unsigned char> buf(lds_bytes + 16, 0xA5);  // poison: kernels must not rely on zeroed LDS
+    dyn_smem = (unsigned char*)(((uintptr_t)buf.data() + 15) & ~(uintptr_t)15);
+    launch(grid, block, body);
+    dyn_smem = nullptr;
+}
+
 void launch(dim3 grid, dim3 block, const std::function<void()>& body) {
     const int nthreads = (int)(block.x * block.y * block.z);
     if (nthreads <= 0 || nthreads > MAX_THREADS) {

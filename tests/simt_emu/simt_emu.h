@@ -53,6 +53,9 @@ extern Cur cur;
 void sync_block();
 void sync_wave();
 void launch(dim3 grid, dim3 block, const std::function<void()>& body);
+// dynamic LDS: one zero-initialised buffer of `lds_bytes` for the launch (workgroups run one at a time)
+extern unsigned char* dyn_smem;
+void launch_dyn(dim3 grid, dim3 block, size_t lds_bytes, const std::function<void()>& body);
 }  // namespace simt
 
 #define threadIdx (simt::cur.tid)

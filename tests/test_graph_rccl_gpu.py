@@ -36,9 +36,10 @@ def test_graph_replay_equals_eager(dtype):
     assert torch.equal(a.flat_p, b.flat_p)  # deterministic kernels, same dropout stream (seed, step)
     assert torch.equal(ra, rb)
     # dropout masks change from step to step inside the graph (keyed on the device-side counter)
-    m5 = b.drop_buf.clone()
+    m5 = b.dropout_masks_of_step()
     replay()
-    assert not torch.equal(m5, b.drop_buf) and abs(b.drop_buf.ne(0).float().mean().item() - 0.9) < 0.01
+    m6 = b.dropout_masks_of_step()
+    assert not torch.equal(m5, m6) and abs(m6.ne(0).float().mean().item() - 0.9) < 0.01
     # a refilled input buffer is picked up by the replay
     x.copy_(torch.randn(x.shape, device=DEV, generator=torch.Generator(DEV).manual_seed(2)))
     r7 = replay().clone()

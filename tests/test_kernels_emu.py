@@ -109,17 +109,6 @@ def test_tpool_split(k, dtype):
     kc.case_tpool_split(k, dtype, 3, 5, 1, 9, 16, 2)
 
 
-@pytest.mark.parametrize("dtype", [F32, BF16])
-def test_gru_cell(k, dtype):
-    kc.case_gru_cell(k, dtype, 36, 32)
-
-
-@pytest.mark.parametrize("dtype", [F32, BF16])
-def test_bias_act_rows(k, dtype):
-    kc.case_bias_act_rows(k, dtype, 3, 3, 4, 16)
-    kc.case_bias_act_rows(k, dtype, 2, 1, 9, 8)
-
-
 @pytest.mark.parametrize("bps", [(4, 3, 16), (2, 1, 4), (3, 5, 9)])
 def test_mask(k, bps):
     kc.case_mask(k, *bps)
@@ -158,3 +147,20 @@ def test_dropout_mask(k):
 
 def test_adam_dev(k):
     kc.case_adam_dev(k, 1027)
+
+
+@pytest.mark.parametrize("dtype", [F32, BF16])
+@pytest.mark.parametrize("shape", [(3, 16, 64, 3, 3), (2, 9, 32, 2, 2), (3, 4, 160, 3, 2)])
+def test_gru_chain(k, dtype, shape):
+    kc.case_gru_chain(k, dtype, *shape)  # 48 rows: one full and one ragged row tile; 64/160 channels: one / two tiles per wave
+
+
+@pytest.mark.parametrize("dtype", [F32, BF16])
+def test_gru_chain_philox(k, dtype):
+    kc.case_gru_chain_philox(k, dtype, 3, 16, 64, 2, 2)
+
+
+def test_gru_chain_reference_fixture(k, golden_dir):
+    import os
+    import numpy as np
+    kc.case_gru_chain_golden(k, np.load(os.path.join(golden_dir, "ops.npz")))

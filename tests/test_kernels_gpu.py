@@ -98,17 +98,6 @@ def test_tpool_split(k, dtype):
     kc.case_tpool_split(k, dtype, 3, 8, 2, 49, 256, 5)
 
 
-@pytest.mark.parametrize("dtype", [F32, BF16])
-def test_gru_cell(k, dtype):
-    kc.case_gru_cell(k, dtype, 512, 256)
-    kc.case_gru_cell(k, dtype, 36, 32)
-
-
-@pytest.mark.parametrize("dtype", [F32, BF16])
-def test_bias_act_rows(k, dtype):
-    kc.case_bias_act_rows(k, dtype, 8, 3, 16, 256)
-
-
 @pytest.mark.parametrize("bps", [(4, 3, 16), (2, 1, 4), (3, 5, 49), (16, 3, 16)])
 def test_mask(k, bps):
     kc.case_mask(k, *bps)
@@ -139,3 +128,20 @@ def test_dropout_mask(k):
 def test_adam_dev(k):
     kc.case_adam_dev(k, 1027)
     kc.case_adam_dev(k, 14583104)
+
+
+@pytest.mark.parametrize("dtype", [F32, BF16])
+@pytest.mark.parametrize("shape", [(3, 16, 256, 3, 5), (2, 49, 256, 5, 3), (4, 4, 32, 3, 5), (40, 16, 256, 3, 5)])
+def test_gru_chain(k, dtype, shape):
+    kc.case_gru_chain(k, dtype, *shape)
+
+
+@pytest.mark.parametrize("dtype", [F32, BF16])
+def test_gru_chain_philox(k, dtype):
+    kc.case_gru_chain_philox(k, dtype, 3, 16, 256, 3, 5)
+
+
+def test_gru_chain_reference_fixture(k, golden_dir):
+    import os
+    import numpy as np
+    kc.case_gru_chain_golden(k, np.load(os.path.join(golden_dir, "ops.npz")))
