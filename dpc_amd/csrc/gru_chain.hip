@@ -657,6 +657,17 @@ int chain_params(const dpc_gru_chain_desc* c, ChainP* p, bool backward) {
     return DPC_OK;
 }
 
+// more than 64 KB of dynamic LDS has to be granted per kernel function (once)
+template <class K> int allow_lds(K kernel, size_t bytes) {
+#ifndef DPC_SIMT_EMU
+    if (bytes > 160 * 1024) return DPC_ERR_UNSUPPORTED;
+    if (hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess) return DPC_ERR_LAUNCH;
+#else
+    (void)kernel; (void)bytes;
+#endif
+    return DPC_OK;
+}
+
 size_t chain_lds(const dpc_gru_chain_desc* c) {
     const int esz = c->dtype == DPC_BF16 ? 2 : 4;
     const size_t tile = (size_t)((c->D * esz + 127) / 128) * CHUNK;
@@ -693,8 +704,10 @@ extern "C" int dpc_gru_chain_fwd(const dpc_gru_chain_desc* c, dpc_stream_t strea
     const unsigned grid = (unsigned)((c->M + TM - 1) / TM);
     const size_t lds = chain_lds(c);
     if (c->dtype == DPC_F32) {
+        if (int e = allow_lds(gru_chain_fwd_kernel<float>, lds)) return e;
         DPC_LAUNCH_DYN((gru_chain_fwd_kernel<float>), dim3(grid), dim3(256), lds, stream, p);
     } else if (c->dtype == DPC_BF16) {
+        if (int e = allow_lds(gru_chain_fwd_kernel<bf16_t>, lds)) return e;
         DPC_LAUNCH_DYN((gru_chain_fwd_kernel<bf16_t>), dim3(grid), dim3(256), lds, stream, p);
     } else {
         return DPC_ERR_ARG;
@@ -710,8 +723,10 @@ extern "C" int dpc_gru_chain_bwd(const dpc_gru_chain_desc* c, dpc_stream_t strea
     const unsigned grid = (unsigned)((c->M + TM - 1) / TM);
     const size_t lds = chain_lds(c);
     if (c->dtype == DPC_F32) {
+        if (int e = allow_lds(gru_chain_bwd_kernel<float>, lds)) return e;
         DPC_LAUNCH_DYN((gru_chain_bwd_kernel<float>), dim3(grid), dim3(256), lds, stream, p);
     } else if (c->dtype == DPC_BF16) {
+        if (int e = allow_lds(gru_chain_bwd_kernel<bf16_t>, lds)) return e;
         DPC_LAUNCH_DYN((gru_chain_bwd_kernel<bf16_t>), dim3(grid), dim3(256), lds, stream, p);
     } else {
         return DPC_ERR_ARG;
