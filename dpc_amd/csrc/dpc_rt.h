@@ -28,6 +28,15 @@
 #define DPC_NOUNROLL _Pragma("unroll 1")
 #endif
 
+// fast transcendental forms for gate math (gfx950: v_exp_f32 / v_rcp_f32, ~1 ulp); exact libm in the host simulator
+#ifdef DPC_SIMT_EMU
+static inline float fast_exp(float x) { return std::exp(x); }
+static inline float fast_rcp(float x) { return 1.f / x; }
+#else
+__device__ __forceinline__ float fast_exp(float x) { return __expf(x); }
+__device__ __forceinline__ float fast_rcp(float x) { return __frcp_rn(x); }
+#endif
+
 #define DPC_OK 0
 #define DPC_ERR_ARG (-1)
 #define DPC_ERR_LAUNCH (-2)

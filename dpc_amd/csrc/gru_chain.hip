@@ -29,7 +29,8 @@ __device__ __host__ __forceinline__ long long mat_off(int i, int D) {  // elemen
     return i == 0 ? 0 : (i == 1 ? 2 * DD : 4 * DD + (long long)(i - 2) * DD);
 }
 
-__device__ __forceinline__ float sigm(float x) { return 1.f / (1.f + expf(-x)); }
+__device__ __forceinline__ float sigm(float x) { return fast_rcp(1.f + fast_exp(-x)); }
+__device__ __forceinline__ float tanh_fast(float x) { return 1.f - 2.f * fast_rcp(1.f + fast_exp(2.f * x)); }  // +-1 at +-inf
 
 // ---------------------------------------------------------------- weight packing (fragment-major)
 // packed[mat][tile n/32][ks][lane = kg*32 + j] = 16 bytes = B[n = tile*32 + j][k = (ks*2 + kg)*E .. +E)
@@ -354,7 +355,7 @@ __device__ __forceinline__ void gru_chain_fwd_body(const ChainP& p, unsigned cha
             const f32x4 h = ldT4<T>(tile_ptr<T>(th, row, col));
             f32x4 o, hn = {0.f, 0.f, 0.f, 0.f};
             DPC_UNROLL
-            for (int e = 0; e < 4; ++e) o[e] = tanhf(pre[e] + b[e]);
+            for (int e = 0; e < 4; ++e) o[e] = tanh_fast(pre[e] + b[e]);
             if (grow < M) {
                 const f32x4 u = ld4(p.U_all + (long long)s * MD + (long long)grow * D + col), k = mask4(p, s, grow, col);
                 DPC_UNROLL

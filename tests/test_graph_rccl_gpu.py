@@ -58,10 +58,16 @@ from dpc_amd.engine import DPCEngine
 from dpc_amd.parallel import make_allreduce, shard_of
 from oracle import dpc_oracle as O
 B = 2
-eng = DPCEngine("resnet18", 64, 8, 5, 3, B, dev, torch.float32, seed=233 + rank)
-eng.load_params(O.make_params_pcg("resnet18"))
 xg = O.make_input_pcg(B * world, 8, 5, 64)
 x = xg[shard_of(B * world, world, rank)].contiguous().to(dev)
+
+def engine():
+    e = DPCEngine("resnet18", 64, 8, 5, 3, B, dev, torch.float32, seed=233 + rank)
+    e.load_params(O.make_params_pcg("resnet18"))
+    return e
+
+# (1) one step by hand, exactly as train_step does the two-bucket exchange; the local gradient is kept for the checks
+eng = engine()
 ones = torch.ones(eng.n_steps, eng.M, eng.D, device=dev)
 ar = make_allreduce(dist, world, force=True)
 eng.forward(x, train=True, dropout_masks=ones)
@@ -73,13 +79,27 @@ def on_tail(tail):
 eng.backward(on_tail_ready=on_tail)
 local = torch.cat([eng.flat_g[:eng.grad_split].clone(), local_tail[0]])
 ar.finish(eng.flat_g[:eng.grad_split])
+avg = eng.flat_g.clone()
 eng.adam_step()
-# then the captured three-graph replay of the same exchange (graph A | all-reduce tail | graph B | all-reduce head | Adam)
-replay = eng.capture_train_step(x, allreduce=ar, warmup=1)
-r2 = replay().clone()
-torch.cuda.synchronize()
-torch.save({{"local": local.cpu(), "avg": None, "params": eng.flat_p.cpu(), "res": res.cpu(), "r2": r2.cpu(),
-            "ngraphs": len(replay.graphs), "steps": eng.step_count}}, os.path.join({out!r}, f"rank{{rank}}.pt"))
+# (2) the same 4 train steps (Philox dropout on) launched three ways must leave bit-identical parameters:
+#     A eager + exchange | C three hipGraphs cut at the exchange points | (world 1 only) D one hipGraph, no exchange
+outs = {{}}
+for tag in ("A", "C") + (("D",) if world == 1 else ()):
+    e = engine()
+    a = make_allreduce(dist, world, force=True) if tag != "D" else None
+    if tag == "A":
+        for _ in range(4):
+            r_ = e.train_step(x, allreduce=a).clone()
+        ng = 0
+    else:
+        rp = e.capture_train_step(x, allreduce=a, warmup=2)
+        for _ in range(2):
+            r_ = rp().clone()
+        ng = len(rp.graphs)
+    torch.cuda.synchronize()
+    outs[tag] = dict(params=e.flat_p.cpu(), res=r_.cpu(), ngraphs=ng, steps=e.step_count)
+torch.save({{"local": local.cpu(), "avg": avg.cpu(), "params": eng.flat_p.cpu(), "res": res.cpu(), "modes": outs}},
+           os.path.join({out!r}, f"rank{{rank}}.pt"))
 dist.barrier()
 dist.destroy_process_group()
 """
@@ -96,20 +116,35 @@ def _run_ranks(world, tmp_path):
     return [torch.load(tmp_path / f"rank{i}.pt") for i in range(world)]
 
 
+def _check_modes(r):
+    m = r["modes"]
+    assert m["C"]["ngraphs"] == 3 and m["A"]["steps"] == m["C"]["steps"] == 4
+    assert torch.equal(m["A"]["params"], m["C"]["params"]) and torch.equal(m["A"]["res"], m["C"]["res"])
+    assert torch.isfinite(m["C"]["res"]).all()
+
+
 def test_rccl_single_rank_exchange_and_graph_cut(tmp_path):
-    """the RCCL path with world_size 1 (all a 1-GPU box can run): two-bucket exchange + three-graph replay"""
+    """the RCCL path with world_size 1 (all a 1-GPU box can run): eager two-bucket exchange == three-graph replay cut at
+    the exchange points == one graph without exchange, bit for bit"""
     (r,) = _run_ranks(1, tmp_path)
-    assert r["ngraphs"] == 3 and r["steps"] == 3 and torch.isfinite(r["r2"]).all()
-    assert r["r2"][0].item() < r["res"][0].item() + 0.5
+    _check_modes(r)
+    m = r["modes"]
+    assert m["D"]["ngraphs"] == 1 and torch.equal(m["A"]["params"], m["D"]["params"])
+    assert torch.equal(r["avg"], r["local"])  # averaging over one rank is the identity
 
 
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two MI355X on the node")
 def test_rccl_two_rank_data_parallel(tmp_path):
-    """as tests/test_parallel_gloo.py, over RCCL/xGMI: identical parameters on both ranks after the averaged step, local
-    gradients differ (per-rank shards, negatives and BN statistics, dpc/main.py:180,211-213)"""
+    """as tests/test_parallel_gloo.py, over RCCL/xGMI: averaged gradient == mean of the local ones, identical parameters
+    on both ranks after the step (eager and graph-replayed), local gradients differ (per-rank shards, negatives and BN
+    statistics, dpc/main.py:180,211-213)"""
     r = _run_ranks(2, tmp_path)
-    assert torch.equal(r[0]["params"], r[1]["params"])
+    assert torch.equal(r[0]["params"], r[1]["params"]) and torch.equal(r[0]["avg"], r[1]["avg"])
     assert not torch.equal(r[0]["local"], r[1]["local"])
+    assert torch.allclose(r[0]["avg"], 0.5 * (r[0]["local"] + r[1]["local"]), rtol=0, atol=1e-6)
+    for i in range(2):
+        _check_modes(r[i])
+    assert torch.equal(r[0]["modes"]["C"]["params"], r[1]["modes"]["C"]["params"])
     p = O.make_params_pcg("resnet18")
     xg = O.make_input_pcg(4, 8, 5, 64)
     for i in range(2):
