@@ -83,6 +83,10 @@ _SIGS = {
     "dpc_gru_pack": [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp],
     "dpc_gru_chain_fwd": [C.POINTER(GruChainDesc), _vp],
     "dpc_gru_chain_bwd": [C.POINTER(GruChainDesc), _vp],
+    "dpc_score_ws_floats": [_i32, _i32, C.POINTER(_i64), C.POINTER(_i64)],
+    "dpc_score_fwd": [_vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp],
+    "dpc_score_bwd": [_vp, _vp, _vp, _i32, _i32, _i32, _vp, _i32, _vp, _vp],
+    "dpc_ce_finalize": [_vp, _i32, _vp, _vp],
     "dpc_adam": [_vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _f32, _f32, _f32, _f32, _vp],
 }
 

@@ -130,6 +130,15 @@ extern "C" int dpc_ce_topk(const float* score, int32_t rows, int32_t cols, int32
     return dpc_launch_status();
 }
 
+// mean loss + top-1/3/5 from per-row (loss term, rank) pairs: the last stage of dpc_ce_topk, exposed for the fused score
+// path (csrc/score_fused.hip), whose forward produces the pairs without a score matrix
+extern "C" int dpc_ce_finalize(const float* row_ws, int32_t rows, float* result, dpc_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!row_ws || rows <= 0 || !result) return DPC_ERR_ARG;
+    DPC_LAUNCH(ce_finalize_kernel, dim3(1), dim3(256), stream, row_ws, rows, result);
+    return dpc_launch_status();
+}
+
 // Adam, weight decay folded into the gradient (torch.optim.Adam semantics), 16-byte accesses
 __global__ void adam_kernel(float* p, const float* g, float* m, float* v, long long n4, long long n, float lr, float b1,
                             float b2, float eps, float wd, float bc1, float bc2, float gscale) {

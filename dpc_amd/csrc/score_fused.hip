@@ -1,0 +1,378 @@
+// score_fused.hip -- the dense contrastive score of DPC_RNN.forward (dpc/model_3d.py:79-84) fused with the
+// CrossEntropyLoss / top-1/3/5 of the train loop (dpc/main.py:178-185,213-218, utils/utils.py:38-55) and with its
+// own backward, flash-attention style: the [R x R] score (R = B*P*SQ: 6 144 at cfg2, 15 680 at cfg5 = 983 MB in
+// f32) and its gradient are NEVER written to HBM in the train step.
+//
+//   forward   S = pred @ finf^T tile by tile on the matrix cores; per row the running (max, sum-exp, #{s > s_target})
+//             stay in registers; a finalize pass turns them into the log-sum-exp, the loss and the three accuracies.
+//   backward  d_pred = dS @ finf and d_finf = dS^T @ pred with dS = (softmax(S) - onehot)/R: every S tile is recomputed
+//             from its operands (K = 256: cheap), turned into dS in registers, rounded to bf16 through a wave-private
+//             LDS tile and multiplied straight into the output accumulators.  One kernel serves both products with the
+//             roles of the operands swapped (the owner rows accumulate, the other side is streamed).
+//
+// Why: with an f32 score in HBM the forward contraction is output-write bound (AI = 128 FLOP/B: 250 TFLOP/s in round 1,
+// 10 % of the bf16 MFMA peak) and the loss re-reads it three times.  Throughput (bf16) mode
+// only: the f32 parity mode and the module boundary (which RETURNS the score) keep the materialised path.
+//
+// Tiling: a workgroup = 4 waves owns 128 rows (32 per wave, operand fragments held in registers for all of K) and a
+// contiguous range of 64-column tiles of the other operand, which arrive in LDS by LDS-DMA, double-buffered; the grid is
+// (row blocks) x (column splits) so that >= 240 workgroups are resident for 48 row blocks, and the per-split partial
+// statistics / f32 output slabs are merged by small follow-up kernels.
+#include "dpc_rt.h"
+#include "../../include/dpc_hip.h"
+
+namespace {
+
+constexpr float L2E = 1.4426950408889634f;
+constexpr float NEG_BIG = -3.0e38f;
+constexpr int BM = 128, BN = 64;
+
+struct ScoreP {
+    const bf16_t* own;    // [R][D] rows that stay in registers
+    const bf16_t* oth;    // [R][D] rows streamed through LDS
+    const bf16_t* othT;   // [D][ldT] the same operand transposed (backward only)
+    int R, D, ldT;
+    int ntiles, tiles_per_split, nsplit;
+    // forward
+    float* diag;          // [R]     target logit s[i][i]
+    float* partial;       // [nsplit][R][4]  (max, sum-exp, rank, -)
+    float* score;         // optional [R][R] f32 (NULL in the train step)
+    // backward
+    const float* lse2;    // [R] (lse + ln R) * log2(e)
+    int lse_by_owner;     // 1: indexed by the owner row (d_pred), 0: by the streamed column (d_finf)
+    float inv_rows;
+    float* out_part;      // [nsplit][R][D] f32
+};
+
+__device__ __forceinline__ int crow(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
+
+// rows [row0, row0 + nrows) x K of a row-major [R][ld] bf16 matrix -> LDS as 128-byte rows, chunk by chunk:
+// tile[chunk c][row][8 swizzled units].  One LDS-DMA instruction of a wave fills 8 rows of one chunk; rows / columns
+// outside the matrix read 16 zero bytes.
+__device__ __forceinline__ void dma_rows(unsigned char* tile, const bf16_t* src, long long ld, int row0, int nrows, int row_limit, int col0,
+                                         int ncols, int col_limit, int wave, int lane) {
+    const char* const zero = (const char*)dpc_zero16;
+    const int chunks = (ncols * 2 + 127) / 128;
+    const int groups = nrows / 8;
+    for (int g = wave; g < chunks * groups; g += 4) {
+        const int c = g / groups, rg = g - c * groups;
+        const int row = rg * 8 + (lane >> 3);
+        const int u = (lane & 7) ^ lds_swz1(row);
+        const int col = col0 + (c * 8 + u) * 8;
+        const bool ok = (row0 + row < row_limit) && (col < col_limit) && ((c * 8 + u) * 8 < ncols);
+        const char* a = (const char*)(src + (long long)(row0 + row) * ld + col);
+        glds16(ok ? a : zero, tile + c * (nrows * 128) + rg * 8 * 128, lane);
+    }
+}
+
+template <int KS>
+__device__ __forceinline__ void load_own(u32x4 (&own)[KS], const ScoreP& p, int r0, int lane) {
+    const int row = r0 + (lane & 31), kg = lane >> 5;
+    DPC_UNROLL
+    for (int ks = 0; ks < KS; ++ks) {
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if (row < p.R) v = *(const u32x4*)(p.own + (long long)row * p.D + (ks * 2 + kg) * 8);
+        own[ks] = v;
+    }
+}
+
+// S[32 rows of the wave][64 columns of the tile] from the register-resident own fragments and the LDS tile
+template <int KS>
+__device__ __forceinline__ void s_tile(f32x16 (&s)[2], const u32x4 (&own)[KS], const unsigned char* tile, int lane) {
+    const int j = lane & 31, kg = lane >> 5;
+    DPC_UNROLL
+    for (int t = 0; t < 2; ++t)
+        DPC_UNROLL
+        for (int r = 0; r < 16; ++r) s[t][r] = 0.f;
+    DPC_UNROLL
+    for (int ks = 0; ks < KS; ++ks) {
+        const int unit = ks * 2 + kg;
+        DPC_UNROLL
+        for (int t = 0; t < 2; ++t) {
+            const u32x4 b = *(const u32x4*)(tile + (unit >> 3) * (BN * 128) + lds_unit_off(t * 32 + j, unit & 7));
+            s[t] = mfma_32x32x16_bf16(own[ks], b, s[t]);
+        }
+    }
+}
+
+// ---------------------------------------------------------------- forward
+template <int KS>
+__global__ __launch_bounds__(256) void score_fwd_kernel(ScoreP p) {
+    DPC_DYN_SMEM(smem);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int rb = blockIdx.x, split = blockIdx.y;
+    const int r0 = rb * BM + wave * 32;
+    const int tile_bytes = ((KS * 32 + 127) / 128) * BN * 128;  // 64 rows x D*2 bytes in 128-byte chunks
+    u32x4 own[KS];
+    load_own<KS>(own, p, r0, lane);
+    // target logit of the wave's rows: dot(pred[i], finf[i]); lane (i, kg) holds half of row i's products
+    float dg[16];
+    {
+        const int row = r0 + (lane & 31), kg = lane >> 5;
+        float acc = 0.f;
+        if (row < p.R) {
+            DPC_UNROLL
+            for (int ks = 0; ks < KS; ++ks) {
+                const u32x4 f = *(const u32x4*)(p.oth + (long long)row * p.D + (ks * 2 + kg) * 8);
+                DPC_UNROLL
+                for (int e = 0; e < 8; ++e) acc += unit_get<bf16_t>(own[ks], e) * unit_get<bf16_t>(f, e);
+            }
+        }
+        acc += __shfl_xor(acc, 32);
+        if (split == 0 && lane < 32 && row < p.R) p.diag[row] = acc;
+        DPC_UNROLL
+        for (int r = 0; r < 16; ++r) dg[r] = __shfl(acc, crow(r, lane));
+    }
+    float m[16], l[16], rk[16];
+    DPC_UNROLL
+    for (int r = 0; r < 16; ++r) { m[r] = NEG_BIG; l[r] = 0.f; rk[r] = 0.f; }
+    const int jt0 = split * p.tiles_per_split;
+    int jt1 = jt0 + p.tiles_per_split;
+    if (jt1 > p.ntiles) jt1 = p.ntiles;
+    if (jt0 < jt1) dma_rows(smem, p.oth, p.D, jt0 * BN, BN, p.R, 0, p.D, p.D, wave, lane);
+    for (int jt = jt0; jt < jt1; ++jt) {
+        const int buf = (jt - jt0) & 1;
+        wait_vmcnt<0>();
+        __syncthreads();  // tile jt has landed; every wave is done with the buffer the next DMA overwrites
+        if (jt + 1 < jt1) dma_rows(smem + (buf ^ 1) * tile_bytes, p.oth, p.D, (jt + 1) * BN, BN, p.R, 0, p.D, p.D, wave, lane);
+        f32x16 s[2];
+        s_tile<KS>(s, own, smem + buf * tile_bytes, lane);
+        const int col0 = jt * BN;
+        const bool on_diag = col0 < r0 + 32 && col0 + BN > r0;  // wave-uniform: the tile contains target columns
+        DPC_UNROLL
+        for (int t = 0; t < 2; ++t) {
+            const int c = col0 + t * 32 + (lane & 31);
+            const bool cv = c < p.R;
+            if (p.score) {
+                DPC_UNROLL
+                for (int r = 0; r < 16; ++r) {
+                    const int grow = r0 + crow(r, lane);
+                    if (cv && grow < p.R) p.score[(long long)grow * p.R + c] = s[t][r];
+                }
+            }
+            DPC_UNROLL
+            for (int r = 0; r < 16; ++r) {
+                const float v = cv ? s[t][r] : NEG_BIG;
+                // rank: logits above the target's; the target column itself never counts (its recomputed value may differ
+                // from dg in the last bit)
+                bool above = v > dg[r];
+                if (on_diag) above = above && (c != r0 + crow(r, lane));
+                rk[r] += above ? 1.f : 0.f;
+                const float mx = v > m[r] ? v : m[r];
+                l[r] = l[r] * exp2f((m[r] - mx) * L2E) + exp2f((v - mx) * L2E);
+                m[r] = mx;
+            }
+        }
+    }
+    // merge the 32 lanes that share each row (xor butterflies stay inside a half-wave)
+    DPC_UNROLL
+    for (int r = 0; r < 16; ++r) {
+        DPC_UNROLL
+        for (int msk = 1; msk <= 16; msk <<= 1) {
+            const float om = __shfl_xor(m[r], msk), ol = __shfl_xor(l[r], msk), ork = __shfl_xor(rk[r], msk);
+            const float mx = om > m[r] ? om : m[r];
+            l[r] = l[r] * exp2f((m[r] - mx) * L2E) + ol * exp2f((om - mx) * L2E);
+            m[r] = mx;
+            rk[r] += ork;
+        }
+        const int grow = r0 + crow(r, lane);
+        if ((lane & 31) == 0 && grow < p.R) {
+            float* o = p.partial + ((long long)split * p.R + grow) * 4;
+            o[0] = m[r]; o[1] = l[r]; o[2] = rk[r]; o[3] = 0.f;
+        }
+    }
+}
+
+// per row: merge the column splits -> lse, loss term, rank; lse2 for the backward
+__global__ void score_finalize_kernel(const float* partial, const float* diag, int R, int nsplit, float* row_ws, float* lse2) {
+    const int row = blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= R) return;
+    float M = NEG_BIG;
+    for (int s = 0; s < nsplit; ++s) {
+        const float v = partial[((long long)s * R + row) * 4];
+        M = v > M ? v : M;
+    }
+    float L = 0.f, rk = 0.f;
+    for (int s = 0; s < nsplit; ++s) {
+        const float* q = partial + ((long long)s * R + row) * 4;
+        L += q[1] * exp2f((q[0] - M) * L2E);
+        rk += q[2];
+    }
+    const float lse = M + logf(L);
+    row_ws[2 * row + 0] = lse - diag[row];
+    row_ws[2 * row + 1] = rk;
+    lse2[row] = (lse + logf((float)R)) * L2E;
+}
+
+// ---------------------------------------------------------------- backward
+// out[owner row][:] = sum over streamed columns c of dS(owner, c) * oth[c][:]      (dS in bf16, f32 accumulate)
+template <int KS>
+__global__ __launch_bounds__(256) void score_bwd_kernel(ScoreP p) {
+    DPC_DYN_SMEM(smem);
+    constexpr int NTD = KS / 2;  // 32-column tiles of D
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int rb = blockIdx.x, split = blockIdx.y;
+    const int r0 = rb * BM + wave * 32;
+    const int tile_bytes = ((KS * 32 + 127) / 128) * BN * 128;   // oth tile: 64 rows x D*2 bytes in 128-byte chunks
+    const int tileT_bytes = KS * 16 * 128; // othT tile: D rows x 128 bytes
+    const int stage_bytes = tile_bytes + tileT_bytes;
+    unsigned char* ptile = smem + 2 * stage_bytes + wave * (32 * 128);  // wave-private dS tile: 32 rows x 64 bf16
+    u32x4 own[KS];
+    load_own<KS>(own, p, r0, lane);
+    f32x16 out[NTD];
+    DPC_UNROLL
+    for (int n = 0; n < NTD; ++n)
+        DPC_UNROLL
+        for (int r = 0; r < 16; ++r) out[n][r] = 0.f;
+    float lo[16];
+    DPC_UNROLL
+    for (int r = 0; r < 16; ++r) {
+        const int grow = r0 + crow(r, lane);
+        lo[r] = (p.lse_by_owner && grow < p.R) ? p.lse2[grow] : 0.f;
+    }
+    const int jt0 = split * p.tiles_per_split;
+    int jt1 = jt0 + p.tiles_per_split;
+    if (jt1 > p.ntiles) jt1 = p.ntiles;
+    if (jt0 < jt1) {
+        dma_rows(smem, p.oth, p.D, jt0 * BN, BN, p.R, 0, p.D, p.D, wave, lane);
+        dma_rows(smem + tile_bytes, p.othT, p.ldT, 0, KS * 16, KS * 16, jt0 * BN, BN, p.ldT, wave, lane);
+    }
+    for (int jt = jt0; jt < jt1; ++jt) {
+        const int buf = (jt - jt0) & 1;
+        wait_vmcnt<0>();
+        __syncthreads();
+        if (jt + 1 < jt1) {
+            unsigned char* nb = smem + (buf ^ 1) * stage_bytes;
+            dma_rows(nb, p.oth, p.D, (jt + 1) * BN, BN, p.R, 0, p.D, p.D, wave, lane);
+            dma_rows(nb + tile_bytes, p.othT, p.ldT, 0, KS * 16, KS * 16, (jt + 1) * BN, BN, p.ldT, wave, lane);
+        }
+        const unsigned char* tile = smem + buf * stage_bytes;
+        const unsigned char* tileT = tile + tile_bytes;
+        f32x16 s[2];
+        s_tile<KS>(s, own, tile, lane);
+        const int col0 = jt * BN;
+        const bool on_diag = col0 < r0 + 32 && col0 + BN > r0;
+        DPC_UNROLL
+        for (int t = 0; t < 2; ++t) {
+            const int cl = t * 32 + (lane & 31), c = col0 + cl;
+            const bool cv = c < p.R;
+            const float lc = (!p.lse_by_owner && cv) ? p.lse2[c] : 0.f;
+            DPC_UNROLL
+            for (int r = 0; r < 16; ++r) {
+                const int row = crow(r, lane);
+                float g = cv ? exp2f(s[t][r] * L2E - (p.lse_by_owner ? lo[r] : lc)) : 0.f;
+                if (on_diag && c == r0 + row) g -= p.inv_rows;
+                if (r0 + row >= p.R) g = 0.f;
+                *(bf16_t*)(ptile + lds_unit_off(row, cl >> 3) + (cl & 7) * 2) = f32_to_bf16(g);
+            }
+        }
+        wave_lds_fence();
+        {
+            const int i = lane & 31, kg = lane >> 5;
+            DPC_UNROLL
+            for (int k2 = 0; k2 < 4; ++k2) {
+                const int unit = k2 * 2 + kg;
+                const u32x4 a = *(const u32x4*)(ptile + lds_unit_off(i, unit));
+                DPC_UNROLL
+                for (int n = 0; n < NTD; ++n) {
+                    const u32x4 b = *(const u32x4*)(tileT + lds_unit_off(n * 32 + i, unit));
+                    out[n] = mfma_32x32x16_bf16(a, b, out[n]);
+                }
+            }
+        }
+        wave_lds_fence();  // the wave's next dS stores must not pass these reads
+    }
+    float* o = p.out_part + (long long)split * p.R * p.D;
+    DPC_UNROLL
+    for (int n = 0; n < NTD; ++n)
+        DPC_UNROLL
+        for (int r = 0; r < 16; ++r) {
+            const int grow = r0 + crow(r, lane);
+            if (grow < p.R) o[(long long)grow * p.D + n * 32 + (lane & 31)] = out[n][r];
+        }
+}
+
+template <class K> int allow_lds(K kernel, size_t bytes) {
+#ifndef DPC_SIMT_EMU
+    if (bytes > 160 * 1024) return DPC_ERR_UNSUPPORTED;
+    if (hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess) return DPC_ERR_LAUNCH;
+#else
+    (void)kernel; (void)bytes;
+#endif
+    return DPC_OK;
+}
+
+// column splits so that (row blocks x splits) fills the chip, each split keeping at least 4 tiles
+void plan_splits(int R, int* ntiles, int* tps, int* nsplit) {
+    const int nrb = (R + BM - 1) / BM;
+    *ntiles = (R + BN - 1) / BN;
+    int s = (256 + nrb - 1) / nrb;
+    if (s < 1) s = 1;
+    const int max_s = *ntiles / 4 > 0 ? *ntiles / 4 : 1;
+    if (s > max_s) s = max_s;
+    if (s > 16) s = 16;
+    *tps = (*ntiles + s - 1) / s;
+    *nsplit = (*ntiles + *tps - 1) / *tps;
+}
+
+}  // namespace
+
+// workspace query: floats needed for `ws` of dpc_score_fwd / dpc_score_bwd (max of both)
+extern "C" int dpc_score_ws_floats(int32_t R, int32_t D, int64_t* fwd_floats, int64_t* bwd_floats) {
+    if (R <= 0 || D <= 0 || !fwd_floats || !bwd_floats) return DPC_ERR_ARG;
+    if (D != 256 && D != 32) return DPC_ERR_UNSUPPORTED;
+    int ntiles, tps, ns;
+    plan_splits(R, &ntiles, &tps, &ns);
+    *fwd_floats = (int64_t)ns * R * 4;
+    *bwd_floats = (int64_t)ns * R * D;
+    return ns;
+}
+
+extern "C" int dpc_score_fwd(const void* pred, const void* finf, int32_t R, int32_t D, float* diag, float* lse2, float* row_ws,
+                             float* score, float* ws, dpc_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!pred || !finf || R <= 0 || !diag || !lse2 || !row_ws || !ws) return DPC_ERR_ARG;
+    if (D != 256 && D != 32) return DPC_ERR_UNSUPPORTED;
+    ScoreP p = {};
+    p.own = (const bf16_t*)pred; p.oth = (const bf16_t*)finf; p.R = R; p.D = D;
+    plan_splits(R, &p.ntiles, &p.tiles_per_split, &p.nsplit);
+    p.diag = diag; p.partial = ws; p.score = score;
+    const dim3 grid((R + BM - 1) / BM, p.nsplit);
+    const size_t chunk_tile = (size_t)((D * 2 + 127) / 128) * BN * 128;
+    const size_t lds = 2 * chunk_tile;
+    if (D == 256) {
+        if (int e = allow_lds(score_fwd_kernel<16>, lds)) return e;
+        DPC_LAUNCH_DYN((score_fwd_kernel<16>), grid, dim3(256), lds, stream, p);
+    } else {
+        if (int e = allow_lds(score_fwd_kernel<2>, lds)) return e;
+        DPC_LAUNCH_DYN((score_fwd_kernel<2>), grid, dim3(256), lds, stream, p);
+    }
+    DPC_LAUNCH(score_finalize_kernel, dim3((R + 255) / 256), dim3(256), stream, (const float*)ws, (const float*)diag, R, p.nsplit, row_ws, lse2);
+    return dpc_launch_status();
+}
+
+// One of the two backward products: out_part[split][r][:] partial sums of  sum_c dS(r, c) oth[c][:]   (by_owner = 1: rows of
+// `own` index the softmax rows -> d_pred with own = pred, oth = finf;  by_owner = 0: transposed roles -> d_finf with
+// own = finf, oth = pred).  othT = oth transposed [D][ldT] (zero beyond column R).  Returns the number of slabs to sum.
+extern "C" int dpc_score_bwd(const void* own, const void* oth, const void* othT, int32_t ldT, int32_t R, int32_t D, const float* lse2,
+                             int32_t by_owner, float* out_part, dpc_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!own || !oth || !othT || R <= 0 || ldT < R || ldT % 8 || !lse2 || !out_part) return DPC_ERR_ARG;
+    if (D != 256 && D != 32) return DPC_ERR_UNSUPPORTED;
+    ScoreP p = {};
+    p.own = (const bf16_t*)own; p.oth = (const bf16_t*)oth; p.othT = (const bf16_t*)othT; p.R = R; p.D = D; p.ldT = ldT;
+    plan_splits(R, &p.ntiles, &p.tiles_per_split, &p.nsplit);
+    p.lse2 = lse2; p.lse_by_owner = by_owner; p.inv_rows = 1.f / (float)R; p.out_part = out_part;
+    const dim3 grid((R + BM - 1) / BM, p.nsplit);
+    const size_t chunk_tile = (size_t)((D * 2 + 127) / 128) * BN * 128;
+    const size_t lds = 2 * (chunk_tile + (size_t)D * 128) + 4 * 32 * 128;
+    if (D == 256) {
+        if (int e = allow_lds(score_bwd_kernel<16>, lds)) return e;
+        DPC_LAUNCH_DYN((score_bwd_kernel<16>), grid, dim3(256), lds, stream, p);
+    } else {
+        if (int e = allow_lds(score_bwd_kernel<2>, lds)) return e;
+        DPC_LAUNCH_DYN((score_bwd_kernel<2>), grid, dim3(256), lds, stream, p);
+    }
+    const int rc = dpc_launch_status();
+    return rc ? rc : p.nsplit;
+}

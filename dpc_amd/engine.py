@@ -142,6 +142,10 @@ def algorithmic_cost(name, args):
     if name == "dpc_pack_input_s2d":        # block, x_s2d, dtype, BN, SL, H, W
         px = args[3] * args[4] * args[5] * args[6]
         return 0.0, float(px * 3 * 4 + px * 4 * _esz(args[2]))
+    if name == "dpc_score_fwd":            # pred, finf, R, D, ...: algorithmic = one R x R x D contraction, operands read once
+        return 2.0 * args[2] * args[2] * args[3], float(2 * args[2] * args[3] * 2)
+    if name == "dpc_score_bwd":            # own, oth, othT, ldT, R, D, ...: one R x R x D contraction (the recompute is not counted)
+        return 2.0 * args[4] * args[4] * args[5], float(2 * args[4] * args[5] * 2 + args[4] * args[5] * 4)
     if name not in ("dpc_conv_igemm", "dpc_conv_wgrad"):
         return 0.0, 0.0
     d = args[0]._obj
@@ -346,7 +350,7 @@ class DPCEngine:
         self._scratch: Dict[Tuple[int, ...], List[torch.Tensor]] = {}
         self._step_count = 0
         self.seed = int(seed)  # dropout stream (the reference seeds the device generator with 233, dpc/model_3d.py:18); per rank
-        self.score_mode = "materialised"
+        self.score_mode = "materialised"  # what the last train step ran ("fused": no [R][R] tensor in HBM)
         self.timer: Optional["KernelTimer"] = None
         self._tag: Optional[str] = None
 
@@ -431,8 +435,16 @@ class DPCEngine:
         self.dscore = self.empty((R, self.ld_d), dt)
         self.row_ws = self.empty((R, 2), f32)
         self.result = self.empty((4,), f32)
-        self.predT = self.empty((D, self.ld_d), dt)   # operands of the score backward
-        self.finfT = self.empty((D, self.ld_d), dt)
+        self.predT = torch.zeros((D, self.ld_d), dtype=dt, device=self.device)   # transposed operands of the score backward
+        self.finfT = torch.zeros((D, self.ld_d), dtype=dt, device=self.device)   # (columns >= R stay zero)
+        # fused score + loss (throughput mode): the [R][R] matrix and its gradient are never materialised in a train step
+        self.score_fusable = dt == torch.bfloat16 and D in (256, 32)
+        self._score_fused = False
+        if self.score_fusable:
+            nf, nb = C.c_int64(0), C.c_int64(0)
+            self.lib.call("dpc_score_ws_floats", R, D, C.byref(nf), C.byref(nb))
+            self.score_ws = self.empty((max(nf.value, nb.value),), f32)
+            self.score_diag, self.score_lse2 = self.empty((R,), f32), self.empty((R,), f32)
         self.d_pred = self.empty((B, P, SQ, D), f32)
         self.d_finf = self.empty((B, P, SQ, D), f32)
         self.d_featrelu = self.empty((self.n_agg, M, D), f32)
@@ -563,9 +575,12 @@ class DPCEngine:
         self.packed_for_step = self._step_count
 
     # ------------------------------------------------------------------ forward
-    def forward(self, block: torch.Tensor, train: bool = False, dropout_masks: Optional[torch.Tensor] = None):
+    def forward(self, block: torch.Tensor, train: bool = False, dropout_masks: Optional[torch.Tensor] = None,
+                materialise: bool = True):
         """block [B,N,3,SL,H,W] f32 on the device.  Returns the score tensor [B,P,SQ,B,P,SQ] (f32, engine-owned).
-        dropout_masks: optional [n_steps,M,D] pre-scaled keep masks (tests); train=True draws them on the device."""
+        dropout_masks: optional [n_steps,M,D] pre-scaled keep masks (tests); train=True draws them on the device.
+        materialise=False (bf16 mode): the score is consumed tile by tile by the fused loss (csrc/score_fused.hip) and
+        never written; the return value is None and loss_topk() / backward() use the fused path."""
         B, N, P, SQ, D, M = self.B, self.N, self.P, self.SQ, self.D, self.M
         if tuple(block.shape) != (B, N, 3, self.SL, self.size, self.size) or block.dtype != torch.float32:
             raise ValueError(f"block must be float32 [B,N,3,SL,H,W] = {(B, N, 3, self.SL, self.size, self.size)}, got {tuple(block.shape)}")
@@ -599,6 +614,14 @@ class DPCEngine:
         self.call("dpc_gru_chain_fwd", C.byref(gd))
         # score (dpc/model_3d.py:79-84): pred [R][D] x feat_inf [R][D]^T
         R = self.R
+        self._score_fused = bool(self.score_fusable and not materialise)
+        if self._score_fused:
+            with self.tag("score"):
+                self.call("dpc_score_fwd", self.pred, self.feat_inf, R, D, self.score_diag, self.score_lse2, self.row_ws, None,
+                          self.score_ws)
+            self.score_mode = "fused"
+            return None
+        self.score_mode = "materialised"
         with self.tag("score"):
             self.gemm(self.pred, self.feat_inf, self.score, R, R, D)
         return self.score.view(B, P, SQ, B, P, SQ)
@@ -621,6 +644,9 @@ class DPCEngine:
     def loss_topk(self, with_grad: bool = True) -> torch.Tensor:
         """[loss, top1, top3, top5] (device f32[4]); fills dscore when with_grad"""
         R = self.R
+        if self._score_fused:  # per-row (loss term, rank) pairs are already there; d/dscore is recomputed inside the backward
+            self.call("dpc_ce_finalize", self.row_ws, R, self.result)
+            return self.result
         self.call("dpc_ce_topk", self.score, R, R, R, self.row_ws, self.result, self.dscore if with_grad else None,
                   L.dtype_code(self.cdtype), self.ld_d)
         return self.result
@@ -639,11 +665,19 @@ class DPCEngine:
             self.dscore[:, :R].copy_(src)  # module-boundary path only (torch hands over an arbitrary d/dscore)
         # score = pred @ finf^T  ->  d_pred = dS @ finf ; d_finf = dS^T @ pred
         self.call("dpc_transpose2d", self.feat_inf, dc, D, self.finfT, dc, self.ld_d, R, D)
-        if self.ld_d != R:
-            self.finfT[:, R:].zero_()
-        with self.tag("score"):
-            self.gemm(self.dscore, self.finfT, self.d_pred, R, D, self.ld_d, lda=self.ld_d, ldb=self.ld_d)
-            self.gemm_tn(self.dscore, self.ld_d, self.pred, D, self.d_finf, R, R, D)
+        if self._score_fused and dscore_external is None:
+            self.call("dpc_transpose2d", self.pred, dc, D, self.predT, dc, self.ld_d, R, D)
+            with self.tag("score"):
+                for own, oth, othT, by_owner, out in ((self.pred, self.feat_inf, self.finfT, 1, self.d_pred),
+                                                      (self.feat_inf, self.pred, self.predT, 0, self.d_finf)):
+                    n = self.call("dpc_score_bwd", own, oth, othT, self.ld_d, R, D, self.score_lse2, by_owner, self.score_ws)
+                    self.call("dpc_reduce_unpack", self.score_ws, n, out, R, 1, D, D, 0, 1, 0)
+        else:
+            if self._score_fused:
+                raise L.DpcError("backward(dscore_external=...) needs a materialised score: call forward(materialise=True)")
+            with self.tag("score"):
+                self.gemm(self.dscore, self.finfT, self.d_pred, R, D, self.ld_d, lda=self.ld_d, ldb=self.ld_d)
+                self.gemm_tn(self.dscore, self.ld_d, self.pred, D, self.d_finf, R, R, D)
         # ---- predict loop + aggregation, reversed: one launch (G_all, dP1, dP2, d_featrelu come back)
         ns = self.n_steps
         self.call("dpc_gru_chain_bwd", C.byref(self.gru_desc))
@@ -735,7 +769,7 @@ class DPCEngine:
         with torch.cuda.stream(side):
             begin()
             self.packed_for_step = -1
-            self.forward(block, train=True)
+            self.forward(block, train=True, materialise=False)
             self.loss_topk(with_grad=True)
             self.backward(on_tail_ready=cut if two_bucket else None)
             if allreduce is not None:
@@ -767,7 +801,7 @@ class DPCEngine:
 
     def train_step(self, block: torch.Tensor, dropout_masks: Optional[torch.Tensor] = None, allreduce=None) -> torch.Tensor:
         """forward + CE/top-k + backward (+ gradient all-reduce) + Adam.  Returns device f32[4] = loss, top1, top3, top5."""
-        self.forward(block, train=True, dropout_masks=dropout_masks)
+        self.forward(block, train=True, dropout_masks=dropout_masks, materialise=False)
         res = self.loss_topk(with_grad=True)
         if allreduce is not None and hasattr(allreduce, "start"):
             self.backward(on_tail_ready=allreduce.start)

@@ -130,7 +130,7 @@ def _worker(rank: int, world: int, args, port: int):
             if train:
                 res = eng.train_step(block, allreduce=allreduce)
             else:  # validate(): dropout off, BN still batch statistics (dpc/main.py:249-282, model_3d.py:28)
-                eng.forward(block, train=False)
+                eng.forward(block, train=False, materialise=False)  # loss / top-k only: the score is never written (bf16)
                 res = eng.loss_topk(with_grad=False)
             if idx % args.print_freq == 0 or not train:
                 vals = res.clone()

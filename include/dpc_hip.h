@@ -164,6 +164,24 @@ int dpc_mask_gen(int8_t* mask, int32_t B, int32_t P, int32_t SQ, dpc_stream_t st
 int dpc_ce_topk(const float* score, int32_t rows, int32_t cols, int32_t ld, float* row_ws, float* result,
                 void* dscore, int32_t dtype_d, int32_t ld_d, dpc_stream_t stream);
 
+/* ---- fused score + loss (throughput mode, bf16 operands): the [R][R] score and its gradient never touch HBM --------
+ * score_fwd: S = pred @ finf^T (dpc/model_3d.py:83) tile by tile; per row the running max / sum-exp / #{s > s_target}
+ *   (target = the diagonal, the closed form of process_output on one GPU) -> row_ws[R][2] = (lse - s_target, rank),
+ *   diag[R] = s_target, lse2[R] = (lse + ln R) log2 e for the backward; `score` (optional, f32 [R][R]) materialises S for a
+ *   caller that reads it.  Follow with dpc_ce_finalize(row_ws, R, result) for loss / top-1/3/5 (dpc/main.py:217-218).
+ * score_bwd: one of the two products of the backward with dS = (softmax(S) - onehot)/R recomputed from the operands:
+ *   by_owner = 1, own = pred, oth = finf, othT = finf^T  -> partial slabs of d_pred = dS @ finf
+ *   by_owner = 0, own = finf, oth = pred, othT = pred^T  -> partial slabs of d_finf = dS^T @ pred
+ *   othT is [D][ldT] (ldT % 8 == 0, zero beyond column R).  Returns the number of [R][D] f32 slabs written to out_part
+ *   (sum them with dpc_reduce_unpack).  dpc_score_ws_floats: workspace sizes (returns the number of slabs / column splits).
+ * D must be 256 (or 32, the width-reduced test networks); other widths: DPC_ERR_UNSUPPORTED (use the materialised path). */
+int dpc_score_ws_floats(int32_t R, int32_t D, int64_t* fwd_floats, int64_t* bwd_floats);
+int dpc_score_fwd(const void* pred, const void* finf, int32_t R, int32_t D, float* diag, float* lse2, float* row_ws,
+                  float* score, float* ws, dpc_stream_t stream);
+int dpc_score_bwd(const void* own, const void* oth, const void* othT, int32_t ldT, int32_t R, int32_t D, const float* lse2,
+                  int32_t by_owner, float* out_part, dpc_stream_t stream);
+int dpc_ce_finalize(const float* row_ws, int32_t rows, float* result, dpc_stream_t stream);
+
 /* ---- Adam with L2 weight decay on flat f32 buffers (dpc/main.py:80-81) --------------- */
 int dpc_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
              float wd, float bias_corr1, float bias_corr2, float grad_scale, dpc_stream_t stream);

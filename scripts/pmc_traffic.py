@@ -9,7 +9,7 @@ def per_kernel(path, counter):
     cur = sqlite3.connect(path).cursor()
     out = {}
     for kn, v, n in cur.execute("select kernel_name, sum(value), count(distinct dispatch_id) from counters_collection where counter_name=? group by kernel_name", (counter,)):
-        out[re.sub(r"\(.*", "", kn).replace("void ", "")] = (v, n)
+        out[re.sub(r"\(.*", "", kn.replace("(anonymous namespace)::", "")).replace("void ", "")] = (v, n)
     return out
 
 fetch = per_kernel(sys.argv[1], "FETCH_SIZE")

@@ -7,7 +7,7 @@ idx = [i for i, r in enumerate(rows) if 'pack_input_s2d' in r[0]]
 last = rows[idx[-1]:]
 t0 = last[0][1]
 for n, s, e, g, w in last:
-    nm = re.sub(r"\(.*", "", n).replace("void ", "").replace("unsigned short", "bf16")
+    nm = re.sub(r"\(.*", "", n.replace("(anonymous namespace)::", "")).replace("void ", "").replace("unsigned short", "bf16")
     if re.search(pat, nm):
         print(f"{(s - t0) / 1e6:9.3f} ms  {(e - s) / 1e3:9.1f} us  grid {g // max(w, 1):6d}  {nm[:80]}")
 print("step span ms", (last[-1][2] - t0) / 1e6, "kernel busy ms", sum(e - s for _, s, e, _, _ in last) / 1e6)

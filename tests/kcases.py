@@ -620,3 +620,61 @@ def case_gru_chain_golden(k: K, ops):
         ref = torch.from_numpy(ops[f"gru::gw::{gate}_gate.weight"]).view(Cg, 2 * Cg)
         assert (gw - ref).abs().max().item() < 1e-4, gate
         assert (Gg.sum(0) - torch.from_numpy(ops[f"gru::gw::{gate}_gate.bias"])).abs().max().item() < 1e-4, gate
+
+
+# ---------------------------------------------------------------- fused score + CE/top-k + backward (csrc/score_fused.hip)
+def case_score_fused(k: K, R, D, seed=31, check_score=True):
+    """dpc_score_fwd / dpc_ce_finalize / dpc_score_bwd (bf16 operands, nothing [R][R] in memory) against the reference's
+    formulation: score = pred @ finf^T (dpc/model_3d.py:83), CrossEntropyLoss with target = arange, calc_topk_accuracy,
+    and autograd's d/dpred, d/dfinf -- computed in f64 from the same bf16-rounded operands."""
+    bf = torch.bfloat16
+    g = torch.Generator().manual_seed(seed)
+    pred = (torch.randn(R, D, generator=g) * (2.0 / D ** 0.5)).to(bf)
+    finf = (torch.randn(R, D, generator=g) * (2.0 / D ** 0.5)).to(bf)
+    idx = torch.arange(0, R, 3)
+    finf[idx] = (finf[idx].float() + 1.5 * pred[idx].float()).to(bf)  # a third of the targets rank high
+    pd, fd = pred.double().requires_grad_(), finf.double().requires_grad_()
+    S = pd @ fd.t()
+    tgt = torch.arange(R)
+    loss = F.cross_entropy(S, tgt)
+    loss.backward()
+    rank = (S.detach() > S.detach().diagonal()[:, None]).sum(1)
+    accs = [(rank < kk).double().mean().item() for kk in (1, 3, 5)]
+    ld = (R + 7) // 8 * 8
+    predT, finfT = k.zeros(D, ld, dtype=bf), k.zeros(D, ld, dtype=bf)
+    predT[:, :R] = k.t(pred.t().contiguous())
+    finfT[:, :R] = k.t(finf.t().contiguous())
+    pk, fk = k.t(pred), k.t(finf)
+    nf, nb = C.c_int64(0), C.c_int64(0)
+    ns = k.lib.call("dpc_score_ws_floats", R, D, C.byref(nf), C.byref(nb))
+    assert ns >= 1
+    ws = k.empty(max(nf.value, nb.value))
+    diag, lse2, row_ws, res = k.empty(R), k.empty(R), k.empty(R, 2), k.empty(4)
+    score = k.empty(R, R) if check_score else None
+    k.call("dpc_score_fwd", pk, fk, R, D, diag, lse2, row_ws, score, ws)
+    k.call("dpc_ce_finalize", row_ws, R, res)
+    k.sync()
+    Sd = S.detach()
+    if check_score:
+        assert relerr(score, Sd) < 1e-5
+    assert (diag.cpu().double() - Sd.diagonal()).abs().max().item() < 1e-4 * max(1.0, Sd.abs().max().item())
+    lse = torch.logsumexp(Sd, 1)
+    assert (row_ws[:, 0].cpu().double() - (lse - Sd.diagonal())).abs().max().item() < 2e-4
+    # a logit within f32 rounding of the target may fall on either side: ranks may differ on a few rows by one
+    dr = (row_ws[:, 1].cpu().double() - rank.double()).abs()
+    assert dr.max().item() <= 1 and (dr > 0).double().mean().item() < 5e-3
+    r = res.cpu()
+    assert abs(r[0].item() - loss.item()) < 1e-4 * max(1.0, abs(loss.item()))
+    for got, exp in zip(r[1:].tolist(), accs):
+        assert abs(got - exp) <= 3.0 / R + 1e-6
+    outs = {}
+    for name, own, oth, othT, by_owner in (("d_pred", pk, fk, finfT, 1), ("d_finf", fk, pk, predT, 0)):
+        n = k.lib.call("dpc_score_bwd", own, oth, othT, ld, R, D, lse2, by_owner, ws, k.lib.stream())
+        assert n == ns
+        out = k.empty(R, D)
+        k.call("dpc_reduce_unpack", ws, n, out, R, 1, D, D, 0, 1, 0)
+        outs[name] = out
+    k.sync()
+    # dS is rounded to bf16 before the second product: 2^-8 relative per term, averaged over R terms
+    assert relerr(outs["d_pred"], pd.grad) < 1.5e-2
+    assert relerr(outs["d_finf"], fd.grad) < 1.5e-2

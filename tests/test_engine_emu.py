@@ -82,3 +82,28 @@ def test_forward_bf16_smoke(emu):
     res = eng.loss_topk(True)
     eng.backward()
     assert torch.isfinite(eng.flat_g).all() and torch.isfinite(res).all()
+
+
+def test_fused_score_path_matches_materialised(emu):
+    """throughput mode: forward(materialise=False) + fused loss + fused score backward (no [R][R] tensor) against the
+    materialised path of the same engine on the same step (same Philox dropout masks: the step counter has not moved)"""
+    B, size = 2, 64
+    eng = DPCEngine("resnet18", size, 8, 5, 3, B, "cpu", torch.bfloat16, WIDTHS, lib=emu)
+    assert eng.score_fusable
+    eng.load_params(O.make_params_pcg("resnet18", WIDTHS))
+    x = O.make_input_pcg(B, 8, 5, size)
+    score = eng.forward(x, train=True, materialise=True)
+    assert score is not None and eng.score_mode == "materialised"
+    res_m = eng.loss_topk(True).clone()
+    eng.backward()
+    g_m, dp_m, df_m = eng.flat_g.clone(), eng.d_pred.clone(), eng.d_finf.clone()
+    assert eng.forward(x, train=True, materialise=False) is None and eng.score_mode == "fused"
+    res_f = eng.loss_topk(True).clone()
+    eng.backward()
+    assert abs(res_f[0].item() - res_m[0].item()) < 1e-4
+    assert res_f[1:].tolist() == pytest.approx(res_m[1:].tolist(), abs=1.01 / eng.R)
+    for a, b in ((eng.d_pred, dp_m), (eng.d_finf, df_m)):
+        assert ((a - b).norm() / b.norm()).item() < 2e-2
+    assert ((eng.flat_g - g_m).norm() / g_m.norm()).item() < 3e-2
+    with pytest.raises(L.DpcError):
+        eng.backward(dscore_external=torch.zeros(eng.R, eng.R))

@@ -201,9 +201,14 @@ def test_cfg5_full_shape_properties():
     eng = DPCEngine("resnet34", 224, 8, 5, P, B, DEV, torch.bfloat16)
     eng.load_params(O.init_params_reference_style("resnet34", seed=0))
     x = torch.randn(B, 8, 3, 5, 224, 224, device=DEV, generator=torch.Generator(DEV).manual_seed(2))
-    res0 = eng.train_step(x).cpu()
+    # (1) the materialised path of the same step: 983 MB of f32 logits + their bf16 gradient
+    eng.forward(x, train=True, materialise=True)
+    res_m = eng.loss_topk(True).clone().cpu()
+    eng.backward()
+    torch.cuda.synchronize()
+    g_m = eng.flat_g.clone()
     R = eng.R
-    assert R == 15680 and eng.SQ == 49 and torch.isfinite(res0).all()
+    assert R == 15680 and eng.SQ == 49 and torch.isfinite(res_m).all()
     assert torch.isfinite(eng.flat_g).all() and eng.flat_g.abs().max().item() > 0
     # CE gradient rows sum to zero; the score is the Gram matrix of its operands (checked on row / column slabs)
     for r0 in (0, 7777, R - 64):
@@ -214,13 +219,24 @@ def test_cfg5_full_shape_properties():
     # loss / top-k of the materialised score against torch on the device (same f32 logits)
     tgt = torch.arange(R, device=DEV)
     loss_t = torch.nn.functional.cross_entropy(eng.score, tgt)
-    assert abs(loss_t.item() - res0[0].item()) < 1e-3 * max(1.0, abs(loss_t.item()))
+    assert abs(loss_t.item() - res_m[0].item()) < 1e-3 * max(1.0, abs(loss_t.item()))
     top5 = eng.score.topk(5, 1).indices
-    for kk, got in zip((1, 3, 5), res0[1:].tolist()):
+    for kk, got in zip((1, 3, 5), res_m[1:].tolist()):
         assert (top5[:, :kk] == tgt[:, None]).any(1).float().mean().item() == pytest.approx(got, abs=1e-6)
     mk = eng.get_mask().view(R, R)
     assert torch.equal((mk == 1).sum(1), torch.ones(R, dtype=torch.long, device=DEV))
     assert int((mk == -3).sum().item()) == B * (P * 49) * (P * 49) - B * P * P * 49
+    # (2) the fused path of the SAME step (same Philox masks): no [R][R] tensor is written
+    assert eng.forward(x, train=True, materialise=False) is None and eng.score_mode == "fused"
+    res_f = eng.loss_topk(True).clone().cpu()
+    eng.backward()
+    torch.cuda.synchronize()
+    assert abs(res_f[0].item() - res_m[0].item()) < 1e-3
+    assert res_f[1:].tolist() == pytest.approx(res_m[1:].tolist(), abs=3.0 / R)
+    e_g = ((eng.flat_g - g_m).norm() / g_m.norm()).item()
+    print(f"cfg5 fused vs materialised: loss {res_f[0].item():.5f} / {res_m[0].item():.5f}, gradient rel-L2 {e_g:.4f}")
+    assert e_g < 3e-2
+    res0 = eng.train_step(x).cpu()
     for _ in range(2):
         res = eng.train_step(x).cpu()
     assert res[0].item() < res0[0].item()
@@ -234,7 +250,11 @@ def test_full_batch_properties(dtype):
     m = DPC_RNN(128, network="resnet18", seed=0)
     eng.load_params({k: v.detach() for k, v in m.named_parameters()})
     x = torch.randn(B, 8, 3, 5, 128, 128, device=DEV, generator=torch.Generator(DEV).manual_seed(1))
-    res0 = eng.train_step(x).cpu()
+    eng.forward(x, train=True, materialise=True)
+    res0 = eng.loss_topk(True).clone().cpu()
+    eng.backward()
+    torch.cuda.synchronize()
+    g_m = eng.flat_g.clone()
     R = eng.R
     assert R == 6144 and torch.isfinite(res0).all()
     # BN invariant: normalised activations have per-channel mean beta=0 / var gamma^2=1 before ReLU.
@@ -247,11 +267,19 @@ def test_full_batch_properties(dtype):
     assert ds.sum(1).abs().max().item() < 1e-3
     chk = eng.pred.float().view(R, -1)[:64] @ eng.feat_inf.float().view(R, -1).t()
     assert (chk - eng.score[:64]).abs().max().item() < 1e-2 * chk.abs().max().item()
+    if dtype == torch.bfloat16:  # the fused score / loss / backward of the same step (what train_step runs in this mode)
+        assert eng.forward(x, train=True, materialise=False) is None and eng.score_mode == "fused"
+        res_f = eng.loss_topk(True).clone().cpu()
+        eng.backward()
+        torch.cuda.synchronize()
+        assert abs(res_f[0].item() - res0[0].item()) < 1e-3
+        assert res_f[1:].tolist() == pytest.approx(res0[1:].tolist(), abs=3.0 / R)
+        assert ((eng.flat_g - g_m).norm() / g_m.norm()).item() < 3e-2
     # mask: exactly one positive per row, on the diagonal (target == arange)
     mk = eng.get_mask().view(R, R)
     assert torch.equal((mk == 1).sum(1), torch.ones(R, dtype=torch.long, device=DEV))
     assert torch.equal((mk == 1).to(torch.int8).argmax(1), torch.arange(R, device=DEV))
     # loss goes down when the same batch is revisited (optimizer + backward are wired correctly)
-    for _ in range(3):
+    for _ in range(4):
         res = eng.train_step(x, dropout_masks=None)
     assert res[0].item() < res0[0].item()

@@ -164,3 +164,8 @@ def test_gru_chain_reference_fixture(k, golden_dir):
     import os
     import numpy as np
     kc.case_gru_chain_golden(k, np.load(os.path.join(golden_dir, "ops.npz")))
+
+
+@pytest.mark.parametrize("rd", [(96, 32), (200, 32), (264, 32), (136, 256)])
+def test_score_fused(k, rd):
+    kc.case_score_fused(k, *rd)

@@ -145,3 +145,12 @@ def test_gru_chain_reference_fixture(k, golden_dir):
     import os
     import numpy as np
     kc.case_gru_chain_golden(k, np.load(os.path.join(golden_dir, "ops.npz")))
+
+
+@pytest.mark.parametrize("rd", [(6144, 256), (6468, 256), (192, 256), (200, 32)])
+def test_score_fused(k, rd):
+    kc.case_score_fused(k, *rd)
+
+
+def test_score_fused_cfg5(k):
+    kc.case_score_fused(k, 15680, 256, check_score=False)  # cfg5: the 983 MB matrix never exists on the device
