@@ -42,7 +42,17 @@ class GruChainDesc(C.Structure):
                 [("p_drop", C.c_float), ("reserved2", C.c_uint32), ("seed", C.c_uint64)] +
                 [(n, C.c_void_p) for n in ("step_dev", "drop_masks", "packed", "bias_u", "bias_r", "bias_o", "bias_1", "bias_2",
                                            "X_all", "H_all", "HR_all", "U_all", "R_all", "O_all", "P1_all", "pred",
-                                           "d_pred", "G_all", "dP1", "dP2", "d_x", "ws")])
+                                           "d_pred", "G_all", "dP1", "dP2", "d_x", "ws", "d_hlast")])
+
+
+class LcHeadDesc(C.Structure):
+    """struct dpc_lc_head_desc (include/dpc_hip.h)"""
+    _fields_ = ([(n, C.c_int32) for n in ("dtype", "B", "SQ", "D", "num_class", "train")] +
+                [("p_drop", C.c_float), ("momentum", C.c_float), ("eps", C.c_float), ("reserved", C.c_uint32), ("seed", C.c_uint64)] +
+                [(n, C.c_void_p) for n in ("step_dev", "drop_mask", "h_last", "bn_weight", "bn_bias", "bn_running_mean", "bn_running_var",
+                                           "bn_num_batches", "fc_weight", "fc_bias", "target", "ctx", "xhat", "bn_out", "y", "stat",
+                                           "logits", "dlogits", "row_ws", "result", "g_fc_weight", "g_fc_bias", "g_bn_weight",
+                                           "g_bn_bias", "dctx", "d_hlast")])
 
 
 class DpcError(RuntimeError):
@@ -87,6 +97,12 @@ _SIGS = {
     "dpc_score_fwd": [_vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp],
     "dpc_score_bwd": [_vp, _vp, _vp, _i32, _i32, _i32, _vp, _i32, _vp, _vp],
     "dpc_ce_finalize": [_vp, _i32, _vp, _vp],
+    "dpc_bn_finalize_running": [_vp, _i32, _i32, _f64, _vp, _vp, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f32, _vp],
+    "dpc_bn_eval_coeffs": [_vp, _vp, _vp, _vp, _f32, _i32, _vp, _vp, _vp, _vp, _vp],
+    "dpc_relu_tpool_fwd": [_vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp],
+    "dpc_relu_tpool_bwd": [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp],
+    "dpc_lc_head_fwd": [C.POINTER(LcHeadDesc), _vp],
+    "dpc_lc_head_bwd": [C.POINTER(LcHeadDesc), _vp],
     "dpc_adam": [_vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _f32, _f32, _f32, _f32, _vp],
 }
 

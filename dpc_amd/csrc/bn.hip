@@ -61,6 +61,63 @@ extern "C" int dpc_bn_finalize(const float* partials, int32_t rows, int32_t C, d
     return dpc_launch_status();
 }
 
+// ---- BatchNorm3d with track_running_stats=True (the LC classifier's backbone, eval/model_3d_lc.py:27-29) --------------------
+// train: batch statistics as above + running_mean/var <- (1-m) running + m batch (variance unbiased, torch semantics);
+// eval: coefficients from the running buffers (dpc_bn_eval_coeffs), no batch statistics at all.
+__global__ __launch_bounds__(1024) void bn_finalize_running_kernel(const float* partials, int rows, int C, double count, const float* gamma,
+                                   const float* beta, float eps, float* mean, float* invstd, float* scale, float* shift,
+                                   float* rmean, float* rvar, long long* nbt, float momentum) {
+    __shared__ double red[2][32][32];
+    const int c = blockIdx.x * 32 + (threadIdx.x & 31), rl = threadIdx.x >> 5;
+    double s1, s2;
+    partial_rows_sum(partials, rows, C, c, rl, s1, s2, red);
+    if (blockIdx.x == 0 && threadIdx.x == 0 && nbt) nbt[0] += 1;
+    if (rl != 0 || c >= C) return;
+    const double m = s1 / count;
+    double var = s2 / count - m * m;
+    if (var < 0.0) var = 0.0;
+    const double is = 1.0 / sqrt(var + (double)eps);
+    mean[c] = (float)m;
+    invstd[c] = (float)is;
+    const float sc = gamma[c] * (float)is;
+    scale[c] = sc;
+    shift[c] = beta[c] - (float)m * sc;
+    const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
+    rmean[c] = (1.f - momentum) * rmean[c] + momentum * (float)m;
+    rvar[c] = (1.f - momentum) * rvar[c] + momentum * (float)unb;
+}
+
+extern "C" int dpc_bn_finalize_running(const float* partials, int32_t rows, int32_t C, double count, const float* gamma, const float* beta,
+                                       float eps, float* mean, float* invstd, float* scale, float* shift, float* running_mean,
+                                       float* running_var, int64_t* num_batches_tracked, float momentum, dpc_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!partials || rows <= 0 || C <= 0 || count <= 0 || !gamma || !beta || !mean || !invstd || !scale || !shift || !running_mean || !running_var)
+        return DPC_ERR_ARG;
+    DPC_LAUNCH(bn_finalize_running_kernel, dim3((C + 31) / 32), dim3(1024), stream, partials, rows, C, count, gamma, beta, eps, mean, invstd, scale,
+               shift, running_mean, running_var, (long long*)num_batches_tracked, momentum);
+    return dpc_launch_status();
+}
+
+__global__ void bn_eval_coeffs_kernel(const float* gamma, const float* beta, const float* rmean, const float* rvar, float eps, int C, float* mean,
+                                      float* invstd, float* scale, float* shift) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float is = 1.f / sqrtf(rvar[c] + eps);
+    mean[c] = rmean[c];
+    invstd[c] = is;
+    const float sc = gamma[c] * is;
+    scale[c] = sc;
+    shift[c] = beta[c] - rmean[c] * sc;
+}
+
+extern "C" int dpc_bn_eval_coeffs(const float* gamma, const float* beta, const float* running_mean, const float* running_var, float eps,
+                                  int32_t C, float* mean, float* invstd, float* scale, float* shift, dpc_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!gamma || !beta || !running_mean || !running_var || C <= 0 || !mean || !invstd || !scale || !shift) return DPC_ERR_ARG;
+    DPC_LAUNCH(bn_eval_coeffs_kernel, dim3((C + 255) / 256), dim3(256), stream, gamma, beta, running_mean, running_var, eps, C, mean, invstd, scale, shift);
+    return dpc_launch_status();
+}
+
 // ------------------------------------------------------------------ forward apply (+res)(+relu)
 // FIXED: 256*E is a multiple of C, so a thread's channel group never changes across the grid-stride
 // loop and the per-channel coefficients live in registers (no 64-bit modulo, no per-element loads).

@@ -32,7 +32,9 @@
 #ifdef DPC_SIMT_EMU
 static inline float fast_exp(float x) { return std::exp(x); }
 static inline float fast_rcp(float x) { return 1.f / x; }
+static inline float fast_exp2(float x) { return std::exp2(x); }
 #else
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }  // one v_exp_f32: no denormal fix-up
 __device__ __forceinline__ float fast_exp(float x) { return __expf(x); }
 __device__ __forceinline__ float fast_rcp(float x) { return __frcp_rn(x); }
 #endif

@@ -99,6 +99,7 @@ struct ChainP {
     void *dP1, *dP2;      // [P][M][D]
     float* d_x;           // [n_agg][M][D] f32: gradient w.r.t. the aggregation inputs
     float* ws;            // [2][M][D] f32 scratch: dh, dx of a prediction-feeding step
+    const float* d_hlast; // optional [M][D] f32: gradient w.r.t. the last state (the LC classifier reads it; NULL = 0)
 };
 
 constexpr int TM = 32;          // rows per workgroup
@@ -542,7 +543,10 @@ __device__ __forceinline__ void gru_chain_bwd_body(const ChainP& p, unsigned cha
     float* dh_ws = p.ws;
     float* dxn_ws = p.ws + MD;
     RM_FOR(D) {
-        if (m0 + row < M) st4(dh_ws + (long long)(m0 + row) * D + col, f32x4{0.f, 0.f, 0.f, 0.f});
+        if (m0 + row < M) {
+            const long long o2 = (long long)(m0 + row) * D + col;
+            st4(dh_ws + o2, p.d_hlast ? ld4(p.d_hlast + o2) : f32x4{0.f, 0.f, 0.f, 0.f});
+        }
     }
     int step = p.n_steps;
     for (int i = p.P - 1; i >= 0; --i) {
@@ -636,12 +640,13 @@ __global__ __launch_bounds__(256) void gru_chain_bwd_kernel(ChainP p) {
 }
 
 int chain_params(const dpc_gru_chain_desc* c, ChainP* p, bool backward) {
-    if (!c || c->M <= 0 || c->D <= 0 || c->SQ <= 0 || c->P <= 0 || c->n_agg <= 0 || c->n_steps != c->n_agg + c->P - 1) return DPC_ERR_ARG;
+    if (!c || c->M <= 0 || c->D <= 0 || c->SQ <= 0 || c->P < 0 || c->n_agg <= 0 || c->n_steps != c->n_agg + (c->P > 0 ? c->P - 1 : 0)) return DPC_ERR_ARG;
     if (c->D % 32 || c->D > 256 || c->M % c->SQ) return DPC_ERR_UNSUPPORTED;
     if (!c->packed || !c->bias_u || !c->bias_r || !c->bias_o || !c->bias_1 || !c->bias_2 || !c->X_all || !c->H_all || !c->HR_all ||
-        !c->U_all || !c->R_all || !c->O_all || !c->P1_all || !c->pred)
+        !c->U_all || !c->R_all || !c->O_all || (c->P > 0 && (!c->P1_all || !c->pred)))
         return DPC_ERR_ARG;
-    if (backward && (!c->d_pred || !c->G_all || !c->dP1 || !c->dP2 || !c->d_x || !c->ws)) return DPC_ERR_ARG;
+    if (backward && (!c->G_all || !c->d_x || !c->ws || (c->P > 0 && (!c->d_pred || !c->dP1 || !c->dP2)))) return DPC_ERR_ARG;
+    if (backward && c->P == 0 && !c->d_hlast) return DPC_ERR_ARG;  // nothing would flow into the recurrence
     if (!(c->p_drop >= 0.f) || !(c->p_drop < 1.f)) return DPC_ERR_ARG;
     p->M = c->M; p->D = c->D; p->SQ = c->SQ; p->P = c->P; p->n_agg = c->n_agg; p->n_steps = c->n_steps;
     p->packed = c->packed;
@@ -654,7 +659,7 @@ int chain_params(const dpc_gru_chain_desc* c, ChainP* p, bool backward) {
     p->X_all = c->X_all; p->H_all = c->H_all; p->HR_all = c->HR_all;
     p->U_all = c->U_all; p->R_all = c->R_all; p->O_all = c->O_all;
     p->P1_all = c->P1_all; p->pred = c->pred;
-    p->d_pred = c->d_pred; p->G_all = c->G_all; p->dP1 = c->dP1; p->dP2 = c->dP2; p->d_x = c->d_x; p->ws = c->ws;
+    p->d_pred = c->d_pred; p->G_all = c->G_all; p->dP1 = c->dP1; p->dP2 = c->dP2; p->d_x = c->d_x; p->ws = c->ws; p->d_hlast = c->d_hlast;
     return DPC_OK;
 }
 

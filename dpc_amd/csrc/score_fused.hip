@@ -96,7 +96,34 @@ __device__ __forceinline__ void s_tile(f32x16 (&s)[2], const u32x4 (&own)[KS], c
 }
 
 // ---------------------------------------------------------------- forward
-template <int KS>
+// statistics of one 32 x 64 tile for the wave's rows.  EDGE: the tile reaches past column R or contains target columns
+// (wave-uniform; the common interior tile takes the branch-free form: per row 2 logits -> one max3, one rescale, two
+// fma + v_exp_f32 + add, two compare-and-count -- everything else would make the kernel VALU-bound, the matrix cores
+// need 1 024 cycles per tile and wave)
+template <bool EDGE>
+__device__ __forceinline__ void tile_stats(const f32x16 (&s)[2], float (&m)[16], float (&l)[16], float (&rk)[16], const float (&dg)[16], int col0,
+                                           int r0, int R, int lane) {
+    const int c0 = col0 + (lane & 31), c1 = c0 + 32;
+    DPC_UNROLL
+    for (int r = 0; r < 16; ++r) {
+        float v0 = s[0][r], v1 = s[1][r];
+        bool a0 = v0 > dg[r], a1 = v1 > dg[r];
+        if (EDGE) {
+            const int grow = r0 + crow(r, lane);
+            if (c0 >= R) { v0 = NEG_BIG; a0 = false; }
+            if (c1 >= R) { v1 = NEG_BIG; a1 = false; }
+            a0 = a0 && c0 != grow;  // the target column never counts (its recomputed value may differ from dg in the last bit)
+            a1 = a1 && c1 != grow;
+        }
+        rk[r] += (a0 ? 1.f : 0.f) + (a1 ? 1.f : 0.f);
+        const float mx = fmaxf(fmaxf(v0, v1), m[r]);
+        const float nm = -mx * L2E;
+        l[r] = l[r] * fast_exp2(fmaf(m[r], L2E, nm)) + fast_exp2(fmaf(v0, L2E, nm)) + fast_exp2(fmaf(v1, L2E, nm));
+        m[r] = mx;
+    }
+}
+
+template <int KS, bool SCORE>
 __global__ __launch_bounds__(256) void score_fwd_kernel(ScoreP p) {
     DPC_DYN_SMEM(smem);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -125,7 +152,7 @@ __global__ __launch_bounds__(256) void score_fwd_kernel(ScoreP p) {
     }
     float m[16], l[16], rk[16];
     DPC_UNROLL
-    for (int r = 0; r < 16; ++r) { m[r] = NEG_BIG; l[r] = 0.f; rk[r] = 0.f; }
+    for (int r = 0; r < 16; ++r) { m[r] = -1.0e30f; l[r] = 0.f; rk[r] = 0.f; }
     const int jt0 = split * p.tiles_per_split;
     int jt1 = jt0 + p.tiles_per_split;
     if (jt1 > p.ntiles) jt1 = p.ntiles;
@@ -138,31 +165,20 @@ __global__ __launch_bounds__(256) void score_fwd_kernel(ScoreP p) {
         f32x16 s[2];
         s_tile<KS>(s, own, smem + buf * tile_bytes, lane);
         const int col0 = jt * BN;
-        const bool on_diag = col0 < r0 + 32 && col0 + BN > r0;  // wave-uniform: the tile contains target columns
-        DPC_UNROLL
-        for (int t = 0; t < 2; ++t) {
-            const int c = col0 + t * 32 + (lane & 31);
-            const bool cv = c < p.R;
-            if (p.score) {
+        if (SCORE) {
+            DPC_UNROLL
+            for (int t = 0; t < 2; ++t) {
+                const int c = col0 + t * 32 + (lane & 31);
                 DPC_UNROLL
                 for (int r = 0; r < 16; ++r) {
                     const int grow = r0 + crow(r, lane);
-                    if (cv && grow < p.R) p.score[(long long)grow * p.R + c] = s[t][r];
+                    if (c < p.R && grow < p.R) p.score[(long long)grow * p.R + c] = s[t][r];
                 }
             }
-            DPC_UNROLL
-            for (int r = 0; r < 16; ++r) {
-                const float v = cv ? s[t][r] : NEG_BIG;
-                // rank: logits above the target's; the target column itself never counts (its recomputed value may differ
-                // from dg in the last bit)
-                bool above = v > dg[r];
-                if (on_diag) above = above && (c != r0 + crow(r, lane));
-                rk[r] += above ? 1.f : 0.f;
-                const float mx = v > m[r] ? v : m[r];
-                l[r] = l[r] * exp2f((m[r] - mx) * L2E) + exp2f((v - mx) * L2E);
-                m[r] = mx;
-            }
         }
+        const bool edge = col0 + BN > p.R || (col0 < r0 + 32 && col0 + BN > r0);  // wave-uniform
+        if (edge) tile_stats<true>(s, m, l, rk, dg, col0, r0, p.R, lane);
+        else tile_stats<false>(s, m, l, rk, dg, col0, r0, p.R, lane);
     }
     // merge the 32 lanes that share each row (xor butterflies stay inside a half-wave)
     DPC_UNROLL
@@ -171,7 +187,7 @@ __global__ __launch_bounds__(256) void score_fwd_kernel(ScoreP p) {
         for (int msk = 1; msk <= 16; msk <<= 1) {
             const float om = __shfl_xor(m[r], msk), ol = __shfl_xor(l[r], msk), ork = __shfl_xor(rk[r], msk);
             const float mx = om > m[r] ? om : m[r];
-            l[r] = l[r] * exp2f((m[r] - mx) * L2E) + ol * exp2f((om - mx) * L2E);
+            l[r] = l[r] * fast_exp2((m[r] - mx) * L2E) + ol * fast_exp2((om - mx) * L2E);
             m[r] = mx;
             rk[r] += ork;
         }
@@ -195,7 +211,7 @@ __global__ void score_finalize_kernel(const float* partial, const float* diag, i
     float L = 0.f, rk = 0.f;
     for (int s = 0; s < nsplit; ++s) {
         const float* q = partial + ((long long)s * R + row) * 4;
-        L += q[1] * exp2f((q[0] - M) * L2E);
+        L += q[1] * exp2f((q[0] - M) * L2E);  // (q[0] = -1e30 for a split that saw no column: term is 0)
         rk += q[2];
     }
     const float lse = M + logf(L);
@@ -251,19 +267,28 @@ __global__ __launch_bounds__(256) void score_bwd_kernel(ScoreP p) {
         f32x16 s[2];
         s_tile<KS>(s, own, tile, lane);
         const int col0 = jt * BN;
-        const bool on_diag = col0 < r0 + 32 && col0 + BN > r0;
+        const bool edge = col0 + BN > p.R || (col0 < r0 + 32 && col0 + BN > r0) || r0 + 32 > p.R;  // wave-uniform
         DPC_UNROLL
         for (int t = 0; t < 2; ++t) {
             const int cl = t * 32 + (lane & 31), c = col0 + cl;
             const bool cv = c < p.R;
             const float lc = (!p.lse_by_owner && cv) ? p.lse2[c] : 0.f;
-            DPC_UNROLL
-            for (int r = 0; r < 16; ++r) {
-                const int row = crow(r, lane);
-                float g = cv ? exp2f(s[t][r] * L2E - (p.lse_by_owner ? lo[r] : lc)) : 0.f;
-                if (on_diag && c == r0 + row) g -= p.inv_rows;
-                if (r0 + row >= p.R) g = 0.f;
-                *(bf16_t*)(ptile + lds_unit_off(row, cl >> 3) + (cl & 7) * 2) = f32_to_bf16(g);
+            unsigned char* pcol = ptile + (cl & 7) * 2;
+            if (!edge) {  // interior tile: fma + v_exp_f32 + convert + store per logit
+                DPC_UNROLL
+                for (int r = 0; r < 16; ++r) {
+                    const float g = fast_exp2(fmaf(s[t][r], L2E, -(p.lse_by_owner ? lo[r] : lc)));
+                    *(bf16_t*)(pcol + lds_unit_off(crow(r, lane), cl >> 3)) = f32_to_bf16(g);
+                }
+            } else {
+                DPC_UNROLL
+                for (int r = 0; r < 16; ++r) {
+                    const int row = crow(r, lane);
+                    float g = cv ? fast_exp2(fmaf(s[t][r], L2E, -(p.lse_by_owner ? lo[r] : lc))) : 0.f;
+                    if (c == r0 + row) g -= p.inv_rows;
+                    if (r0 + row >= p.R) g = 0.f;
+                    *(bf16_t*)(pcol + lds_unit_off(row, cl >> 3)) = f32_to_bf16(g);
+                }
             }
         }
         wave_lds_fence();
@@ -341,11 +366,13 @@ extern "C" int dpc_score_fwd(const void* pred, const void* finf, int32_t R, int3
     const size_t chunk_tile = (size_t)((D * 2 + 127) / 128) * BN * 128;
     const size_t lds = 2 * chunk_tile;
     if (D == 256) {
-        if (int e = allow_lds(score_fwd_kernel<16>, lds)) return e;
-        DPC_LAUNCH_DYN((score_fwd_kernel<16>), grid, dim3(256), lds, stream, p);
+        if (int e = allow_lds(score_fwd_kernel<16, false>, lds)) return e;
+        if (int e = allow_lds(score_fwd_kernel<16, true>, lds)) return e;
+        if (score) { DPC_LAUNCH_DYN((score_fwd_kernel<16, true>), grid, dim3(256), lds, stream, p); } else { DPC_LAUNCH_DYN((score_fwd_kernel<16, false>), grid, dim3(256), lds, stream, p); }
     } else {
-        if (int e = allow_lds(score_fwd_kernel<2>, lds)) return e;
-        DPC_LAUNCH_DYN((score_fwd_kernel<2>), grid, dim3(256), lds, stream, p);
+        if (int e = allow_lds(score_fwd_kernel<2, false>, lds)) return e;
+        if (int e = allow_lds(score_fwd_kernel<2, true>, lds)) return e;
+        if (score) { DPC_LAUNCH_DYN((score_fwd_kernel<2, true>), grid, dim3(256), lds, stream, p); } else { DPC_LAUNCH_DYN((score_fwd_kernel<2, false>), grid, dim3(256), lds, stream, p); }
     }
     DPC_LAUNCH(score_finalize_kernel, dim3((R + 255) / 256), dim3(256), stream, (const float*)ws, (const float*)diag, R, p.nsplit, row_ws, lse2);
     return dpc_launch_status();

@@ -204,6 +204,7 @@ int dpc_dropout_mask(float* mask, int64_t n, float p, uint64_t seed, const int32
  * (dpc/model_3d.py:62-72: agg over the first N-P blocks, then P x {network_pred, agg step}; backbone/convrnn.py:24-34,76-79;
  *  network_pred dpc/model_3d.py:36-40).  Rows m = (b, s) of the [B*SQ][D] state are independent sequences (1x1 convolutions):
  *  a workgroup owns 32 rows for all steps.  T = compute dtype (dtype field); all buffers are caller-owned.
+ *  P = 0: aggregation only (n_steps = n_agg), the classifier head of eval/model_3d_lc.py reads H_all[n_steps].
  * dpc_gru_pack repacks the five f32 parameters (gate weights [D][2D] = [x half | h half], network_pred [D][D]) into the
  *  fragment-major operand layout both kernels stream (`packed`: 16 * D * D elements of T); call it once per optimizer step.
  * Dropout on the carried state: drop_masks != NULL -> explicit pre-scaled keep masks [n_steps][M][D]; else step_dev != NULL ->
@@ -229,11 +230,55 @@ typedef struct dpc_gru_chain_desc {
     void *dP1, *dP2;      /* [P][M][D] T         gradients at the pre-activations of network_pred */
     float* d_x;           /* [n_agg][M][D] f32   gradient w.r.t. the aggregation inputs */
     float* ws;            /* [2][M][D] f32       scratch of the backward kernel */
+    const float* d_hlast; /* optional [M][D] f32  d loss / d (last state): seeds the backward (P = 0: the LC classifier, eval/model_3d_lc.py:58-60) */
 } dpc_gru_chain_desc;
 int dpc_gru_pack(const float* w_update, const float* w_reset, const float* w_out, const float* w_pred0, const float* w_pred2,
                  int32_t D, int32_t dtype, void* packed, dpc_stream_t stream);
 int dpc_gru_chain_fwd(const dpc_gru_chain_desc* c, dpc_stream_t stream);
 int dpc_gru_chain_bwd(const dpc_gru_chain_desc* c, dpc_stream_t stream);
+
+/* ---- downstream classifier LC (eval/model_3d_lc.py:12-65) ------------------------------------------
+ * Shares the backbone and ConvGRU kernels; what differs:
+ *  - the backbone's BatchNorm3d layers track running statistics (model_3d_lc.py:27-29): dpc_bn_finalize_running is
+ *    dpc_bn_finalize + the momentum update of running_mean / running_var (unbiased) in train mode, dpc_bn_eval_coeffs builds
+ *    scale / shift from the running buffers in eval mode;
+ *  - relu_tpool: feat[n][(b,s)][d] = mean_t relu(x[b*N+n][t][s][d])  (ReLU BEFORE the temporal mean, model_3d_lc.py:52-54)
+ *    and its backward dx = (x > 0) d_feat / T;
+ *  - the head (model_3d_lc.py:58-64, eval/test.py:244-255): spatial mean of the last ConvGRU state -> BatchNorm1d ->
+ *    Dropout(p) -> Linear -> CrossEntropyLoss + top-1, forward and backward.  result[0..1] = mean loss, accuracy. */
+int dpc_bn_finalize_running(const float* partials, int32_t rows, int32_t C, double count, const float* gamma, const float* beta,
+                            float eps, float* mean, float* invstd, float* scale, float* shift, float* running_mean,
+                            float* running_var, int64_t* num_batches_tracked, float momentum, dpc_stream_t stream);
+int dpc_bn_eval_coeffs(const float* gamma, const float* beta, const float* running_mean, const float* running_var, float eps,
+                       int32_t C, float* mean, float* invstd, float* scale, float* shift, dpc_stream_t stream);
+int dpc_relu_tpool_fwd(const void* x, int32_t dtype, int32_t B, int32_t N, int32_t T, int32_t SQ, int32_t D, void* feat,
+                       dpc_stream_t stream);
+int dpc_relu_tpool_bwd(const void* x, const float* d_feat, int32_t dtype, int32_t B, int32_t N, int32_t T, int32_t SQ, int32_t D,
+                       void* dx, dpc_stream_t stream);
+typedef struct dpc_lc_head_desc {
+    int32_t dtype, B, SQ, D, num_class, train;
+    float p_drop, momentum, eps;
+    uint32_t reserved;
+    uint64_t seed;
+    const int32_t* step_dev;      /* Philox step counter (train, when drop_mask is NULL) */
+    const float* drop_mask;       /* optional explicit pre-scaled keep mask [B][D] */
+    const void* h_last;           /* [B*SQ][D] T: last ConvGRU state */
+    const float *bn_weight, *bn_bias;
+    float *bn_running_mean, *bn_running_var;
+    int64_t* bn_num_batches;      /* optional */
+    const float *fc_weight, *fc_bias;   /* [num_class][D], [num_class] */
+    const int64_t* target;        /* [B] class indices */
+    float *ctx, *xhat, *bn_out, *y;     /* [B][D] f32: spatial mean, normalised, BN output (= LC.forward's `context`), after dropout */
+    float* stat;                  /* [2][D] mean / invstd used */
+    float *logits, *dlogits;      /* [B][num_class]: LC.forward's `output`; d loss / d logits */
+    float *row_ws, *result;       /* [B][2], [2] */
+    /* backward */
+    float *g_fc_weight, *g_fc_bias, *g_bn_weight, *g_bn_bias;
+    float* dctx;                  /* [B][D] scratch */
+    float* d_hlast;               /* [B*SQ][D] f32: seed of dpc_gru_chain_bwd */
+} dpc_lc_head_desc;
+int dpc_lc_head_fwd(const dpc_lc_head_desc* c, dpc_stream_t stream);
+int dpc_lc_head_bwd(const dpc_lc_head_desc* c, dpc_stream_t stream);
 
 #ifdef __cplusplus
 }

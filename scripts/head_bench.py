@@ -1,0 +1,48 @@
+"""isolated timing of the head kernels (fused score fwd/bwd, fused ConvGRU recurrence fwd/bwd) at BASELINE sizes"""
+import ctypes as C, os, sys, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+from dpc_amd import _lib as L
+import kcases as kc
+
+k = kc.K(L.load_hip(), "cuda:0")
+bf = torch.bfloat16
+reps = int(os.environ.get("REPS", "10"))
+
+def timeit(fn, name, flops=None):
+    fn(); torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(reps):
+        fn()
+    b.record(); torch.cuda.synchronize()
+    us = a.elapsed_time(b) * 1e3 / reps
+    print(f"{name:40s} {us:9.1f} us" + (f"  {flops / us / 1e6:8.1f} TFLOP/s" if flops else ""), flush=True)
+
+for R in (6144, 15680):
+    D = 256
+    g = torch.Generator(device="cuda").manual_seed(1)
+    pred = (torch.randn(R, D, device="cuda", generator=g) * 0.1).to(bf)
+    finf = (torch.randn(R, D, device="cuda", generator=g) * 0.1).to(bf)
+    ld = (R + 7) // 8 * 8
+    predT, finfT = torch.zeros(D, ld, dtype=bf, device="cuda"), torch.zeros(D, ld, dtype=bf, device="cuda")
+    predT[:, :R] = pred.t(); finfT[:, :R] = finf.t()
+    nf, nb = C.c_int64(0), C.c_int64(0)
+    ns = k.lib.call("dpc_score_ws_floats", R, D, C.byref(nf), C.byref(nb))
+    ws = k.empty(max(nf.value, nb.value))
+    diag, lse2, row_ws = k.empty(R), k.empty(R), k.empty(R, 2)
+    fl = 2.0 * R * R * D
+    timeit(lambda: k.call("dpc_score_fwd", pred, finf, R, D, diag, lse2, row_ws, None, ws), f"score_fwd R={R} (splits {ns})", fl)
+    timeit(lambda: k.lib.call("dpc_score_bwd", pred, finf, finfT, ld, R, D, lse2, 1, ws, k.lib.stream()), f"score_bwd d_pred R={R}", fl)
+    timeit(lambda: k.lib.call("dpc_score_bwd", finf, pred, predT, ld, R, D, lse2, 0, ws, k.lib.stream()), f"score_bwd d_finf R={R}", fl)
+
+for (B, SQ, P) in ((128, 16, 3), (64, 49, 5)):
+    d, dev, *_ = kc._chain_setup(k, bf, B, SQ, 256, P, 8 - P, seed=3)
+    step = torch.tensor([1], dtype=torch.int32, device="cuda")
+    d.step_dev = step.data_ptr()
+    M, ns_ = B * SQ, 8 - 1
+    fl_f = 2.0 * M * 256 * 256 * (6 * ns_ + 2 * P)
+    timeit(lambda: k.call("dpc_gru_chain_fwd", C.byref(d)), f"gru_chain_fwd M={M} P={P}", fl_f)
+    timeit(lambda: k.call("dpc_gru_chain_bwd", C.byref(d)), f"gru_chain_bwd M={M} P={P}", fl_f)
+    d.step_dev = None
+    timeit(lambda: k.call("dpc_gru_chain_fwd", C.byref(d)), f"gru_chain_fwd M={M} P={P} (eval, no dropout)", fl_f)

@@ -7,7 +7,7 @@ cols = [r[1] for r in cur.execute("pragma table_info(counters_collection)")]
 q = "select kernel_name, counter_name, sum(value), count(distinct dispatch_id) from counters_collection group by kernel_name, counter_name"
 agg = defaultdict(dict); calls = {}
 for kn, cn, v, n in cur.execute(q):
-    nm = re.sub(r"\(.*", "", kn).replace("void ", "").replace("unsigned short", "bf16")
+    nm = re.sub(r"\(.*", "", kn.replace("(anonymous namespace)::", "")).replace("void ", "").replace("unsigned short", "bf16")
     agg[nm][cn] = v; calls[nm] = n
 names = sorted({c for d in agg.values() for c in d})
 print("kernel".ljust(60), "calls", *[n[-18:].rjust(19) for n in names])
