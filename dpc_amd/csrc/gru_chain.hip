@@ -270,10 +270,10 @@ __device__ __forceinline__ f32x4 mask4(const ChainP& p, int s, int grow, int col
 }
 
 // ---------------------------------------------------------------- forward chain
-template <class T, int NT>
+template <class T, int NT, int DC>
 __device__ __forceinline__ void gru_chain_fwd_body(const ChainP& p, unsigned char* smem) {
     constexpr int E = Elt<T>::PER16;
-    const int D = p.D, M = p.M;
+    const int D = DC > 0 ? DC : p.D, M = p.M;  // DC: compile-time feature size (256) -> shifts instead of divisions in the row-major passes
     const int tile_bytes = (D * (16 / E) + 127) / 128 * CHUNK;
     unsigned char* tx = smem;
     unsigned char* th = smem + tile_bytes;
@@ -422,11 +422,11 @@ __device__ __forceinline__ void gru_chain_fwd_body(const ChainP& p, unsigned cha
 //   dx = [G_u|G_r|G_o] @ [Wu_x;Wr_x;Wo_x];  dh <- dhprev + [G_u|G_r] @ [Wu_h;Wr_h]
 // dh lives in p.ws[0] (f32 [M][D]), the dx of a step that feeds a prediction in p.ws[1]: thread-private state (every element
 // is read and written by the same thread in every pass), kept in L2-resident memory instead of registers.
-template <class T, int NT>
+template <class T, int NT, int DC>
 __device__ __forceinline__ void gru_step_bwd(const ChainP& p, int s, int m0, int wave, int lane, unsigned char* tu, unsigned char* tr,
                                              unsigned char* to, float* stage, float* dx_out) {
     constexpr int E = Elt<T>::PER16;
-    const int D = p.D, M = p.M;
+    const int D = DC > 0 ? DC : p.D, M = p.M;
     const int ld = D + SPAD;
     const int KSD = D / (2 * E);
     const long long MD = (long long)M * D;
@@ -522,10 +522,10 @@ __device__ __forceinline__ void gru_step_bwd(const ChainP& p, int s, int m0, int
     __syncthreads();  // tiles and staging are free again
 }
 
-template <class T, int NT>
+template <class T, int NT, int DC>
 __device__ __forceinline__ void gru_chain_bwd_body(const ChainP& p, unsigned char* smem) {
     constexpr int E = Elt<T>::PER16;
-    const int D = p.D, M = p.M;
+    const int D = DC > 0 ? DC : p.D, M = p.M;
     const int tile_bytes = (D * (16 / E) + 127) / 128 * CHUNK;
     unsigned char* tu = smem;
     unsigned char* tr = smem + tile_bytes;
@@ -554,7 +554,7 @@ __device__ __forceinline__ void gru_chain_bwd_body(const ChainP& p, unsigned cha
         const bool feeds = i < p.P - 1;
         if (feeds) {
             --step;
-            gru_step_bwd<T, NT>(p, step, m0, wave, lane, tu, tr, to, stage, dxn_ws);
+            gru_step_bwd<T, NT, DC>(p, step, m0, wave, lane, tu, tr, to, stage, dxn_ws);
         }
         RM_FOR(D) {
             const int grow = m0 + row;
@@ -615,7 +615,7 @@ __device__ __forceinline__ void gru_chain_bwd_body(const ChainP& p, unsigned cha
     }
     for (int t = p.n_agg - 1; t >= 0; --t) {
         --step;
-        gru_step_bwd<T, NT>(p, step, m0, wave, lane, tu, tr, to, stage, p.d_x + (long long)t * MD);
+        gru_step_bwd<T, NT, DC>(p, step, m0, wave, lane, tu, tr, to, stage, p.d_x + (long long)t * MD);
     }
 }
 
@@ -625,18 +625,20 @@ __global__ __launch_bounds__(256) void gru_chain_fwd_kernel(ChainP p) {
     DPC_DYN_SMEM(smem);
     const int wave = threadIdx.x >> 6, ntiles = p.D / 32;
     const int ntw = wave < ntiles ? (wave + 4 < ntiles ? 2 : 1) : 0;
-    if (ntw == 2) gru_chain_fwd_body<T, 2>(p, smem);
-    else if (ntw == 1) gru_chain_fwd_body<T, 1>(p, smem);
-    else gru_chain_fwd_body<T, 0>(p, smem);
+    if (p.D == 256) gru_chain_fwd_body<T, 2, 256>(p, smem);  // the reference's feature size: every wave owns two tiles
+    else if (ntw == 2) gru_chain_fwd_body<T, 2, 0>(p, smem);
+    else if (ntw == 1) gru_chain_fwd_body<T, 1, 0>(p, smem);
+    else gru_chain_fwd_body<T, 0, 0>(p, smem);
 }
 template <class T>
 __global__ __launch_bounds__(256) void gru_chain_bwd_kernel(ChainP p) {
     DPC_DYN_SMEM(smem);
     const int wave = threadIdx.x >> 6, ntiles = p.D / 32;
     const int ntw = wave < ntiles ? (wave + 4 < ntiles ? 2 : 1) : 0;
-    if (ntw == 2) gru_chain_bwd_body<T, 2>(p, smem);
-    else if (ntw == 1) gru_chain_bwd_body<T, 1>(p, smem);
-    else gru_chain_bwd_body<T, 0>(p, smem);
+    if (p.D == 256) gru_chain_bwd_body<T, 2, 256>(p, smem);
+    else if (ntw == 2) gru_chain_bwd_body<T, 2, 0>(p, smem);
+    else if (ntw == 1) gru_chain_bwd_body<T, 1, 0>(p, smem);
+    else gru_chain_bwd_body<T, 0, 0>(p, smem);
 }
 
 int chain_params(const dpc_gru_chain_desc* c, ChainP* p, bool backward) {

@@ -76,23 +76,36 @@ __device__ __forceinline__ void load_own(u32x4 (&own)[KS], const ScoreP& p, int 
     }
 }
 
-// S[32 rows of the wave][64 columns of the tile] from the register-resident own fragments and the LDS tile
+// S[32 rows of the wave][64 columns of the tile] from the register-resident own fragments and the LDS tile.
+// The B fragments of K step ks + PF are requested before the MFMAs of step ks are issued: hipcc otherwise emits
+// ds_read -> s_waitcnt lgkmcnt(0) -> v_mfma per step and every MFMA eats a full LDS round trip (measured: 37 % of
+// the wave's cycles parked in s_waitcnt).
 template <int KS>
 __device__ __forceinline__ void s_tile(f32x16 (&s)[2], const u32x4 (&own)[KS], const unsigned char* tile, int lane) {
+    constexpr int PF = KS >= 4 ? 3 : (KS - 1 > 0 ? KS - 1 : 1);  // K steps in flight ahead of the MFMAs
     const int j = lane & 31, kg = lane >> 5;
     DPC_UNROLL
     for (int t = 0; t < 2; ++t)
         DPC_UNROLL
         for (int r = 0; r < 16; ++r) s[t][r] = 0.f;
-    DPC_UNROLL
-    for (int ks = 0; ks < KS; ++ks) {
+    u32x4 b[KS][2];
+    // hand-issued reads (invisible to hipcc's wait-count pass, which would re-serialise them); in order, counted below
+    auto req = [&](auto ks_) {
+        constexpr int ks = decltype(ks_)::value;
         const int unit = ks * 2 + kg;
+        const unsigned char* a0 = tile + (unit >> 3) * (BN * 128) + lds_unit_off(j, unit & 7);
+        lds_read_b128_async(b[ks][0], a0);
+        lds_read_b128_async_off<32 * 128>(b[ks][1], a0);  // row j + 32: same swizzle (swz1(r + 32) == swz1(r))
+    };
+    static_for<(PF < KS ? PF : KS)>([&](auto ks_) { req(ks_); });
+    static_for<KS>([&](auto ks_) {
+        constexpr int ks = decltype(ks_)::value;
+        if constexpr (ks + PF < KS) req(std::integral_constant<int, ks + PF>{});
+        constexpr int later = (KS - 1 - ks) < PF ? (KS - 1 - ks) : PF;  // K steps requested after this one
+        lds_wait_tie_n(2 * later, b[ks][0], b[ks][1]);
         DPC_UNROLL
-        for (int t = 0; t < 2; ++t) {
-            const u32x4 b = *(const u32x4*)(tile + (unit >> 3) * (BN * 128) + lds_unit_off(t * 32 + j, unit & 7));
-            s[t] = mfma_32x32x16_bf16(own[ks], b, s[t]);
-        }
-    }
+        for (int t = 0; t < 2; ++t) s[t] = mfma_32x32x16_bf16(own[ks], b[ks][t], s[t]);
+    });
 }
 
 // ---------------------------------------------------------------- forward
@@ -292,18 +305,31 @@ __global__ __launch_bounds__(256) void score_bwd_kernel(ScoreP p) {
             }
         }
         wave_lds_fence();
-        {
+        {   // out[n] += dS[32 x 64] @ othT[n][64]^T : 4 K steps x (1 A + NTD B) fragments; the reads of step k2 + 1 are in
+            // flight while the MFMAs of step k2 run (hand-issued, counted: see s_tile)
             const int i = lane & 31, kg = lane >> 5;
-            DPC_UNROLL
-            for (int k2 = 0; k2 < 4; ++k2) {
+            u32x4 a[4], b[4][NTD];
+            auto req = [&](auto k2_) {
+                constexpr int k2 = decltype(k2_)::value;
                 const int unit = k2 * 2 + kg;
-                const u32x4 a = *(const u32x4*)(ptile + lds_unit_off(i, unit));
-                DPC_UNROLL
-                for (int n = 0; n < NTD; ++n) {
-                    const u32x4 b = *(const u32x4*)(tileT + lds_unit_off(n * 32 + i, unit));
-                    out[n] = mfma_32x32x16_bf16(a, b, out[n]);
-                }
-            }
+                lds_read_b128_async(a[k2], ptile + lds_unit_off(i, unit));
+                const unsigned char* b0 = tileT + lds_unit_off(i, unit);
+                static_for<NTD>([&](auto n_) {
+                    constexpr int n = decltype(n_)::value;
+                    lds_read_b128_async_off<n * 32 * 128>(b[k2][n], b0);  // rows n*32 + i: same swizzle every 32 rows
+                });
+            };
+            req(std::integral_constant<int, 0>{});
+            static_for<4>([&](auto k2_) {
+                constexpr int k2 = decltype(k2_)::value;
+                if constexpr (k2 + 1 < 4) req(std::integral_constant<int, k2 + 1>{});
+                constexpr int later = k2 + 1 < 4 ? 1 + NTD : 0;
+                static_for<NTD>([&](auto n_) {
+                    constexpr int n = decltype(n_)::value;
+                    lds_wait_tie<later>(a[k2], b[k2][n]);
+                    out[n] = mfma_32x32x16_bf16(a[k2], b[k2][n], out[n]);
+                });
+            });
         }
         wave_lds_fence();  // the wave's next dS stores must not pass these reads
     }
