@@ -137,7 +137,7 @@ __device__ __forceinline__ void tile_stats(const f32x16 (&s)[2], float (&m)[16],
 }
 
 template <int KS, bool SCORE>
-__global__ __launch_bounds__(256) void score_fwd_kernel(ScoreP p) {
+__global__ __launch_bounds__(256, 2) void score_fwd_kernel(ScoreP p) {  // 2 workgroups per CU: one's MFMAs cover the other's exp/compare VALU work
     DPC_DYN_SMEM(smem);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int rb = blockIdx.x, split = blockIdx.y;
@@ -354,10 +354,10 @@ template <class K> int allow_lds(K kernel, size_t bytes) {
 }
 
 // column splits so that (row blocks x splits) fills the chip, each split keeping at least 4 tiles
-void plan_splits(int R, int* ntiles, int* tps, int* nsplit) {
+void plan_splits(int R, int target_wgs, int* ntiles, int* tps, int* nsplit) {
     const int nrb = (R + BM - 1) / BM;
     *ntiles = (R + BN - 1) / BN;
-    int s = (256 + nrb - 1) / nrb;
+    int s = (target_wgs + nrb - 1) / nrb;
     if (s < 1) s = 1;
     const int max_s = *ntiles / 4 > 0 ? *ntiles / 4 : 1;
     if (s > max_s) s = max_s;
@@ -372,11 +372,12 @@ void plan_splits(int R, int* ntiles, int* tps, int* nsplit) {
 extern "C" int dpc_score_ws_floats(int32_t R, int32_t D, int64_t* fwd_floats, int64_t* bwd_floats) {
     if (R <= 0 || D <= 0 || !fwd_floats || !bwd_floats) return DPC_ERR_ARG;
     if (D != 256 && D != 32) return DPC_ERR_UNSUPPORTED;
-    int ntiles, tps, ns;
-    plan_splits(R, &ntiles, &tps, &ns);
-    *fwd_floats = (int64_t)ns * R * 4;
-    *bwd_floats = (int64_t)ns * R * D;
-    return ns;
+    int ntiles, tps, nsf, nsb;
+    plan_splits(R, 512, &ntiles, &tps, &nsf);  // forward: two workgroups per CU
+    plan_splits(R, 256, &ntiles, &tps, &nsb);
+    *fwd_floats = (int64_t)nsf * R * 4;
+    *bwd_floats = (int64_t)nsb * R * D;
+    return nsb;
 }
 
 extern "C" int dpc_score_fwd(const void* pred, const void* finf, int32_t R, int32_t D, float* diag, float* lse2, float* row_ws,
@@ -386,7 +387,7 @@ extern "C" int dpc_score_fwd(const void* pred, const void* finf, int32_t R, int3
     if (D != 256 && D != 32) return DPC_ERR_UNSUPPORTED;
     ScoreP p = {};
     p.own = (const bf16_t*)pred; p.oth = (const bf16_t*)finf; p.R = R; p.D = D;
-    plan_splits(R, &p.ntiles, &p.tiles_per_split, &p.nsplit);
+    plan_splits(R, 512, &p.ntiles, &p.tiles_per_split, &p.nsplit);
     p.diag = diag; p.partial = ws; p.score = score;
     const dim3 grid((R + BM - 1) / BM, p.nsplit);
     const size_t chunk_tile = (size_t)((D * 2 + 127) / 128) * BN * 128;
@@ -414,7 +415,7 @@ extern "C" int dpc_score_bwd(const void* own, const void* oth, const void* othT,
     if (D != 256 && D != 32) return DPC_ERR_UNSUPPORTED;
     ScoreP p = {};
     p.own = (const bf16_t*)own; p.oth = (const bf16_t*)oth; p.othT = (const bf16_t*)othT; p.R = R; p.D = D; p.ldT = ldT;
-    plan_splits(R, &p.ntiles, &p.tiles_per_split, &p.nsplit);
+    plan_splits(R, 256, &p.ntiles, &p.tiles_per_split, &p.nsplit);
     p.lse2 = lse2; p.lse_by_owner = by_owner; p.inv_rows = 1.f / (float)R; p.out_part = out_part;
     const dim3 grid((R + BM - 1) / BM, p.nsplit);
     const size_t chunk_tile = (size_t)((D * 2 + 127) / 128) * BN * 128;
