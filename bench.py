@@ -104,6 +104,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch the step kernel by kernel instead of replaying a hipGraph")
+    ap.add_argument("--score-path", default="auto", choices=["auto", "fused", "materialised"],
+                    help="contrastive score + loss: fused (no [R][R] tensor in HBM) or materialised; auto = fused for R >= 8192")
     args = ap.parse_args()
     cfg = dict(CONFIGS[args.config])
     for k in ("batch", "net", "img_dim", "pred_step"):
@@ -132,7 +134,7 @@ def main():
     from dpc_amd.parallel import make_allreduce
 
     cdt = torch.bfloat16 if args.dtype == "bf16" else torch.float32
-    eng = DPCEngine(net, img, 8, 5, P, batch, dev, cdt, seed=233 + rank)
+    eng = DPCEngine(net, img, 8, 5, P, batch, dev, cdt, seed=233 + rank, score_path=args.score_path)
     init = DPC_RNN(img, network=net, pred_step=P, seed=0)  # reference init, same on all ranks
     eng.load_params({k: v.detach() for k, v in init.named_parameters()})
     del init
@@ -236,6 +238,8 @@ def main():
                     "us_per_step": round(1e3 * sc["ms"] / rs, 1), "launches_per_step": sc["launches"] // rs,
                     "flops_per_step": round(sc["flops"] / rs / 1e9, 2), "flops_unit": "GFLOP (algorithmic: 3 x 2 R^2 D)",
                     "score_bytes_f32": R * R * 4,
+                    "includes": ("the softmax statistics / loss and the recomputation of dS inside the backward (no [R][R] tensor is "
+                                 "written)" if eng.score_mode == "fused" else "the three GEMMs only (CE/top-k and dS are a separate kernel)"),
                 }
             hb = [s[n] for n in HBM_FAMILY if n in s]
             if hb:

@@ -131,7 +131,8 @@ __device__ __forceinline__ void tile_stats(const f32x16 (&s)[2], float (&m)[16],
         rk[r] += (a0 ? 1.f : 0.f) + (a1 ? 1.f : 0.f);
         const float mx = fmaxf(fmaxf(v0, v1), m[r]);
         const float nm = -mx * L2E;
-        l[r] = l[r] * fast_exp2(fmaf(m[r], L2E, nm)) + fast_exp2(fmaf(v0, L2E, nm)) + fast_exp2(fmaf(v1, L2E, nm));
+        // (m - mx) first: with the -1e30 start value an fma against the ROUNDED product nm leaves a residual of ~1e22 -> 0 * inf
+        l[r] = l[r] * fast_exp2((m[r] - mx) * L2E) + fast_exp2(fmaf(v0, L2E, nm)) + fast_exp2(fmaf(v1, L2E, nm));
         m[r] = mx;
     }
 }

@@ -332,7 +332,7 @@ class DPCEngine:
     def __init__(self, network: str = "resnet18", sample_size: int = 128, num_seq: int = 8, seq_len: int = 5,
                  pred_step: int = 3, batch: int = 4, device="cuda", compute_dtype=torch.float32,
                  widths: Sequence[int] = LAYER_WIDTH, lib: Optional[L.Lib] = None,
-                 lr: float = 1e-3, wd: float = 1e-5, dropout: float = 0.1, seed: int = 233):
+                 lr: float = 1e-3, wd: float = 1e-5, dropout: float = 0.1, seed: int = 233, score_path: str = "auto"):
         self.device = torch.device(device)
         self.lib = L.lib_for(self.device, lib)  # raises unless HIP device (or an explicit simulator handle in tests)
         self.cdtype = compute_dtype
@@ -438,7 +438,14 @@ class DPCEngine:
         self.predT = torch.zeros((D, self.ld_d), dtype=dt, device=self.device)   # transposed operands of the score backward
         self.finfT = torch.zeros((D, self.ld_d), dtype=dt, device=self.device)   # (columns >= R stay zero)
         # fused score + loss (throughput mode): the [R][R] matrix and its gradient are never materialised in a train step
-        self.score_fusable = dt == torch.bfloat16 and D in (256, 32)
+        # score_path: "fused" | "materialised" | "auto".  Measured on MI355X (profiles/r02_head_kernels.txt): the fused forward
+        # (72 us at R = 6 144) beats GEMM + three-sweep CE (173 us), the fused backward (2 x 140 us + slab sums) loses to the
+        # two plain GEMMs over a materialised bf16 dS (176 us) -- exp() is quarter rate and K = 256 gives the matrix cores
+        # too little to hide it behind; at R = 15 680 both total the same and fusion saves 1.5 GB of traffic-heavy buffers.
+        if score_path not in ("auto", "fused", "materialised"):
+            raise ValueError("score_path must be auto, fused or materialised")
+        fusable = dt == torch.bfloat16 and D in (256, 32)
+        self.score_fusable = fusable and (score_path == "fused" or (score_path == "auto" and R >= 8192))
         self._score_fused = False
         if self.score_fusable:
             nf, nb = C.c_int64(0), C.c_int64(0)

@@ -246,7 +246,7 @@ def test_cfg5_full_shape_properties():
 def test_full_batch_properties(dtype):
     """BASELINE.json configs[1] size (r18, 128^2, B=128/GPU): size-independent invariants."""
     B = 128
-    eng = DPCEngine("resnet18", 128, 8, 5, 3, B, DEV, dtype)
+    eng = DPCEngine("resnet18", 128, 8, 5, 3, B, DEV, dtype, score_path="fused")  # both paths are exercised below
     m = DPC_RNN(128, network="resnet18", seed=0)
     eng.load_params({k: v.detach() for k, v in m.named_parameters()})
     x = torch.randn(B, 8, 3, 5, 128, 128, device=DEV, generator=torch.Generator(DEV).manual_seed(1))

@@ -166,6 +166,6 @@ def test_gru_chain_reference_fixture(k, golden_dir):
     kc.case_gru_chain_golden(k, np.load(os.path.join(golden_dir, "ops.npz")))
 
 
-@pytest.mark.parametrize("rd", [(96, 32), (200, 32), (264, 32), (136, 256)])
+@pytest.mark.parametrize("rd", [(24, 32), (96, 32), (200, 32), (264, 32), (136, 256)])
 def test_score_fused(k, rd):
     kc.case_score_fused(k, *rd)
