@@ -60,6 +60,7 @@ __global__ void gru_pack_kernel(PackSrc src, int D, T* packed) {
     case M_W2T: wi = 4; base = 0; sn = 1; sk = D; break;
     default: wi = 3; base = 0; sn = 1; sk = D; break;  // M_W1T
     }
+    if (!src.w[wi]) return;  // P = 0 (LC classifier): no network_pred matrices
     const float* w = src.w[wi] + base;
     const int KS = K / (2 * E);
     const long long nunits = (long long)D * K / E;
@@ -696,7 +697,7 @@ size_t chain_lds(const dpc_gru_chain_desc* c) {
 extern "C" int dpc_gru_pack(const float* w_update, const float* w_reset, const float* w_out, const float* w_pred0, const float* w_pred2,
                             int32_t D, int32_t dtype, void* packed, dpc_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
-    if (!w_update || !w_reset || !w_out || !w_pred0 || !w_pred2 || !packed || D <= 0) return DPC_ERR_ARG;
+    if (!w_update || !w_reset || !w_out || !packed || D <= 0 || (!w_pred0) != (!w_pred2)) return DPC_ERR_ARG;  // w_pred*: NULL for P = 0
     if (D % 32 || D > 256) return DPC_ERR_UNSUPPORTED;
     PackSrc src;
     src.w[0] = w_update; src.w[1] = w_reset; src.w[2] = w_out; src.w[3] = w_pred0; src.w[4] = w_pred2;

@@ -198,6 +198,10 @@ class _ConvBN:
         self.stat_rows = eng.lib.call("dpc_conv_stats_rows", C.byref(self.desc_f))
         eng.need_stats(self.stat_rows * 2 * Co)
         self.mean, self.invstd, self.scale, self.shift = (eng.empty((Co,), torch.float32) for _ in range(4))
+        if eng.bn_running:  # track_running_stats=True (eval/model_3d_lc.py:27-29): buffers in the reference's state_dict layout
+            eng.BUF[bnname + ".running_mean"] = torch.zeros(Co, dtype=torch.float32, device=eng.device)
+            eng.BUF[bnname + ".running_var"] = torch.ones(Co, dtype=torch.float32, device=eng.device)
+            eng.BUF[bnname + ".num_batches_tracked"] = torch.zeros((), dtype=torch.int64, device=eng.device)
         ns = C.c_int32(0)
         eng.lib.call("dpc_conv_wgrad", C.byref(self.desc_w), None, None, Co, None, C.byref(ns), eng.lib.stream())
         eng.need_part(ns.value * Co * Kp)
@@ -220,9 +224,20 @@ class _ConvBN:
 
     def forward(self, x: torch.Tensor):
         e = self.eng
+        g, b = e.PRM[self.bnname + ".weight"], e.PRM[self.bnname + ".bias"]
+        if e.bn_running and not e.train_mode:  # eval: coefficients from the running buffers, no batch statistics
+            e.call("dpc_conv_igemm", C.byref(self.desc_f), x, self.wp, self.raw, None, None)
+            e.call("dpc_bn_eval_coeffs", g, b, e.BUF[self.bnname + ".running_mean"], e.BUF[self.bnname + ".running_var"], BN_EPS,
+                   self.Co, self.mean, self.invstd, self.scale, self.shift)
+            return
         e.call("dpc_conv_igemm", C.byref(self.desc_f), x, self.wp, self.raw, None, e.stats)
-        e.call("dpc_bn_finalize", e.stats, self.stat_rows, self.Co, float(self.rows), e.PRM[self.bnname + ".weight"],
-               e.PRM[self.bnname + ".bias"], BN_EPS, self.mean, self.invstd, self.scale, self.shift)
+        if e.bn_running:
+            e.call("dpc_bn_finalize_running", e.stats, self.stat_rows, self.Co, float(self.rows), g, b, BN_EPS, self.mean, self.invstd,
+                   self.scale, self.shift, e.BUF[self.bnname + ".running_mean"], e.BUF[self.bnname + ".running_var"],
+                   e.BUF[self.bnname + ".num_batches_tracked"], e.BN_MOMENTUM)
+        else:
+            e.call("dpc_bn_finalize", e.stats, self.stat_rows, self.Co, float(self.rows), g, b, BN_EPS, self.mean, self.invstd,
+                   self.scale, self.shift)
 
     def apply(self, y: torch.Tensor, relu: bool, res: Optional[torch.Tensor] = None, res_unit: "Optional[_ConvBN]" = None):
         e = self.eng
@@ -329,6 +344,9 @@ class _Block:
 
 
 class DPCEngine:
+    BN_RUNNING = False
+    BN_MOMENTUM = 0.1  # torch.nn.BatchNorm3d default
+
     def __init__(self, network: str = "resnet18", sample_size: int = 128, num_seq: int = 8, seq_len: int = 5,
                  pred_step: int = 3, batch: int = 4, device="cuda", compute_dtype=torch.float32,
                  widths: Sequence[int] = LAYER_WIDTH, lib: Optional[L.Lib] = None,
@@ -355,7 +373,11 @@ class DPCEngine:
         self._tag: Optional[str] = None
 
         # ---- flat f32 arenas: parameters, gradients, Adam moments
-        self.shapes = param_shapes(network, widths)
+        self._score_path = score_path
+        self.bn_running = type(self).BN_RUNNING  # BatchNorm3d with running statistics (the LC classifier's backbone)
+        self.train_mode = True       # only matters when bn_running: eval uses the running buffers
+        self.BUF: Dict[str, torch.Tensor] = {}
+        self.shapes = self._param_shapes()
         self.offsets: Dict[str, Tuple[int, int]] = {}
         off = 0
         for k, shp in self.shapes.items():
@@ -402,6 +424,16 @@ class DPCEngine:
                              f"({self.last_duration},{self.last_size}); see dpc/model_3d.py:24-25,53-55")
         self.units: List[_ConvBN] = [self.stem] + [u for b in self.blocks for u in b.units()]
 
+        self._build_head()
+        self._finish_buffers()
+
+    # ---- head of DPC_RNN: ConvGRU aggregate/predict, contrastive score, loss (subclasses build another head)
+    def _param_shapes(self):
+        return param_shapes(self.network, self.widths)
+
+    def _build_head(self):
+        batch, pred_step, num_seq, widths, dt = self.B, self.P, self.N, self.widths, self.cdtype
+        score_path = self._score_path
         # ---- ConvGRU / predictor / score buffers.  rows M = (b, s)
         B, P, SQ, D, N = batch, pred_step, self.SQ, self.D, num_seq
         M = B * SQ
@@ -482,6 +514,9 @@ class DPCEngine:
                         ("O_all", self.O_all), ("P1_all", self.P1_all), ("pred", self.pred), ("d_pred", self.d_pred),
                         ("G_all", self.G_all), ("dP1", self.dP1), ("dP2", self.dP2), ("d_x", self.d_featrelu), ("ws", self.gru_ws)):
             setattr(gd, name, t.data_ptr())
+
+    def _finish_buffers(self):
+        widths, dt, f32 = self.widths, self.cdtype, torch.float32
         prs = C.c_int32(0)  # stem backward: partial rows of the pooled reduction (sized by query, not by coincidence)
         ps_ = self.pool_shape
         self.lib.call("dpc_pooled_bn_bwd_reduce", None, None, None, L.dtype_code(dt), ps_[0] * ps_[1] * ps_[2] * ps_[3], widths[0],
@@ -577,11 +612,48 @@ class DPCEngine:
             u.pack()
         Pm = self.PRM
         self.call("dpc_gru_pack", Pm["agg.ConvGRUCell_00.update_gate.weight"], Pm["agg.ConvGRUCell_00.reset_gate.weight"],
-                  Pm["agg.ConvGRUCell_00.out_gate.weight"], Pm["network_pred.0.weight"], Pm["network_pred.2.weight"], self.D, dc,
+                  Pm["agg.ConvGRUCell_00.out_gate.weight"], Pm.get("network_pred.0.weight"), Pm.get("network_pred.2.weight"), self.D, dc,
                   self.gru_packed)
         self.packed_for_step = self._step_count
 
     # ------------------------------------------------------------------ forward
+    def _backbone_forward(self, block: torch.Tensor) -> torch.Tensor:
+        """2d3d-ResNet (backbone/resnet_2d3d.py:259-270) on block [B,N,3,SL,H,W]: returns the last block's output
+        [B*N, T, ls, ls, D] (channels-last, no final ReLU)"""
+        B, N = self.B, self.N
+        block = block.contiguous()
+        dc = L.dtype_code(self.cdtype)
+        self.pack_weights()
+        self.call("dpc_pack_input_s2d", block, self.x_s2d, dc, B * N, self.SL, self.size, self.size)
+        self.stem.forward(self.x_s2d)
+        st = self.stem.out_shape
+        self.call("dpc_bn_relu_maxpool_fwd", self.stem.raw, dc, st[0] * st[1], st[2], st[3], self.widths[0], self.stem.scale,
+                  self.stem.shift, self.pooled, self.pool_arg)
+        x = self.pooled
+        for blk in self.blocks:
+            x = blk.forward(x)
+        return x
+
+    def _backbone_backward(self, d: torch.Tensor, on_tail_ready=None):
+        """backward of _backbone_forward from d = d loss / d (last block output); fills the backbone's gradients"""
+        dc = L.dtype_code(self.cdtype)
+        for bi in reversed(range(len(self.blocks))):
+            if on_tail_ready is not None and bi == self.n_head_blocks - 1:
+                on_tail_ready(self.flat_g[self.grad_split:])
+            d = self.blocks[bi].backward(d, need_dx=True)
+        # stem: max-pool routing (ReLU mask folded into the saved argmax) -> BN -> weight grad; the video has no grad
+        st = self.stem.out_shape
+        u, C0 = self.stem, self.widths[0]
+        pr = C.c_int32(0)
+        ps = self.pool_shape
+        self.call("dpc_pooled_bn_bwd_reduce", d, self.pool_arg, self.pooled, dc, ps[0] * ps[1] * ps[2] * ps[3], C0,
+                  self.PRM[u.bnname + ".weight"], self.PRM[u.bnname + ".bias"], self.stats, C.byref(pr))
+        self.call("dpc_bn_bwd_finalize", self.stats, pr.value, C0, float(u.rows), self.G[u.bnname + ".weight"],
+                  self.G[u.bnname + ".bias"], self.coef)
+        self.call("dpc_pool_bn_bwd_apply", d, self.pool_arg, u.raw, dc, st[0] * st[1], st[2], st[3], C0, u.mean, u.invstd,
+                  self.PRM[u.bnname + ".weight"], self.coef, self.stem_dz)
+        self.stem.wgrad(self.x_s2d, self.stem_dz)
+
     def forward(self, block: torch.Tensor, train: bool = False, dropout_masks: Optional[torch.Tensor] = None,
                 materialise: bool = True):
         """block [B,N,3,SL,H,W] f32 on the device.  Returns the score tensor [B,P,SQ,B,P,SQ] (f32, engine-owned).
@@ -593,18 +665,8 @@ class DPCEngine:
             raise ValueError(f"block must be float32 [B,N,3,SL,H,W] = {(B, N, 3, self.SL, self.size, self.size)}, got {tuple(block.shape)}")
         if block.device != self.device:
             raise ValueError("block is on the wrong device")
-        block = block.contiguous()
+        x = self._backbone_forward(block)
         dc = L.dtype_code(self.cdtype)
-        self.pack_weights()
-        # backbone
-        self.call("dpc_pack_input_s2d", block, self.x_s2d, dc, B * N, self.SL, self.size, self.size)
-        self.stem.forward(self.x_s2d)
-        st = self.stem.out_shape
-        self.call("dpc_bn_relu_maxpool_fwd", self.stem.raw, dc, st[0] * st[1], st[2], st[3], self.widths[0], self.stem.scale,
-                  self.stem.shift, self.pooled, self.pool_arg)
-        x = self.pooled
-        for blk in self.blocks:
-            x = blk.forward(x)
         fs = self.feat_shape
         self.call("dpc_tpool_split_fwd", x, dc, B, N, fs[1], SQ, D, P, self.feat_relu, self.feat_inf)
         # dropout masks on the carried hidden state (backbone/convrnn.py:78)
@@ -706,25 +768,8 @@ class DPCEngine:
         # ---- temporal pool / split, backbone
         fs = self.feat_shape
         self.call("dpc_tpool_split_bwd", self.blocks[-1].out, self.d_featrelu, self.d_finf, dc, B, N, fs[1], SQ, D, P, self.d_feat)
-        d = self.d_feat
-        for bi in reversed(range(len(self.blocks))):
-            if on_tail_ready is not None and bi == self.n_head_blocks - 1:
-                on_tail_ready(self.flat_g[self.grad_split:])
-            d = self.blocks[bi].backward(d, need_dx=True)
-        # stem: max-pool routing (ReLU mask folded into the saved argmax) -> BN -> weight grad; the video has no grad
-        st = self.stem.out_shape
-        u, C0 = self.stem, self.widths[0]
-        pr = C.c_int32(0)
-        ps = self.pool_shape
-        self.call("dpc_pooled_bn_bwd_reduce", d, self.pool_arg, self.pooled, dc, ps[0] * ps[1] * ps[2] * ps[3], C0,
-                  self.PRM[u.bnname + ".weight"], self.PRM[u.bnname + ".bias"], self.stats, C.byref(pr))
-        self.call("dpc_bn_bwd_finalize", self.stats, pr.value, C0, float(u.rows), self.G[u.bnname + ".weight"],
-                  self.G[u.bnname + ".bias"], self.coef)
-        self.call("dpc_pool_bn_bwd_apply", d, self.pool_arg, u.raw, dc, st[0] * st[1], st[2], st[3], C0, u.mean, u.invstd,
-                  self.PRM[u.bnname + ".weight"], self.coef, self.stem_dz)
-        self.stem.wgrad(self.x_s2d, self.stem_dz)
+        self._backbone_backward(self.d_feat, on_tail_ready)
 
-    # ------------------------------------------------------------------ optimizer / full step
     @property
     def step_count(self) -> int:
         """completed optimizer steps (host mirror of dev_step)"""

@@ -332,3 +332,159 @@ def init_params_reference_style(network: str = "resnet18", seed: int = 0,
             torch.nn.init.orthogonal_(w, 1, generator=g)
             params[k] = w
     return params
+
+
+# --------------------------------------------------------------------------
+# LC downstream classifier (eval/model_3d_lc.py:12-65, eval/test.py:244-255) -- SURVEY.md section 8 f3
+# --------------------------------------------------------------------------
+BN_MOMENTUM = 0.1  # torch.nn.BatchNorm default
+
+
+def lc_state_dict_keys(network: str = "resnet18", num_class: int = 101, widths: Sequence[int] = LAYER_WIDTH) -> List[str]:
+    """state_dict keys of the reference LC, in its order (BatchNorm buffers interleaved; backbone built with
+    track_running_stats=True, model_3d_lc.py:27-29; ConvGRU alias keys, convrnn.py:55-58)"""
+    keys: List[str] = []
+    base = [k for k in param_shapes(network, widths, with_alias=True) if not k.startswith("network_pred.")]
+    for k in base:
+        keys.append(k)
+        if k.startswith("backbone.") and k.endswith(".bias"):
+            pre = k[: -len("bias")]
+            keys += [pre + "running_mean", pre + "running_var", pre + "num_batches_tracked"]
+    keys += ["final_bn.weight", "final_bn.bias", "final_bn.running_mean", "final_bn.running_var", "final_bn.num_batches_tracked",
+             "final_fc.1.weight", "final_fc.1.bias"]
+    return keys
+
+
+def lc_shapes(network: str = "resnet18", num_class: int = 101, widths: Sequence[int] = LAYER_WIDTH) -> "Dict[str, Tuple[int, ...]]":
+    base = param_shapes(network, widths, with_alias=True)
+    D = widths[3]
+    out: Dict[str, Tuple[int, ...]] = {}
+    for k in lc_state_dict_keys(network, num_class, widths):
+        if k in base:
+            out[k] = base[k]
+        elif k.endswith("num_batches_tracked"):
+            out[k] = ()
+        elif k.startswith("final_fc.1."):
+            out[k] = (num_class, D) if k.endswith("weight") else (num_class,)
+        elif k.startswith("final_bn."):
+            out[k] = (D,)
+        else:  # running_mean / running_var of a backbone BatchNorm3d: its channel count
+            out[k] = base[k.rsplit(".", 1)[0] + ".weight"]
+    return out
+
+
+def make_lc_params_pcg(network: str = "resnet18", num_class: int = 101, widths: Sequence[int] = LAYER_WIDTH) -> Params:
+    """portable recipe for every LC state_dict entry: as make_params_pcg (key i -> PCG64(3000+i)); running_mean 0.1 n,
+    running_var 1 + 0.1 |n|, num_batches_tracked 0, the Linear scaled 1/sqrt(fan_in)"""
+    shapes = lc_shapes(network, num_class, widths)
+    params: Params = {}
+    for i, (k, shp) in enumerate(shapes.items()):
+        if k.startswith("agg.cell_list.0."):
+            params[k] = params[k.replace("agg.cell_list.0.", "agg.ConvGRUCell_00.")]
+            continue
+        if k.endswith("num_batches_tracked"):
+            params[k] = torch.zeros((), dtype=torch.int64)
+            continue
+        n = np.random.Generator(np.random.PCG64(3000 + i)).standard_normal(shp, dtype=np.float32)
+        if k.endswith("running_mean"):
+            v = 0.1 * n
+        elif k.endswith("running_var"):
+            v = 1.0 + 0.1 * np.abs(n)
+        elif len(shp) >= 2:
+            v = n / np.float32(math.sqrt(int(np.prod(shp[1:]))))
+        elif ".bn" in k or "downsample.1" in k or k.startswith("final_bn"):
+            v = (1.0 + 0.1 * n) if k.endswith("weight") else 0.1 * n
+        else:
+            v = 0.05 * n
+        params[k] = torch.from_numpy(np.ascontiguousarray(v, dtype=np.float32))
+    return params
+
+
+def _bn_running(x: torch.Tensor, p: Params, new: Params, pre: str, train: bool, dims, shp, eps: float = BN_EPS) -> torch.Tensor:
+    """BatchNorm with track_running_stats=True (torch.nn.functional.batch_norm semantics): train = batch statistics and
+    running <- (1-m) running + m batch (unbiased variance); eval = running statistics"""
+    g, b = p[pre + "weight"].view(shp), p[pre + "bias"].view(shp)
+    if train:
+        mean = x.mean(dims, keepdim=True)
+        var = x.var(dims, unbiased=False, keepdim=True)
+        n = x.numel() / x.shape[1]
+        with torch.no_grad():
+            new[pre + "running_mean"] = (1 - BN_MOMENTUM) * p[pre + "running_mean"] + BN_MOMENTUM * mean.reshape(-1).to(torch.float32)
+            new[pre + "running_var"] = (1 - BN_MOMENTUM) * p[pre + "running_var"] + BN_MOMENTUM * (var.reshape(-1) * n / max(n - 1, 1)).to(torch.float32)
+            new[pre + "num_batches_tracked"] = p[pre + "num_batches_tracked"] + 1
+    else:
+        mean, var = p[pre + "running_mean"].view(shp).to(x.dtype), p[pre + "running_var"].view(shp).to(x.dtype)
+    return (x - mean) / torch.sqrt(var + eps) * g + b
+
+
+def _lc_block(x, p, new, pre, is3d, stride, final_relu, train):
+    """BasicBlock2d / 3d with running-stat BatchNorm (resnet_2d3d.py:47-116, track_running_stats=True)"""
+    s1, pad = ((stride,) * 3, (1, 1, 1)) if is3d else ((1, stride, stride), (0, 1, 1))
+    bn = lambda t, name: _bn_running(t, p, new, pre + name + ".", train, (0, 2, 3, 4), (1, -1, 1, 1, 1))
+    out = F.relu(bn(F.conv3d(x, p[pre + "conv1.weight"], None, s1, pad), "bn1"))
+    out = bn(F.conv3d(out, p[pre + "conv2.weight"], None, 1, pad), "bn2")
+    if (pre + "downsample.0.weight") in p:
+        res = bn(F.conv3d(x, p[pre + "downsample.0.weight"], None, s1, 0), "downsample.1")
+    else:
+        res = x
+    out = out + res
+    return F.relu(out) if final_relu else out
+
+
+def lc_forward(p: Params, block: torch.Tensor, network: str = "resnet18", train: bool = False,
+               gru_masks: Optional[List[torch.Tensor]] = None, fc_mask: Optional[torch.Tensor] = None):
+    """LC.forward (model_3d_lc.py:47-65).  Returns output [B,1,num_class], context [B,1,D] and the dict of updated buffers
+    (train mode).  gru_masks: pre-scaled masks [B,D,ls,ls] per ConvGRU step (None = no dropout); fc_mask [B,D] likewise."""
+    B, N, Cc, SL, H, W = block.shape
+    last_duration, last_size = derived_sizes(H, SL)
+    D = p["final_bn.weight"].shape[0]
+    new: Params = {}
+    plan = LAYER_PLAN[network]
+    x = block.reshape(B * N, Cc, SL, H, W)
+    x = F.conv3d(x, p["backbone.conv1.weight"], None, (1, 2, 2), (0, 3, 3))
+    x = F.relu(_bn_running(x, p, new, "backbone.bn1.", train, (0, 2, 3, 4), (1, -1, 1, 1, 1)))
+    x = F.max_pool3d(x, (1, 3, 3), (1, 2, 2), (0, 1, 1))
+    for li in range(4):
+        for bi in range(plan[li]):
+            stride = 2 if (li > 0 and bi == 0) else 1
+            last = li == 3 and bi == plan[li] - 1
+            x = _lc_block(x, p, new, f"backbone.layer{li + 1}.{bi}.", li >= 2, stride, not last, train)
+    feature = F.avg_pool3d(F.relu(x), (last_duration, 1, 1), stride=1)  # model_3d_lc.py:52-54: ReLU first
+    feature = feature.view(B, N, D, last_size, last_size)
+    h = torch.zeros(B, D, last_size, last_size, dtype=block.dtype)
+    for t in range(N):  # convrnn.py:76-79
+        h = convgru_cell(feature[:, t], h, p)
+        if gru_masks is not None:
+            h = h * gru_masks[t]
+    context = h.mean(dim=(2, 3))  # model_3d_lc.py:58-60: avg_pool3d over the spatial extent of the LAST state
+    context = _bn_running(context.unsqueeze(-1), p, new, "final_bn.", train, (0, 2), (1, -1, 1)).squeeze(-1)  # BatchNorm1d on [B,C,1]
+    y = context * fc_mask if fc_mask is not None else context
+    output = y @ p["final_fc.1.weight"].t() + p["final_fc.1.bias"]
+    return output.view(B, 1, -1), context.view(B, 1, D), new
+
+
+def lc_loss_acc(output: torch.Tensor, target: torch.Tensor):
+    """eval/test.py:244-255: CrossEntropyLoss on [B*N', C] logits with the clip label repeated, top-1 accuracy"""
+    B, Np, Cn = output.shape
+    flat = output.reshape(B * Np, Cn)
+    tgt = target.view(B, 1).repeat(1, Np).view(-1)
+    loss = F.cross_entropy(flat, tgt)
+    acc = (flat.argmax(1) == tgt).float().mean()
+    return loss, acc
+
+
+def lc_train_step_reference(p: Params, block: torch.Tensor, target: torch.Tensor, network: str = "resnet18",
+                            gru_masks=None, fc_mask=None):
+    """train-mode forward + loss + backward; returns loss, acc, {name: grad}, output, context, updated buffers"""
+    names = [k for k in p if not k.startswith("agg.cell_list.0.") and p[k].dtype.is_floating_point and
+             not k.endswith(("running_mean", "running_var"))]
+    leaves = {k: p[k].detach().clone().requires_grad_(True) for k in names}
+    full = dict(p)
+    full.update(leaves)
+    for k in p:
+        if k.startswith("agg.cell_list.0."):
+            full[k] = leaves[k.replace("agg.cell_list.0.", "agg.ConvGRUCell_00.")]
+    output, context, new = lc_forward(full, block, network, True, gru_masks, fc_mask)
+    loss, acc = lc_loss_acc(output, target)
+    grads = torch.autograd.grad(loss, [leaves[k] for k in names])
+    return loss.detach(), acc.item(), dict(zip(names, grads)), output.detach(), context.detach(), new

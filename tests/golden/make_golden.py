@@ -285,6 +285,54 @@ def golden_ckpt_layout():
     print("wrote ckpt_layout.json", os.path.getsize(os.path.join(HERE, "ckpt_layout.json")) // 1024, "KiB")
 
 
+# ---------------------------------------------------------------- LC downstream classifier
+def golden_lc():
+    """eval/model_3d_lc.py LC (reference class, imported): state_dict layout, eval-mode output / context, and a train-mode
+    step with both dropouts disabled: loss, accuracy, gradient norms + subsamples, updated running statistics."""
+    import json
+    sys.path.append(f"{REF}/eval")
+    from model_3d_lc import LC
+    out = {}
+    m = LC(sample_size=64, num_seq=8, seq_len=5, network="resnet18", dropout=0.5, num_class=101)
+    sd = O.make_lc_params_pcg("resnet18", 101)
+    print("LC load_state_dict:", m.load_state_dict(sd, strict=True))
+    layout = [[k, list(v.shape), str(v.dtype)] for k, v in m.state_dict().items()]
+    with open(os.path.join(HERE, "lc_layout.json"), "w") as f:
+        json.dump({"resnet18_101": layout, "param_order": [k for k, _ in m.named_parameters()]}, f, indent=0)
+    x = O.make_input_pcg(2, 8, 5, 64)
+    target = torch.tensor([[3], [77]])
+    m.eval()
+    with torch.no_grad():
+        o, c = m(x)
+    out["eval_output"], out["eval_context"] = o.numpy(), c.numpy()
+    m.train()
+    m.agg.dropout_layer.p = 0.0
+    m.final_fc[0].p = 0.0
+    o, c = m(x)
+    B, N_, Dn = o.size()
+    flat = o.view(B * N_, Dn)
+    tgt = target.repeat(1, N_).view(-1)                    # eval/test.py:250-251
+    loss = nn.CrossEntropyLoss()(flat, tgt)
+    acc = (flat.argmax(1) == tgt).float().mean()
+    loss.backward()
+    out["train_output"], out["train_context"] = o.detach().numpy(), c.detach().numpy()
+    out["train_loss_acc"] = np.array([loss.item(), acc.item()])
+    names = [k for k, _ in m.named_parameters()]
+    out["param_names"] = np.array(names)
+    out["grad_norm"] = np.array([p_.grad.norm().item() for _, p_ in m.named_parameters()])
+    for k, p_ in m.named_parameters():
+        g_ = p_.grad.flatten()
+        st = max(1, g_.numel() // 512)
+        out["grad_sub::" + k] = g_[::st].numpy().copy()
+        out["grad_substride::" + k] = np.array(st)
+    new_sd = m.state_dict()
+    for k in ("backbone.bn1", "backbone.layer3.0.bn1", "backbone.layer4.1.bn2", "final_bn"):
+        out["rm::" + k] = new_sd[k + ".running_mean"].numpy().copy()
+        out["rv::" + k] = new_sd[k + ".running_var"].numpy().copy()
+        out["nbt::" + k] = np.array(int(new_sd[k + ".num_batches_tracked"]))
+    save("lc.npz", **out)
+
+
 # ---------------------------------------------------------------- G4 per-op fixtures
 def golden_ops():
     out = {}
@@ -344,7 +392,7 @@ def golden_ops():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["mask", "ops", "eval", "eval_p5", "train", "anchor", "ckpt"]
+    which = sys.argv[1:] or ["mask", "ops", "eval", "eval_p5", "train", "anchor", "ckpt", "lc"]
     if "mask" in which:
         golden_mask()
     if "ops" in which:
@@ -357,5 +405,7 @@ if __name__ == "__main__":
         golden_eval_p5()
     if "ckpt" in which:
         golden_ckpt_layout()
+    if "lc" in which:
+        golden_lc()
     if "anchor" in which:
         golden_anchor16()

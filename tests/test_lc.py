@@ -1,0 +1,123 @@
+"""SURVEY.md section 8 f3 -- the LC downstream classifier (eval/model_3d_lc.py, eval/test.py), CPU tier:
+the oracle restatement against fixtures produced by the reference's own LC class (tests/golden/lc.npz, lc_layout.json),
+the module / engine state_dict layout, and the LCEngine kernel schedule (host simulator, width-reduced net) vs the oracle."""
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+import torch
+
+from dpc_amd import _lib as L
+from dpc_amd.lc import LC, LCEngine, lc_state_dict_keys
+from oracle import dpc_oracle as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+WIDTHS = (8, 16, 32, 32)
+TOL = 5e-4
+
+
+@pytest.fixture(scope="module")
+def emu():
+    subprocess.run(["make", "-s", "-j8", "emu"], cwd=ROOT, check=True)
+    return L.load_emulator()
+
+
+def test_oracle_vs_reference_lc(golden_dir):
+    g = np.load(os.path.join(golden_dir, "lc.npz"), allow_pickle=False)
+    p = O.make_lc_params_pcg("resnet18", 101)
+    x = O.make_input_pcg(2, 8, 5, 64)
+    with torch.no_grad():
+        out, ctx, _ = O.lc_forward(p, x, "resnet18", train=False)
+    assert (out - torch.from_numpy(g["eval_output"])).abs().max().item() < TOL
+    assert (ctx - torch.from_numpy(g["eval_context"])).abs().max().item() < TOL
+    target = torch.tensor([3, 77])
+    loss, acc, grads, out_t, ctx_t, new = O.lc_train_step_reference(p, x, target, "resnet18")
+    assert (out_t - torch.from_numpy(g["train_output"])).abs().max().item() < TOL
+    assert (ctx_t - torch.from_numpy(g["train_context"])).abs().max().item() < TOL
+    assert abs(loss.item() - g["train_loss_acc"][0]) < TOL and acc == pytest.approx(float(g["train_loss_acc"][1]))
+    names = [str(n) for n in g["param_names"]]
+    assert names == list(grads.keys())
+    for i, n in enumerate(names):
+        assert grads[n].norm().item() == pytest.approx(float(g["grad_norm"][i]), rel=5e-3, abs=1e-7), n
+        st = int(g["grad_substride::" + n])
+        rs = torch.from_numpy(g["grad_sub::" + n])
+        assert ((grads[n].flatten()[::st] - rs).norm() / rs.norm().clamp_min(1e-12)).item() < 2e-2, n
+    for k in ("backbone.bn1", "backbone.layer3.0.bn1", "backbone.layer4.1.bn2", "final_bn"):
+        assert np.allclose(new[k + ".running_mean"].numpy(), g["rm::" + k], rtol=1e-4, atol=1e-5), k
+        assert np.allclose(new[k + ".running_var"].numpy(), g["rv::" + k], rtol=1e-4, atol=1e-5), k
+        assert int(new[k + ".num_batches_tracked"]) == int(g["nbt::" + k]) == 1
+
+
+def test_state_dict_layout_matches_reference(golden_dir):
+    lay = json.load(open(os.path.join(golden_dir, "lc_layout.json")))
+    ref_keys = [k for k, _, _ in lay["resnet18_101"]]
+    assert lc_state_dict_keys("resnet18", 101) == ref_keys == O.lc_state_dict_keys("resnet18", 101)
+    m = LC(sample_size=64, num_seq=8, seq_len=5, network="resnet18", dropout=0.5, num_class=101)
+    sd = m.state_dict()
+    assert [[k, list(v.shape), str(v.dtype)] for k, v in sd.items()] == lay["resnet18_101"]
+    assert [k for k, _ in m.named_parameters()] == lay["param_order"]
+    m.load_state_dict(O.make_lc_params_pcg("resnet18", 101), strict=True)
+    with pytest.raises(L.DpcError):
+        m(torch.zeros(1, 8, 3, 5, 64, 64))  # CPU tensors: no fallback
+
+
+def _engine(emu, dtype=torch.float32, B=2, NC=11):
+    eng = LCEngine("resnet18", 64, 8, 5, B, "cpu", dtype, WIDTHS, lib=emu, num_class=NC)
+    p = O.make_lc_params_pcg("resnet18", NC, WIDTHS)
+    eng.load_params(p)
+    return eng, p
+
+
+def test_engine_eval_and_train_vs_oracle(emu):
+    B, NC = 2, 11
+    eng, p = _engine(emu, B=B, NC=NC)
+    assert list(eng.state_dict().keys()) == O.lc_state_dict_keys("resnet18", NC, WIDTHS)
+    x = O.make_input_pcg(B, 8, 5, 64)
+    target = torch.tensor([3, 7])
+    # ---- eval: running statistics everywhere, no dropout
+    out, ctx = eng.forward(x, target, train=False)
+    with torch.no_grad():
+        ro, rc, _ = O.lc_forward(p, x, "resnet18", train=False)
+    assert (out - ro).abs().max().item() < 1e-3 and (ctx - rc).abs().max().item() < 1e-3
+    rl, ra = O.lc_loss_acc(ro, target)
+    assert abs(eng.result[0].item() - rl.item()) < 1e-4 and eng.result[1].item() == pytest.approx(ra.item())
+    assert int(eng.BUF["backbone.bn1.num_batches_tracked"]) == 0
+    with pytest.raises(L.DpcError):
+        eng.backward()
+    # ---- train: batch statistics, injected dropout masks shared with the oracle
+    g = torch.Generator().manual_seed(3)
+    ls, D = eng.last_size, eng.D
+    keep = (torch.rand(8, B, ls, ls, D, generator=g) > 0.1).float() / 0.9
+    fc_keep = (torch.rand(B, D, generator=g) > 0.5).float() / 0.5
+    masks_ref = [keep[i].permute(0, 3, 1, 2).contiguous() for i in range(8)]
+    loss, acc, grads, ro, rc, new = O.lc_train_step_reference(p, x, target, "resnet18", masks_ref, fc_keep)
+    out, ctx = eng.forward(x, target, train=True, gru_masks=keep.reshape(8, eng.M, D), fc_mask=fc_keep)
+    assert (out - ro).abs().max().item() < 1e-3 and (ctx - rc).abs().max().item() < 1e-3
+    assert abs(eng.result[0].item() - loss.item()) < 1e-4 and eng.result[1].item() == pytest.approx(acc)
+    eng.backward()
+    for k, r in grads.items():
+        e = (eng.G[k] - r).abs().max().item() / max(r.abs().max().item(), 1e-8)
+        assert e < 2e-3, (k, e)
+    for k, v in new.items():
+        if v.dtype.is_floating_point:
+            assert torch.allclose(eng.BUF[k], v, rtol=1e-4, atol=1e-5), k
+        else:
+            assert int(eng.BUF[k]) == int(v) == 1, k
+    # ---- one fused train step with in-kernel (Philox) dropout: finite, parameters move, loss on the batch goes down
+    before = eng.flat_p.clone()
+    r = eng.train_step(x, target).clone()
+    assert torch.isfinite(r).all() and eng.step_count == 1 and not torch.equal(before, eng.flat_p)
+    assert int(eng.BUF["final_bn.num_batches_tracked"]) == 2
+
+
+def test_engine_bf16_runs(emu):
+    eng, p = _engine(emu, torch.bfloat16)
+    x = O.make_input_pcg(2, 8, 5, 64)
+    target = torch.tensor([1, 4])
+    out, _ = eng.forward(x, target, train=False)
+    with torch.no_grad():
+        ro, _, _ = O.lc_forward(p, x, "resnet18", train=False)
+    assert (out - ro).abs().max().item() < 0.15 * max(ro.abs().max().item(), 1.0)
+    assert torch.isfinite(eng.result).all()
