@@ -617,14 +617,20 @@ class DPCEngine:
         self.packed_for_step = self._step_count
 
     # ------------------------------------------------------------------ forward
-    def _backbone_forward(self, block: torch.Tensor) -> torch.Tensor:
-        """2d3d-ResNet (backbone/resnet_2d3d.py:259-270) on block [B,N,3,SL,H,W]: returns the last block's output
-        [B*N, T, ls, ls, D] (channels-last, no final ReLU)"""
+    def load_frames(self, frames: torch.Tensor, aug: torch.Tensor, gray: Optional[torch.Tensor], ds: int = 3):
+        """GPU-side input pipeline (dpc_amd/data.py): decoded uint8 frames [B,F,H0,W0,3] + the loader's per-clip draws ->
+        the stem's operand, without an f32 video in between.  Follow with forward(None, ...) / train_step(None, ...)."""
+        from .data import frames_to_input
+        frames_to_input(self.lib, frames, aug, gray, self.N, self.SL, ds, self.size, None, self.x_s2d)
+
+    def _backbone_forward(self, block: Optional[torch.Tensor]) -> torch.Tensor:
+        """2d3d-ResNet (backbone/resnet_2d3d.py:259-270) on block [B,N,3,SL,H,W] (None: the stem operand was filled by
+        load_frames): returns the last block's output [B*N, T, ls, ls, D] (channels-last, no final ReLU)"""
         B, N = self.B, self.N
-        block = block.contiguous()
         dc = L.dtype_code(self.cdtype)
         self.pack_weights()
-        self.call("dpc_pack_input_s2d", block, self.x_s2d, dc, B * N, self.SL, self.size, self.size)
+        if block is not None:
+            self.call("dpc_pack_input_s2d", block.contiguous(), self.x_s2d, dc, B * N, self.SL, self.size, self.size)
         self.stem.forward(self.x_s2d)
         st = self.stem.out_shape
         self.call("dpc_bn_relu_maxpool_fwd", self.stem.raw, dc, st[0] * st[1], st[2], st[3], self.widths[0], self.stem.scale,
@@ -661,10 +667,11 @@ class DPCEngine:
         materialise=False (bf16 mode): the score is consumed tile by tile by the fused loss (csrc/score_fused.hip) and
         never written; the return value is None and loss_topk() / backward() use the fused path."""
         B, N, P, SQ, D, M = self.B, self.N, self.P, self.SQ, self.D, self.M
-        if tuple(block.shape) != (B, N, 3, self.SL, self.size, self.size) or block.dtype != torch.float32:
-            raise ValueError(f"block must be float32 [B,N,3,SL,H,W] = {(B, N, 3, self.SL, self.size, self.size)}, got {tuple(block.shape)}")
-        if block.device != self.device:
-            raise ValueError("block is on the wrong device")
+        if block is not None:
+            if tuple(block.shape) != (B, N, 3, self.SL, self.size, self.size) or block.dtype != torch.float32:
+                raise ValueError(f"block must be float32 [B,N,3,SL,H,W] = {(B, N, 3, self.SL, self.size, self.size)}, got {tuple(block.shape)}")
+            if block.device != self.device:
+                raise ValueError("block is on the wrong device")
         x = self._backbone_forward(block)
         dc = L.dtype_code(self.cdtype)
         fs = self.feat_shape

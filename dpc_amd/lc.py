@@ -159,7 +159,7 @@ class LCEngine(DPCEngine):
         reference does; ``self.result`` = device f32[2] (mean CE loss, top-1 accuracy).  gru_masks [N,M,D] / fc_mask [B,D]:
         optional explicit pre-scaled dropout masks (tests); train=True without them draws Philox masks in the kernels."""
         B, N, SQ, D, M = self.B, self.N, self.SQ, self.D, self.M
-        if tuple(block.shape) != (B, N, 3, self.SL, self.size, self.size) or block.dtype != torch.float32:
+        if block is not None and (tuple(block.shape) != (B, N, 3, self.SL, self.size, self.size) or block.dtype != torch.float32):
             raise ValueError(f"block must be float32 [B,N,3,SL,H,W] = {(B, N, 3, self.SL, self.size, self.size)}")
         self.train_mode = bool(train)
         self.target.copy_(target.reshape(B).to(self.device, torch.int64))
