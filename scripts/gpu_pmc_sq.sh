@@ -1,0 +1,14 @@
+#!/bin/bash
+# SQ counter tables (two passes) of one cfg2 train step, all kernels
+R=$GRAFT_REPO_ROOT; mkdir -p $R/gpurun_out
+cd /tmp && export TMPDIR=/tmp
+B="python $R/bench.py --no-graph --steps 1 --warmup 1 --no-cpu-baseline --no-roofline"
+i=0
+for set in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_MFMA" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_SALU"; do
+  i=$((i+1))
+  (timeout 300 rocprofv3 --kernel-trace --pmc $set -d $R/gpurun_out/sq_$i -o pmc -- $B 2>&1 | tail -2) > $R/gpurun_out/sq_$i.log
+  f=$(ls $R/gpurun_out/sq_$i/*.db 2>/dev/null | head -1)
+  [ -n "$f" ] && python $R/scripts/pmc_table.py $f "." > $R/gpurun_out/sq_$i.txt 2>&1
+  rm -rf $R/gpurun_out/sq_$i/*.db
+done
+head -30 $R/gpurun_out/sq_1.txt

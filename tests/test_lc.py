@@ -105,11 +105,41 @@ def test_engine_eval_and_train_vs_oracle(emu):
             assert torch.allclose(eng.BUF[k], v, rtol=1e-4, atol=1e-5), k
         else:
             assert int(eng.BUF[k]) == int(v) == 1, k
-    # ---- one fused train step with in-kernel (Philox) dropout: finite, parameters move, loss on the batch goes down
+    # ---- fused Adam on the LC arena (the Philox form of both dropouts is covered at kernel level: test_lc_head_philox)
     before = eng.flat_p.clone()
-    r = eng.train_step(x, target).clone()
-    assert torch.isfinite(r).all() and eng.step_count == 1 and not torch.equal(before, eng.flat_p)
-    assert int(eng.BUF["final_bn.num_batches_tracked"]) == 2
+    eng.adam_step()
+    assert eng.step_count == 1 and not torch.equal(before, eng.flat_p)
+
+
+def test_lc_head_philox(emu):
+    """head with in-kernel dropout: keep rate 1 - p, masks change with the optimizer step, backward consistent with forward"""
+    import ctypes as C
+    B, SQ, D, NC = 64, 4, 32, 11
+    g = torch.Generator().manual_seed(1)
+    h = torch.randn(B * SQ, D, generator=g)
+    bufs = {n: torch.zeros(B, D) for n in ("ctx", "xhat", "bn_out", "y", "dctx")}
+    t = dict(bn_weight=torch.ones(D), bn_bias=torch.zeros(D), bn_running_mean=torch.zeros(D), bn_running_var=torch.ones(D),
+             bn_num_batches=torch.zeros((), dtype=torch.int64), fc_weight=torch.randn(NC, D, generator=g) * 0.2, fc_bias=torch.zeros(NC),
+             target=torch.arange(B) % NC, stat=torch.zeros(2, D), logits=torch.zeros(B, NC), dlogits=torch.zeros(B, NC),
+             row_ws=torch.zeros(B, 2), result=torch.zeros(2), g_fc_weight=torch.zeros(NC, D), g_fc_bias=torch.zeros(NC),
+             g_bn_weight=torch.zeros(D), g_bn_bias=torch.zeros(D), d_hlast=torch.zeros(B * SQ, D), h_last=h, **bufs)
+    step = torch.tensor([4], dtype=torch.int32)
+    d = L.LcHeadDesc()
+    d.dtype, d.B, d.SQ, d.D, d.num_class, d.train = L.F32, B, SQ, D, NC, 1
+    d.p_drop, d.momentum, d.eps, d.seed = 0.5, 0.1, 1e-5, 667
+    d.step_dev = step.data_ptr()
+    for k, v in t.items():
+        setattr(d, k, v.data_ptr())
+    emu.call("dpc_lc_head_fwd", C.byref(d), emu.stream())
+    y4 = t["y"].clone()
+    keep = (y4 != 0) | (t["bn_out"] == 0)
+    assert abs(keep.float().mean().item() - 0.5) < 0.05
+    assert torch.allclose(y4[keep], (t["bn_out"] * 2.0)[keep])
+    emu.call("dpc_lc_head_bwd", C.byref(d), emu.stream())
+    assert torch.isfinite(t["d_hlast"]).all() and t["g_fc_weight"].abs().max().item() > 0
+    step.fill_(5)
+    emu.call("dpc_lc_head_fwd", C.byref(d), emu.stream())
+    assert not torch.equal(y4 != 0, t["y"] != 0) and int(t["bn_num_batches"]) == 2
 
 
 def test_engine_bf16_runs(emu):
