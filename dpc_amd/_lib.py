@@ -55,6 +55,12 @@ class LcHeadDesc(C.Structure):
                                            "g_bn_bias", "dctx", "d_hlast")])
 
 
+class PackEntry(C.Structure):
+    """struct dpc_pack_entry (include/dpc_hip.h)"""
+    _fields_ = [("in_", C.c_void_p), ("out", C.c_void_p), ("d0", C.c_int32), ("d1", C.c_int32), ("d2", C.c_int32), ("block0", C.c_int32),
+                ("s0", C.c_int64), ("s1", C.c_int64), ("s2", C.c_int64)]
+
+
 class DpcError(RuntimeError):
     pass
 
@@ -66,6 +72,7 @@ _SIGS = {
     "dpc_conv_igemm": [C.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _vp],
     "dpc_conv_wgrad": [C.POINTER(ConvDesc), _vp, _vp, _i32, _vp, C.POINTER(_i32), _vp],
     "dpc_pack3d": [_vp, _vp, _i32, _i32, _i32, _i32, _i64, _i64, _i64, _vp],
+    "dpc_pack3d_multi": [_vp, _i32, _i32, _i32, _vp],
     "dpc_reduce_unpack": [_vp, _i32, _vp, _i32, _i32, _i32, _i64, _i64, _i64, _i32, _vp],
     "dpc_transpose2d": [_vp, _i32, _i32, _vp, _i32, _i32, _i32, _i32, _vp],
     "dpc_pack_input_s2d": [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp],

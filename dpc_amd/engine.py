@@ -210,17 +210,12 @@ class _ConvBN:
         eng.need_stats(pr.value * 2 * Co)
 
     # ---- per-optimizer-step repack of the f32 parameter into MFMA operand layouts
-    def pack(self):
-        e = self.eng
-        w = e.PRM[self.wname]
-        dc = L.dtype_code(e.cdtype)
-        if self.stem:
-            e.call("dpc_pack_stem_weight", w, self.wp, dc, self.Co)
-            return
+    def pack_entries(self):
+        """(source, destination, d0, d1, d2, s0, s1, s2) of this unit's repacks; the engine runs them all in one launch"""
+        w = self.eng.PRM[self.wname]
         Ci, Co, t = self.Ci, self.Co, self.taps
         # wp[co][tap][ci] = w[co][ci][tap] ; wd[ci][tap][co] = w[co][ci][tap]
-        e.call("dpc_pack3d", w, self.wp, dc, Co, t, Ci, Ci * t, 1, t)
-        e.call("dpc_pack3d", w, self.wd, dc, Ci, t, Co, t, 1, Ci * t)
+        return [(w, self.wp, Co, t, Ci, Ci * t, 1, t), (w, self.wd, Ci, t, Co, t, 1, Ci * t)]
 
     def forward(self, x: torch.Tensor):
         e = self.eng
@@ -374,6 +369,7 @@ class DPCEngine:
 
         # ---- flat f32 arenas: parameters, gradients, Adam moments
         self._score_path = score_path
+        self._pack_table = None
         self.bn_running = type(self).BN_RUNNING  # BatchNorm3d with running statistics (the LC classifier's backbone)
         self.train_mode = True       # only matters when bn_running: eval uses the running buffers
         self.BUF: Dict[str, torch.Tensor] = {}
@@ -608,8 +604,18 @@ class DPCEngine:
         if self.packed_for_step == self._step_count:
             return
         dc = L.dtype_code(self.cdtype)
-        for u in self.units:
-            u.pack()
+        if self._pack_table is None:  # static: built once (addresses and shapes never change)
+            ents = [e for u in self.units if not u.stem for e in u.pack_entries()]
+            tab = (L.PackEntry * len(ents))()
+            blk = 0
+            for i, (src, dst, d0, d1, d2, s0, s1, s2) in enumerate(ents):
+                tab[i] = L.PackEntry(src.data_ptr(), dst.data_ptr(), d0, d1, d2, blk, s0, s1, s2)
+                blk += max(1, min(64, (d0 * d1 * d2 + 1023) // 1024))
+            raw = torch.frombuffer(bytearray(bytes(tab)), dtype=torch.uint8).clone()
+            self._pack_table = (raw.to(self.device), len(ents), blk)
+        tab_dev, n_ent, n_blk = self._pack_table
+        self.call("dpc_pack_stem_weight", self.PRM[self.stem.wname], self.stem.wp, dc, self.stem.Co)
+        self.call("dpc_pack3d_multi", tab_dev, n_ent, n_blk, dc)
         Pm = self.PRM
         self.call("dpc_gru_pack", Pm["agg.ConvGRUCell_00.update_gate.weight"], Pm["agg.ConvGRUCell_00.reset_gate.weight"],
                   Pm["agg.ConvGRUCell_00.out_gate.weight"], Pm.get("network_pred.0.weight"), Pm.get("network_pred.2.weight"), self.D, dc,

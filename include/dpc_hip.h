@@ -79,6 +79,15 @@ int dpc_conv_wgrad(const dpc_conv_desc* d, const void* src, const void* dy, int3
  * K-contiguous operand layouts above without touching the parameters themselves. */
 int dpc_pack3d(const float* in, void* out, int32_t dtype_out, int32_t d0, int32_t d1, int32_t d2,
                int64_t s0, int64_t s1, int64_t s2, dpc_stream_t stream);
+/* the same for a whole table of tensors in one launch (all per-step weight repacks of the conv stack): entry e is served by
+ * blocks [block0[e], block0[e+1]) of a grid of total_blocks x 256 threads; the table lives in DEVICE memory. */
+typedef struct dpc_pack_entry {
+    const void* in;   /* f32 source */
+    void* out;        /* destination, dtype_out elements, contiguous [d0][d1][d2] */
+    int32_t d0, d1, d2, block0;
+    int64_t s0, s1, s2;
+} dpc_pack_entry;
+int dpc_pack3d_multi(const dpc_pack_entry* table_dev, int32_t n_entries, int32_t total_blocks, int32_t dtype_out, dpc_stream_t stream);
 /* out[i0*s0+i1*s1+i2*s2] (f32) = sum_{k<nsplit} part[k][i0][i1][i2]  (+ out if accumulate) */
 int dpc_reduce_unpack(const float* part, int32_t nsplit, float* out, int32_t d0, int32_t d1, int32_t d2,
                       int64_t s0, int64_t s1, int64_t s2, int32_t accumulate, dpc_stream_t stream);
