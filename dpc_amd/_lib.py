@@ -110,8 +110,8 @@ _SIGS = {
     "dpc_relu_tpool_bwd": [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp],
     "dpc_lc_head_fwd": [C.POINTER(LcHeadDesc), _vp],
     "dpc_lc_head_bwd": [C.POINTER(LcHeadDesc), _vp],
-    "dpc_frames_to_input": [_vp, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _i32, _i32, _i32, _i32, C.POINTER(C.c_float), C.POINTER(C.c_float),
-                            _vp, _vp, _i32, _vp],
+    "dpc_frames_to_input": [_vp, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _i32,
+                            C.POINTER(C.c_float), C.POINTER(C.c_float), _vp, _vp, _i32, _vp],
     "dpc_adam": [_vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _f32, _f32, _f32, _f32, _vp],
 }
 

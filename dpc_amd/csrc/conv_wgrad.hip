@@ -556,7 +556,8 @@ extern "C" int dpc_conv_wgrad(const dpc_conv_desc* d, const void* src, const voi
     // of tm x tn floats written, then re-read by the reduction) over at least `min_chunks` chunks -- the small
     // ConvGRU gradients ran 4 chunks per 64 KB slab
     static const int min_chunks = getenv("DPC_WGRAD_MINCHUNKS") ? atoi(getenv("DPC_WGRAD_MINCHUNKS")) : 16;
-    int want = 1536 / (p.ntm * p.ntn);
+    static const int target_blocks = getenv("DPC_WGRAD_BLOCKS") ? atoi(getenv("DPC_WGRAD_BLOCKS")) : 512;  // fewer f32 slabs to write and re-read; 512 workgroups still fill the chip twice (sweep: profiles/r02_sweeps.txt)
+    int want = target_blocks / (p.ntm * p.ntn);
     if (want > nchunks / min_chunks) want = nchunks / min_chunks;
     if (want < 1) want = 1;
     if (want > nchunks) want = nchunks;

@@ -141,7 +141,8 @@ extern "C" int dpc_reduce_unpack(const float* part, int32_t nsplit, float* out, 
                                  int64_t s0, int64_t s1, int64_t s2, int32_t accumulate, dpc_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (!part || !out || nsplit <= 0 || d0 <= 0 || d1 <= 0 || d2 <= 0) return DPC_ERR_ARG;
-    if (d1 > 1 && d1 <= RUT_MAXT && s1 == 1 && s2 == d1 && s0 == (int64_t)d1 * d2 && d0 <= 65535) {
+    // few slabs only: with hundreds of slabs (layer1: 512 x 147 KB) the 8 split lanes of the generic kernel win (measured)
+    if (nsplit <= 16 && d1 > 1 && d1 <= RUT_MAXT && s1 == 1 && s2 == d1 && s0 == (int64_t)d1 * d2 && d0 <= 65535) {
         DPC_LAUNCH(reduce_unpack_t_kernel, dim3((unsigned)d0, (unsigned)((d2 + RUT_CW - 1) / RUT_CW)), dim3(256), stream, part, nsplit, out, d0, d1, d2,
                    accumulate);
         return dpc_launch_status();

@@ -610,7 +610,7 @@ class DPCEngine:
             blk = 0
             for i, (src, dst, d0, d1, d2, s0, s1, s2) in enumerate(ents):
                 tab[i] = L.PackEntry(src.data_ptr(), dst.data_ptr(), d0, d1, d2, blk, s0, s1, s2)
-                blk += max(1, min(64, (d0 * d1 * d2 + 1023) // 1024))
+                blk += max(1, min(1024, (d0 * d1 * d2 + 511) // 512))
             raw = torch.frombuffer(bytearray(bytes(tab)), dtype=torch.uint8).clone()
             self._pack_table = (raw.to(self.device), len(ents), blk)
         tab_dev, n_ent, n_blk = self._pack_table

@@ -293,14 +293,18 @@ int dpc_lc_head_bwd(const dpc_lc_head_desc* c, dpc_stream_t stream);
  * frames u8 [B][F][H0][W0][3] (decoded RGB, HWC) -> block f32 [B][N][3][SL][H][W] (the DPC_RNN / LC input) and / or the stem's
  * space-to-depth operand (what dpc_pack_input_s2d writes), applying per clip: frame sampling frame(n, sl) = start + (n*SL + sl)*ds,
  * the crop box (x1, y1) of RandomCrop / RandomSizedCrop, RandomHorizontalFlip (flip), per-frame RandomGray channel choice
- * (gray [B][N*SL], -1 = keep colour; NULL = none), ToTensor (/255) and Normalize(mean3, std3; HOST arrays of 3 floats).
- * The random draws stay on the host (they are a handful of integers per clip); resizing and ColorJitter are not covered. */
+ * (gray [B][N*SL], -1 = keep colour; NULL = none), Scale with NEAREST interpolation (xtab [W] / ytab [H]: device tables output
+ * column / row -> column / row inside the crop_w x crop_h crop box, produced by PIL on the host; NULL = no scaling),
+ * ToTensor (/255) and Normalize(mean3, std3; HOST arrays of 3 floats).  flip: 0 none, 1 after crop + scale (k400 recipe),
+ * 2 of the full frame before the crop (ucf101 recipe, dpc/main.py:114-123).  The random draws stay on the host (a handful of
+ * integers per clip); the BILINEAR resize of RandomSizedCrop and ColorJitter are not covered. */
 typedef struct dpc_clip_aug {
     int32_t start, x1, y1, flip;
 } dpc_clip_aug;
 int dpc_frames_to_input(const uint8_t* frames, int32_t B, int32_t F, int32_t H0, int32_t W0, const dpc_clip_aug* aug,
-                        const int8_t* gray, int32_t N, int32_t SL, int32_t ds, int32_t H, int32_t W, const float* mean3,
-                        const float* std3, float* block, void* s2d, int32_t dtype_s2d, dpc_stream_t stream);
+                        const int8_t* gray, int32_t N, int32_t SL, int32_t ds, int32_t H, int32_t W, const int32_t* xtab,
+                        const int32_t* ytab, int32_t crop_w, int32_t crop_h, const float* mean3, const float* std3, float* block,
+                        void* s2d, int32_t dtype_s2d, dpc_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -16,12 +16,18 @@ from dpc_amd.data import MEAN, STD, draw_clip_params, frames_to_input
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def reference_clip(frames_u8, start, x1, y1, flip, gray, num_seq, seq_len, ds, size):
-    """dataset_3d.py:94-111 for one video given the loader's draws"""
+def reference_clip(frames_u8, start, x1, y1, flip, gray, num_seq, seq_len, ds, size, crop=None):
+    """dataset_3d.py:94-111 for one video given the loader's draws.  flip 1: k400 recipe (crop, then flip); flip 2: ucf101 recipe
+    (flip the frame, crop `crop`, Scale to `size` with the default NEAREST), dpc/main.py:114-132"""
+    crop = crop or size
     idx = (np.arange(num_seq)[:, None] * ds * seq_len + start + np.arange(seq_len)[None, :] * ds).reshape(-1)  # idx_sampler
     seq = [Image.fromarray(frames_u8[i]) for i in idx]
-    seq = [im.crop((x1, y1, x1 + size, y1 + size)) for im in seq]                     # RandomCrop (consistent box)
-    if flip:
+    if flip == 2:
+        seq = [im.transpose(Image.FLIP_LEFT_RIGHT) for im in seq]                     # RandomHorizontalFlip first
+    seq = [im.crop((x1, y1, x1 + crop, y1 + crop)) for im in seq]                     # RandomCrop (consistent box)
+    if crop != size:
+        seq = [im.resize((size, size), Image.NEAREST) for im in seq]                  # Scale(size=(size, size)), default interpolation
+    if flip == 1:
         seq = [im.transpose(Image.FLIP_LEFT_RIGHT) for im in seq]                     # RandomHorizontalFlip
     out = []
     for im, g in zip(seq, gray):
@@ -58,14 +64,30 @@ def run_case(lib, dev, B, F, H0, W0, N, SL, ds, size, seed):
     assert torch.equal(s2b.cpu(), chk2.cpu())
 
 
+def run_ucf_case(lib, dev, B, F, H0, W0, N, SL, ds, crop, size, seed):
+    """the ucf101 recipe: flip (before the crop) -> RandomCrop(crop) -> Scale(size) NEAREST -> RandomGray -> ToTensor -> Normalize"""
+    rng = np.random.default_rng(seed)
+    frames = rng.integers(0, 256, (B, F, H0, W0, 3), dtype=np.uint8)
+    aug, gray = draw_clip_params(rng, B, F, N, SL, ds, H0, W0, crop, flip_code=2)
+    aug[0, 3], aug[-1, 3] = 2, 0
+    exp = torch.stack([reference_clip(frames[b], *aug[b], gray[b], N, SL, ds, size, crop) for b in range(B)])
+    fr, au, gr = (torch.from_numpy(a).to(dev) for a in (frames, aug, gray))
+    block = torch.empty(B, N, 3, SL, size, size, device=dev)
+    frames_to_input(lib, fr, au, gr, N, SL, ds, size, block, None, crop=crop)
+    assert torch.equal(block.cpu(), exp)
+
+
 def test_frames_to_input_emu():
     subprocess.run(["make", "-s", "-j8", "emu"], cwd=ROOT, check=True)
     run_case(L.load_emulator(), "cpu", 2, 40, 20, 24, 3, 2, 3, 16, seed=1)
+    run_ucf_case(L.load_emulator(), "cpu", 2, 40, 40, 50, 3, 2, 3, 28, 16, seed=2)   # crop 28 -> 16 (the 224 -> 128 ratio)
+    run_ucf_case(L.load_emulator(), "cpu", 2, 40, 40, 50, 3, 2, 3, 34, 14, seed=3)   # a ratio whose rounding is not symmetric
 
 
 @pytest.mark.gpu
 def test_frames_to_input_gpu():
     run_case(L.load_hip(), "cuda:0", 3, 130, 150, 200, 8, 5, 3, 128, seed=2)  # kinetics-style: short side 150, crop 128
+    run_ucf_case(L.load_hip(), "cuda:0", 2, 130, 256, 340, 8, 5, 3, 224, 128, seed=4)  # ucf101: short side 256, crop 224, scale 128
 
 
 @pytest.mark.gpu
