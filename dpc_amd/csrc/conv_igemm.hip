@@ -472,7 +472,10 @@ static bool plan_parity(IGemmParams& p, int bke) {
         const int cw = c % g.sw, ch = (c / g.sw) % g.sh, ct = c / (g.sw * g.sh);
         par.tile_start[c] = tiles;
         if (par.cnt[0][ct] * par.cnt[1][ch] * par.cnt[2][cw] > 64) return false;
-        const long long rows = (long long)par.N * par.dimc[0][ct] * par.dimc[1][ch] * par.dimc[2][cw];
+        long long rows = (long long)par.N * par.dimc[0][ct] * par.dimc[1][ch] * par.dimc[2][cw];
+        // in-place accumulation (addend == out): positions no tap reaches keep their value, so their classes get no tiles --
+        // a 1x1 stride-2 downsample's input-gradient touches 1/4 (2D) or 1/8 (3D) of dx instead of rewriting all of it
+        if (p.addend && p.addend == p.out && par.cnt[0][ct] * par.cnt[1][ch] * par.cnt[2][cw] == 0) rows = 0;
         tiles += (int)((rows + 127) / 128);
     }
     for (int c = par.ncls; c < 9; ++c) par.tile_start[c] = tiles;

@@ -313,14 +313,11 @@ class _Block:
         dz = e.scratch(oshape, exclude=[dout, draw2])
         self.c2.bn_backward(dout, self.out if self.final_relu else None, self.final_relu, draw2, dz)
         # dout is dead from here on
-        partial = None
+        draw_d = None
         if self.ds is not None:
-            draw_d = dout  # reuse
+            draw_d = e.scratch(oshape, exclude=[dout, draw2, dz])  # lives until the block's last input-gradient
             self.ds.bn_backward(dz, None, False, draw_d, None)
             self.ds.wgrad(self.x_in, draw_d)
-            if need_dx:
-                partial = e.scratch(ishape, exclude=[])
-                self.ds.dgrad(draw_d, partial, None)
         self.c2.wgrad(self.act1, draw2)
         dact1 = dout  # out-shape buffer, free again
         self.c2.dgrad(draw2, dact1, None)
@@ -330,8 +327,11 @@ class _Block:
         if not need_dx:
             return None
         if self.ds is not None:
-            dx = e.scratch(ishape, exclude=[partial])
-            self.c1.dgrad(draw1, dx, partial)
+            # dx = main path; the strided 1x1 downsample then accumulates IN PLACE on the positions it reads (1/4 of dx in 2D,
+            # 1/8 in 3D) -- round 1 wrote a full, 75-88 % zero tensor and re-read it as the addend
+            dx = e.scratch(ishape, exclude=[])
+            self.c1.dgrad(draw1, dx, None)
+            self.ds.dgrad(draw_d, dx, dx)
         else:
             dx = dact1  # same shape as the input; dact1 is dead
             self.c1.dgrad(draw1, dx, dz)

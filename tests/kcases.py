@@ -109,6 +109,28 @@ def case_conv_dgrad(k: K, dtype, N, Ci, Co, T, H, W, ks, st, pd, seed=1):
     assert relerr(out, cl(gx) + add) < tol(dtype)
 
 
+def case_conv_dgrad_inplace(k: K, dtype, N, Ci, Co, T, H, W, ks, st, pd, seed=5):
+    """input-gradient accumulated IN PLACE (addend == out): the engine adds a strided 1x1 downsample's gradient onto the
+    main path's dx; positions no tap reaches must keep their value exactly"""
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(N, Ci, T, H, W, generator=g).requires_grad_()
+    w = q(torch.randn(Co, Ci, *ks, generator=g) * 0.1, dtype)
+    y = F.conv3d(x, w, None, st, pd)
+    gy = q(torch.randn(y.shape, generator=g), dtype)
+    gx = torch.autograd.grad(y, x, gy)[0]
+    To, Ho, Wo = y.shape[2:]
+    taps = ks[0] * ks[1] * ks[2]
+    d = conv_desc(dtype, dtype, 1, N, (T, H, W), (To, Ho, Wo), Co, Co, Ci, taps * Co, Ci, ks, st, pd)
+    base = q(torch.randn(N, T, H, W, Ci, generator=g), dtype)
+    out = k.t(base.clone(), dtype)
+    wd = k.t(w.permute(1, 2, 3, 4, 0).reshape(Ci, taps * Co), dtype)
+    k.call("dpc_conv_igemm", C.byref(d), k.t(cl(gy), dtype), wd, out, out, None)
+    k.sync()
+    assert relerr(out, cl(gx) + base) < tol(dtype)
+    untouched = cl(gx) == 0
+    assert torch.equal(out.cpu().float()[untouched], base[untouched])
+
+
 def case_conv_wgrad(k: K, dtype, N, Ci, Co, T, H, W, ks, st, pd, seed=2):
     g = torch.Generator().manual_seed(seed)
     x = q(torch.randn(N, Ci, T, H, W, generator=g), dtype)

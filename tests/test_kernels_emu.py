@@ -169,3 +169,9 @@ def test_gru_chain_reference_fixture(k, golden_dir):
 @pytest.mark.parametrize("rd", [(24, 32), (96, 32), (200, 32), (264, 32), (136, 256)])
 def test_score_fused(k, rd):
     kc.case_score_fused(k, *rd)
+
+
+@pytest.mark.parametrize("dtype", [F32, BF16])
+@pytest.mark.parametrize("shape", [(2, 16, 32, 1, 8, 8, (1, 1, 1), (1, 2, 2), (0, 0, 0)), (2, 16, 24, 5, 6, 6, (1, 1, 1), (2, 2, 2), (0, 0, 0)), (1, 16, 16, 2, 7, 9, (1, 3, 3), (1, 2, 2), (0, 1, 1))])
+def test_conv_dgrad_inplace(k, dtype, shape):
+    kc.case_conv_dgrad_inplace(k, dtype, *shape)

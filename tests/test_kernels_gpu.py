@@ -154,3 +154,9 @@ def test_score_fused(k, rd):
 
 def test_score_fused_cfg5(k):
     kc.case_score_fused(k, 15680, 256, check_score=False)  # cfg5: the 983 MB matrix never exists on the device
+
+
+@pytest.mark.parametrize("dtype", [F32, BF16])
+@pytest.mark.parametrize("shape", [(5, 64, 128, 3, 32, 32, (1, 1, 1), (1, 2, 2), (0, 0, 0)), (5, 128, 256, 5, 16, 16, (1, 1, 1), (2, 2, 2), (0, 0, 0)), (3, 64, 128, 2, 32, 32, (1, 3, 3), (1, 2, 2), (0, 1, 1))])
+def test_conv_dgrad_inplace(k, dtype, shape):
+    kc.case_conv_dgrad_inplace(k, dtype, *shape)
