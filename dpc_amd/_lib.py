@@ -112,6 +112,7 @@ _SIGS = {
     "dpc_lc_head_bwd": [C.POINTER(LcHeadDesc), _vp],
     "dpc_frames_to_input": [_vp, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _i32,
                             C.POINTER(C.c_float), C.POINTER(C.c_float), _vp, _vp, _i32, _vp],
+    "dpc_stem_wgrad_fused": [C.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(_i32), _vp],
     "dpc_adam": [_vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _f32, _f32, _f32, _f32, _vp],
 }
 

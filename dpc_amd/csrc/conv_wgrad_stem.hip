@@ -27,9 +27,20 @@ struct WgradStemParams {
     long long src_bytes, dy_bytes;
     FastDiv d_cpf, d_nseg;
     int cpf;              // chunks per frame = H * nseg
+    // FUSED: dy is never read -- it is produced on the fly from the stem's max-pool / BatchNorm backward
+    const void* raw;      // [NF][H][W][Co] raw conv output (same geometry as dy)
+    const void* dpool;    // [NF][Ho][Wo][Co] gradient at the pooled output
+    const uint8_t* argmax;
+    const float *mean, *invstd, *gamma, *coef;
+    int Ho, Wo;
 };
 
-__global__ __launch_bounds__(256, 3) void wgrad_stem_kernel(WgradStemParams p) {
+// FUSED = true: the [64 positions][64 co] dy sub-tile is not DMA'd but COMPUTED by the workgroup from the pooled gradient
+// (routed through the saved argmax bytes), the raw conv output and the BatchNorm-backward coefficients -- what
+// dpc_pool_bn_bwd_apply wrote to a 2.7 GB tensor (1.2 ms) that this kernel then read back.  The loads of chunk c+1 are in
+// flight during the MFMAs of chunk c; the values are transformed and ds_written after them.
+template <bool FUSED>
+__global__ __launch_bounds__(256, FUSED ? 2 : 3) void wgrad_stem_kernel(WgradStemParams p) {
     constexpr int PW = 68, NPOS = 4 * PW;       // patch: 4 rows x (64 + 3, padded to 68) positions of 32 bytes
     constexpr int NPB = (NPOS + 31) / 32;        // 9 pieces of 32 positions
     constexpr int NIB = (NPB + 3) / 4;
@@ -100,6 +111,71 @@ __global__ __launch_bounds__(256, 3) void wgrad_stem_kernel(WgradStemParams p) {
         DPC_UNROLL
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
+    // ---- FUSED producer state: this lane makes logical unit (lane & 7) of positions a_pos[0], a_pos[1]
+    const int fu = lane & 7;                    // 8 output channels tile_m*64 + 8*fu ..
+    float f_mu[8], f_is[8], f_ga[8], f_c1[8], f_c2[8];
+    if (FUSED) {
+        DPC_UNROLL
+        for (int e = 0; e < 8; ++e) {
+            const int c = tile_m * 64 + fu * 8 + e;
+            f_mu[e] = p.mean[c]; f_is[e] = p.invstd[c]; f_ga[e] = p.gamma[c] * f_is[e]; f_c1[e] = p.coef[c]; f_c2[e] = p.coef[p.Co + c];
+        }
+    }
+    u32x4 f_raw[2], f_g[2][2][2];
+    u32x2 f_am[2][2][2];
+    int f_want[2][2][2];   // tap index the position is inside window (a, b), or -1
+    bool f_ok[2];
+    auto fused_load = [&](int chunk) {
+        const unsigned frame = fdiv((unsigned)chunk, p.d_cpf);
+        const int rem = chunk - (int)frame * p.cpf;
+        const int h = (int)fdiv((unsigned)rem, p.d_nseg);
+        const int w0 = (rem - h * p.nseg) * 64;
+        const u32x4 z4 = {0u, 0u, 0u, 0u};
+        DPC_UNROLL
+        for (int i = 0; i < 2; ++i) {
+            const int w = w0 + a_pos[i];
+            f_ok[i] = w < p.W;
+            f_raw[i] = z4;
+            if (f_ok[i]) f_raw[i] = *(const u32x4*)((const char*)p.raw + ((((long long)frame * p.H + h) * p.W + w) * p.dy_ld + tile_m * 64 + fu * 8) * 2);
+            DPC_UNROLL
+            for (int a = 0; a < 2; ++a)
+                DPC_UNROLL
+                for (int b = 0; b < 2; ++b) {
+                    const int oh = (h >> 1) + a, ow = (w >> 1) + b;
+                    const bool use = f_ok[i] && (a == 0 || (h & 1)) && (b == 0 || (w & 1)) && oh < p.Ho && ow < p.Wo;
+                    f_want[i][a][b] = use ? (h - (2 * oh - 1)) * 3 + (w - (2 * ow - 1)) : -1;
+                    f_g[i][a][b] = z4;
+                    f_am[i][a][b] = u32x2{0x09090909u, 0x09090909u};
+                    if (use) {
+                        const unsigned ui = (unsigned)(((int)frame * p.Ho + oh) * p.Wo + ow) * (unsigned)p.Co + (unsigned)(tile_m * 64 + fu * 8);
+                        f_g[i][a][b] = *(const u32x4*)((const bf16_t*)p.dpool + ui);
+                        f_am[i][a][b] = *(const u32x2*)(p.argmax + ui);
+                    }
+                }
+        }
+    };
+    auto fused_store = [&](int buf) {
+        unsigned char* stage = lds + buf * STAGE;
+        DPC_UNROLL
+        for (int i = 0; i < 2; ++i) {
+            float ov[8];
+            DPC_UNROLL
+            for (int e = 0; e < 8; ++e) {
+                float g = 0.f;
+                DPC_UNROLL
+                for (int a = 0; a < 2; ++a)
+                    DPC_UNROLL
+                    for (int b = 0; b < 2; ++b) {
+                        const int am = (int)((f_am[i][a][b][e >> 2] >> (8 * (e & 3))) & 0xffu);
+                        if (am == f_want[i][a][b]) g += unit_get<bf16_t>(f_g[i][a][b], e);
+                    }
+                const float xh = (unit_get<bf16_t>(f_raw[i], e) - f_mu[e]) * f_is[e];
+                ov[e] = f_ok[i] ? f_ga[e] * (g - f_c1[e] - xh * f_c2[e]) : 0.f;
+            }
+            *(u32x4*)(stage + (wv + 4 * i) * 1024 + pl * 128 + (((fu ^ (2 * (pl & 3))) & 7) << 4)) = unit_pack<bf16_t>(ov);
+        }
+    };
+
     auto issue = [&](int chunk, int buf) {
         unsigned char* stage = lds + buf * STAGE;
         const unsigned frame = fdiv((unsigned)chunk, p.d_cpf);
@@ -110,10 +186,12 @@ __global__ __launch_bounds__(256, 3) void wgrad_stem_kernel(WgradStemParams p) {
         const unsigned a_base = (unsigned)(pos * p.dy_ld * 2 - a_lo);
         // patch origin = image (h - ph, w0 - pw); offsets may wrap below zero for border positions (those lanes are masked)
         const unsigned b_base = (unsigned)((pos - (long long)p.ph * p.W - p.pw) * 32 - b_lo);
-        DPC_UNROLL
-        for (int i = 0; i < 2; ++i) {
-            const bool ok = w0 + a_pos[i] < p.W;
-            glds16_buf(rs_a, ok ? a_base + a_off[i] : DPC_BUF_OOB, 0u, stage + (wv + 4 * i) * 1024, lane);
+        if (!FUSED) {
+            DPC_UNROLL
+            for (int i = 0; i < 2; ++i) {
+                const bool ok = w0 + a_pos[i] < p.W;
+                glds16_buf(rs_a, ok ? a_base + a_off[i] : DPC_BUF_OOB, 0u, stage + (wv + 4 * i) * 1024, lane);
+            }
         }
         DPC_UNROLL
         for (int i = 0; i < NIB; ++i) {
@@ -152,12 +230,19 @@ __global__ __launch_bounds__(256, 3) void wgrad_stem_kernel(WgradStemParams p) {
         }
     };
 
-    if (c_begin < c_end) issue(c_begin, 0);
+    if (c_begin < c_end) {
+        issue(c_begin, 0);
+        if (FUSED) { fused_load(c_begin); fused_store(0); }
+    }
     __syncthreads();
     for (int ch = c_begin; ch < c_end; ++ch) {
         const int buf = (ch - c_begin) & 1;
-        if (ch + 1 < c_end) issue(ch + 1, buf ^ 1);
+        if (ch + 1 < c_end) {
+            issue(ch + 1, buf ^ 1);
+            if (FUSED) fused_load(ch + 1);   // in flight during the MFMAs below
+        }
         compute(buf);
+        if (FUSED && ch + 1 < c_end) fused_store(buf ^ 1);
         __syncthreads();
     }
 
@@ -173,9 +258,7 @@ __global__ __launch_bounds__(256, 3) void wgrad_stem_kernel(WgradStemParams p) {
     }
 }
 
-// returns 1 when the shape is not served; with part == NULL only *nsplit is set
-int dpc_wgrad_stem_try(const dpc_conv_desc* d, const void* src, const void* dy, int dy_ld, float* part, int32_t* nsplit,
-                       hipStream_t stream) {
+static int stem_plan(const dpc_conv_desc* d, int dy_ld, WgradStemParams* p) {
     static const int on = getenv("DPC_WGRAD_STEM") ? atoi(getenv("DPC_WGRAD_STEM")) : 1;
     if (!on || d->dtype_in != DPC_BF16 || d->mode != 0) return 1;
     if (d->KT != 1 || d->KH != 4 || d->KW != 4 || d->st != 1 || d->sh != 1 || d->sw != 1 || d->pt != 0) return 1;
@@ -183,25 +266,58 @@ int dpc_wgrad_stem_try(const dpc_conv_desc* d, const void* src, const void* dy, 
     if (d->RT != d->ST || d->RH != d->SH || d->RW != d->SW || d->RW < 48) return 1;  // narrow images: mostly padding, generic kernel
     const long long M = (long long)d->N * d->RT * d->RH * d->RW;
     const long long sb = M * 32, db = M * dy_ld * 2;
-    WgradStemParams p;
-    p.Co = d->Co; p.dy_ld = dy_ld; p.H = d->RH; p.W = d->RW; p.NF = d->N * d->RT;
-    p.nseg = (d->RW + 63) / 64; p.ph = d->ph; p.pw = d->pw;
-    p.cpf = d->RH * p.nseg;
-    p.d_cpf = make_fastdiv((uint32_t)p.cpf); p.d_nseg = make_fastdiv((uint32_t)p.nseg);
-    p.ntm = d->Co / 64;
-    p.src_bytes = sb; p.dy_bytes = db;
-    const int nchunks = p.NF * p.cpf;
-    int want = 1024 / p.ntm;
+    p->Co = d->Co; p->dy_ld = dy_ld; p->H = d->RH; p->W = d->RW; p->NF = d->N * d->RT;
+    p->nseg = (d->RW + 63) / 64; p->ph = d->ph; p->pw = d->pw;
+    p->cpf = d->RH * p->nseg;
+    p->d_cpf = make_fastdiv((uint32_t)p->cpf); p->d_nseg = make_fastdiv((uint32_t)p->nseg);
+    p->ntm = d->Co / 64;
+    p->src_bytes = sb; p->dy_bytes = db;
+    const int nchunks = p->NF * p->cpf;
+    int want = 1024 / p->ntm;
     if (want > nchunks / 16) want = nchunks / 16;
     if (want < 1) want = 1;
-    p.kcps = (nchunks + want - 1) / want;
-    p.nks = (nchunks + p.kcps - 1) / p.kcps;
-    if ((long long)(p.kcps + 2 * p.nseg * 4) * 64 * dy_ld * 2 >= (1ll << 31)) return 1;  // a workgroup's window must stay 32-bit addressable
+    p->kcps = (nchunks + want - 1) / want;
+    p->nks = (nchunks + p->kcps - 1) / p->kcps;
+    if ((long long)(p->kcps + 2 * p->nseg * 4) * 64 * dy_ld * 2 >= (1ll << 31)) return 1;  // a workgroup's window must stay 32-bit addressable
+    return 0;
+}
+
+// returns 1 when the shape is not served; with part == NULL only *nsplit is set
+int dpc_wgrad_stem_try(const dpc_conv_desc* d, const void* src, const void* dy, int dy_ld, float* part, int32_t* nsplit,
+                       hipStream_t stream) {
+    WgradStemParams p = {};
+    if (stem_plan(d, dy_ld, &p)) return 1;
     if (nsplit) *nsplit = p.nks;
     if (!part) return DPC_OK;
     if (!src || !dy) return DPC_ERR_ARG;
     if (((uintptr_t)src % 16) || ((uintptr_t)dy % 16)) return DPC_ERR_UNSUPPORTED;
     p.src = src; p.dy = dy; p.part = part;
-    DPC_LAUNCH(wgrad_stem_kernel, dim3((unsigned)(p.ntm * p.nks)), dim3(256), stream, p);
+    DPC_LAUNCH((wgrad_stem_kernel<false>), dim3((unsigned)(p.ntm * p.nks)), dim3(256), stream, p);
+    return dpc_launch_status();
+}
+
+// Weight gradient of the stem convolution straight from the gradient at the POOLED output: BatchNorm backward and the
+// max-pool routing (dpc_pool_bn_bwd_apply's arithmetic, bit for bit: dz is rounded to bf16 before the MFMAs in both forms)
+// happen inside the kernel, the full-resolution dz tensor is never written.  desc = the stem's weight-gradient descriptor
+// (space-to-depth form); raw / mean / invstd / gamma / coef as for dpc_pool_bn_bwd_apply; dpool / argmax at the pooled
+// resolution ((H-1)/2+1, (W-1)/2+1).  With part == NULL only *nsplit is set.  DPC_ERR_UNSUPPORTED: use the two-kernel form.
+extern "C" int dpc_stem_wgrad_fused(const dpc_conv_desc* d, const void* src_s2d, const void* raw, const void* dpool, const uint8_t* argmax,
+                                    const float* mean, const float* invstd, const float* gamma, const float* coef, float* part,
+                                    int32_t* nsplit, dpc_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!d) return DPC_ERR_ARG;
+    static const int on = getenv("DPC_STEM_FUSED") ? atoi(getenv("DPC_STEM_FUSED")) : 1;
+    WgradStemParams p = {};
+    if (!on || d->dtype_out != DPC_F32 || stem_plan(d, d->Co, &p)) return DPC_ERR_UNSUPPORTED;
+    const long long pooled = (long long)p.NF * ((p.H - 1) / 2 + 1) * ((p.W - 1) / 2 + 1) * d->Co;
+    if (pooled * 2 >= (1ll << 31)) return DPC_ERR_UNSUPPORTED;  // 32-bit element offsets into the pooled tensors
+    if (nsplit) *nsplit = p.nks;
+    if (!part) return DPC_OK;
+    if (!src_s2d || !raw || !dpool || !argmax || !mean || !invstd || !gamma || !coef) return DPC_ERR_ARG;
+    if (((uintptr_t)src_s2d % 16) || ((uintptr_t)raw % 16) || ((uintptr_t)dpool % 16) || ((uintptr_t)argmax % 8)) return DPC_ERR_UNSUPPORTED;
+    p.src = src_s2d; p.dy = raw; p.part = part;  // p.dy only sizes the (unused) dy window
+    p.raw = raw; p.dpool = dpool; p.argmax = argmax; p.mean = mean; p.invstd = invstd; p.gamma = gamma; p.coef = coef;
+    p.Ho = (p.H - 1) / 2 + 1; p.Wo = (p.W - 1) / 2 + 1;
+    DPC_LAUNCH((wgrad_stem_kernel<true>), dim3((unsigned)(p.ntm * p.nks)), dim3(256), stream, p);
     return dpc_launch_status();
 }

@@ -521,7 +521,21 @@ class DPCEngine:
         self.coef = self.empty((2, max(widths)), f32)
         self.stats = self.empty((max(self._stats_need, 1),), f32)
         self.part = self.empty((max(self._part_need, 1),), f32)
-        self.stem_dz = self.empty(tuple(self.stem.raw.shape), dt)
+        # stem backward: fused weight gradient when the kernel serves the shape (bf16, image >= 96 px wide), else dz + generic path
+        ns = C.c_int32(0)
+        self._stem_fused = False
+        if dt == torch.bfloat16:
+            try:
+                self._stem_fused = self.lib.call("dpc_stem_wgrad_fused", C.byref(self.stem.desc_w), None, None, None, None, None, None, None,
+                                                 None, None, C.byref(ns), self.lib.stream()) == 0
+            except L.DpcError:
+                self._stem_fused = False
+        if self._stem_fused:
+            self.need_part(ns.value * widths[0] * 256)
+            self.part = self.empty((max(self._part_need, 1),), f32)
+            self.stem_dz = None
+        else:
+            self.stem_dz = self.empty(tuple(self.stem.raw.shape), dt)
         self.packed_for_step = -1
 
     # ------------------------------------------------------------------ plumbing
@@ -662,6 +676,12 @@ class DPCEngine:
                   self.PRM[u.bnname + ".weight"], self.PRM[u.bnname + ".bias"], self.stats, C.byref(pr))
         self.call("dpc_bn_bwd_finalize", self.stats, pr.value, C0, float(u.rows), self.G[u.bnname + ".weight"],
                   self.G[u.bnname + ".bias"], self.coef)
+        if self._stem_fused:  # BN backward + pool routing inside the weight-gradient kernel: no 2.7 GB dz tensor (csrc/conv_wgrad_stem.hip)
+            ns = C.c_int32(0)
+            self.call("dpc_stem_wgrad_fused", C.byref(u.desc_w), self.x_s2d, u.raw, d, self.pool_arg, u.mean, u.invstd,
+                      self.PRM[u.bnname + ".weight"], self.coef, self.part, C.byref(ns))
+            self.call("dpc_unpack_stem_wgrad", self.part, ns.value, self.G[u.wname], C0)
+            return
         self.call("dpc_pool_bn_bwd_apply", d, self.pool_arg, u.raw, dc, st[0] * st[1], st[2], st[3], C0, u.mean, u.invstd,
                   self.PRM[u.bnname + ".weight"], self.coef, self.stem_dz)
         self.stem.wgrad(self.x_s2d, self.stem_dz)

@@ -151,6 +151,13 @@ int dpc_pooled_bn_bwd_reduce(const void* dy, const uint8_t* argmax, const void* 
 int dpc_pool_bn_bwd_apply(const void* dy, const uint8_t* argmax, const void* x, int32_t dtype, int32_t NT, int32_t H,
                           int32_t W, int32_t C, const float* mean, const float* invstd, const float* gamma,
                           const float* coef, void* dx, dpc_stream_t stream);
+/* the stem's weight gradient straight from the gradient at the pooled output (throughput mode): pool_bn_bwd_apply's arithmetic
+ * runs inside the weight-gradient kernel, the 2.7 GB full-resolution dz tensor is never written or re-read.  desc = the stem's
+ * weight-gradient descriptor (space-to-depth form, dtype_in bf16, dtype_out f32).  part / nsplit as dpc_conv_wgrad (finish with
+ * dpc_unpack_stem_wgrad).  DPC_ERR_UNSUPPORTED -> run dpc_pool_bn_bwd_apply + dpc_conv_wgrad instead. */
+int dpc_stem_wgrad_fused(const dpc_conv_desc* d, const void* src_s2d, const void* raw, const void* dpool, const uint8_t* argmax,
+                         const float* mean, const float* invstd, const float* gamma, const float* coef, float* part,
+                         int32_t* nsplit, dpc_stream_t stream);
 
 /* ---- temporal mean + ReLU split (dpc/model_3d.py:53-59) -----------------------------
  * x [B*N][T][SQ][D] -> feat_relu [N][B*SQ][D] (GRU input, time-major) and

@@ -175,3 +175,8 @@ def test_score_fused(k, rd):
 @pytest.mark.parametrize("shape", [(2, 16, 32, 1, 8, 8, (1, 1, 1), (1, 2, 2), (0, 0, 0)), (2, 16, 24, 5, 6, 6, (1, 1, 1), (2, 2, 2), (0, 0, 0)), (1, 16, 16, 2, 7, 9, (1, 3, 3), (1, 2, 2), (0, 1, 1))])
 def test_conv_dgrad_inplace(k, dtype, shape):
     kc.case_conv_dgrad_inplace(k, dtype, *shape)
+
+
+def test_stem_wgrad_fused(k):
+    kc.case_stem_wgrad_fused(k, 2, 2, 128, 128)   # one 64-position segment per row
+    kc.case_stem_wgrad_fused(k, 1, 1, 20, 200)    # ragged last segment, odd pooled width

@@ -160,3 +160,9 @@ def test_score_fused_cfg5(k):
 @pytest.mark.parametrize("shape", [(5, 64, 128, 3, 32, 32, (1, 1, 1), (1, 2, 2), (0, 0, 0)), (5, 128, 256, 5, 16, 16, (1, 1, 1), (2, 2, 2), (0, 0, 0)), (3, 64, 128, 2, 32, 32, (1, 3, 3), (1, 2, 2), (0, 1, 1))])
 def test_conv_dgrad_inplace(k, dtype, shape):
     kc.case_conv_dgrad_inplace(k, dtype, *shape)
+
+
+def test_stem_wgrad_fused(k):
+    kc.case_stem_wgrad_fused(k, 3, 2, 128, 128)
+    kc.case_stem_wgrad_fused(k, 2, 1, 64, 224)
+    kc.case_stem_wgrad_fused(k, 1, 2, 30, 200)
