@@ -39,6 +39,12 @@ struct WgradStemParams {
 // (routed through the saved argmax bytes), the raw conv output and the BatchNorm-backward coefficients -- what
 // dpc_pool_bn_bwd_apply wrote to a 2.7 GB tensor (1.2 ms) that this kernel then read back.  The loads of chunk c+1 are in
 // flight during the MFMAs of chunk c; the values are transformed and ds_written after them.
+// MEASURED (MI355X, batch 128, 128 x 128): 2.14 ms per launch against 1.22 ms (pool_bn_bwd_apply) + 0.67 ms (FUSED = false), i.e.
+// slower by 0.25 ms per step: a chunk's register gathers (2 x raw + up to 8 window loads per lane) see HBM latency that one chunk
+// of MFMA work (~0.5 us) does not cover, and the registers that hold them cost the third workgroup per CU.  Re-mapping lanes to
+// an even/odd column pair (4 shared gathers, compile-time taps) at 3 workgroups/CU spilled and ran 3.8 ms.  The engine therefore
+// keeps this variant opt-in (DPCEngine(stem_fused=True) / DPC_STEM_FUSED=1): it removes the 2.7 GB dz tensor, not time.  Making it
+// pay needs the gathers staged by LDS-DMA two chunks ahead (~21 KB of staging per stage) -- not built.
 template <bool FUSED>
 __global__ __launch_bounds__(256, FUSED ? 2 : 3) void wgrad_stem_kernel(WgradStemParams p) {
     constexpr int PW = 68, NPOS = 4 * PW;       // patch: 4 rows x (64 + 3, padded to 68) positions of 32 bytes
@@ -306,9 +312,8 @@ extern "C" int dpc_stem_wgrad_fused(const dpc_conv_desc* d, const void* src_s2d,
                                     int32_t* nsplit, dpc_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (!d) return DPC_ERR_ARG;
-    static const int on = getenv("DPC_STEM_FUSED") ? atoi(getenv("DPC_STEM_FUSED")) : 1;
     WgradStemParams p = {};
-    if (!on || d->dtype_out != DPC_F32 || stem_plan(d, d->Co, &p)) return DPC_ERR_UNSUPPORTED;
+    if (d->dtype_out != DPC_F32 || stem_plan(d, d->Co, &p)) return DPC_ERR_UNSUPPORTED;
     const long long pooled = (long long)p.NF * ((p.H - 1) / 2 + 1) * ((p.W - 1) / 2 + 1) * d->Co;
     if (pooled * 2 >= (1ll << 31)) return DPC_ERR_UNSUPPORTED;  // 32-bit element offsets into the pooled tensors
     if (nsplit) *nsplit = p.nks;

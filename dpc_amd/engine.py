@@ -25,6 +25,7 @@ from __future__ import annotations
 
 import contextlib
 import ctypes as C
+import os
 import math
 from typing import Dict, List, Optional, Sequence, Tuple
 
@@ -345,7 +346,7 @@ class DPCEngine:
     def __init__(self, network: str = "resnet18", sample_size: int = 128, num_seq: int = 8, seq_len: int = 5,
                  pred_step: int = 3, batch: int = 4, device="cuda", compute_dtype=torch.float32,
                  widths: Sequence[int] = LAYER_WIDTH, lib: Optional[L.Lib] = None,
-                 lr: float = 1e-3, wd: float = 1e-5, dropout: float = 0.1, seed: int = 233, score_path: str = "auto"):
+                 lr: float = 1e-3, wd: float = 1e-5, dropout: float = 0.1, seed: int = 233, score_path: str = "auto", stem_fused: bool | None = None):
         self.device = torch.device(device)
         self.lib = L.lib_for(self.device, lib)  # raises unless HIP device (or an explicit simulator handle in tests)
         self.cdtype = compute_dtype
@@ -369,6 +370,10 @@ class DPCEngine:
 
         # ---- flat f32 arenas: parameters, gradients, Adam moments
         self._score_path = score_path
+        # Fused stem weight gradient (no full-resolution dz tensor).  Bit-identical to the two-kernel form but measured SLOWER on
+        # MI355X (2.14 ms against 1.22 + 0.67 ms, profiles/r02_sweeps.txt) -- its per-chunk gathers are not covered by one chunk of
+        # MFMA work -- so it is opt-in: it saves 2.7 GB (cfg2) / 8.2 GB (cfg5) of HBM, not time.
+        self._want_stem_fused = bool(int(os.environ.get("DPC_STEM_FUSED", "0"))) if stem_fused is None else bool(stem_fused)
         self._pack_table = None
         self.bn_running = type(self).BN_RUNNING  # BatchNorm3d with running statistics (the LC classifier's backbone)
         self.train_mode = True       # only matters when bn_running: eval uses the running buffers
@@ -521,10 +526,10 @@ class DPCEngine:
         self.coef = self.empty((2, max(widths)), f32)
         self.stats = self.empty((max(self._stats_need, 1),), f32)
         self.part = self.empty((max(self._part_need, 1),), f32)
-        # stem backward: fused weight gradient when the kernel serves the shape (bf16, image >= 96 px wide), else dz + generic path
+        # stem backward: fused weight gradient when asked for and the kernel serves the shape (bf16, image >= 96 px wide), else dz + generic path
         ns = C.c_int32(0)
         self._stem_fused = False
-        if dt == torch.bfloat16:
+        if dt == torch.bfloat16 and self._want_stem_fused:
             try:
                 self._stem_fused = self.lib.call("dpc_stem_wgrad_fused", C.byref(self.stem.desc_w), None, None, None, None, None, None, None,
                                                  None, None, C.byref(ns), self.lib.stream()) == 0

@@ -283,3 +283,19 @@ def test_full_batch_properties(dtype):
     for _ in range(4):
         res = eng.train_step(x, dropout_masks=None)
     assert res[0].item() < res0[0].item()
+
+
+def test_stem_fused_step_is_bit_identical():
+    """The opt-in fused stem weight gradient (csrc/conv_wgrad_stem.hip, no dz tensor) gives the same step, bit for bit."""
+    x = torch.randn(4, 8, 3, 5, 128, 128, device=DEV, generator=torch.Generator(DEV).manual_seed(5))
+    m = DPC_RNN(128, network="resnet18", seed=0)
+    out = []
+    for fused in (False, True):
+        eng = DPCEngine("resnet18", 128, 8, 5, 3, 4, DEV, torch.bfloat16, stem_fused=fused)
+        assert eng._stem_fused == fused
+        eng.load_params({k: v.detach() for k, v in m.named_parameters()})
+        res = eng.train_step(x).clone()
+        torch.cuda.synchronize()
+        out.append((res.cpu(), eng.flat_g.clone(), eng.flat_p.clone()))
+    assert torch.equal(out[0][0], out[1][0])
+    assert torch.equal(out[0][1], out[1][1]) and torch.equal(out[0][2], out[1][2])
