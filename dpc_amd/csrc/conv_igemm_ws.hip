@@ -39,7 +39,14 @@ struct WsParams {
     // consecutive clips, so the temporal taps that fall into the zero padding are the same for the whole tile
     // and are skipped as a K sub-range (22 % of the chunks at T = 3, 33 % at T = 2).
     int tgroup, lHW, ppt, tpt, cpkt;  // on/off, log2(RH*RW), planes per tile, tiles per t, chunks per temporal tap
+    int plane;                        // 1: served by igemm_wsp_kernel (a tile is one 16 x 16 plane, staged as a patch)
+    int dbg;                          // DPC_WS_PROBE builds only (scripts/probes/ws_probe.py): phases to leave out, for timing
 };
+#ifdef DPC_WS_PROBE
+#define WS_DBG(bit) (p.dbg & (bit))
+#else
+#define WS_DBG(bit) 0
+#endif
 
 // workgroup barrier that waits for nothing but this wave's LDS traffic
 __device__ __forceinline__ void ws_barrier() { barrier_lds_only(); }
@@ -398,6 +405,417 @@ __global__ __launch_bounds__(512, 2) void igemm_ws_kernel(WsParams p) {
     }
 }
 
+
+// =====================================================================================================================
+// Plane variant: 1x3x3 unit-stride convs (forward and input-gradient) over 16 x 16 planes -- layer2 of the 128 x 128
+// configurations (backbone/resnet_2d3d.py:14-32: conv3x3x3 with a 1x3x3 kernel in the 2d blocks).
+//
+// igemm_ws_kernel re-reads every source row once per tap: 18 chunks x (32 KB of rows + 16 KB of weights) = 864 one-KB
+// LDS-DMA pieces per 256-row tile, and the loaders cannot issue them faster than ~80 pieces/us per CU -- its chunk period on
+// layer2 is 1.0 us against 0.43 us of MFMA work (40 % of peak, profiles/r02_r18_128_step_timeline.txt).  Here a tile IS one
+// 16 x 16 plane and its source is staged ONCE as a zero-padded 18 x 18 patch, 64 channels at a time (41 pieces): the K order
+// becomes (channel group, tap), all nine taps of a group read the same patch at tap-dependent offsets, and only the weights
+// (16 pieces per chunk) stream through the ring -- 371 pieces per tile instead of 864, so the loop is bound by the matrix
+// cores.  LDS: two patches (ping-pong by group, 41 KB each) + a ring of four 16 KB weight stages = 146 KB.
+//   * loaders: after the barrier that publishes chunk c they issue <= 2 pieces of the NEXT group's patch (its buffer was read
+//     last by the previous group, i.e. free since this group's first barrier) and then the weights of chunk c+3.  LDS-DMA of a
+//     wave completes in issue order, so "weights of chunk c landed" (counted vmcnt: the ops issued after them are known)
+//     implies the patch pieces issued before them landed -- a group's patch is complete six chunks before its first use.
+//   * compute waves: as igemm_ws_kernel (fragment reads one step ahead, barrier between MFMA steps 2 and 3); the patch
+//     position of a lane's row moves by a tap-dependent constant, and the XOR swizzle (slot = unit ^ ((patch column >> 1) & 7))
+//     is re-derived per chunk (a dozen VALU operations against 32 MFMAs).
+//   * epilogue: staged through the patch buffer of the tile's LAST group; the loaders refill that buffer only after the
+//     first barrier of the next tile, which the compute waves reach after their epilogue.
+struct PlaneAddr {
+    const unsigned char* a[2];
+    const unsigned char* b;
+};
+#ifdef DPC_SIMT_EMU
+__device__ __forceinline__ void frag_read_p(FragSet& f, const PlaneAddr& q, int kslot, int boff) {
+    f.a[0] = *(const u32x4*)(q.a[0] + kslot);
+    f.a[1] = *(const u32x4*)(q.a[1] + kslot);
+    for (int j = 0; j < 4; ++j) f.b[j] = *(const u32x4*)(q.b + boff + 4096 * j);
+}
+#else
+__device__ __forceinline__ void frag_read_p(FragSet& f, const PlaneAddr& q, int kslot, int boff) {
+    const uint32_t pa0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const unsigned char*)q.a[0] + (uint32_t)kslot;
+    const uint32_t pa1 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const unsigned char*)q.a[1] + (uint32_t)kslot;
+    const uint32_t pb = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const unsigned char*)q.b + (uint32_t)boff;
+    asm volatile("ds_read_b128 %0, %6\n\t"
+                 "ds_read_b128 %1, %7\n\t"
+                 "ds_read_b128 %2, %8\n\t"
+                 "ds_read_b128 %3, %8 offset:4096\n\t"
+                 "ds_read_b128 %4, %8 offset:8192\n\t"
+                 "ds_read_b128 %5, %8 offset:12288"
+                 : "=&v"(f.a[0]), "=&v"(f.a[1]), "=&v"(f.b[0]), "=&v"(f.b[1]), "=&v"(f.b[2]), "=&v"(f.b[3])
+                 : "v"(pa0), "v"(pa1), "v"(pb)
+                 : "memory");
+}
+#endif
+
+// LDS addresses as integers (32-bit on the device: pointer arithmetic on generic pointers drags an address-space cast with a
+// null check into every step; the simulator keeps host addresses)
+#ifdef DPC_SIMT_EMU
+typedef uintptr_t ldsa_t;
+static inline ldsa_t ldsa(const void* p) { return (uintptr_t)p; }
+#else
+typedef uint32_t ldsa_t;
+__device__ __forceinline__ ldsa_t ldsa(const void* p) { return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void*)p; }
+#endif
+// the six fragment reads of one K step on their own (first step of a tile)
+__device__ __forceinline__ void frag_read_p2(FragSet& f, ldsa_t xa, ldsa_t xb) {
+#ifdef DPC_SIMT_EMU
+    f.a[0] = *(const u32x4*)xa;
+    f.a[1] = *(const u32x4*)(xa + 4608);
+    for (int j = 0; j < 4; ++j) f.b[j] = *(const u32x4*)(xb + 4096 * j);
+#else
+    asm volatile("ds_read_b128 %0, %6\n\t"             // same order as step_il: a0 b0 b1 a1 b2 b3
+                 "ds_read_b128 %2, %7\n\t"
+                 "ds_read_b128 %3, %7 offset:4096\n\t"
+                 "ds_read_b128 %1, %6 offset:4608\n\t"
+                 "ds_read_b128 %4, %7 offset:8192\n\t"
+                 "ds_read_b128 %5, %7 offset:12288"
+                 : "=&v"(f.a[0]), "=&v"(f.a[1]), "=&v"(f.b[0]), "=&v"(f.b[1]), "=&v"(f.b[2]), "=&v"(f.b[3])
+                 : "v"(xa), "v"(xb)
+                 : "memory");
+#endif
+}
+// One K step of a compute wave with the NEXT step's six fragment reads interleaved between its eight MFMAs (hipcc otherwise
+// issues the reads as a burst in front of the MFMAs, and the matrix pipe idles while they issue -- probe: +61 us of 400 on
+// layer2, scripts/probes/ws_probe.py).  `use` must have landed (caller waits); `ld` is written.
+// pa: LDS address of the first A fragment (the second is 36 patch positions = 4608 bytes further); pb: of the first B fragment.
+template <bool LOAD>
+__device__ __forceinline__ void step_il(f32x16 (&acc)[2][4], const FragSet& use, FragSet& ld, ldsa_t xa, ldsa_t xb) {
+#ifdef DPC_SIMT_EMU
+    if (LOAD) {
+        ld.a[0] = *(const u32x4*)xa;
+        ld.a[1] = *(const u32x4*)(xa + 4608);
+        for (int j = 0; j < 4; ++j) ld.b[j] = *(const u32x4*)(xb + 4096 * j);
+    }
+    mma_step(acc, use);
+#else
+    // MFMAs stay compiler intrinsics (it allocates the accumulators and knows the matrix-pipe hazards); the reads are single
+    // untracked ds_read_b128 statements, and a scheduling barrier after every instruction pins the order written here.
+    // Counted waits: LDS operations of a wave complete in order.  On entry the only reads that may be outstanding are the six
+    // of `use`, issued in the order a0 b0 b1 a1 b2 b3 (the order below, one per MFMA gap of the previous step); every MFMA
+    // waits for exactly the operand it is the first to need, so each read has six MFMA gaps (~190 cycles) to land.
+#define DPC_IL_READ(dst, addr, off) \
+    if (LOAD) { asm volatile("ds_read_b128 %0, %1 offset:" #off : "=v"(dst) : "v"(addr) : "memory"); } \
+    __builtin_amdgcn_sched_barrier(0)
+#define DPC_IL_WAIT(n) \
+    asm volatile("s_waitcnt lgkmcnt(" #n ")" ::: "memory"); \
+    __builtin_amdgcn_sched_barrier(0)
+#define DPC_IL_MMA(i, j) \
+    acc[i][j] = mfma_32x32x16_bf16(use.a[i], use.b[j], acc[i][j]); \
+    __builtin_amdgcn_sched_barrier(0)
+    __builtin_amdgcn_sched_barrier(0);
+    DPC_IL_WAIT(4); DPC_IL_MMA(0, 0); DPC_IL_READ(ld.a[0], xa, 0);       // needs a0 b0; outstanding after: b1 a1 b2 b3 | a0'
+    DPC_IL_WAIT(4); DPC_IL_MMA(0, 1); DPC_IL_READ(ld.b[0], xb, 0);       // needs b1
+    DPC_IL_WAIT(4); DPC_IL_MMA(1, 0); DPC_IL_READ(ld.b[1], xb, 4096);    // needs a1
+    DPC_IL_MMA(1, 1); DPC_IL_READ(ld.a[1], xa, 4608);
+    DPC_IL_WAIT(5); DPC_IL_MMA(0, 2); DPC_IL_READ(ld.b[2], xb, 8192);    // needs b2
+    DPC_IL_MMA(1, 2); DPC_IL_READ(ld.b[3], xb, 12288);
+    DPC_IL_WAIT(6); DPC_IL_MMA(0, 3);                                     // needs b3
+    DPC_IL_MMA(1, 3);
+#undef DPC_IL_READ
+#undef DPC_IL_WAIT
+#undef DPC_IL_MMA
+#endif
+}
+__device__ __forceinline__ void mfma_drain() {}
+// s_waitcnt vmcnt(n) for a wave-uniform run-time n (the immediate must be a constant)
+__device__ __forceinline__ void wait_vmcnt_dyn(int n) {
+    switch (n) {
+        case 0: wait_vmcnt<0>(); break;
+        case 1: wait_vmcnt<1>(); break;
+        case 2: wait_vmcnt<2>(); break;
+        case 3: wait_vmcnt<3>(); break;
+        case 4: wait_vmcnt<4>(); break;
+        case 5: wait_vmcnt<5>(); break;
+        case 6: wait_vmcnt<6>(); break;
+        case 7: wait_vmcnt<7>(); break;
+        case 8: wait_vmcnt<8>(); break;
+        case 9: wait_vmcnt<9>(); break;
+        case 10: wait_vmcnt<10>(); break;
+        case 11: wait_vmcnt<11>(); break;
+        default: wait_vmcnt<12>(); break;  // n >= 12: waiting for fewer outstanding operations is always safe
+    }
+}
+
+template <bool HAS_ADD>
+__global__ __launch_bounds__(512, 2) void igemm_wsp_kernel(WsParams p) {
+    typedef bf16_t TO;
+    constexpr int BM = 256, BN = 128;
+    constexpr int PWD = 18, NPP = PWD * PWD, NPIECE = (NPP + 7) / 8, PATCH = NPIECE * 1024;  // 324 positions, 41 pieces
+    constexpr int BST = BN * 128, NSB = 4;
+    constexpr int EPO = 8;
+    constexpr int MAXP = (NPIECE + 3) / 4;  // patch pieces per loader wave
+    static_assert(4 * 8192 <= PATCH, "epilogue staging fits a patch buffer");
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * PATCH + NSB * BST];
+    unsigned char* const bring = lds + 2 * PATCH;
+
+    const GatherGeom& g = p.g;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+#ifdef DPC_SIMT_EMU
+    const int wv = tid >> 6;
+#else
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+#endif
+    const int n_tile = blockIdx.x / p.gm;
+    const int m_prog = blockIdx.x % p.gm;
+    const int G = g.Ci >> 6;       // channel groups of 64
+    const int nkc = 9 * G;         // chunks per tile: (group, tap)
+    const int my_tiles = (p.ntm - m_prog + p.gm - 1) / p.gm;
+    const int total = my_tiles * nkc;
+    const char* const zero = (const char*)dpc_zero16;
+
+    if (wv >= 4) {
+        // ------------------------------------------------------------------ loader waves
+        const int lw = wv - 4;
+        const int rl = lane >> 3;
+        const BufRsrc rs_a = make_buf_rsrc(p.src, p.src_bytes);
+        const BufRsrc rs_b = make_buf_rsrc(p.wgt, p.wgt_bytes);
+        const int ub = (lane & 7) ^ lds_swz1(8 * lw + rl);   // weights: same stage image as igemm_ws_kernel
+        unsigned wrow[4];
+        DPC_UNROLL
+        for (int i = 0; i < 4; ++i) {
+            const int n = n_tile * BN + 8 * (lw + 4 * i) + rl;
+            wrow[i] = n < p.Ncol ? (unsigned)(n * p.ldw + ub * 8) * 2u : DPC_BUF_OOB;
+        }
+        // patch piece j = lw + 4i holds patch positions 8j .. 8j+7; a lane fetches unit (slot ^ swizzle(patch column)) of its
+        // position.  The offsets are relative to the plane: the same for every tile.
+        unsigned poff[MAXP];
+        DPC_UNROLL
+        for (int i = 0; i < MAXP; ++i) {
+            const int pp = 8 * (lw + 4 * i) + rl;
+            const int pr = pp / PWD, pc = pp - pr * PWD;
+            const bool ok = pp < NPP && pr >= 1 && pr <= 16 && pc >= 1 && pc <= 16;
+            const int up = (lane & 7) ^ ((pc >> 1) & 7);
+            poff[i] = ok ? (unsigned)((((pr - 1) * 16 + (pc - 1)) * g.src_ld + up * 8) * 2) : DPC_BUF_OOB;
+        }
+        const int n_mine = (NPIECE - lw + 3) / 4;
+        int issued = 0;               // operations issued in the current slot
+        auto issue_patch = [&](int gg, int i0, int i1) {   // pieces [i0, i1) of this wave, of global group gg
+            const int tl = gg / G, grp = gg - tl * G;
+            const int mt = m_prog + tl * p.gm;
+            const unsigned soff = (unsigned)((mt * BM * g.src_ld + grp * 64) * 2);
+            unsigned char* dst = lds + (gg & 1) * PATCH;
+            DPC_UNROLL
+            for (int i = 0; i < MAXP; ++i)
+                if (i >= i0 && i < i1 && i < n_mine && !WS_DBG(4)) {
+                    glds16_buf(rs_a, poff[i], soff, dst + (lw + 4 * i) * 1024, lane);
+                    ++issued;
+                }
+        };
+        auto issue_b = [&](int gc) {
+            const int gg = gc / 9, tap = gc - gg * 9;
+            const int grp = gg % G;
+            const int kd = tap * g.Ci + grp * 64;
+            unsigned char* st = bring + (gc % NSB) * BST;
+            if (WS_DBG(4)) return;
+            DPC_UNROLL
+            for (int i = 0; i < 4; ++i) glds16_buf(rs_b, wrow[i], (unsigned)kd * 2u, st + (lw + 4 * i) * 1024, lane);
+            issued += 4;
+        };
+        // A slot = what is issued between two chunk barriers: patch pieces first, the weights of chunk c+3 last.  The weights of
+        // chunk c are the last operations of slot c-3, so "at most (slot c-2) + (slot c-1) operations outstanding" means landed.
+        // The prologue counts as slots -3 (patch of group 0 + chunk 0), -2 (chunk 1), -1 (chunk 2).
+        if (total > 0) {
+            issue_patch(0, 0, MAXP);
+            issue_b(0);
+        }
+        issued = 0;
+        if (total > 1) issue_b(1);
+        int o2 = issued;
+        issued = 0;
+        if (total > 2) issue_b(2);
+        int o1 = issued;
+        for (int gc = 0; gc < total; ++gc) {
+            wait_vmcnt_dyn(o1 + o2);
+            if (!WS_DBG(32)) ws_barrier();  // chunk gc (and, at a group's first chunk, its patch) is published; every reader is done with chunk gc-1
+            const int gg = gc / 9, q = gc - gg * 9;
+            issued = 0;
+            if (q < (MAXP + 1) / 2 && (gg + 1) * 9 < total) issue_patch(gg + 1, 2 * q, 2 * q + 2);
+            if (gc + 3 < total) issue_b(gc + 3);
+            o2 = o1;
+            o1 = issued;
+            if (q == 8 && (gg + 1) % G == 0) if (!WS_DBG(32)) ws_barrier();  // matches the compute waves' "tile fully read" barrier
+        }
+    }
+
+    // ---------------------------------------------------------------------- compute waves
+    const int l31 = lane & 31, lhi = lane >> 5;
+    // A-fragment addresses.  Row r of the tile is pixel (r >> 4, r & 15); for tap (kh, kw) it reads patch position
+    // (r>>4 + dh) * 18 + (r&15) + dw with (dh, dw) = (kh, kw) forward, (2-kh, 2-kw) input-gradient; the second fragment (+32 rows =
+    // +2 image rows) is 36 positions = 4608 bytes further in the same patch column.  The 16-byte slots of a position are
+    // XOR-swizzled by (patch column >> 1) & 7: a ds_read_b128 lane group is 8 + 8 lanes of two image rows
+    // (MI355X_MICROARCH.md, LDS) whose columns c+{0..3,12..15} and c+{4..11} then cover 16 distinct (column parity, slot) pairs =
+    // all 64 banks; swizzling by the position (row pitch 18) does not.  Everything that depends on the lane is tabulated per kw
+    // (12 registers); the kh / patch-buffer part is a scalar added per chunk.
+    // slot bits = ((2kk + lhi) ^ p7) << 4 = ((lhi ^ p7) << 4) ^ (kk << 5), and every base below is a multiple of 128: the address
+    // of step kk is (chunk base + va[kw]) ^ (kk << 5) -- one register per kw instead of a 12-entry table.
+    int va[3];
+    {
+        const int pos0 = ((wv * 64 + l31) >> 4) * PWD + (l31 & 15);
+        DPC_UNROLL
+        for (int kw = 0; kw < 3; ++kw) {
+            const int dw = g.mode == 0 ? kw : 2 - kw;
+            const int p7 = (((l31 & 15) + dw) >> 1) & 7;
+            va[kw] = (pos0 + dw) * 128 + ((lhi ^ p7) << 4);
+        }
+    }
+    const ldsa_t lds0 = ldsa(lds);
+    const int vb = lds_unit_off(l31, lhi);   // B fragment of step 0; step kk: ^ (kk << 5) (stage bases are multiples of 16 KB)
+    const int cu = lane & 15, er = lane >> 4;
+    const int col0 = n_tile * BN + cu * EPO;
+    float s1[EPO], s2[EPO];
+    DPC_UNROLL
+    for (int e = 0; e < EPO; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
+
+    int gc = 0;
+    for (int t = 0; wv < 4 && t < my_tiles; ++t) {
+        const int mt = m_prog + t * p.gm;
+        f32x16 acc[2][4];
+        DPC_UNROLL
+        for (int i = 0; i < 2; ++i)
+            DPC_UNROLL
+            for (int j = 0; j < 4; ++j)
+                DPC_UNROLL
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        u32x4 av0[8], av1[8];
+        auto fetch_addend = [&](int i, u32x4 (&dst)[8]) {
+            DPC_UNROLL
+            for (int it = 0; it < 8; ++it) {
+                const int row = mt * BM + wv * 64 + i * 32 + er + 4 * it;
+                const bool ok = row < g.M && col0 < p.Ncol;
+                const char* a = (const char*)p.addend + ((long long)row * p.ldo + col0) * 2;
+                dst[it] = *(const u32x4*)(ok ? a : zero);
+            }
+        };
+        // Chunk loop: (channel group, kh) outer, kw unrolled (its address table is then a compile-time choice).  Four steps per
+        // chunk, each = 8 MFMAs with the next step's reads interleaved; the barrier that publishes chunk c+1 sits in front of step
+        // 3 of chunk c (whose interleaved reads are the first fragments of chunk c+1), after this wave's last reads of chunk c
+        // have landed -- the same protocol as igemm_ws_kernel.
+        {
+            FragSet f0, f1;
+            if (!WS_DBG(32)) ws_barrier();  // first chunk of the tile (and its patch) published
+            ldsa_t a_row = lds0 + ((t * G) & 1) * PATCH + (g.mode == 0 ? 0 : 2) * (PWD * 128);
+            ldsa_t b_st = lds0 + 2 * PATCH + (gc % NSB) * BST;
+            ldsa_t pa = a_row + va[0];
+            ldsa_t pb = b_st + vb;
+            frag_read_p2(f0, pa, pb);
+            for (int gk = 0; gk < 3 * G; ++gk) {   // (group, kh)
+                const int grp = gk / 3, kh = gk - grp * 3;
+                const bool last_gk = gk + 1 == 3 * G;
+                const int kh_n = kh == 2 ? 0 : kh + 1, gg_n = t * G + (kh == 2 ? grp + 1 : grp);
+                const ldsa_t a_row_n = lds0 + (gg_n & 1) * PATCH + (g.mode == 0 ? kh_n : 2 - kh_n) * (PWD * 128);
+                static_for<3>([&](auto KWc) {
+                    constexpr int KW = decltype(KWc)::value;
+                    const bool last = last_gk && KW == 2;   // last chunk of the tile
+                    if (HAS_ADD && last) fetch_addend(0, av0);
+                    step_il<true>(acc, f0, f1, pa ^ 32, pb ^ 32);
+                    step_il<true>(acc, f1, f0, pa ^ 64, pb ^ 64);
+                    step_il<true>(acc, f0, f1, pa ^ 96, pb ^ 96);
+                    frag_wait<0>(f1);   // this wave's last reads of the chunk have landed
+                    if (!WS_DBG(32)) ws_barrier();  // next chunk published -- or, after the tile's last chunk, "tile fully read"
+                    ++gc;
+                    b_st = lds0 + 2 * PATCH + (gc % NSB) * BST;
+                    if (KW == 2) a_row = a_row_n;
+                    pa = a_row + va[(KW + 1) % 3];
+                    pb = b_st + vb;
+                    // after the tile's last chunk these reads fetch nothing useful (the next tile re-reads after ITS first barrier):
+                    // keeping them unconditional keeps the MFMAs out of a branch -- accumulators that flow through both arms
+                    // of a branch are copied at the join (hundreds of spilled registers)
+                    step_il<true>(acc, f1, f0, pa, pb);
+                });
+            }
+            mfma_drain();
+        }
+
+        // ---- epilogue: two passes of 32 rows through this wave's 8 KB of the last group's patch buffer
+        unsigned char* mine = lds + ((t * G + G - 1) & 1) * PATCH + wv * 8192;
+        if (WS_DBG(2)) {  // probe: no epilogue at all (the accumulators stay live through one store)
+            if (acc[0][0][0] == 12345.f) *(float*)p.out = acc[1][3][5];
+            continue;
+        }
+        DPC_UNROLL
+        for (int i = 0; i < 2; ++i) {
+            TO* tile = (TO*)mine;
+            DPC_UNROLL
+            for (int j = 0; j < 4; ++j)
+                DPC_UNROLL
+                for (int r = 0; r < 16; ++r) {
+                    const int row_l = (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                    tile[row_l * BN + j * 32 + l31] = f32_to_bf16(acc[i][j][r]);
+                }
+            wave_lds_fence();
+            if (HAS_ADD && i == 0) fetch_addend(1, av1);
+            u32x4 ov[8];
+            DPC_UNROLL
+            for (int it = 0; it < 8; ++it) {
+                const int row_l = er + 4 * it;
+                ov[it] = *(const u32x4*)(mine + (row_l * BN + cu * EPO) * 2);
+            }
+            wave_lds_fence();
+            DPC_UNROLL
+            for (int it = 0; it < 8; ++it) {
+                const int row = mt * BM + wv * 64 + i * 32 + er + 4 * it;
+                if (row < g.M && col0 < p.Ncol && !WS_DBG(1)) {
+                    u32x4 o = ov[it];
+                    if (HAS_ADD) {
+                        const u32x4 a = i == 0 ? av0[it] : av1[it];
+                        float sv[EPO];
+                        DPC_UNROLL
+                        for (int e = 0; e < EPO; ++e) sv[e] = unit_get<TO>(o, e) + unit_get<TO>(a, e);
+                        o = unit_pack<TO>(sv);
+                    }
+                    *(u32x4*)((char*)p.out + ((long long)row * p.ldo + col0) * 2) = o;
+                    if (!HAS_ADD) {
+                        DPC_UNROLL
+                        for (int e = 0; e < EPO; ++e) {
+                            const float v = unit_get<TO>(o, e);
+                            s1[e] += v;
+                            s2[e] += v * v;
+                        }
+                    }
+                }
+            }
+        }
+    }
+
+    if (!HAS_ADD && p.stats) {
+        DPC_UNROLL
+        for (int e = 0; e < EPO; ++e) {
+            s1[e] += __shfl_xor(s1[e], 16); s1[e] += __shfl_xor(s1[e], 32);
+            s2[e] += __shfl_xor(s2[e], 16); s2[e] += __shfl_xor(s2[e], 32);
+        }
+        float* red = (float*)lds;  // [4 waves][2][128]
+        __syncthreads();
+        if (wv < 4 && lane < 16) {
+            DPC_UNROLL
+            for (int e = 0; e < EPO; ++e) {
+                red[(wv * 2 + 0) * BN + cu * EPO + e] = s1[e];
+                red[(wv * 2 + 1) * BN + cu * EPO + e] = s2[e];
+            }
+        }
+        __syncthreads();
+        if (tid < BN) {
+            const int col = n_tile * BN + tid;
+            if (col < p.Ncol) {
+                float a = 0.f, b = 0.f;
+                DPC_UNROLL
+                for (int w = 0; w < 4; ++w) {
+                    a += red[(w * 2 + 0) * BN + tid];
+                    b += red[(w * 2 + 1) * BN + tid];
+                }
+                p.stats[((long long)m_prog * 2 + 0) * p.Ncol + col] = a;
+                p.stats[((long long)m_prog * 2 + 1) * p.Ncol + col] = b;
+            }
+        }
+    }
+}
+
 static int env_int(const char* name, int dflt) {
     const char* e = getenv(name);
     return e ? atoi(e) : dflt;
@@ -427,6 +845,11 @@ static bool ws_plan(const dpc_conv_desc* d, WsParams* p) {
     p->ntn = (d->Co + 127) / 128;
     p->ntm = (g.M + 255) / 256;
     p->tgroup = 0; p->lHW = 0; p->ppt = 1; p->tpt = 1; p->cpkt = 1;
+    {
+        static const int plane_on = env_int("DPC_IGEMM_WS_PLANE", 1);
+        p->plane = plane_on && g.KT == 1 && g.KH == 3 && g.KW == 3 && g.pt == 0 && g.ph == 1 && g.pw == 1 && unit_strides && g.RT == g.ST &&
+                   g.RH == 16 && g.RW == 16 && g.SH == 16 && g.SW == 16 && g.Ci % 64 == 0;
+    }
     {
         static const int tg_on = env_int("DPC_IGEMM_WS_TGROUP", 1);
         const int hw = g.RH * g.RW, lhw = ilog2_exact(hw);
@@ -462,8 +885,15 @@ int dpc_conv_ws_try(const dpc_conv_desc* d, const void* src, const void* wgt, vo
     if (addend && stats) return 1;  // not a combination of this path: the generic kernel serves it
     if (((uintptr_t)out % 16) || ((uintptr_t)addend % 16) || ((uintptr_t)src % 16) || ((uintptr_t)wgt % 16)) return 1;
     p.src = src; p.wgt = wgt; p.out = out; p.addend = addend; p.stats = stats;
+    p.dbg = getenv("DPC_WS_DBG") ? atoi(getenv("DPC_WS_DBG")) : 0;
     dim3 grid((unsigned)(p.gm * p.ntn)), block(512);
-    if (addend) {
+    if (p.plane) {
+        if (addend) {
+            DPC_LAUNCH((igemm_wsp_kernel<true>), grid, block, stream, p);
+        } else {
+            DPC_LAUNCH((igemm_wsp_kernel<false>), grid, block, stream, p);
+        }
+    } else if (addend) {
         DPC_LAUNCH((igemm_ws_kernel<true>), grid, block, stream, p);
     } else {
         DPC_LAUNCH((igemm_ws_kernel<false>), grid, block, stream, p);

@@ -1,0 +1,13 @@
+#!/bin/bash
+R=$GRAFT_REPO_ROOT; cd $R; mkdir -p gpurun_out
+(timeout 900 python -m pytest tests/test_kernels_gpu.py -m gpu -q -p no:cacheprovider -k "conv_fwd or conv_dgrad" 2>&1 | tail -5) > gpurun_out/i_tests.log
+(timeout 300 python bench.py --no-cpu-baseline --steps 100 2>&1 | tail -1) > gpurun_out/i_bench_cfg2.log
+(DPC_IGEMM_WS_PLANE=0 timeout 300 python bench.py --no-cpu-baseline --steps 100 2>&1 | tail -1) > gpurun_out/i_bench_cfg2_noplane.log
+cd /tmp && export TMPDIR=/tmp
+(timeout 400 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_r02i -o bench -- python $R/bench.py --no-graph --steps 3 --warmup 1 --no-cpu-baseline --no-roofline 2>&1 | tail -3) > $R/gpurun_out/i_rocprof.log
+cd $R
+f=$(ls gpurun_out/prof_r02i/*.db 2>/dev/null | head -1)
+[ -n "$f" ] && python scripts/rocpd_stats.py $f > gpurun_out/prof_r02i_stats.txt 2>&1
+[ -n "$f" ] && python scripts/timeline.py $f > gpurun_out/prof_r02i_timeline.txt 2>&1
+rm -rf gpurun_out/prof_r02i/*.db
+cat gpurun_out/i_tests.log; for f in i_bench_cfg2 i_bench_cfg2_noplane; do python -c "import json,sys; d=json.loads(open('gpurun_out/$f.log').read().strip().splitlines()[-1]); print('$f', d['value'], d['ms_per_step'], d['roofline']['frac'], d['roofline']['ms_per_step'])"; done; grep -E "igemm_ws" gpurun_out/prof_r02i_stats.txt

@@ -28,6 +28,8 @@ def k():
     (70, 64, 64, 1, 32, 32, (1, 3, 3), (1, 1, 1), (0, 1, 1)),    # 560 patch tiles > 256 workgroups: tile pipeline of the role-specialised kernel
     (70, 128, 128, 1, 16, 16, (1, 3, 3), (1, 1, 1), (0, 1, 1)),  # >= 16384 rows: loader/compute specialised kernel, 70 tiles
     (90, 256, 264, 3, 8, 8, (3, 3, 3), (1, 1, 1), (1, 1, 1)),    # same, 3x3x3, three column tiles (last ragged), ragged last row tile
+    (150, 128, 128, 4, 16, 16, (1, 3, 3), (1, 1, 1), (0, 1, 1)), # plane variant (16 x 16 planes as patches): 600 tiles, 2-3 per workgroup
+    (33, 64, 264, 2, 16, 16, (1, 3, 3), (1, 1, 1), (0, 1, 1)),   # plane variant: one channel group, three column tiles (last ragged)
 ])
 def test_conv_fwd(k, dtype, shape):
     kc.case_conv_fwd(k, dtype, *shape)
@@ -44,6 +46,8 @@ def test_conv_fwd(k, dtype, shape):
     (66, 128, 128, 1, 16, 16, (1, 3, 3), (1, 1, 1), (0, 1, 1)),  # unit-stride input-gradient on the specialised kernel
     (87, 256, 256, 3, 8, 8, (3, 3, 3), (1, 1, 1), (1, 1, 1)),
     (3, 16, 32, 2, 9, 7, (1, 3, 3), (1, 2, 2), (0, 1, 1)),
+    (150, 128, 128, 4, 16, 16, (1, 3, 3), (1, 1, 1), (0, 1, 1)), # plane variant, flipped taps + residual addend, 600 tiles
+    (40, 128, 256, 2, 16, 16, (1, 3, 3), (1, 1, 1), (0, 1, 1)),  # plane variant, four channel groups
 ])
 def test_conv_dgrad(k, dtype, shape):
     kc.case_conv_dgrad(k, dtype, *shape)

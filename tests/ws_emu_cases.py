@@ -28,6 +28,11 @@ def main():
     # unit-stride input gradient (+ residual addend): the GEMM's columns are the conv's input channels
     kc.case_conv_dgrad(k, BF16, 2, 128, 64, 2, 9, 16, (1, 3, 3), (1, 1, 1), (0, 1, 1))
     kc.case_conv_dgrad(k, BF16, 1, 128, 128, 3, 6, 6, (3, 3, 3), (1, 1, 1), (1, 1, 1))
+    # plane variant (igemm_wsp_kernel): 16 x 16 planes staged as patches, K order (channel group, tap); 2 programs walk 2-3 tiles
+    kc.case_conv_fwd(k, BF16, 3, 128, 128, 2, 16, 16, (1, 3, 3), (1, 1, 1), (0, 1, 1))      # layer2's shape: two channel groups
+    kc.case_conv_fwd(k, BF16, 5, 64, 136, 1, 16, 16, (1, 3, 3), (1, 1, 1), (0, 1, 1))       # one group, odd tile count, ragged column tile
+    kc.case_conv_dgrad(k, BF16, 2, 128, 256, 2, 16, 16, (1, 3, 3), (1, 1, 1), (0, 1, 1))    # four groups + residual addend
+    kc.case_conv_dgrad_inplace(k, BF16, 1, 128, 128, 1, 16, 16, (1, 3, 3), (1, 1, 1), (0, 1, 1))  # a single tile
     # role-specialised patch kernel (conv_halo_ws_kernel): DPC_HALO_WS_GM = 3 workgroups walk 24 / 8 tiles each
     kc.case_conv_fwd(k, BF16, 2, 64, 64, 2, 9, 33, (1, 3, 3), (1, 1, 1), (0, 1, 1))
     kc.case_conv_fwd(k, BF16, 1, 64, 40, 1, 20, 12, (1, 3, 3), (1, 1, 1), (0, 1, 1))
