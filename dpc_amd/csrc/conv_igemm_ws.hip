@@ -92,6 +92,76 @@ __device__ __forceinline__ void mma_step(f32x16 (&acc)[2][4], const FragSet& f) 
         for (int j = 0; j < 4; ++j) acc[i][j] = mfma_32x32x16_bf16(f.a[i], f.b[j], acc[i][j]);
 }
 
+// LDS addresses as integers (32-bit on the device: pointer arithmetic on generic pointers drags an address-space cast with a
+// null check into every step; the simulator keeps host addresses)
+#ifdef DPC_SIMT_EMU
+typedef uintptr_t ldsa_t;
+static inline ldsa_t ldsa(const void* p) { return (uintptr_t)p; }
+#else
+typedef uint32_t ldsa_t;
+__device__ __forceinline__ ldsa_t ldsa(const void* p) { return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void*)p; }
+#endif
+// the six fragment reads of one K step on their own (first step of a tile)
+template <int AOFF>
+__device__ __forceinline__ void frag_read_p2(FragSet& f, ldsa_t xa, ldsa_t xb) {
+#ifdef DPC_SIMT_EMU
+    f.a[0] = *(const u32x4*)xa;
+    f.a[1] = *(const u32x4*)(xa + AOFF);
+    for (int j = 0; j < 4; ++j) f.b[j] = *(const u32x4*)(xb + 4096 * j);
+#else
+    asm volatile("ds_read_b128 %0, %6\n\t"             // same order as step_il: a0 b0 b1 a1 b2 b3
+                 "ds_read_b128 %2, %7\n\t"
+                 "ds_read_b128 %3, %7 offset:4096\n\t"
+                 "ds_read_b128 %1, %6 offset:%8\n\t"
+                 "ds_read_b128 %4, %7 offset:8192\n\t"
+                 "ds_read_b128 %5, %7 offset:12288"
+                 : "=&v"(f.a[0]), "=&v"(f.a[1]), "=&v"(f.b[0]), "=&v"(f.b[1]), "=&v"(f.b[2]), "=&v"(f.b[3])
+                 : "v"(xa), "v"(xb), "n"(AOFF)
+                 : "memory");
+#endif
+}
+// One K step of a compute wave with the NEXT step's six fragment reads interleaved between its eight MFMAs (hipcc otherwise
+// issues the reads as a burst in front of the MFMAs, and the matrix pipe idles while they issue -- probe: +61 us of 400 on
+// layer2, scripts/probes/ws_probe.py).  `use` must have landed (caller waits); `ld` is written.
+// xa: LDS address of the first A fragment (the second is AOFF bytes further); xb: of the first B fragment (+4096 per column block).
+template <bool LOAD, int AOFF>
+__device__ __forceinline__ void step_il(f32x16 (&acc)[2][4], const FragSet& use, FragSet& ld, ldsa_t xa, ldsa_t xb) {
+#ifdef DPC_SIMT_EMU
+    if (LOAD) {
+        ld.a[0] = *(const u32x4*)xa;
+        ld.a[1] = *(const u32x4*)(xa + AOFF);
+        for (int j = 0; j < 4; ++j) ld.b[j] = *(const u32x4*)(xb + 4096 * j);
+    }
+    mma_step(acc, use);
+#else
+    // MFMAs stay compiler intrinsics (it allocates the accumulators and knows the matrix-pipe hazards); the reads are single
+    // untracked ds_read_b128 statements, and a scheduling barrier after every instruction pins the order written here.
+    // Counted waits: LDS operations of a wave complete in order.  On entry the only reads that may be outstanding are the six
+    // of `use`, issued in the order a0 b0 b1 a1 b2 b3 (the order below, one per MFMA gap of the previous step); every MFMA
+    // waits for exactly the operand it is the first to need, so each read has six MFMA gaps (~190 cycles) to land.
+#define DPC_IL_READ(dst, addr, off) \
+    if (LOAD) { asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off) : "memory"); } \
+    __builtin_amdgcn_sched_barrier(0)
+#define DPC_IL_WAIT(n) \
+    asm volatile("s_waitcnt lgkmcnt(" #n ")" ::: "memory"); \
+    __builtin_amdgcn_sched_barrier(0)
+#define DPC_IL_MMA(i, j) \
+    acc[i][j] = mfma_32x32x16_bf16(use.a[i], use.b[j], acc[i][j]); \
+    __builtin_amdgcn_sched_barrier(0)
+    __builtin_amdgcn_sched_barrier(0);
+    DPC_IL_WAIT(4); DPC_IL_MMA(0, 0); DPC_IL_READ(ld.a[0], xa, 0);       // needs a0 b0; outstanding after: b1 a1 b2 b3 | a0'
+    DPC_IL_WAIT(4); DPC_IL_MMA(0, 1); DPC_IL_READ(ld.b[0], xb, 0);       // needs b1
+    DPC_IL_WAIT(4); DPC_IL_MMA(1, 0); DPC_IL_READ(ld.b[1], xb, 4096);    // needs a1
+    DPC_IL_MMA(1, 1); DPC_IL_READ(ld.a[1], xa, AOFF);
+    DPC_IL_WAIT(5); DPC_IL_MMA(0, 2); DPC_IL_READ(ld.b[2], xb, 8192);    // needs b2
+    DPC_IL_MMA(1, 2); DPC_IL_READ(ld.b[3], xb, 12288);
+    DPC_IL_WAIT(6); DPC_IL_MMA(0, 3);                                     // needs b3
+    DPC_IL_MMA(1, 3);
+#undef DPC_IL_READ
+#undef DPC_IL_WAIT
+#undef DPC_IL_MMA
+#endif
+}
 template <bool HAS_ADD>
 __global__ __launch_bounds__(512, 2) void igemm_ws_kernel(WsParams p) {
     typedef bf16_t T;
@@ -246,12 +316,10 @@ __global__ __launch_bounds__(512, 2) void igemm_ws_kernel(WsParams p) {
 
     // ---------------------------------------------------------------------- compute waves
     const int l31 = lane & 31, lhi = lane >> 5;
-    int frag_a[4], frag_b[4];
-    DPC_UNROLL
-    for (int kk = 0; kk < 4; ++kk) {
-        frag_a[kk] = lds_unit_off(wv * 64 + l31, 2 * kk + lhi);          // rows +32: +4096 B
-        frag_b[kk] = BM * 128 + lds_unit_off(l31, 2 * kk + lhi);          // columns +32: +4096 B
-    }
+    // fragment addresses of K step 0 inside a stage (rows / columns +32: +4096 B); step kk: ^ (kk << 5), see step_il
+    const ldsa_t lds0 = ldsa(lds);
+    const int fa0 = lds_unit_off(wv * 64 + l31, lhi);
+    const int fb0 = BM * 128 + lds_unit_off(l31, lhi);
     // epilogue lane constants: a pass stages 32 rows x 128 columns (8 KB) per wave
     const int cu = lane & 15, er = lane >> 4;  // output unit column, first row of the lane inside a pass (rows er + 4*it)
     const int col0 = n_tile * BN + cu * EPO;
@@ -260,6 +328,9 @@ __global__ __launch_bounds__(512, 2) void igemm_ws_kernel(WsParams p) {
     for (int e = 0; e < EPO; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
 
     int gc = 0;
+#ifndef DPC_SIMT_EMU
+    __builtin_amdgcn_s_setprio(3);   // the compute waves win the SIMD's issue arbitration against their loader partner (-1..2 %)
+#endif
     for (int t = 0; wv < 4 && t < my_tiles; ++t) {
         const int mt = m_prog + t * p.gm;
         int kc_lo, kc_hi;
@@ -275,7 +346,7 @@ __global__ __launch_bounds__(512, 2) void igemm_ws_kernel(WsParams p) {
         // The chunk loop is software-pipelined ACROSS the chunk barrier: the barrier that publishes chunk
         // gc+1 sits between MFMA steps 2 and 3 of chunk gc (all LDS reads of chunk gc are complete by then, so
         // it is also the "stage gc may be refilled" point), and the first fragments of chunk gc+1 are read
-        // under the 8 MFMAs of step 3.  Fragment reads are inline asm with hand-counted waits: left to itself
+        // between the 8 MFMAs of step 3 (step_il: one read per MFMA gap, per-operand counted waits).  Left to itself
         // hipcc reuses one register set (every step then waits out a full LDS round trip: 64 % of the MFMA
         // rate measured) or, given two sets, waits lgkmcnt(0) -- i.e. also for the reads it has just issued.
         // Barrier sequence per tile, identical to the loaders': B(c0) B(c1) ... B(c_last) B("tile fully read").
@@ -295,32 +366,22 @@ __global__ __launch_bounds__(512, 2) void igemm_ws_kernel(WsParams p) {
         {
             FragSet f0, f1;
             ws_barrier();  // first chunk of the tile published
-            const unsigned char* st = lds + (gc % NST) * STAGE;
-            frag_read(f0, st, frag_a[0], frag_b[0]);
+            ldsa_t pa = lds0 + (gc % NST) * STAGE + fa0, pb = lds0 + (gc % NST) * STAGE + fb0;
+            frag_read_p2<4096>(f0, pa, pb);
             for (int kc = 0; kc < nkc_t; ++kc) {
                 if (HAS_ADD && kc + 1 == nkc_t) fetch_addend(0, av0);  // lands under the last chunk's 32 MFMAs
-                frag_read(f1, st, frag_a[1], frag_b[1]);
-                frag_wait<6>(f0);
-                mma_step(acc, f0);
-                sched_fence();
-                frag_read(f0, st, frag_a[2], frag_b[2]);
-                frag_wait<6>(f1);
-                mma_step(acc, f1);
-                sched_fence();
-                frag_read(f1, st, frag_a[3], frag_b[3]);
-                frag_wait<6>(f0);
-                mma_step(acc, f0);
-                sched_fence();
-                frag_wait<0>(f1);
+                step_il<true, 4096>(acc, f0, f1, pa ^ 32, pb ^ 32);
+                step_il<true, 4096>(acc, f1, f0, pa ^ 64, pb ^ 64);
+                step_il<true, 4096>(acc, f0, f1, pa ^ 96, pb ^ 96);
+                frag_wait<0>(f1);   // this wave's last reads of the chunk have landed
                 ws_barrier();  // next chunk published -- or, after the tile's last chunk, "tile fully read"
                 stage_last = gc % NST;
                 ++gc;
-                if (kc + 1 < nkc_t) {
-                    st = lds + (gc % NST) * STAGE;
-                    frag_read(f0, st, frag_a[0], frag_b[0]);
-                }
-                mma_step(acc, f1);
-                sched_fence();
+                pa = lds0 + (gc % NST) * STAGE + fa0;
+                pb = lds0 + (gc % NST) * STAGE + fb0;
+                // after the tile's last chunk these reads fetch nothing useful (the next tile re-reads after ITS first barrier):
+                // unconditional, so that the MFMAs stay out of a branch (accumulators joined after a branch are copied and spill)
+                step_il<true, 4096>(acc, f1, f0, pa, pb);
             }
         }
 
@@ -426,103 +487,6 @@ __global__ __launch_bounds__(512, 2) void igemm_ws_kernel(WsParams p) {
 //     is re-derived per chunk (a dozen VALU operations against 32 MFMAs).
 //   * epilogue: staged through the patch buffer of the tile's LAST group; the loaders refill that buffer only after the
 //     first barrier of the next tile, which the compute waves reach after their epilogue.
-struct PlaneAddr {
-    const unsigned char* a[2];
-    const unsigned char* b;
-};
-#ifdef DPC_SIMT_EMU
-__device__ __forceinline__ void frag_read_p(FragSet& f, const PlaneAddr& q, int kslot, int boff) {
-    f.a[0] = *(const u32x4*)(q.a[0] + kslot);
-    f.a[1] = *(const u32x4*)(q.a[1] + kslot);
-    for (int j = 0; j < 4; ++j) f.b[j] = *(const u32x4*)(q.b + boff + 4096 * j);
-}
-#else
-__device__ __forceinline__ void frag_read_p(FragSet& f, const PlaneAddr& q, int kslot, int boff) {
-    const uint32_t pa0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const unsigned char*)q.a[0] + (uint32_t)kslot;
-    const uint32_t pa1 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const unsigned char*)q.a[1] + (uint32_t)kslot;
-    const uint32_t pb = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const unsigned char*)q.b + (uint32_t)boff;
-    asm volatile("ds_read_b128 %0, %6\n\t"
-                 "ds_read_b128 %1, %7\n\t"
-                 "ds_read_b128 %2, %8\n\t"
-                 "ds_read_b128 %3, %8 offset:4096\n\t"
-                 "ds_read_b128 %4, %8 offset:8192\n\t"
-                 "ds_read_b128 %5, %8 offset:12288"
-                 : "=&v"(f.a[0]), "=&v"(f.a[1]), "=&v"(f.b[0]), "=&v"(f.b[1]), "=&v"(f.b[2]), "=&v"(f.b[3])
-                 : "v"(pa0), "v"(pa1), "v"(pb)
-                 : "memory");
-}
-#endif
-
-// LDS addresses as integers (32-bit on the device: pointer arithmetic on generic pointers drags an address-space cast with a
-// null check into every step; the simulator keeps host addresses)
-#ifdef DPC_SIMT_EMU
-typedef uintptr_t ldsa_t;
-static inline ldsa_t ldsa(const void* p) { return (uintptr_t)p; }
-#else
-typedef uint32_t ldsa_t;
-__device__ __forceinline__ ldsa_t ldsa(const void* p) { return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void*)p; }
-#endif
-// the six fragment reads of one K step on their own (first step of a tile)
-__device__ __forceinline__ void frag_read_p2(FragSet& f, ldsa_t xa, ldsa_t xb) {
-#ifdef DPC_SIMT_EMU
-    f.a[0] = *(const u32x4*)xa;
-    f.a[1] = *(const u32x4*)(xa + 4608);
-    for (int j = 0; j < 4; ++j) f.b[j] = *(const u32x4*)(xb + 4096 * j);
-#else
-    asm volatile("ds_read_b128 %0, %6\n\t"             // same order as step_il: a0 b0 b1 a1 b2 b3
-                 "ds_read_b128 %2, %7\n\t"
-                 "ds_read_b128 %3, %7 offset:4096\n\t"
-                 "ds_read_b128 %1, %6 offset:4608\n\t"
-                 "ds_read_b128 %4, %7 offset:8192\n\t"
-                 "ds_read_b128 %5, %7 offset:12288"
-                 : "=&v"(f.a[0]), "=&v"(f.a[1]), "=&v"(f.b[0]), "=&v"(f.b[1]), "=&v"(f.b[2]), "=&v"(f.b[3])
-                 : "v"(xa), "v"(xb)
-                 : "memory");
-#endif
-}
-// One K step of a compute wave with the NEXT step's six fragment reads interleaved between its eight MFMAs (hipcc otherwise
-// issues the reads as a burst in front of the MFMAs, and the matrix pipe idles while they issue -- probe: +61 us of 400 on
-// layer2, scripts/probes/ws_probe.py).  `use` must have landed (caller waits); `ld` is written.
-// pa: LDS address of the first A fragment (the second is 36 patch positions = 4608 bytes further); pb: of the first B fragment.
-template <bool LOAD>
-__device__ __forceinline__ void step_il(f32x16 (&acc)[2][4], const FragSet& use, FragSet& ld, ldsa_t xa, ldsa_t xb) {
-#ifdef DPC_SIMT_EMU
-    if (LOAD) {
-        ld.a[0] = *(const u32x4*)xa;
-        ld.a[1] = *(const u32x4*)(xa + 4608);
-        for (int j = 0; j < 4; ++j) ld.b[j] = *(const u32x4*)(xb + 4096 * j);
-    }
-    mma_step(acc, use);
-#else
-    // MFMAs stay compiler intrinsics (it allocates the accumulators and knows the matrix-pipe hazards); the reads are single
-    // untracked ds_read_b128 statements, and a scheduling barrier after every instruction pins the order written here.
-    // Counted waits: LDS operations of a wave complete in order.  On entry the only reads that may be outstanding are the six
-    // of `use`, issued in the order a0 b0 b1 a1 b2 b3 (the order below, one per MFMA gap of the previous step); every MFMA
-    // waits for exactly the operand it is the first to need, so each read has six MFMA gaps (~190 cycles) to land.
-#define DPC_IL_READ(dst, addr, off) \
-    if (LOAD) { asm volatile("ds_read_b128 %0, %1 offset:" #off : "=v"(dst) : "v"(addr) : "memory"); } \
-    __builtin_amdgcn_sched_barrier(0)
-#define DPC_IL_WAIT(n) \
-    asm volatile("s_waitcnt lgkmcnt(" #n ")" ::: "memory"); \
-    __builtin_amdgcn_sched_barrier(0)
-#define DPC_IL_MMA(i, j) \
-    acc[i][j] = mfma_32x32x16_bf16(use.a[i], use.b[j], acc[i][j]); \
-    __builtin_amdgcn_sched_barrier(0)
-    __builtin_amdgcn_sched_barrier(0);
-    DPC_IL_WAIT(4); DPC_IL_MMA(0, 0); DPC_IL_READ(ld.a[0], xa, 0);       // needs a0 b0; outstanding after: b1 a1 b2 b3 | a0'
-    DPC_IL_WAIT(4); DPC_IL_MMA(0, 1); DPC_IL_READ(ld.b[0], xb, 0);       // needs b1
-    DPC_IL_WAIT(4); DPC_IL_MMA(1, 0); DPC_IL_READ(ld.b[1], xb, 4096);    // needs a1
-    DPC_IL_MMA(1, 1); DPC_IL_READ(ld.a[1], xa, 4608);
-    DPC_IL_WAIT(5); DPC_IL_MMA(0, 2); DPC_IL_READ(ld.b[2], xb, 8192);    // needs b2
-    DPC_IL_MMA(1, 2); DPC_IL_READ(ld.b[3], xb, 12288);
-    DPC_IL_WAIT(6); DPC_IL_MMA(0, 3);                                     // needs b3
-    DPC_IL_MMA(1, 3);
-#undef DPC_IL_READ
-#undef DPC_IL_WAIT
-#undef DPC_IL_MMA
-#endif
-}
-__device__ __forceinline__ void mfma_drain() {}
 // s_waitcnt vmcnt(n) for a wave-uniform run-time n (the immediate must be a constant)
 __device__ __forceinline__ void wait_vmcnt_dyn(int n) {
     switch (n) {
@@ -598,12 +562,12 @@ __global__ __launch_bounds__(512, 2) void igemm_wsp_kernel(WsParams p) {
         int issued = 0;               // operations issued in the current slot
         auto issue_patch = [&](int gg, int i0, int i1) {   // pieces [i0, i1) of this wave, of global group gg
             const int tl = gg / G, grp = gg - tl * G;
-            const int mt = m_prog + tl * p.gm;
+            const int mt = WS_DBG(512) ? m_prog & 7 : m_prog + tl * p.gm;
             const unsigned soff = (unsigned)((mt * BM * g.src_ld + grp * 64) * 2);
             unsigned char* dst = lds + (gg & 1) * PATCH;
             DPC_UNROLL
             for (int i = 0; i < MAXP; ++i)
-                if (i >= i0 && i < i1 && i < n_mine && !WS_DBG(4)) {
+                if (i >= i0 && i < i1 && i < n_mine && !WS_DBG(4 | 128)) {
                     glds16_buf(rs_a, poff[i], soff, dst + (lw + 4 * i) * 1024, lane);
                     ++issued;
                 }
@@ -613,7 +577,7 @@ __global__ __launch_bounds__(512, 2) void igemm_wsp_kernel(WsParams p) {
             const int grp = gg % G;
             const int kd = tap * g.Ci + grp * 64;
             unsigned char* st = bring + (gc % NSB) * BST;
-            if (WS_DBG(4)) return;
+            if (WS_DBG(4 | 256)) return;
             DPC_UNROLL
             for (int i = 0; i < 4; ++i) glds16_buf(rs_b, wrow[i], (unsigned)kd * 2u, st + (lw + 4 * i) * 1024, lane);
             issued += 4;
@@ -674,6 +638,9 @@ __global__ __launch_bounds__(512, 2) void igemm_wsp_kernel(WsParams p) {
     for (int e = 0; e < EPO; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
 
     int gc = 0;
+#ifndef DPC_SIMT_EMU
+    __builtin_amdgcn_s_setprio(3);   // the compute waves win the SIMD's issue arbitration against their loader partner (-1..2 %)
+#endif
     for (int t = 0; wv < 4 && t < my_tiles; ++t) {
         const int mt = m_prog + t * p.gm;
         f32x16 acc[2][4];
@@ -704,7 +671,7 @@ __global__ __launch_bounds__(512, 2) void igemm_wsp_kernel(WsParams p) {
             ldsa_t b_st = lds0 + 2 * PATCH + (gc % NSB) * BST;
             ldsa_t pa = a_row + va[0];
             ldsa_t pb = b_st + vb;
-            frag_read_p2(f0, pa, pb);
+            frag_read_p2<4608>(f0, pa, pb);
             for (int gk = 0; gk < 3 * G; ++gk) {   // (group, kh)
                 const int grp = gk / 3, kh = gk - grp * 3;
                 const bool last_gk = gk + 1 == 3 * G;
@@ -714,9 +681,9 @@ __global__ __launch_bounds__(512, 2) void igemm_wsp_kernel(WsParams p) {
                     constexpr int KW = decltype(KWc)::value;
                     const bool last = last_gk && KW == 2;   // last chunk of the tile
                     if (HAS_ADD && last) fetch_addend(0, av0);
-                    step_il<true>(acc, f0, f1, pa ^ 32, pb ^ 32);
-                    step_il<true>(acc, f1, f0, pa ^ 64, pb ^ 64);
-                    step_il<true>(acc, f0, f1, pa ^ 96, pb ^ 96);
+                    step_il<true, 4608>(acc, f0, f1, pa ^ 32, pb ^ 32);
+                    step_il<true, 4608>(acc, f1, f0, pa ^ 64, pb ^ 64);
+                    step_il<true, 4608>(acc, f0, f1, pa ^ 96, pb ^ 96);
                     frag_wait<0>(f1);   // this wave's last reads of the chunk have landed
                     if (!WS_DBG(32)) ws_barrier();  // next chunk published -- or, after the tile's last chunk, "tile fully read"
                     ++gc;
@@ -727,10 +694,9 @@ __global__ __launch_bounds__(512, 2) void igemm_wsp_kernel(WsParams p) {
                     // after the tile's last chunk these reads fetch nothing useful (the next tile re-reads after ITS first barrier):
                     // keeping them unconditional keeps the MFMAs out of a branch -- accumulators that flow through both arms
                     // of a branch are copied at the join (hundreds of spilled registers)
-                    step_il<true>(acc, f1, f0, pa, pb);
+                    step_il<true, 4608>(acc, f1, f0, pa, pb);
                 });
             }
-            mfma_drain();
         }
 
         // ---- epilogue: two passes of 32 rows through this wave's 8 KB of the last group's patch buffer
