@@ -411,6 +411,48 @@ __global__ __launch_bounds__(64 * NWM * NWN, 2) void wgrad2_kernel(Wgrad2Params 
     auto compute = [&](int buf) {
         const unsigned char* As = lds + buf * STAGE + wm * SUB;
         const unsigned char* Bs = lds + buf * STAGE + (NWM + wn) * SUB;
+#ifndef DPC_SIMT_EMU
+        if constexpr (ESZ == 2) {
+            // 16 MFMAs per chunk with their operand reads software-pipelined by hand (scheme of conv_wgrad_patch.hip).  Operand loads
+            // in program order per K step: A0 B0 B1 A1 (two ds_read_b64_tr_b16 each); MFMAs (0,0) (0,1) (1,0) (1,1) first need
+            // B0, B1, A1, nothing.  Before MFMA m the loads up to LOOKAHEAD operands beyond its own are issued; the counted wait lets
+            // exactly those stay in flight.  Register sets alternate by K-step parity.
+            constexpr int LOOKAHEAD = 4;
+            const uint32_t as = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const unsigned char*)As;
+            const uint32_t bs = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const unsigned char*)Bs;
+            uint32_t ad[2][2];  // [operand A/B][fragment]
+            DPC_UNROLL
+            for (int i = 0; i < 2; ++i) { ad[0][i] = as + fo[i]; ad[1][i] = bs + fo[i]; }
+            u32x2 lo[2][2][2], hi[2][2][2];  // [K-step parity][operand][fragment]
+            auto load = [&](auto Ic) {
+                constexpr int I = decltype(Ic)::value;
+                constexpr int kk = I / 4, r4 = I % 4;
+                constexpr int op = (r4 == 1 || r4 == 2) ? 1 : 0, fr = (r4 >= 2) ? 1 : 0;   // A0 B0 B1 A1
+                asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(lo[kk & 1][op][fr]) : "v"(ad[op][fr]), "n"((kk * 16) * RB) : "memory");
+                __builtin_amdgcn_sched_barrier(0);
+                asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(hi[kk & 1][op][fr]) : "v"(ad[op][fr]), "n"((kk * 16 + 4) * RB) : "memory");
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            __builtin_amdgcn_sched_barrier(0);
+            static_for<16>([&](auto Mc) {
+                constexpr int m = decltype(Mc)::value;
+                constexpr int kk = m / 4, q = m % 4;
+                constexpr int idx = 4 * kk + (q == 0 ? 1 : q == 1 ? 2 : 3);
+                constexpr int idx_prev = m == 0 ? -1 : (q == 0 ? 4 * (kk - 1) + 3 : 4 * kk + (q == 1 ? 1 : q == 2 ? 2 : 3));
+                constexpr int f_prev = m == 0 ? 0 : (idx_prev + 1 + LOOKAHEAD < 16 ? idx_prev + 1 + LOOKAHEAD : 16);
+                constexpr int f_now = idx + 1 + LOOKAHEAD < 16 ? idx + 1 + LOOKAHEAD : 16;
+                static_for<f_now - f_prev>([&](auto Dc) { load(std::integral_constant<int, f_prev + decltype(Dc)::value>{}); });
+                asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(2 * (f_now - idx - 1)) : "memory");
+                __builtin_amdgcn_sched_barrier(0);
+                constexpr int i = q >> 1, j = q & 1, s = kk & 1;
+                const u32x4 av = {lo[s][0][i][0], lo[s][0][i][1], hi[s][0][i][0], hi[s][0][i][1]};
+                const u32x4 bv = {lo[s][1][j][0], lo[s][1][j][1], hi[s][1][j][0], hi[s][1][j][1]};
+                acc[i][j] = mfma_32x32x16_bf16(av, bv, acc[i][j]);
+                __builtin_amdgcn_sched_barrier(0);
+            });
+            return;
+        }
+#endif
         if (ESZ == 2) {
             DPC_UNROLL
             for (int kk = 0; kk < 4; ++kk) {

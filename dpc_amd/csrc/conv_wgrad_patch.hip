@@ -140,6 +140,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_patch_kernel(WgradPatchParams p)
     DPC_UNROLL
     for (int kw = 0; kw < 3; ++kw) fb[kw] = 8192 + linb + slot_off(wj * 32, ph + kw);
 
+#ifdef DPC_SIMT_EMU
     auto compute = [&](int buf) {
         const unsigned char* st = lds + buf * STAGE;
         DPC_UNROLL
@@ -160,6 +161,54 @@ __global__ __launch_bounds__(256, 2) void wgrad_patch_kernel(WgradPatchParams p)
                 }
         }
     };
+#else
+    // The 36 MFMAs of a chunk with their operand reads software-pipelined by hand.  Left to hipcc the loop is "4 reads, wait for
+    // them, 1 MFMA" (an LDS round trip per 32-cycle MFMA; 49-61 % matrix-pipe busy measured on the three instantiations).
+    // Operand loads in program order: per K step kk the A fragment, then the nine tap fragments B(kk, tap) -- 40 loads of two
+    // ds_read_b64_tr_b16 each.  Before MFMA m the loads up to LOOKAHEAD operands beyond its own have been issued, and the counted
+    // wait lets exactly those stay in flight (a wave's LDS operations complete in order).  A scheduling barrier after every
+    // instruction pins the order written here; the reads are untracked asm, so nothing may touch a destination before its wait.
+    constexpr int LOOKAHEAD = 4, RB = 8;
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)lds;
+    auto compute = [&](int buf) {
+        const uint32_t sa = lds0 + buf * STAGE + fa;
+        uint32_t sb[3];
+        DPC_UNROLL
+        for (int kw = 0; kw < 3; ++kw) sb[kw] = lds0 + buf * STAGE + fb[kw];
+        u32x2 alo[2], ahi[2], blo[RB], bhi[RB];
+        auto load = [&](auto Ic) {
+            constexpr int I = decltype(Ic)::value;
+            constexpr int kk = I / 10, r10 = I % 10;
+            if constexpr (r10 == 0) {
+                asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(alo[kk & 1]) : "v"(sa), "n"((kk * 16) * 128) : "memory");
+                __builtin_amdgcn_sched_barrier(0);
+                asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(ahi[kk & 1]) : "v"(sa), "n"((kk * 16 + 4) * 128) : "memory");
+                __builtin_amdgcn_sched_barrier(0);
+            } else {
+                constexpr int tap = r10 - 1, kh = tap / 3, kw = tap % 3, j = 9 * kk + tap;
+                constexpr int pos = ((kk * 16) / RW + kh) * PW + (kk * 16) % RW + kw;
+                asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(blo[j % RB]) : "v"(sb[kw]), "n"(pos * 128) : "memory");
+                __builtin_amdgcn_sched_barrier(0);
+                asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(bhi[j % RB]) : "v"(sb[kw]), "n"((pos + 4) * 128) : "memory");
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+        __builtin_amdgcn_sched_barrier(0);
+        static_for<36>([&](auto Mc) {
+            constexpr int m = decltype(Mc)::value;
+            constexpr int kk = m / 9, tap = m % 9, idx = 10 * kk + 1 + tap;
+            constexpr int f_prev = m == 0 ? 0 : ((idx - 1 + (tap == 0 ? -1 : 0)) + 1 + LOOKAHEAD < 40 ? (idx - 1 + (tap == 0 ? -1 : 0)) + 1 + LOOKAHEAD : 40);
+            constexpr int f_now = idx + 1 + LOOKAHEAD < 40 ? idx + 1 + LOOKAHEAD : 40;
+            static_for<f_now - f_prev>([&](auto Dc) { load(std::integral_constant<int, f_prev + decltype(Dc)::value>{}); });
+            asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(2 * (f_now - idx - 1)) : "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            const u32x4 av = {alo[kk & 1][0], alo[kk & 1][1], ahi[kk & 1][0], ahi[kk & 1][1]};
+            const u32x4 bv = {blo[m % RB][0], blo[m % RB][1], bhi[m % RB][0], bhi[m % RB][1]};
+            acc[tap] = mfma_32x32x16_bf16(av, bv, acc[tap]);
+            __builtin_amdgcn_sched_barrier(0);
+        });
+    };
+#endif
 
     // chunks whose source plane t + kt - pt falls outside the clip contribute nothing: skip them
     auto next_valid = [&](int c) {

@@ -218,6 +218,7 @@ __global__ __launch_bounds__(256, FUSED ? 2 : 3) void wgrad_stem_kernel(WgradSte
     // patch: position (gq>>1)*8 + ph4, + (gq&1) for the odd tap of the column block's pair, channels 4*(s16&3)..
     const int fb = 8192 + ((gq >> 1) * 8 + ph4 + (gq & 1)) * 32 + 8 * (s16 & 3);
 
+#ifdef DPC_SIMT_EMU
     auto compute = [&](int buf) {
         const unsigned char* st = lds + buf * STAGE;
         DPC_UNROLL
@@ -235,6 +236,50 @@ __global__ __launch_bounds__(256, FUSED ? 2 : 3) void wgrad_stem_kernel(WgradSte
             }
         }
     };
+#else
+    // The 16 MFMAs of a chunk with their operand reads software-pipelined by hand (same scheme as conv_wgrad_patch.hip: loads in
+    // program order A(kk), B(kk, 0..3); before MFMA m the loads up to LOOKAHEAD operands beyond its own are issued and the counted
+    // wait lets exactly those stay in flight; a scheduling barrier after every instruction pins the order).
+    constexpr int LOOKAHEAD = 4, RB = 8;
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)lds;
+    auto compute = [&](int buf) {
+        const uint32_t sa = lds0 + buf * STAGE + fa;
+        const uint32_t sb = lds0 + buf * STAGE + fb + wj * (2 * PW * 32);
+        u32x2 alo[2], ahi[2], blo[RB], bhi[RB];
+        auto load = [&](auto Ic) {
+            constexpr int I = decltype(Ic)::value;
+            constexpr int kk = I / 5, r5 = I % 5;
+            if constexpr (r5 == 0) {
+                asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(alo[kk & 1]) : "v"(sa), "n"((kk * 16) * 128) : "memory");
+                __builtin_amdgcn_sched_barrier(0);
+                asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(ahi[kk & 1]) : "v"(sa), "n"((kk * 16 + 4) * 128) : "memory");
+                __builtin_amdgcn_sched_barrier(0);
+            } else {
+                constexpr int c = r5 - 1, j = 4 * kk + c;
+                constexpr int off = ((c >> 1) * PW + kk * 16 + 2 * (c & 1)) * 32;
+                asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(blo[j % RB]) : "v"(sb), "n"(off) : "memory");
+                __builtin_amdgcn_sched_barrier(0);
+                asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(bhi[j % RB]) : "v"(sb), "n"(off + 4 * 32) : "memory");
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+        __builtin_amdgcn_sched_barrier(0);
+        static_for<16>([&](auto Mc) {
+            constexpr int m = decltype(Mc)::value;
+            constexpr int kk = m / 4, c = m % 4, idx = 5 * kk + 1 + c;
+            constexpr int idx_prev = idx - 1 + (c == 0 ? -1 : 0);
+            constexpr int f_prev = m == 0 ? 0 : (idx_prev + 1 + LOOKAHEAD < 20 ? idx_prev + 1 + LOOKAHEAD : 20);
+            constexpr int f_now = idx + 1 + LOOKAHEAD < 20 ? idx + 1 + LOOKAHEAD : 20;
+            static_for<f_now - f_prev>([&](auto Dc) { load(std::integral_constant<int, f_prev + decltype(Dc)::value>{}); });
+            asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(2 * (f_now - idx - 1)) : "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            const u32x4 av = {alo[kk & 1][0], alo[kk & 1][1], ahi[kk & 1][0], ahi[kk & 1][1]};
+            const u32x4 bv = {blo[m % RB][0], blo[m % RB][1], bhi[m % RB][0], bhi[m % RB][1]};
+            acc[c] = mfma_32x32x16_bf16(av, bv, acc[c]);
+            __builtin_amdgcn_sched_barrier(0);
+        });
+    };
+#endif
 
     if (c_begin < c_end) {
         issue(c_begin, 0);
