@@ -487,25 +487,6 @@ __global__ __launch_bounds__(512, 2) void igemm_ws_kernel(WsParams p) {
 //     is re-derived per chunk (a dozen VALU operations against 32 MFMAs).
 //   * epilogue: staged through the patch buffer of the tile's LAST group; the loaders refill that buffer only after the
 //     first barrier of the next tile, which the compute waves reach after their epilogue.
-// s_waitcnt vmcnt(n) for a wave-uniform run-time n (the immediate must be a constant)
-__device__ __forceinline__ void wait_vmcnt_dyn(int n) {
-    switch (n) {
-        case 0: wait_vmcnt<0>(); break;
-        case 1: wait_vmcnt<1>(); break;
-        case 2: wait_vmcnt<2>(); break;
-        case 3: wait_vmcnt<3>(); break;
-        case 4: wait_vmcnt<4>(); break;
-        case 5: wait_vmcnt<5>(); break;
-        case 6: wait_vmcnt<6>(); break;
-        case 7: wait_vmcnt<7>(); break;
-        case 8: wait_vmcnt<8>(); break;
-        case 9: wait_vmcnt<9>(); break;
-        case 10: wait_vmcnt<10>(); break;
-        case 11: wait_vmcnt<11>(); break;
-        default: wait_vmcnt<12>(); break;  // n >= 12: waiting for fewer outstanding operations is always safe
-    }
-}
-
 template <bool HAS_ADD>
 __global__ __launch_bounds__(512, 2) void igemm_wsp_kernel(WsParams p) {
     typedef bf16_t TO;
@@ -596,7 +577,7 @@ __global__ __launch_bounds__(512, 2) void igemm_wsp_kernel(WsParams p) {
         if (total > 2) issue_b(2);
         int o1 = issued;
         for (int gc = 0; gc < total; ++gc) {
-            wait_vmcnt_dyn(o1 + o2);
+            wait_vmcnt_upto(o1 + o2);
             if (!WS_DBG(32)) ws_barrier();  // chunk gc (and, at a group's first chunk, its patch) is published; every reader is done with chunk gc-1
             const int gg = gc / 9, q = gc - gg * 9;
             issued = 0;

@@ -37,7 +37,13 @@ struct WgradPatchParams {
     int cpf;
     int KT, pt, T;       // temporal taps: a workgroup owns ONE kt; T = frames per clip
     FastDiv d_T;
+    int dbg;             // DPC_WS_PROBE builds only: phases to leave out, for timing (scripts/probes/wgrad_probe.py)
 };
+#ifdef DPC_WS_PROBE
+#define WP_DBG(bit) (p.dbg & (bit))
+#else
+#define WP_DBG(bit) 0
+#endif
 
 // RW: image width rounded up to 8/16/32/64.  A chunk is 64/RW image rows of RW columns; columns >= the real
 // width and rows >= the image height are out-of-range lanes of the dy DMA (zeros: they add nothing), so any
@@ -50,7 +56,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_patch_kernel(WgradPatchParams p)
     constexpr int NPB = (NPOS + 7) / 8;    // B pieces (8 positions = 1 KB each)
     constexpr int NIB = (NPB + 3) / 4;     // B pieces per wave
     constexpr int STAGE = 8192 + NPB * 1024;
-    __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * STAGE];
+    // ring of three stages (two chunks in flight) for the 32-wide images, two stages elsewhere
+    constexpr int NST = (RW == 32 && 2 * 3 * STAGE <= 160 * 1024) ? 3 : 2;   // measured: 32 -> -3 %, 16 -> +4 %, 8 -> 0
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[NST * STAGE];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -106,8 +114,18 @@ __global__ __launch_bounds__(256, 2) void wgrad_patch_kernel(WgradPatchParams p)
         DPC_UNROLL
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
-    auto issue = [&](int chunk, int buf) {
-        unsigned char* stage = lds + buf * STAGE;
+    // DMA of one chunk = 2 pieces of dy + up to NIB pieces of the patch per wave.  prep() resolves the chunk's per-piece offsets
+    // (out-of-image rows become out-of-range lanes), piece(i) issues one of them: the pieces of the NEXT chunk are issued one at
+    // a time between the MFMAs of the current one instead of as a burst in front of them.  MEASURED (scripts/probes/wgrad_probe.py,
+    // layer1 / layer2 / layer3 of cfg2): MFMA + operand reads alone 257 / 239 / 385 us, DMA + barriers alone 250 / 176 / 229 us,
+    // together 381 / 325 / 446 us -- and that sum does not move with the placement of the DMA instructions (burst: 362 / 320 / 455)
+    // nor with a third stage: the two streams share the LDS (each MFMA needs 1 KB of transposed reads; ds_read_b64_tr_b16 reaches
+    // its peak only from ~4 waves per SIMD, this kernel runs 2), not the issue slots.
+    constexpr int NPC = 2 + NIB;
+    unsigned dma_v[NPC];
+    unsigned char* dma_stage = lds;
+    auto dma_prep = [&](int chunk, int buf, bool real) {   // !real (no chunk left): every lane out of range -- the pieces write zeros
+        dma_stage = lds + buf * STAGE;                      // into the free stage, and the MFMA stream needs no branch around them
         const unsigned frame = fdiv((unsigned)chunk, p.d_cpf);
         const int h0 = (chunk - (int)frame * p.cpf) * ROWS;
         const unsigned a_base = (unsigned)(((int)frame * p.RH + h0) * p.W) * (unsigned)p.dy_ld * 2u;
@@ -115,15 +133,30 @@ __global__ __launch_bounds__(256, 2) void wgrad_patch_kernel(WgradPatchParams p)
         DPC_UNROLL
         for (int i = 0; i < 2; ++i) {
             const bool ok = (unsigned)(h0 + a_row[i]) < (unsigned)p.RH;
-            glds16_buf(rs_a, ok ? a_base + a_off[i] : DPC_BUF_OOB, 0u, stage + (wv + 4 * i) * 1024, lane);
+            dma_v[i] = ok && real ? a_base + a_off[i] : DPC_BUF_OOB;
         }
         DPC_UNROLL
         for (int i = 0; i < NIB; ++i) {
-            if (wv + 4 * i < NPB) {
-                const bool ok = (unsigned)(h0 + b_row[i]) < (unsigned)p.RH;
-                glds16_buf(rs_b, ok ? b_base + b_off[i] : DPC_BUF_OOB, 0u, stage + 8192 + (wv + 4 * i) * 1024, lane);
+            const bool ok = (unsigned)(h0 + b_row[i]) < (unsigned)p.RH;
+            dma_v[2 + i] = ok && real ? b_base + b_off[i] : DPC_BUF_OOB;
+        }
+    };
+    auto dma_piece = [&](auto Ic) {
+        constexpr int I = decltype(Ic)::value;
+        if (WP_DBG(1)) return;
+        if constexpr (I < 2) {
+            glds16_buf(rs_a, dma_v[I], 0u, dma_stage + (wv + 4 * I) * 1024, lane);
+        } else {
+            if constexpr (4 * (I - 2) + 3 < NPB) {   // every wave has this piece
+                glds16_buf(rs_b, dma_v[I], 0u, dma_stage + 8192 + (wv + 4 * (I - 2)) * 1024, lane);
+            } else {
+                if (wv + 4 * (I - 2) < NPB) glds16_buf(rs_b, dma_v[I], 0u, dma_stage + 8192 + (wv + 4 * (I - 2)) * 1024, lane);
             }
         }
+    };
+    auto issue = [&](int chunk, int buf) {
+        dma_prep(chunk, buf, true);
+        static_for<NPC>([&](auto Ic) { dma_piece(Ic); });
     };
 
     // ---- fragment lane offsets
@@ -142,6 +175,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_patch_kernel(WgradPatchParams p)
 
 #ifdef DPC_SIMT_EMU
     auto compute = [&](int buf) {
+        static_for<NPC>([&](auto Ic) { dma_piece(Ic); });
         const unsigned char* st = lds + buf * STAGE;
         DPC_UNROLL
         for (int kk = 0; kk < 4; ++kk) {
@@ -206,6 +240,10 @@ __global__ __launch_bounds__(256, 2) void wgrad_patch_kernel(WgradPatchParams p)
             const u32x4 bv = {blo[m % RB][0], blo[m % RB][1], bhi[m % RB][0], bhi[m % RB][1]};
             acc[tap] = mfma_32x32x16_bf16(av, bv, acc[tap]);
             __builtin_amdgcn_sched_barrier(0);
+            if constexpr (m % 4 == 1 && m / 4 < NPC) {   // next chunk's DMA piece m/4, behind an MFMA that has just been issued
+                dma_piece(std::integral_constant<int, m / 4>{});
+                __builtin_amdgcn_sched_barrier(0);
+            }
         });
     };
 #endif
@@ -221,16 +259,44 @@ __global__ __launch_bounds__(256, 2) void wgrad_patch_kernel(WgradPatchParams p)
         }
         return c;
     };
+    // Chunk c lives in stage c mod NST.  Three stages: chunk c+2 is issued while chunk c is computed, i.e. a DMA piece has two
+    // chunk periods (~1-2 us) to land instead of one (worth 3 % on the 32-wide images only).
+    // The wait before the barrier is counted -- the pieces of the newest chunk stay in flight (LDS-DMA of a wave lands in issue
+    // order) -- and the barrier itself is the raw instruction: __syncthreads() would drain every outstanding load.
+    int n_mine = 2;   // DMA pieces this wave issues per chunk
+    DPC_UNROLL
+    for (int i = 0; i < NIB; ++i) n_mine += (wv + 4 * i < NPB) ? 1 : 0;
     int cur = next_valid(c_begin), buf = 0;
-    if (cur < c_end) issue(cur, 0);
-    __syncthreads();
-    while (cur < c_end) {
-        const int nxt = next_valid(cur + 1);
-        if (nxt < c_end) issue(nxt, buf ^ 1);
-        compute(buf);
+    if (NST == 3) {
+        int nxt = c_end;
+        if (cur < c_end) {
+            issue(cur, 0);
+            nxt = next_valid(cur + 1);
+            if (nxt < c_end) issue(nxt, 1);
+        }
+        while (cur < c_end) {
+            if (nxt < c_end) wait_vmcnt_upto(n_mine); else wait_vmcnt<0>();
+            if (!WP_DBG(4)) barrier_lds_only();   // chunk cur landed for every wave; everyone is done with the stage chunk nxt2 goes to
+            const int nxt2 = nxt < c_end ? next_valid(nxt + 1) : c_end;
+            dma_prep(nxt2 < c_end ? nxt2 : cur, buf >= 1 ? buf - 1 : 2, nxt2 < c_end);
+            if (!WP_DBG(2)) compute(buf);
+            else static_for<NPC>([&](auto Ic) { dma_piece(Ic); });
+            cur = nxt;
+            nxt = nxt2;
+            buf = buf == 2 ? 0 : buf + 1;
+        }
+    } else {
+        if (cur < c_end) issue(cur, 0);
         __syncthreads();
-        cur = nxt;
-        buf ^= 1;
+        while (cur < c_end) {
+            const int nxt = next_valid(cur + 1);
+            dma_prep(nxt < c_end ? nxt : cur, buf ^ 1, nxt < c_end);
+            if (!WP_DBG(2)) compute(buf);
+            else static_for<NPC>([&](auto Ic) { dma_piece(Ic); });
+            __syncthreads();
+            cur = nxt;
+            buf ^= 1;
+        }
     }
 
     // ---- partial slab: rows = co, columns = tap*Ci + ci
@@ -290,6 +356,7 @@ int dpc_wgrad_patch_try(const dpc_conv_desc* d, const void* src, const void* dy,
     if (!src || !dy) return DPC_ERR_ARG;
     if (((uintptr_t)src % 16) || ((uintptr_t)dy % 16)) return DPC_ERR_UNSUPPORTED;
     p.src = src; p.dy = dy; p.part = part;
+    p.dbg = getenv("DPC_WS_DBG") ? atoi(getenv("DPC_WS_DBG")) : 0;
     dim3 grid((unsigned)(p.ntm * p.ntc * p.KT * p.nks)), block(256);
     if (rwp == 64) {
         DPC_LAUNCH((wgrad_patch_kernel<64>), grid, block, stream, p);

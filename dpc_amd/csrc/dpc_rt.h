@@ -340,6 +340,25 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {
 #endif
 }
 
+// wait until at most n (wave-uniform, run-time) vector-memory operations of this wave are outstanding
+__device__ __forceinline__ void wait_vmcnt_upto(int n) {
+    switch (n) {
+        case 0: wait_vmcnt<0>(); break;
+        case 1: wait_vmcnt<1>(); break;
+        case 2: wait_vmcnt<2>(); break;
+        case 3: wait_vmcnt<3>(); break;
+        case 4: wait_vmcnt<4>(); break;
+        case 5: wait_vmcnt<5>(); break;
+        case 6: wait_vmcnt<6>(); break;
+        case 7: wait_vmcnt<7>(); break;
+        case 8: wait_vmcnt<8>(); break;
+        case 9: wait_vmcnt<9>(); break;
+        case 10: wait_vmcnt<10>(); break;
+        case 11: wait_vmcnt<11>(); break;
+        default: wait_vmcnt<12>(); break;  // n >= 12: waiting for fewer outstanding operations is always safe
+    }
+}
+
 // compile-time unrolled loop: body(std::integral_constant<int, I>) for I = 0..N-1 (the index is usable as a
 // template argument / instruction immediate inside the body)
 template <class F, int... Is> __device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, Is...>) {
