@@ -16,7 +16,7 @@ fetch = per_kernel(sys.argv[1], "FETCH_SIZE")
 write = per_kernel(sys.argv[2], "WRITE_SIZE")
 tag = sys.argv[3]
 res = {}
-for fam, pat in (("dpc_conv_igemm", r"igemm_kernel|igemm_ws_kernel|conv_halo_kernel|conv_halo_ws_kernel"),
+for fam, pat in (("dpc_conv_igemm", r"igemm_kernel|igemm_ws_kernel|igemm_wsp_kernel|conv_halo_kernel|conv_halo_ws_kernel"),
                  ("dpc_conv_wgrad", r"wgrad_kernel|wgrad2_kernel|wgrad_patch_kernel|wgrad_stem_kernel")):
     f = sum(v for k, (v, n) in fetch.items() if re.search(pat, k))
     w = sum(v for k, (v, n) in write.items() if re.search(pat, k))
