@@ -32,7 +32,16 @@ build/emu/simt_emu.o: $(EMU)/simt_emu.cpp $(EMU)/simt_emu.h
 	@mkdir -p build/emu
 	$(HOSTCXX) -O2 -g -std=c++17 -fPIC -I$(EMU) -c $< -o $@
 
+# timing probes only (scripts/probes/*.py): the two loader/compute kernels rebuilt with -DDPC_WS_PROBE (phases can be left out
+# through DPC_WS_DBG; results are then wrong by design), linked with the product objects
+PROBE_SRCS := conv_igemm_ws conv_wgrad_patch
+probe: all
+	@mkdir -p build/probe
+	for f in $(PROBE_SRCS); do $(HIPCC) --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -Iinclude -DDPC_WS_PROBE -c $(CSRC)/$$f.hip -o build/probe/$$f.o || exit 1; done
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o scripts/probes/libdpc_probe.so $(patsubst %,build/probe/%.o,$(PROBE_SRCS)) \
+		$(filter-out $(patsubst %,build/hip/%.o,$(PROBE_SRCS)),$(OBJS))
+
 clean:
 	rm -rf build dpc_amd/libdpc_hip.so $(EMU)/libdpc_emu.so
 
-.PHONY: all emu clean
+.PHONY: all emu probe clean
