@@ -832,7 +832,11 @@ int dpc_conv_ws_try(const dpc_conv_desc* d, const void* src, const void* wgt, vo
     if (addend && stats) return 1;  // not a combination of this path: the generic kernel serves it
     if (((uintptr_t)out % 16) || ((uintptr_t)addend % 16) || ((uintptr_t)src % 16) || ((uintptr_t)wgt % 16)) return 1;
     p.src = src; p.wgt = wgt; p.out = out; p.addend = addend; p.stats = stats;
+#ifdef DPC_WS_PROBE
     p.dbg = getenv("DPC_WS_DBG") ? atoi(getenv("DPC_WS_DBG")) : 0;
+#else
+    p.dbg = 0;
+#endif
     dim3 grid((unsigned)(p.gm * p.ntn)), block(512);
     if (p.plane) {
         if (addend) {

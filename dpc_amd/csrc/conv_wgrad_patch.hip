@@ -356,7 +356,11 @@ int dpc_wgrad_patch_try(const dpc_conv_desc* d, const void* src, const void* dy,
     if (!src || !dy) return DPC_ERR_ARG;
     if (((uintptr_t)src % 16) || ((uintptr_t)dy % 16)) return DPC_ERR_UNSUPPORTED;
     p.src = src; p.dy = dy; p.part = part;
+#ifdef DPC_WS_PROBE
     p.dbg = getenv("DPC_WS_DBG") ? atoi(getenv("DPC_WS_DBG")) : 0;
+#else
+    p.dbg = 0;
+#endif
     dim3 grid((unsigned)(p.ntm * p.ntc * p.KT * p.nks)), block(256);
     if (rwp == 64) {
         DPC_LAUNCH((wgrad_patch_kernel<64>), grid, block, stream, p);
