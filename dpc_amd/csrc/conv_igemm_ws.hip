@@ -89,7 +89,7 @@ __device__ __forceinline__ void mma_step(f32x16 (&acc)[2][4], const FragSet& f) 
     DPC_UNROLL
     for (int i = 0; i < 2; ++i)
         DPC_UNROLL
-        for (int j = 0; j < 4; ++j) acc[i][j] = mfma_32x32x16_bf16(f.a[i], f.b[j], acc[i][j]);
+        for (int j = 0; j < 4; ++j) acc[i][j] = mfma_32x32x16_bf16(f.b[j], f.a[i], acc[i][j]);   // transposed block, see stage_block
 }
 
 // LDS addresses as integers (32-bit on the device: pointer arithmetic on generic pointers drags an address-space cast with a
@@ -146,7 +146,7 @@ __device__ __forceinline__ void step_il(f32x16 (&acc)[2][4], const FragSet& use,
     asm volatile("s_waitcnt lgkmcnt(" #n ")" ::: "memory"); \
     __builtin_amdgcn_sched_barrier(0)
 #define DPC_IL_MMA(i, j) \
-    acc[i][j] = mfma_32x32x16_bf16(use.a[i], use.b[j], acc[i][j]); \
+    acc[i][j] = mfma_32x32x16_bf16(use.b[j], use.a[i], acc[i][j]); \
     __builtin_amdgcn_sched_barrier(0)
     __builtin_amdgcn_sched_barrier(0);
     DPC_IL_WAIT(4); DPC_IL_MMA(0, 0); DPC_IL_READ(ld.a[0], xa, 0);       // needs a0 b0; outstanding after: b1 a1 b2 b3 | a0'
@@ -162,6 +162,23 @@ __device__ __forceinline__ void step_il(f32x16 (&acc)[2][4], const FragSet& use,
 #undef DPC_IL_MMA
 #endif
 }
+
+// The MFMAs are issued with the operands swapped (weights as the first operand): acc[i][j] then holds the TRANSPOSED 32 x 32
+// block -- a lane owns ONE tile row (l & 31) and four consecutive output columns per register quad -- so the epilogue stages a
+// quad as one packed 8-byte LDS write (16 per 32-row pass instead of 64 two-byte writes; 37 of 347 us on layer2 were staging).
+// Staging rows are 272 bytes apart: the 16 lanes of a ds_write_b64 group then hit 16 disjoint bank pairs, and the row reads
+// (ds_read_b128, 4 rows per instruction) stay conflict-free.
+constexpr int WS_STG_ROW = 272, WS_STG_WAVE = 32 * WS_STG_ROW;
+__device__ __forceinline__ void stage_block(unsigned char* mine, const f32x16 (&acc)[4], int l31, int lhi) {
+    DPC_UNROLL
+    for (int j = 0; j < 4; ++j)
+        DPC_UNROLL
+        for (int k = 0; k < 4; ++k) {
+            u32x2 v = {bf16x2_pack(acc[j][4 * k], acc[j][4 * k + 1]), bf16x2_pack(acc[j][4 * k + 2], acc[j][4 * k + 3])};
+            *(u32x2*)(mine + l31 * WS_STG_ROW + (j * 32 + 8 * k + 4 * lhi) * 2) = v;
+        }
+}
+
 template <bool HAS_ADD>
 __global__ __launch_bounds__(512, 2) void igemm_ws_kernel(WsParams p) {
     typedef bf16_t T;
@@ -386,24 +403,17 @@ __global__ __launch_bounds__(512, 2) void igemm_ws_kernel(WsParams p) {
         }
 
         // ---- epilogue: two passes of 32 rows through this wave's 8 KB of the free stage
-        unsigned char* mine = lds + stage_last * STAGE + wv * 8192;
+        unsigned char* mine = lds + stage_last * STAGE + wv * WS_STG_WAVE;   // 34 KB of the 48 KB stage every wave has finished reading
         DPC_UNROLL
         for (int i = 0; i < 2; ++i) {
-            TO* tile = (TO*)mine;
-            DPC_UNROLL
-            for (int j = 0; j < 4; ++j)
-                DPC_UNROLL
-                for (int r = 0; r < 16; ++r) {
-                    const int row_l = (r & 3) + 8 * (r >> 2) + 4 * lhi;
-                    tile[row_l * BN + j * 32 + l31] = f32_to_bf16(acc[i][j][r]);
-                }
+            stage_block(mine, acc[i], l31, lhi);
             wave_lds_fence();  // wave-private region: LDS operations of one wave complete in order, no workgroup barrier
             if (HAS_ADD && i == 0) fetch_addend(1, av1);  // the first pass's accumulators are dead: room for the second pass's addend
             u32x4 ov[8];
             DPC_UNROLL
             for (int it = 0; it < 8; ++it) {
                 const int row_l = er + 4 * it;
-                ov[it] = *(const u32x4*)(mine + (row_l * BN + cu * EPO) * 2);
+                ov[it] = *(const u32x4*)(mine + row_l * WS_STG_ROW + cu * EPO * 2);
             }
             wave_lds_fence();  // the second pass overwrites what this one has just read
             DPC_UNROLL
@@ -495,7 +505,7 @@ __global__ __launch_bounds__(512, 2) void igemm_wsp_kernel(WsParams p) {
     constexpr int BST = BN * 128, NSB = 4;
     constexpr int EPO = 8;
     constexpr int MAXP = (NPIECE + 3) / 4;  // patch pieces per loader wave
-    static_assert(4 * 8192 <= PATCH, "epilogue staging fits a patch buffer");
+    static_assert(4 * WS_STG_WAVE <= PATCH, "epilogue staging fits a patch buffer");
     __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * PATCH + NSB * BST];
     unsigned char* const bring = lds + 2 * PATCH;
 
@@ -681,28 +691,21 @@ __global__ __launch_bounds__(512, 2) void igemm_wsp_kernel(WsParams p) {
         }
 
         // ---- epilogue: two passes of 32 rows through this wave's 8 KB of the last group's patch buffer
-        unsigned char* mine = lds + ((t * G + G - 1) & 1) * PATCH + wv * 8192;
+        unsigned char* mine = lds + ((t * G + G - 1) & 1) * PATCH + wv * WS_STG_WAVE;
         if (WS_DBG(2)) {  // probe: no epilogue at all (the accumulators stay live through one store)
             if (acc[0][0][0] == 12345.f) *(float*)p.out = acc[1][3][5];
             continue;
         }
         DPC_UNROLL
         for (int i = 0; i < 2; ++i) {
-            TO* tile = (TO*)mine;
-            DPC_UNROLL
-            for (int j = 0; j < 4; ++j)
-                DPC_UNROLL
-                for (int r = 0; r < 16; ++r) {
-                    const int row_l = (r & 3) + 8 * (r >> 2) + 4 * lhi;
-                    tile[row_l * BN + j * 32 + l31] = f32_to_bf16(acc[i][j][r]);
-                }
+            stage_block(mine, acc[i], l31, lhi);
             wave_lds_fence();
             if (HAS_ADD && i == 0) fetch_addend(1, av1);
             u32x4 ov[8];
             DPC_UNROLL
             for (int it = 0; it < 8; ++it) {
                 const int row_l = er + 4 * it;
-                ov[it] = *(const u32x4*)(mine + (row_l * BN + cu * EPO) * 2);
+                ov[it] = *(const u32x4*)(mine + row_l * WS_STG_ROW + cu * EPO * 2);
             }
             wave_lds_fence();
             DPC_UNROLL

@@ -1,6 +1,6 @@
 #!/bin/bash
 R=$GRAFT_REPO_ROOT; cd $R; mkdir -p gpurun_out
-(timeout 900 python -m pytest tests/test_kernels_gpu.py -m gpu -q -p no:cacheprovider -k "wgrad or stem" 2>&1 | tail -3) > gpurun_out/j_tests.log
+(timeout 900 python -m pytest tests/test_kernels_gpu.py -m gpu -q -p no:cacheprovider -k "conv or gemm" 2>&1 | tail -3) > gpurun_out/j_tests.log
 (timeout 900 python -m pytest tests/test_configs_gpu.py -m gpu -q -p no:cacheprovider 2>&1 | tail -3) >> gpurun_out/j_tests.log
 (timeout 300 python bench.py --no-cpu-baseline 2>&1 | tail -1) > gpurun_out/j_bench_cfg2.log
 cd /tmp && export TMPDIR=/tmp
