@@ -45,7 +45,13 @@ struct HaloParams {
     int vec_out;
     unsigned src_bytes;
     int ws;  // shape served by the role-specialised kernel
+    int dbg; // DPC_WS_PROBE builds only: phases to leave out, for timing (scripts/probes/halo_probe.py)
 };
+#ifdef DPC_WS_PROBE
+#define HP_DBG(bit) (p.dbg & (bit))
+#else
+#define HP_DBG(bit) 0
+#endif
 
 // UPP = 16-byte units per position: 8 (one tap = one 128-byte chunk) or 2 (one chunk = 4 kw taps, KW == 4)
 template <class T, class TO, int KH, int KW, int UPP>
@@ -322,7 +328,8 @@ __global__ __launch_bounds__(512, 2) void conv_halo_ws_kernel(HaloParams p) {
     constexpr int LIT = UPP == 8 ? 8 : (BM == 128 ? 3 : 5);       // DMA pieces per helper wave and patch: LIT x 256 lanes x 16 B >= positions x (UPP+1) slots
     constexpr int PATCH = LIT * 256 * 16;
     constexpr int STG = BM * BN * 2;
-    constexpr int NPB = 3;
+    constexpr int NPB = 3;                        // patch ring: two tiles of lookahead (a fourth buffer = all 160 KB of LDS was measured: no change)
+    static_assert(NPB * PATCH + 2 * STG <= 160 * 1024, "one workgroup per CU");
     __shared__ __attribute__((aligned(1024))) unsigned char lds[NPB * PATCH + 2 * STG];
 
     const int tid = threadIdx.x;
@@ -332,7 +339,11 @@ __global__ __launch_bounds__(512, 2) void conv_halo_ws_kernel(HaloParams p) {
 #else
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
 #endif
-    const int m_prog = blockIdx.x;
+    // Workgroup b runs on XCD b & 7 (its own L2).  The tiles of one frame are consecutive tile indices and neighbouring row bands
+    // share two of their six patch rows: give every XCD a contiguous range of tile slots, so that those re-reads hit its L2
+    // instead of going to HBM a second time (round-robin slots put neighbouring bands on different XCDs: 1.5x input traffic).
+    int m_prog = blockIdx.x;
+    if ((p.gm & 7) == 0 && !HP_DBG(16)) m_prog = (m_prog & 7) * (p.gm >> 3) + (m_prog >> 3);
     const int ntiles = (p.ntm - m_prog + p.gm - 1) / p.gm;  // >= 1
     const char* const zero = (const char*)dpc_zero16;
 
@@ -347,6 +358,9 @@ __global__ __launch_bounds__(512, 2) void conv_halo_ws_kernel(HaloParams p) {
 
     if (wv < 4) {
         // ------------------------------------------------------------------ compute waves
+#ifndef DPC_SIMT_EMU
+        if (!HP_DBG(32)) __builtin_amdgcn_s_setprio(3);   // win the SIMD's issue arbitration against the helper wave
+#endif
         const int wm = wv >> 1, wn = wv & 1;
         const int l31 = lane & 31, lhi = lane >> 5;
         u32x4 fbr[NTAPS][4];
@@ -391,8 +405,8 @@ __global__ __launch_bounds__(512, 2) void conv_halo_ws_kernel(HaloParams p) {
                 DPC_UNROLL
                 for (int i = 0; i < MI; ++i) lds_read_b128_async_off<ch * CBP + kk * KKSTEP>(ring[s % R][i], rowp[kh][i]);
             };
-            static_for<D>(fetch);
-            static_for<S>([&](auto sc) {
+            if (!HP_DBG(2)) static_for<D>(fetch);
+            if (!HP_DBG(2)) static_for<S>([&](auto sc) {
                 constexpr int s = decltype(sc)::value;
                 if constexpr (s + D < S) fetch(std::integral_constant<int, s + D>{});
                 constexpr int ahead = (S - 1 - s) < D ? (S - 1 - s) : D;
@@ -403,6 +417,7 @@ __global__ __launch_bounds__(512, 2) void conv_halo_ws_kernel(HaloParams p) {
                 sched_fence();
             });
             TO* tile = (TO*)(lds + NPB * PATCH + (j & 1) * STG);
+            if (!HP_DBG(4))
             DPC_UNROLL
             for (int i = 0; i < MI; ++i)
                 DPC_UNROLL
@@ -443,7 +458,7 @@ __global__ __launch_bounds__(512, 2) void conv_halo_ws_kernel(HaloParams p) {
             for (int it = 0; it < LIT; ++it) {
                 const int h = hb + (hrc[it] >> 16), w = wb + (hrc[it] & 0xffff);
                 const bool ok = ((unsigned)h < (unsigned)p.H) & ((unsigned)w < (unsigned)p.W);
-                glds16_buf(rs, ok ? base + rel[it] : DPC_BUF_OOB, 0u, patch + (it * 256 + hw * 64) * 16, lane);
+                if (!HP_DBG(1)) glds16_buf(rs, ok ? base + rel[it] : DPC_BUF_OOB, 0u, patch + (it * 256 + hw * 64) * 16, lane);
             }
         };
         const int cu = htid & 7, rbase = htid >> 3;  // output unit column; tile rows rbase + 32*q
@@ -505,14 +520,18 @@ __global__ __launch_bounds__(512, 2) void conv_halo_ws_kernel(HaloParams p) {
             }
         };
         issue(0);
-        if (ntiles > 1) issue(1);
+        DPC_UNROLL
+        for (int a = 1; a < NPB - 1; ++a)
+            if (ntiles > a) issue(a);
         if (HAS_ADD) fetch_addend(0, av);
         for (int j = 0; j <= ntiles; ++j) {
-            // patch j must have landed.  Newer than its pieces are: this wave's stores of tile j-2 and the LIT pieces
-            // of patch j+1.  Loads (LDS-DMA included) complete in order among themselves, so "at most LIT
-            // outstanding" implies every piece of patch j is done whatever the stores do.
+            // patch j must have landed.  Newer than its pieces are: this wave's stores of older tiles and the LIT pieces of each
+            // of the patches j+1 .. j+NPB-2.  Loads (LDS-DMA included) complete in order among themselves, so "at most that many
+            // outstanding" implies every piece of patch j is done whatever the stores do.  (The addend loads of the residual
+            // variant are requested between two patches: counting them as absent only makes the wait stricter.)
             if (j < ntiles) {
-                if (j + 1 < ntiles) wait_vmcnt<LIT>(); else wait_vmcnt<0>();
+                const int newer = ntiles - 1 - j < NPB - 2 ? ntiles - 1 - j : NPB - 2;
+                if (newer >= 2) wait_vmcnt<2 * LIT>(); else if (newer == 1) wait_vmcnt<LIT>(); else wait_vmcnt<0>();
             }
             barrier_lds_only();  // B1(j)
             if (HAS_ADD) {
@@ -520,13 +539,13 @@ __global__ __launch_bounds__(512, 2) void conv_halo_ws_kernel(HaloParams p) {
                 DPC_UNROLL
                 for (int q = 0; q < NQ; ++q) avn[q] = av[q];
                 if (j < ntiles && j >= 1) fetch_addend(j, avn);
-                if (j >= 1) epilogue(j - 1, av);
+                if (j >= 1 && !HP_DBG(8)) epilogue(j - 1, av);
                 DPC_UNROLL
                 for (int q = 0; q < NQ; ++q) av[q] = avn[q];
-            } else if (j >= 1) {
+            } else if (j >= 1 && !HP_DBG(8)) {
                 epilogue(j - 1, av);
             }
-            if (j + 2 < ntiles) issue(j + 2);  // into the buffer of patch j-1, released at B2(j-1)
+            if (j + NPB - 1 < ntiles) issue(j + NPB - 1);  // into the buffer of patch j-1, released at B2(j-1)
             barrier_lds_only();  // B2(j)
         }
         // every patch has been consumed (last B2 passed): the first patch buffer becomes the reduction scratch
@@ -612,6 +631,11 @@ int dpc_conv_halo_try(const dpc_conv_desc* d, const void* src, const void* wgt, 
     HaloParams p;
     if (!halo_plan(d, &p)) return 1;
     p.src = src; p.wgt = wgt; p.out = out; p.addend = addend; p.stats = stats;
+#ifdef DPC_WS_PROBE
+    p.dbg = getenv("DPC_WS_DBG") ? atoi(getenv("DPC_WS_DBG")) : 0;
+#else
+    p.dbg = 0;
+#endif
     const int epo = d->dtype_out == DPC_BF16 ? 8 : 4;
     p.vec_out = (d->Co % epo == 0 && d->ldo % epo == 0 && ((uintptr_t)out % 16 == 0) && ((uintptr_t)addend % 16 == 0)) ? 1 : 0;
     const bool ws_go = p.ws && p.vec_out && ((uintptr_t)src % 16 == 0) && !(d->KH == 4 && addend);
