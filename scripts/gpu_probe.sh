@@ -1,4 +1,7 @@
 #!/bin/bash
+# all phase probes with the current build ('make probe' first) -> gpurun_out/probe_*.txt
 R=$GRAFT_REPO_ROOT; cd $R; mkdir -p gpurun_out
-(timeout 300 python scripts/probes/halo_probe.py 2>&1 | tail -12) > gpurun_out/halo_probe.txt
-cat gpurun_out/halo_probe.txt
+for p in ws wgrad halo overlap; do
+  (timeout 300 python scripts/probes/${p}_probe.py 2>&1 | grep -v amdgpu.ids | tail -24) > gpurun_out/probe_$p.txt
+done
+tail -5 gpurun_out/probe_ws.txt

@@ -39,10 +39,14 @@ def run(tag, dbg, plane=True, reps=20):
     print(f"{tag:58s} dbg={dbg:3d}  {us:8.1f} us  {flops / us * 1e-6:7.1f} TFLOP/s-equivalent", flush=True)
 
 
+run("full kernel (first timing of the process: clocks still settling)", 0)
 run("full kernel", 0)
+run("no global stores / stats in the epilogue", 1)
 run("no epilogue", 2)
+run("no DMA (loaders only keep the barriers)", 4)
 run("no DMA, no epilogue", 6)
 run("no patch DMA, no epilogue", 130)
 run("no weight DMA, no epilogue", 258)
 run("patches of 8 planes only (cache-resident source), no epilogue", 514)
+run("no DMA, no epilogue, no barriers (MFMA + fragment reads)", 38)
 run("full kernel again", 0)
