@@ -289,10 +289,11 @@ __global__ __launch_bounds__(512, 2) void igemm_ws_kernel(WsParams p) {
             DPC_UNROLL
             for (int i = 0; i < 8; ++i) {
                 const bool ok = (vmask[i] & sel) == sel;
-                glds16_buf(rs_a, ok ? rowoff[i] + tapoff : DPC_BUF_OOB, 0u, st + (lw + 4 * i) * 1024, lane);
+                if (!WS_DBG(4 | 128)) glds16_buf(rs_a, ok ? rowoff[i] + tapoff : DPC_BUF_OOB, 0u, st + (lw + 4 * i) * 1024, lane);
             }
             DPC_UNROLL
-            for (int i = 0; i < 4; ++i) glds16_buf(rs_b, wrow[i], (unsigned)kd * 2u, st + BM * 128 + (lw + 4 * i) * 1024, lane);
+            for (int i = 0; i < 4; ++i)
+                if (!WS_DBG(4 | 256)) glds16_buf(rs_b, wrow[i], (unsigned)kd * 2u, st + BM * 128 + (lw + 4 * i) * 1024, lane);
         };
         // chunk counter -> (tile, kc) of the NEXT chunk to issue
         int it_tile = 0, it_kc = 0, it_hi = 0;
@@ -402,6 +403,10 @@ __global__ __launch_bounds__(512, 2) void igemm_ws_kernel(WsParams p) {
             }
         }
 
+        if (WS_DBG(2)) {  // probe: no epilogue at all (the accumulators stay live through one store)
+            if (acc[0][0][0] == 12345.f) *(float*)p.out = acc[1][3][5];
+            continue;
+        }
         // ---- epilogue: two passes of 32 rows through this wave's 8 KB of the free stage
         unsigned char* mine = lds + stage_last * STAGE + wv * WS_STG_WAVE;   // 34 KB of the 48 KB stage every wave has finished reading
         DPC_UNROLL
@@ -497,6 +502,11 @@ __global__ __launch_bounds__(512, 2) void igemm_ws_kernel(WsParams p) {
 //     is re-derived per chunk (a dozen VALU operations against 32 MFMAs).
 //   * epilogue: staged through the patch buffer of the tile's LAST group; the loaders refill that buffer only after the
 //     first barrier of the next tile, which the compute waves reach after their epilogue.
+// MEASURED DEAD END: the same scheme for the 3x3x3 convs of layer3 (four 8 x 8 planes of one output frame index per tile, one
+// 50-piece patch set per (channel group, temporal tap), conflict-free slot swizzle ((column >> 1) + 4 (row & 1)) found by
+// exhaustive search).  Leaving the A-operand DMA out of igemm_ws_kernel saves 123 of 424 us on that layer, but the variant
+// with 9x fewer A pieces ran 431 us against 438 us (4 415 vs 4 415 clips/s, same box): what the probe removes with the DMA is
+// also its LDS traffic and the data-dependent switching power, not just issue slots.  Not kept.
 template <bool HAS_ADD>
 __global__ __launch_bounds__(512, 2) void igemm_wsp_kernel(WsParams p) {
     typedef bf16_t TO;

@@ -11,17 +11,22 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(
 import kcases as kc  # noqa: E402
 from dpc_amd import _lib as L  # noqa: E402
 
+SHAPE = os.environ.get("WS_PROBE_SHAPE", "layer2")
 lib = L.Lib(os.path.join(os.path.dirname(os.path.abspath(__file__)), "libdpc_probe.so"), "hip")
 dev = torch.device("cuda:0")
 BF = torch.bfloat16
-N, T, H, W, Ci, Co = 1024, 5, 16, 16, 128, 128
-d = kc.conv_desc(BF, BF, 0, N, (T, H, W), (T, H, W), Ci, Ci, Co, 9 * Ci, Co, (1, 3, 3), (1, 1, 1), (0, 1, 1))
+if SHAPE == "layer3":   # igemm_ws_kernel: 3x3x3, 8x8 planes, 256 -> 256 (two column tiles, temporally grouped tiles)
+    N, T, H, W, Ci, Co, KS, PD = 1024, 3, 8, 8, 256, 256, (3, 3, 3), (1, 1, 1)
+else:                   # igemm_wsp_kernel: 1x3x3, 16x16 planes, 128 -> 128
+    N, T, H, W, Ci, Co, KS, PD = 1024, 5, 16, 16, 128, 128, (1, 3, 3), (0, 1, 1)
+TAPS = KS[0] * KS[1] * KS[2]
+d = kc.conv_desc(BF, BF, 0, N, (T, H, W), (T, H, W), Ci, Ci, Co, TAPS * Ci, Co, KS, (1, 1, 1), PD)
 src = torch.randn(N, T, H, W, Ci, device=dev).to(BF)
-wgt = (torch.randn(Co, 9 * Ci, device=dev) * 0.05).to(BF)
+wgt = (torch.randn(Co, TAPS * Ci, device=dev) * 0.05).to(BF)
 out = torch.empty(N, T, H, W, Co, device=dev, dtype=BF)
 rows = lib.call("dpc_conv_stats_rows", C.byref(d))
 stats = torch.zeros(rows, 2, Co, device=dev)
-flops = 2.0 * N * T * H * W * Co * 9 * Ci
+flops = 2.0 * N * T * H * W * Co * TAPS * Ci
 
 
 def run(tag, dbg, plane=True, reps=20):

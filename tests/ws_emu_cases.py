@@ -33,6 +33,10 @@ def main():
     kc.case_conv_fwd(k, BF16, 5, 64, 136, 1, 16, 16, (1, 3, 3), (1, 1, 1), (0, 1, 1))       # one group, odd tile count, ragged column tile
     kc.case_conv_dgrad(k, BF16, 2, 128, 256, 2, 16, 16, (1, 3, 3), (1, 1, 1), (0, 1, 1))    # four groups + residual addend
     kc.case_conv_dgrad_inplace(k, BF16, 1, 128, 128, 1, 16, 16, (1, 3, 3), (1, 1, 1), (0, 1, 1))  # a single tile
+    # 3x3x3 over 8 x 8 planes on the temporally grouped tiles of igemm_ws_kernel (layer3's shape)
+    kc.case_conv_fwd(k, BF16, 9, 64, 128, 3, 8, 8, (3, 3, 3), (1, 1, 1), (1, 1, 1))         # T = 3: border frames skip a tap; ragged last tile (9 clips)
+    kc.case_conv_fwd(k, BF16, 4, 128, 136, 2, 8, 8, (3, 3, 3), (1, 1, 1), (1, 1, 1))        # T = 2, two channel groups, ragged column tile
+    kc.case_conv_dgrad(k, BF16, 5, 128, 128, 3, 8, 8, (3, 3, 3), (1, 1, 1), (1, 1, 1))      # flipped taps + residual addend
     # role-specialised patch kernel (conv_halo_ws_kernel): DPC_HALO_WS_GM = 3 workgroups walk 24 / 8 tiles each
     kc.case_conv_fwd(k, BF16, 2, 64, 64, 2, 9, 33, (1, 3, 3), (1, 1, 1), (0, 1, 1))
     kc.case_conv_fwd(k, BF16, 1, 64, 40, 1, 20, 12, (1, 3, 3), (1, 1, 1), (0, 1, 1))
