@@ -35,10 +35,12 @@ struct WsParams {
     int Ncol, ldw, ldo;
     int gm, ntn, ntm;
     unsigned src_bytes, wgt_bytes;
-    // temporal grouping (3x3x3 stride-1 convs): a tile holds planes of ONE output frame index t, taken from
-    // consecutive clips, so the temporal taps that fall into the zero padding are the same for the whole tile
-    // and are skipped as a K sub-range (22 % of the chunks at T = 3, 33 % at T = 2).
-    int tgroup, lHW, ppt, tpt, cpkt;  // on/off, log2(RH*RW), planes per tile, tiles per t, chunks per temporal tap
+    // temporal grouping (3x3x3 stride-1 convs): a tile holds 256 consecutive pixels of ONE output frame index t, taken
+    // from consecutive clips (whole planes when the plane size divides 256, else a tile straddles clips -- 14 x 14 and
+    // 7 x 7 planes of the 224-pixel configurations), so the temporal taps that fall into the zero padding are the same
+    // for the whole tile and are skipped as a K sub-range (22 % of the chunks at T = 3, 33 % at T = 2).
+    int tgroup, hw, nclip, tpt, cpkt;  // on/off, RH*RW, clips, tiles per t, chunks per temporal tap
+    FastDiv d_hw;
     int plane;                        // 1: served by igemm_wsp_kernel (a tile is one 16 x 16 plane, staged as a patch)
     int dbg;                          // DPC_WS_PROBE builds only (scripts/probes/ws_probe.py): phases to leave out, for timing
 };
@@ -205,8 +207,9 @@ __global__ __launch_bounds__(512, 2) void igemm_ws_kernel(WsParams p) {
     auto tile_row = [&](int mt, int r) -> int {
         if (!p.tgroup) return mt * BM + r;
         const int t = mt / p.tpt;
-        const int clip = (mt - t * p.tpt) * p.ppt + (r >> p.lHW);
-        return clip < g.M / (g.RT << p.lHW) ? (((clip * g.RT + t) << p.lHW) + (r & ((1 << p.lHW) - 1))) : g.M;
+        const unsigned idx = (unsigned)((mt - t * p.tpt) * BM + r);   // pixel of frame t, counted across the clips
+        const unsigned clip = fdiv(idx, p.d_hw);
+        return (int)clip < p.nclip ? (int)((clip * (unsigned)g.RT + (unsigned)t) * (unsigned)p.hw + (idx - clip * (unsigned)p.hw)) : g.M;
     };
     // K chunks [lo, hi) of a tile: all of them, or those of the temporal taps that hit real frames
     auto tile_chunks = [&](int mt, int& lo, int& hi) {
@@ -804,7 +807,7 @@ static bool ws_plan(const dpc_conv_desc* d, WsParams* p) {
     p->wgt_bytes = (unsigned)wbytes;
     p->ntn = (d->Co + 127) / 128;
     p->ntm = (g.M + 255) / 256;
-    p->tgroup = 0; p->lHW = 0; p->ppt = 1; p->tpt = 1; p->cpkt = 1;
+    p->tgroup = 0; p->hw = 1; p->nclip = 0; p->tpt = 1; p->cpkt = 1; p->d_hw = make_fastdiv(1);
     {
         static const int plane_on = env_int("DPC_IGEMM_WS_PLANE", 1);
         p->plane = plane_on && g.KT == 1 && g.KH == 3 && g.KW == 3 && g.pt == 0 && g.ph == 1 && g.pw == 1 && unit_strides && g.RT == g.ST &&
@@ -812,11 +815,11 @@ static bool ws_plan(const dpc_conv_desc* d, WsParams* p) {
     }
     {
         static const int tg_on = env_int("DPC_IGEMM_WS_TGROUP", 1);
-        const int hw = g.RH * g.RW, lhw = ilog2_exact(hw);
-        if (tg_on && g.KT > 1 && unit_strides && g.RT == g.ST && g.RT > 1 && lhw >= 0 && hw <= 256) {
-            p->tgroup = 1; p->lHW = lhw; p->ppt = 256 / hw;
-            const int nclip = g.M / (g.RT * hw);
-            p->tpt = (nclip + p->ppt - 1) / p->ppt;
+        const int hw = g.RH * g.RW;
+        if (tg_on && g.KT > 1 && unit_strides && g.RT == g.ST && g.RT > 1) {
+            p->tgroup = 1; p->hw = hw; p->d_hw = make_fastdiv((uint32_t)hw);
+            p->nclip = g.M / (g.RT * hw);
+            p->tpt = (int)(((long long)p->nclip * hw + 255) / 256);
             p->cpkt = g.KH * g.KW * (g.Ci / 64);
             p->ntm = g.RT * p->tpt;
         }

@@ -30,7 +30,9 @@ def k():
     (90, 256, 264, 3, 8, 8, (3, 3, 3), (1, 1, 1), (1, 1, 1)),    # same, 3x3x3, three column tiles (last ragged), ragged last row tile
     (150, 128, 128, 4, 16, 16, (1, 3, 3), (1, 1, 1), (0, 1, 1)), # plane variant (16 x 16 planes as patches): 600 tiles, 2-3 per workgroup
     (33, 64, 264, 2, 16, 16, (1, 3, 3), (1, 1, 1), (0, 1, 1)),   # plane variant: one channel group, three column tiles (last ragged)
-    (530, 128, 128, 3, 8, 8, (3, 3, 3), (1, 1, 1), (1, 1, 1)),   # 3x3x3 over 8 x 8 planes (layer3): temporally grouped tiles, 399 of them, ragged last clip group
+    (530, 128, 128, 3, 8, 8, (3, 3, 3), (1, 1, 1), (1, 1, 1)),
+    (110, 256, 256, 3, 14, 14, (3, 3, 3), (1, 1, 1), (1, 1, 1)), # layer3 of the 224-pixel family: 196-pixel planes, grouped tiles straddle clips
+    (300, 256, 256, 2, 7, 7, (3, 3, 3), (1, 1, 1), (1, 1, 1)),   # layer4 of the 224-pixel family: 49-pixel planes, T = 2   # 3x3x3 over 8 x 8 planes (layer3): temporally grouped tiles, 399 of them, ragged last clip group
 ])
 def test_conv_fwd(k, dtype, shape):
     kc.case_conv_fwd(k, dtype, *shape)
@@ -50,6 +52,7 @@ def test_conv_fwd(k, dtype, shape):
     (150, 128, 128, 4, 16, 16, (1, 3, 3), (1, 1, 1), (0, 1, 1)), # plane variant, flipped taps + residual addend, 600 tiles
     (40, 128, 256, 2, 16, 16, (1, 3, 3), (1, 1, 1), (0, 1, 1)),  # plane variant, four channel groups
     (300, 256, 256, 2, 8, 8, (3, 3, 3), (1, 1, 1), (1, 1, 1)),   # same family, T = 2, flipped taps + residual addend
+    (110, 256, 256, 3, 14, 14, (3, 3, 3), (1, 1, 1), (1, 1, 1)), # 224-pixel family, flipped taps + residual addend
 ])
 def test_conv_dgrad(k, dtype, shape):
     kc.case_conv_dgrad(k, dtype, *shape)

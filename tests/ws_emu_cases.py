@@ -33,6 +33,10 @@ def main():
     kc.case_conv_fwd(k, BF16, 5, 64, 136, 1, 16, 16, (1, 3, 3), (1, 1, 1), (0, 1, 1))       # one group, odd tile count, ragged column tile
     kc.case_conv_dgrad(k, BF16, 2, 128, 256, 2, 16, 16, (1, 3, 3), (1, 1, 1), (0, 1, 1))    # four groups + residual addend
     kc.case_conv_dgrad_inplace(k, BF16, 1, 128, 128, 1, 16, 16, (1, 3, 3), (1, 1, 1), (0, 1, 1))  # a single tile
+    # temporally grouped tiles whose 256 rows straddle clips (plane sizes that do not divide 256: the 224-pixel family)
+    kc.case_conv_fwd(k, BF16, 7, 64, 128, 3, 7, 7, (3, 3, 3), (1, 1, 1), (1, 1, 1))         # 49-pixel planes, T = 3
+    kc.case_conv_fwd(k, BF16, 3, 64, 128, 2, 14, 14, (3, 3, 3), (1, 1, 1), (1, 1, 1))       # 196-pixel planes, T = 2
+    kc.case_conv_dgrad(k, BF16, 4, 128, 64, 3, 7, 7, (3, 3, 3), (1, 1, 1), (1, 1, 1))       # flipped taps + residual addend
     # 3x3x3 over 8 x 8 planes on the temporally grouped tiles of igemm_ws_kernel (layer3's shape)
     kc.case_conv_fwd(k, BF16, 9, 64, 128, 3, 8, 8, (3, 3, 3), (1, 1, 1), (1, 1, 1))         # T = 3: border frames skip a tap; ragged last tile (9 clips)
     kc.case_conv_fwd(k, BF16, 4, 128, 136, 2, 8, 8, (3, 3, 3), (1, 1, 1), (1, 1, 1))        # T = 2, two channel groups, ragged column tile
