@@ -268,6 +268,48 @@ __global__ __launch_bounds__(256, (BN == 64 ? 3 : 2)) void igemm_kernel(IGemmPar
             for (int i = 0; i < BROWS; ++i) *(u32x4*)(base + BM * 128 + 4096 * i) = rb[i];
         };
         auto mma_chunk = [&](int bufoff) {
+#ifndef DPC_SIMT_EMU
+            if constexpr (sizeof(T) == 2 && sizeof(TO) == 2 && NT == 2) {   // measured: -8 % on the 128-wide tile, +2 % on the 64-wide one (three
+                                                                          // workgroups per CU); the f32-output variants are register-bound: both left to hipcc
+                // bf16: the chunk's MFMAs with hand-pipelined fragment reads (scheme of conv_wgrad_patch.hip / conv_wgrad.hip:
+                // operand loads in program order per K step -- A0 B0 [B1] A1 --, LOOKAHEAD operands beyond the one an MFMA first
+                // needs are in flight, counted lgkmcnt, a scheduling barrier after every instruction).  hipcc's own order is
+                // "all reads of a K step, wait, its MFMAs": an LDS round trip per 2 NT x 32 cycles of matrix work.
+                constexpr int LOOKAHEAD = 4, NOP = 2 + NT, NLOAD = 4 * NOP, NMMA = 8 * NT;
+                const uint32_t l0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)lds + (uint32_t)bufoff;
+                u32x4 fa[2][2], fb[2][NT];   // [K-step parity][fragment]
+                auto load = [&](auto Ic) {
+                    constexpr int I = decltype(Ic)::value;
+                    constexpr int kk = I / NOP, r = I % NOP;
+                    if constexpr (r == 0 || r == NOP - 1) {       // A0 first, A1 last
+                        constexpr int i = r == 0 ? 0 : 1;
+                        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fa[kk & 1][i]) : "v"(l0 + (uint32_t)frag_a[kk]), "n"(4096 * i) : "memory");
+                    } else {
+                        constexpr int j = r - 1;
+                        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fb[kk & 1][j]) : "v"(l0 + (uint32_t)frag_b[kk]), "n"(4096 * j) : "memory");
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                };
+                __builtin_amdgcn_sched_barrier(0);
+                static_for<NMMA>([&](auto Mc) {
+                    constexpr int m = decltype(Mc)::value;
+                    constexpr int kk = m / (2 * NT), q = m % (2 * NT), i = q / NT, j = q % NT;
+                    // operand this MFMA is the first to need: (0,0) -> B0; (0,j>0) -> Bj; (1,0) -> A1; (1,j>0) -> nothing new
+                    constexpr int need = NOP * kk + (i == 0 ? 1 + j : NOP - 1);
+                    constexpr int mp = m == 0 ? 0 : m - 1;
+                    constexpr int kkp = mp / (2 * NT), qp = mp % (2 * NT), ip = qp / NT, jp = qp % NT;
+                    constexpr int need_prev = m == 0 ? -1 : NOP * kkp + (ip == 0 ? 1 + jp : NOP - 1);
+                    constexpr int f_prev = m == 0 ? 0 : (need_prev + 1 + LOOKAHEAD < NLOAD ? need_prev + 1 + LOOKAHEAD : NLOAD);
+                    constexpr int f_now = need + 1 + LOOKAHEAD < NLOAD ? need + 1 + LOOKAHEAD : NLOAD;
+                    static_for<(f_now > f_prev ? f_now - f_prev : 0)>([&](auto Dc) { load(std::integral_constant<int, f_prev + decltype(Dc)::value>{}); });
+                    asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(f_now - need - 1) : "memory");
+                    __builtin_amdgcn_sched_barrier(0);
+                    acc[i][j] = mfma_unit<T>(fa[kk & 1][i], fb[kk & 1][j], acc[i][j]);
+                    __builtin_amdgcn_sched_barrier(0);
+                });
+                return;
+            }
+#endif
             DPC_UNROLL
             for (int kk = 0; kk < 4; ++kk) {
                 u32x4 fa[2], fb[NT];
