@@ -196,7 +196,7 @@ def main():
             "final_loss": round(loss[0], 4),
         }
         if timer is not None:
-            s = timer.summary()
+            s = timer.summary(rs)
             ig = s.get("dpc_conv_igemm")
             peak = MFMA_PEAK_BF16 if args.dtype == "bf16" else MFMA_PEAK_F32
             traffic = None
@@ -220,7 +220,7 @@ def main():
                     "flops_unit": "GFLOP (algorithmic)",
                     "ms_per_step": round(ig["ms"] / rs, 3),
                     "algorithmic_GBps": round(ig["bytes"] / (ig["ms"] * 1e-3) / 1e9, 1),
-                    "timed": f"separate instrumented pass of {rs} steps (HIP events on the launch stream)",
+                    "timed": f"separate instrumented pass of {rs} steps (HIP events on the launch stream; per launch position the median over the steps)",
                 }
             wg = s.get("dpc_conv_wgrad")
             if wg and wg["ms"] > 0:
