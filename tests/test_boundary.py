@@ -49,3 +49,27 @@ def test_module_mirrors_reference_boundary():
         m(torch.zeros(1, 8, 3, 5, 128, 128))  # CPU tensors: no fallback
     m34 = DPC_RNN(224, network="resnet34")
     assert sum(p.numel() for p in m34.parameters()) == 32947776
+
+
+def test_kernel_timer_charges_the_median_per_launch_position(monkeypatch):
+    """bench.py's roofline pass: an event pair also contains host time between the first event and the launch; with several
+    identical steps recorded, every launch position is charged the median of its samples (engine.KernelTimer.summary)."""
+    from dpc_amd import engine as E
+
+    class Ev:
+        def __init__(self, t):
+            self.t = t
+
+        def elapsed_time(self, other):
+            return other.t - self.t
+
+    monkeypatch.setattr(torch.cuda, "synchronize", lambda *a, **k: None)
+    tm = E.KernelTimer(["a", "b"])
+    for x, y in ((1.0, 2.0), (1.1, 2.1), (30.0, 2.0), (0.9, 1.9)):   # four steps; one hiccup on "a"
+        tm.records.append(("a", None, Ev(0.0), Ev(x), 1.0, 8.0))
+        tm.records.append(("b", "score", Ev(0.0), Ev(y), 2.0, 4.0))
+    s = tm.summary(4)
+    assert s["a"]["launches"] == 4 and abs(s["a"]["ms"] - 4 * 1.05) < 1e-9 and s["a"]["bytes"] == 32.0
+    assert abs(s["b"]["ms"] - 4 * 2.0) < 1e-9 and abs(s["tag:score"]["ms"] - 8.0) < 1e-9
+    assert abs(tm.summary(1)["a"]["ms"] - 33.0) < 1e-9          # plain totals when the steps are not declared
+    assert abs(tm.summary(3)["a"]["ms"] - 33.0) < 1e-9          # ... or do not divide the record count
