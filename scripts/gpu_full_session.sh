@@ -1,5 +1,5 @@
 #!/bin/bash
-# round-2 GPU session K: full gpu tier, smoke, bench lines (cfg2/cfg4/cfg5, f32, torchrun), CLI smokes, profiles, PMC traffic
+# round-2 GPU full session: full gpu tier, smoke, bench lines (cfg2/cfg4/cfg5, f32, torchrun), CLI smokes, profiles, PMC traffic
 R=$GRAFT_REPO_ROOT; cd $R; mkdir -p gpurun_out
 (timeout 1700 python -m pytest tests -m gpu -q -rP -p no:cacheprovider 2>&1) > gpurun_out/k_test_full.log
 grep -E "passed|failed|error|bf16 anchor:|cfg5 fused|LC gradients|resnet|Error|assert " gpurun_out/k_test_full.log | tail -60 > gpurun_out/k_test.log

@@ -1,4 +1,4 @@
-"""HBM traffic of the dominant kernel family from the rocprofv3 PMC passes of scripts/gpu_pmc.sh
+"""HBM traffic of the dominant kernel family from the rocprofv3 PMC passes of scripts/gpu_pmc_traffic.sh
 (FETCH_SIZE and WRITE_SIZE collected in separate --pmc runs, KiB units).  Correction per
 /opt/skills/guides/MI355X_MICROARCH.md §HBM: on gfx950 FETCH_SIZE reports exactly 1/2 of the bytes of
 wide (16 B/lane) coalesced streaming reads -- every load of these kernels is such a load -- so the read
