@@ -20,11 +20,23 @@ static inline unsigned grid_for(long long n, int block = 256, int cap = 8192) {
 __device__ __forceinline__ void partial_rows_sum(const float* partials, int rows, int C, int c, int rl, double& s1, double& s2,
                                                  double (*red)[32][32]) {
     s1 = 0.0; s2 = 0.0;
-    if (c < C)
-        for (int r = rl; r < rows; r += 32) {
+    if (c < C) {
+        // four rows per trip, loaded before any is added: the loop is a chain of L2 round trips otherwise (1024 partial rows of
+        // the backward reduction: 10.8 us per call, 20 calls per step).  The summation order stays fixed: ((r, r+32), (r+64, r+96)).
+        int r = rl;
+        for (; r + 96 < rows; r += 128) {
+            const float a0 = partials[((long long)r * 2 + 0) * C + c], b0 = partials[((long long)r * 2 + 1) * C + c];
+            const float a1 = partials[((long long)(r + 32) * 2 + 0) * C + c], b1 = partials[((long long)(r + 32) * 2 + 1) * C + c];
+            const float a2 = partials[((long long)(r + 64) * 2 + 0) * C + c], b2 = partials[((long long)(r + 64) * 2 + 1) * C + c];
+            const float a3 = partials[((long long)(r + 96) * 2 + 0) * C + c], b3 = partials[((long long)(r + 96) * 2 + 1) * C + c];
+            s1 += ((double)a0 + (double)a1) + ((double)a2 + (double)a3);
+            s2 += ((double)b0 + (double)b1) + ((double)b2 + (double)b3);
+        }
+        for (; r < rows; r += 32) {
             s1 += (double)partials[((long long)r * 2 + 0) * C + c];
             s2 += (double)partials[((long long)r * 2 + 1) * C + c];
         }
+    }
     red[0][rl][c & 31] = s1;
     red[1][rl][c & 31] = s2;
     __syncthreads();
