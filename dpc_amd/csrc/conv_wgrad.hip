@@ -254,7 +254,9 @@ struct Wgrad2Params {
     int Co, dy_ld;
     int nks, kcps;
     int ntm, ntn;
-    int lRW, lRH;  // log2
+    int lRW, lRH;  // log2 of the (padded) image width / height the chunk rows are decomposed with
+    int RWm, RHm;  // padded width / height - 1
+    int Mv;        // rows of the padded position grid (== g.M when RW, RH are powers of two)
     int xcd_remap;
 };
 
@@ -295,7 +297,10 @@ __global__ __launch_bounds__(64 * NWM * NWN, 2) void wgrad2_kernel(Wgrad2Params 
     const int tile_m = id % p.ntm;
     const int ks = id / p.ntm;
 
-    const int nchunks_total = (g.M + BKP - 1) / BKP;
+    // Images whose width / height are not powers of two (the 224-pixel family: 28, 14, 7) are walked on a grid padded to the next
+    // power of two: a chunk row decomposes as (row & RWm, row >> lRW) as before, rows that fall into the padding are out-of-image
+    // lanes (zeros: they add nothing), and the REAL row pitch is used for every address.  12-23 % of the rows are padding there.
+    const int nchunks_total = (p.Mv + BKP - 1) / BKP;
     const int c_begin = ks * p.kcps;
     const int c_end = (c_begin + p.kcps < nchunks_total) ? c_begin + p.kcps : nchunks_total;
 
@@ -303,14 +308,18 @@ __global__ __launch_bounds__(64 * NWM * NWN, 2) void wgrad2_kernel(Wgrad2Params 
     const int rowlane = lane / SPR, pslot = lane % SPR;
     const int lslot = (ESZ == 2) ? (pslot ^ (2 * (rowlane & 3))) : pslot;
     const int cch = lslot * E;  // channel inside the 64-channel sub-tile
-    int r_row[RR], r_w[RR], r_h[RR], r_q[RR];
+    int r_row[RR], r_w[RR], r_h[RR], r_q[RR], r_dh[RR], r_real[RR];
+    bool r_wok[RR];
     DPC_UNROLL
     for (int rr = 0; rr < RR; ++rr) {
         const int r = (wv + rr * NW) * RPI + rowlane;
         r_row[rr] = r;
-        r_w[rr] = (r & (g.RW - 1)) * g.sw - g.pw;
-        r_h[rr] = ((r >> p.lRW) & (g.RH - 1)) * g.sh - g.ph;
+        r_w[rr] = (r & p.RWm) * g.sw - g.pw;
+        r_h[rr] = ((r >> p.lRW) & p.RHm) * g.sh - g.ph;
         r_q[rr] = r >> (p.lRW + p.lRH);
+        r_dh[rr] = r >> p.lRW;                               // image rows below the chunk's first one
+        r_wok[rr] = (r & p.RWm) < g.RW;                      // not a padding column
+        r_real[rr] = r_dh[rr] * g.RW + (r & p.RWm);          // row offset in the real tensor (== r without padding)
     }
     // Thread-constant parts of every DMA source address.  In a chunk that stays inside one (n, t) plane
     // (PU) the position of row r is (n, t, h0 + r/RW, r%RW) with only (n, t, h0) -- block-uniform --
@@ -323,7 +332,7 @@ __global__ __launch_bounds__(64 * NWM * NWN, 2) void wgrad2_kernel(Wgrad2Params 
         const int co = tile_m * TM + sa * 64 + cch;
         const bool ok = co + E <= p.dy_ld && co < p.Co;
         DPC_UNROLL
-        for (int rr = 0; rr < RR; ++rr) a_off[rr][sa] = ok ? (r_row[rr] * p.dy_ld + co) * ESZ : -1;
+        for (int rr = 0; rr < RR; ++rr) a_off[rr][sa] = ok && r_wok[rr] ? (r_real[rr] * p.dy_ld + co) * ESZ : -1;
     }
     TapPos tp[NWN];
     int b_off[RR][NWN], b_h[RR][NWN];
@@ -352,9 +361,12 @@ __global__ __launch_bounds__(64 * NWM * NWN, 2) void wgrad2_kernel(Wgrad2Params 
     auto issue = [&](int chunk, int buf) {
         const int m0 = chunk * BKP;  // block-uniform
         unsigned char* stage = lds + buf * STAGE;
-        const char* abase = (const char*)p.dy + (long long)m0 * p.dy_ld * ESZ;
         const unsigned q0 = (unsigned)m0 >> (p.lRW + p.lRH);
-        const int h0 = PU ? (int)(((unsigned)m0 >> p.lRW) & (unsigned)(g.RH - 1)) * g.sh : 0;
+        const int h0v = PU ? (int)(((unsigned)m0 >> p.lRW) & (unsigned)p.RHm) : 0;   // first image row of the chunk
+        const int h0 = h0v * g.sh;
+        // first real row of the chunk: (plane q0, image row h0v) on the real pitch; without padding this is m0 itself
+        const long long m0r = PU ? ((long long)q0 * g.RH + h0v) * g.RW : (long long)m0;
+        const char* abase = (const char*)p.dy + m0r * p.dy_ld * ESZ;
         const char* bbase = (const char*)p.src;
         bool tv[NWN];
         if (PU) {
@@ -368,7 +380,7 @@ __global__ __launch_bounds__(64 * NWM * NWN, 2) void wgrad2_kernel(Wgrad2Params 
         for (int rr = 0; rr < RR; ++rr) {
             const int rg = wv + rr * NW;
             if (rg < 8) {
-                const bool mok = m0 + r_row[rr] < g.M;
+                const bool mok = m0 + r_row[rr] < p.Mv && r_wok[rr] && (!PU || h0v + r_dh[rr] < g.RH);
                 DPC_UNROLL
                 for (int sa = 0; sa < NWM; ++sa)
                     glds16((mok & (a_off[rr][sa] >= 0)) ? abase + a_off[rr][sa] : zero, stage + sa * SUB + rg * 1024, lane);
@@ -574,11 +586,19 @@ extern "C" int dpc_conv_wgrad(const dpc_conv_desc* d, const void* src, const voi
     rc = dpc_wgrad_stem_try(d, src, dy, dy_ld, part, nsplit, stream);   // space-to-depth stem: same idea, 4x4 taps of 32-byte positions
     if (rc != 1) return rc;
     const int bkp = 8 * per16;
-    const int nchunks = (p.g.M + bkp - 1) / bkp;
-    const int lrw = ilog2_exact(d->RW), lrh = ilog2_exact(d->RH);
-    // wgrad2 decomposes a chunk row index as (row % RW, row / RW): needs power-of-two RW, RH and chunks that start
-    // at a row boundary (RW divides the chunk length)
-    const bool v2 = lrw >= 0 && lrh >= 0 && bkp % d->RW == 0 && !wgrad_use_v1();
+    // wgrad2 decomposes a chunk row index as (row % RWp, row / RWp) with RWp, RHp = width / height rounded up to powers of two
+    // (padding rows are masked lanes): the chunk must start at a row boundary (RWp divides the chunk length); with padding it
+    // must also stay inside one (n, t) plane and at least 60 % of the padded grid must be real (else the generic kernel).
+    int rwp = 1, rhp = 1;
+    while (rwp < d->RW) rwp <<= 1;
+    while (rhp < d->RH) rhp <<= 1;
+    const bool padded = rwp != d->RW || rhp != d->RH;
+    const long long mv = (long long)d->N * d->RT * rhp * rwp;
+    static const int pad_on = getenv("DPC_WGRAD2_PAD") ? atoi(getenv("DPC_WGRAD2_PAD")) : 1;
+    const bool v2 = bkp % rwp == 0 && !wgrad_use_v1() && mv < (1ll << 31) &&
+                    (!padded || (pad_on && (rwp * rhp) % bkp == 0 && (long long)d->RW * d->RH * 10 >= (long long)rwp * rhp * 6));
+    const int lrw = ilog2_exact(rwp), lrh = ilog2_exact(rhp);
+    const int nchunks = (int)(((v2 ? mv : (long long)p.g.M) + bkp - 1) / bkp);
     int tm, tn, nwm = 0, nwn = 0;
     if (v2) {
         // 64 x 64 per wave; the block is NWM x NWN waves.  NWN = 3 fits every 3x3 / 3x3x3 reduction
@@ -613,8 +633,9 @@ extern "C" int dpc_conv_wgrad(const dpc_conv_desc* d, const void* src, const voi
         Wgrad2Params q;
         q.g = p.g; q.src = src; q.dy = dy; q.part = part; q.Co = d->Co; q.dy_ld = dy_ld;
         q.nks = p.nks; q.kcps = p.kcps; q.ntm = p.ntm; q.ntn = p.ntn; q.lRW = lrw; q.lRH = lrh;
+        q.RWm = rwp - 1; q.RHm = rhp - 1; q.Mv = (int)mv;
         { const char* e = getenv("DPC_WGRAD_XCD"); q.xcd_remap = (e && e[0] == '0') ? 0 : 1; }
-        const bool pu = (d->RW * d->RH) % bkp == 0;  // a chunk never leaves its (n, t) plane
+        const bool pu = (rwp * rhp) % bkp == 0;  // a chunk never leaves its (n, t) plane
         if (d->dtype_in == DPC_F32) return launch_wgrad2<float>(q, nwm, nwn, pu, stream);
         return launch_wgrad2<bf16_t>(q, nwm, nwn, pu, stream);
     }

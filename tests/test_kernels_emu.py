@@ -72,6 +72,9 @@ def test_conv_dgrad(k, dtype, shape):
     (1, 16, 72, 1, 1, 128, (1, 1, 1), (1, 1, 1), (0, 0, 0)),    # rows longer than a bf16 chunk too
     (1, 64, 128, 2, 14, 14, (3, 3, 3), (1, 1, 1), (1, 1, 1)),   # 14x14 -> width 16, ragged last chunk of a plane
     (1, 64, 64, 1, 5, 56, (1, 3, 3), (1, 1, 1), (0, 1, 1)),     # width 56 -> 64: one image row per chunk
+    (2, 64, 128, 1, 28, 27, (1, 3, 3), (1, 2, 2), (0, 1, 1)),   # strided, 14 x 14 output: transpose-read kernel on a grid padded to 16 x 16
+    (2, 64, 64, 3, 14, 14, (3, 3, 3), (2, 2, 2), (1, 1, 1)),    # 3x3x3 stride 2, 7 x 7 output padded to 8 x 8 (one plane per chunk)
+    (3, 64, 128, 2, 14, 14, (1, 1, 1), (1, 2, 2), (0, 0, 0)),   # strided 1x1 (downsample), 7 x 7 output padded to 8 x 8
 ])
 def test_conv_wgrad(k, dtype, shape):
     kc.case_conv_wgrad(k, dtype, *shape)

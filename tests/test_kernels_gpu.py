@@ -70,6 +70,10 @@ def test_conv_dgrad(k, dtype, shape):
     (6, 128, 128, 2, 28, 28, (1, 3, 3), (1, 1, 1), (0, 1, 1)),
     (8, 256, 256, 3, 14, 14, (3, 3, 3), (1, 1, 1), (1, 1, 1)),
     (16, 256, 256, 2, 7, 7, (3, 3, 3), (1, 1, 1), (1, 1, 1)),
+    (6, 64, 128, 2, 56, 56, (1, 3, 3), (1, 2, 2), (0, 1, 1)),    # 224-pixel family, strided: transpose-read kernel on padded grids (28 -> 32)
+    (8, 128, 256, 5, 28, 28, (3, 3, 3), (2, 2, 2), (1, 1, 1)),   # 14 x 14 output padded to 16 x 16
+    (16, 256, 256, 3, 14, 14, (3, 3, 3), (2, 2, 2), (1, 1, 1)),  # 7 x 7 output padded to 8 x 8: one plane per chunk
+    (8, 128, 256, 5, 28, 28, (1, 1, 1), (2, 2, 2), (0, 0, 0)),   # strided 1x1 downsample
 ])
 def test_conv_wgrad(k, dtype, shape):
     kc.case_conv_wgrad(k, dtype, *shape)
