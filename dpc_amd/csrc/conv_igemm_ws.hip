@@ -12,7 +12,9 @@
 //     24 ds_read_b128 + 32 MFMA per 128-byte K chunk, nothing else in the loop;
 //   * waves 4..7 (one per SIMD) only load: 12 LDS-DMA pieces per chunk each, three chunks in flight
 //     in a ring of three 48 KB stages, counted s_waitcnt vmcnt(12) (never 0) before the one barrier
-//     per chunk that publishes the oldest stage.  Their issue stalls cost the matrix cores nothing,
+//     per chunk that publishes the oldest stage.  Their issue stalls no longer hold MFMA issue (the DMA is
+//     not free for all that: round-2 probes, profiles/r02_phase_probes.txt, still see 12-28 % of a launch go
+//     when it is left out -- LDS write traffic and power, see the note at igemm_wsp_kernel),
 //     and they run ahead across tile boundaries: the next tile's first two chunks land while the
 //     compute waves are in the epilogue, so there is no prologue after the first tile.
 //   * 256-row tiles halve the weight bytes per MFMA: 48 KB per 32 MFMA-per-SIMD = 47 B/clk/CU of
