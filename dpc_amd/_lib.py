@@ -95,6 +95,7 @@ _SIGS = {
     "dpc_ce_topk": [_vp, _i32, _i32, _i32, _vp, _vp, _vp, _i32, _i32, _vp],
     "dpc_step_advance": [_vp, _vp, _f64, _f64, _vp],
     "dpc_adam_dev": [_vp, _vp, _vp, _vp, _i64, _f32, _f64, _f64, _f32, _f32, _vp, _f32, _vp],
+    "dpc_counter_advance": [_vp, _vp],
     "dpc_copy2d_f32": [_vp, _i64, _vp, _i64, _i32, _i32, _vp],
     "dpc_dropout_mask": [_vp, _i64, _f32, C.c_uint64, _vp, _vp],
     "dpc_gru_pack": [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp],

@@ -79,28 +79,32 @@ def load_optimizer_state(eng, opt_sd: dict, use_saved_lr: bool = True) -> None:
     if len(ids) != len(names):
         raise ValueError(f"loaded state dict contains {len(ids)} parameters, the model has {len(names)} "
                          "(torch.optim.Optimizer.load_state_dict raises the same way)")
-    steps = set()
-    eng.flat_m.zero_()
-    eng.flat_v.zero_()
-    for pos, i in enumerate(ids):
-        st = opt_sd["state"].get(i)
-        if st is None:
-            continue
-        k = names[pos]
-        o, n = eng.offsets[k]
-        if tuple(st["exp_avg"].shape) != tuple(eng.shapes[k]):
-            raise ValueError(f"optimizer state {i} has shape {tuple(st['exp_avg'].shape)}, parameter {k} is {eng.shapes[k]}")
-        eng.flat_m[o:o + n].copy_(st["exp_avg"].reshape(-1).to(torch.float32))
-        eng.flat_v[o:o + n].copy_(st["exp_avg_sq"].reshape(-1).to(torch.float32))
-        steps.add(int(float(st["step"])))
-    if len(steps) > 1:
-        raise ValueError(f"per-parameter Adam step counts differ ({sorted(steps)}): the fused optimizer keeps one")
-    eng.step_count = steps.pop() if steps else 0
     g0 = groups[0]
     if g0.get("amsgrad") or g0.get("maximize"):
         raise ValueError("amsgrad / maximize checkpoints are not supported (the reference uses neither, dpc/main.py:80-81)")
     if tuple(g0.get("betas", (0.9, 0.999))) != (0.9, 0.999) or float(g0.get("eps", 1e-8)) != 1e-8:
         raise ValueError("non-default Adam betas / eps in the checkpoint (the reference uses the defaults)")
+    # validate everything BEFORE touching the arenas: a rejected file must leave the engine's Adam state as it was
+    steps, todo = set(), []
+    for pos, i in enumerate(ids):
+        st = opt_sd["state"].get(i)
+        if st is None:
+            continue
+        k = names[pos]
+        for field in ("exp_avg", "exp_avg_sq"):
+            if tuple(st[field].shape) != tuple(eng.shapes[k]):
+                raise ValueError(f"optimizer state {i} ({field}) has shape {tuple(st[field].shape)}, parameter {k} is {eng.shapes[k]}")
+        steps.add(int(float(st["step"])))
+        todo.append((k, st))
+    if len(steps) > 1:
+        raise ValueError(f"per-parameter Adam step counts differ ({sorted(steps)}): the fused optimizer keeps one")
+    eng.flat_m.zero_()
+    eng.flat_v.zero_()
+    for k, st in todo:
+        o, n = eng.offsets[k]
+        eng.flat_m[o:o + n].copy_(st["exp_avg"].reshape(-1).to(torch.float32))
+        eng.flat_v[o:o + n].copy_(st["exp_avg_sq"].reshape(-1).to(torch.float32))
+    eng.step_count = steps.pop() if steps else 0
     if use_saved_lr:  # optimizer.load_state_dict restores the group's hyper-parameters (dpc/main.py:97-98)
         eng.lr = float(g0["lr"])
         eng.wd = float(g0.get("weight_decay", eng.wd))
@@ -111,21 +115,23 @@ def load_model_state(eng, state_dict: "Dict[str, torch.Tensor]", strict: bool = 
     unexpected keys or a shape mismatch.  strict=False: neq_load_customized (backbone/resnet_2d3d.py:310-333) --
     keys present on both sides are loaded, the rest is reported.  Returns (missing, unexpected)."""
     sd = {_strip(k): v for k, v in state_dict.items()}
-    mine = set(eng.PRM.keys())
+    bufs = getattr(eng, "BUF", {})  # BatchNorm running buffers of the LC classifier's engine (empty for DPC-RNN)
+    mine = set(eng.PRM.keys()) | set(bufs.keys())
     aliases = {k.replace(ALIAS_FROM, ALIAS_TO) for k in mine if k.startswith(ALIAS_FROM)}
     unexpected = [k for k in sd if k not in mine and k not in aliases]
-    missing = [k for k in list(eng.PRM.keys()) + sorted(aliases) if k not in sd]
+    missing = [k for k in list(eng.PRM.keys()) + list(bufs.keys()) + sorted(aliases) if k not in sd]
     if strict and (missing or unexpected):
-        raise RuntimeError("Error(s) in loading state_dict for DPC_RNN:\n\tMissing key(s) in state_dict: "
+        raise RuntimeError(f"Error(s) in loading state_dict for {'LC' if bufs else 'DPC_RNN'}:\n\tMissing key(s) in state_dict: "
                            f"{missing}.\n\tUnexpected key(s) in state_dict: {unexpected}.")
     load = {}
     for k, v in sd.items():
         tgt = k.replace(ALIAS_TO, ALIAS_FROM) if k in aliases else k
         if tgt not in mine:
             continue
-        if tuple(v.shape) != tuple(eng.shapes[tgt]):
+        want = tuple(eng.shapes[tgt]) if tgt in eng.shapes else tuple(bufs[tgt].shape)
+        if tuple(v.shape) != want:
             raise RuntimeError(f"size mismatch for {k}: copying a param with shape {tuple(v.shape)} from checkpoint, "
-                               f"the shape in current model is {tuple(eng.shapes[tgt])}.")
+                               f"the shape in current model is {want}.")
         if tgt in load and k in aliases:
             continue  # the cell's own key wins over its alias (they hold the same tensor in reference files)
         load[tgt] = v

@@ -147,7 +147,7 @@ __global__ void lc_ctx_bn_kernel(const T* h, int B, int SQ, int D, const float* 
         if (drop) k = drop[o];
         else if (step_dev) {
             float kk[4];
-            dropout_keep4(seed, step, (uint32_t)(o >> 2), thresh24, inv_keep, kk);
+            dropout_keep4(seed, step, (uint32_t)(o >> 2), thresh24, inv_keep, kk, DPC_PHILOX_STREAM_LC_FC);
             k = kk[o & 3];
         }
         xhat[o] = xh;

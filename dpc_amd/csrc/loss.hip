@@ -185,6 +185,19 @@ extern "C" int dpc_step_advance(int32_t* step_dev, float* bias_corr_dev, double 
     return dpc_launch_status();
 }
 
+// draw counter of the dropout streams: advanced by every train-mode forward (not by the optimizer step), so a caller that never
+// runs the engine's own Adam -- the nn.Module boundary with a torch optimizer -- still sees fresh masks each forward
+__global__ void counter_advance_kernel(int32_t* ctr) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) ctr[0] += 1;
+}
+
+extern "C" int dpc_counter_advance(int32_t* counter_dev, dpc_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!counter_dev) return DPC_ERR_ARG;
+    DPC_LAUNCH(counter_advance_kernel, dim3(1), dim3(64), stream, counter_dev);
+    return dpc_launch_status();
+}
+
 __global__ void adam_dev_kernel(float* p, const float* g, float* m, float* v, long long n4, long long n, float lr, float b1,
                                 float b2, float omb1, float omb2, float eps, float wd, const float* bc, float gscale) {
     const float step = lr / bc[0];

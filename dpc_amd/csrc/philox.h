@@ -26,8 +26,13 @@ __device__ __host__ __forceinline__ Philox4 philox4x32_10(uint32_t c0, uint32_t 
 
 // pre-scaled keep masks of elements 4*blk .. 4*blk+3 (element index = position in [n_steps][M][D]) at optimizer step `step`:
 // keep (value 1/(1-p)) iff the 24-bit uniform u = word >> 8 satisfies u >= p * 2^24  (P[keep] = 1 - p)
-__device__ __host__ __forceinline__ void dropout_keep4(uint64_t seed, uint32_t step, uint32_t blk, uint32_t thresh24, float inv_keep, float* out4) {
-    const Philox4 r = philox4x32_10(blk, step, 0u, 0u, (uint32_t)seed, (uint32_t)(seed >> 32));
+// `stream` (counter word c2) separates independent mask streams drawn under one (seed, step): 0 = the ConvGRU's carried state,
+// 1 = the classifier head's Dropout(0.5) (eval/model_3d_lc.py:42) -- never seed + k, which would collide with rank k's stream.
+#define DPC_PHILOX_STREAM_GRU 0u
+#define DPC_PHILOX_STREAM_LC_FC 1u
+__device__ __host__ __forceinline__ void dropout_keep4(uint64_t seed, uint32_t step, uint32_t blk, uint32_t thresh24, float inv_keep, float* out4,
+                                                       uint32_t stream = DPC_PHILOX_STREAM_GRU) {
+    const Philox4 r = philox4x32_10(blk, step, stream, 0u, (uint32_t)seed, (uint32_t)(seed >> 32));
     DPC_UNROLL
     for (int e = 0; e < 4; ++e) out4[e] = (r.v[e] >> 8) >= thresh24 ? inv_keep : 0.f;
 }

@@ -470,6 +470,9 @@ class DPCEngine:
         # optimizer-step counter and Adam bias corrections in device memory: a captured hipGraph advances them on replay
         self.dev_step = torch.zeros(1, dtype=torch.int32, device=self.device)
         self.dev_bc = torch.ones(2, dtype=f32, device=self.device)
+        # dropout draw counter: every train-mode forward advances it, the recurrence keys its Philox masks on it.  Not the optimizer
+        # step: the nn.Module boundary with an external torch optimizer never runs adam_step() and would redraw one mask forever
+        self.dev_draw = torch.zeros(1, dtype=torch.int32, device=self.device)
         self.P1_all = self.empty((P, M, D), dt)       # relu(W1 h + b1)
         self.dP1 = self.empty((P, M, D), dt)          # grads at the pre-activations of network_pred
         self.dP2 = self.empty((P, M, D), dt)
@@ -706,9 +709,10 @@ class DPCEngine:
         self.stem.wgrad(self.x_s2d, self.stem_dz)
 
     def forward(self, block: torch.Tensor, train: bool = False, dropout_masks: Optional[torch.Tensor] = None,
-                materialise: bool = True):
+                materialise: bool = True, new_draw: bool = True):
         """block [B,N,3,SL,H,W] f32 on the device.  Returns the score tensor [B,P,SQ,B,P,SQ] (f32, engine-owned).
         dropout_masks: optional [n_steps,M,D] pre-scaled keep masks (tests); train=True draws them on the device.
+        new_draw=False repeats the previous forward's Philox masks (tests comparing two paths on one step).
         materialise=False (bf16 mode): the score is consumed tile by tile by the fused loss (csrc/score_fused.hip) and
         never written; the return value is None and loss_topk() / backward() use the fused path."""
         B, N, P, SQ, D, M = self.B, self.N, self.P, self.SQ, self.D, self.M
@@ -726,12 +730,15 @@ class DPCEngine:
             self.drop_all = dropout_masks.to(self.device, torch.float32).contiguous()
             if tuple(self.drop_all.shape) != (self.n_steps, M, D):
                 raise ValueError(f"dropout_masks must be [n_steps, M, D] = {(self.n_steps, M, D)}")
-        else:  # train: Philox masks are generated inside the recurrence kernel, keyed on (seed, optimizer step)
+        else:  # train: Philox masks are generated inside the recurrence kernel, keyed on (seed, draw counter)
             self.drop_all = None
         # aggregate + predict (dpc/model_3d.py:62-72): the whole recurrence in one launch
         gd = self.gru_desc
         gd.drop_masks = self.drop_all.data_ptr() if dropout_masks is not None else None
-        gd.step_dev = self.dev_step.data_ptr() if (dropout_masks is None and train and self.p_drop > 0) else None
+        draw = dropout_masks is None and train and self.p_drop > 0
+        if draw and new_draw:  # a new draw per train-mode forward (the backward of THIS forward regenerates the same bits)
+            self.call("dpc_counter_advance", self.dev_draw)
+        gd.step_dev = self.dev_draw.data_ptr() if draw else None
         self.call("dpc_gru_chain_fwd", C.byref(gd))
         # score (dpc/model_3d.py:79-84): pred [R][D] x feat_inf [R][D]^T
         R = self.R
@@ -748,10 +755,10 @@ class DPCEngine:
         return self.score.view(B, P, SQ, B, P, SQ)
 
     def dropout_masks_of_step(self) -> torch.Tensor:
-        """[n_steps, M, D] pre-scaled keep masks the recurrence kernels generate in train mode at the CURRENT optimizer step
-        (same Philox stream, materialised by dpc_dropout_mask): diagnostics and tests."""
+        """[n_steps, M, D] pre-scaled keep masks the recurrence kernels generated in the LAST train-mode forward (same Philox
+        stream at the current draw counter, materialised by dpc_dropout_mask): diagnostics and tests."""
         buf = self.empty((self.n_steps, self.M, self.D), torch.float32)
-        self.call("dpc_dropout_mask", buf, buf.numel(), float(self.p_drop), self.seed, self.dev_step)
+        self.call("dpc_dropout_mask", buf, buf.numel(), float(self.p_drop), self.seed, self.dev_draw)
         return buf
 
     def get_mask(self) -> torch.Tensor:
@@ -831,6 +838,7 @@ class DPCEngine:
     def step_count(self, t: int):  # checkpoint resume: host value -> device counter
         self._step_count = int(t)
         self.dev_step.fill_(int(t))
+        self.dev_draw.fill_(int(t))  # one draw per step in the engine-owned loop: a resumed run continues the same mask stream
 
     def adam_step(self, grad_scale: float = 1.0):
         self._step_count += 1

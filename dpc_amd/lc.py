@@ -92,6 +92,7 @@ class LCEngine(DPCEngine):
         self.gru_ws = self.empty((2, M, D), f32)
         self.dev_step = torch.zeros(1, dtype=torch.int32, device=self.device)
         self.dev_bc = torch.ones(2, dtype=f32, device=self.device)
+        self.dev_draw = torch.zeros(1, dtype=torch.int32, device=self.device)  # dropout draw counter (one per train-mode forward)
         self.drop_all = None
         self.dWx, self.dWh, self.dWo = self.empty((3 * D, D), f32), self.empty((2 * D, D), f32), self.empty((D, D), f32)
         self.db = self.empty((3 * D,), f32)
@@ -119,7 +120,7 @@ class LCEngine(DPCEngine):
             setattr(gd, name, t.data_ptr())
         hd = self.head_desc = L.LcHeadDesc()
         hd.dtype, hd.B, hd.SQ, hd.D, hd.num_class, hd.train = L.dtype_code(dt), B, SQ, D, NC, 1
-        hd.p_drop, hd.momentum, hd.eps, hd.seed = self.p_drop_fc, self.BN_MOMENTUM, BN_EPS, self.seed + 1
+        hd.p_drop, hd.momentum, hd.eps, hd.seed = self.p_drop_fc, self.BN_MOMENTUM, BN_EPS, self.seed  # own Philox stream id, same key
         G = self.G
         for name, t in (("h_last", self.H_all[N]), ("bn_weight", Pm["final_bn.weight"]), ("bn_bias", Pm["final_bn.bias"]),
                         ("bn_running_mean", self.BUF["final_bn.running_mean"]), ("bn_running_var", self.BUF["final_bn.running_var"]),
@@ -172,14 +173,16 @@ class LCEngine(DPCEngine):
             gru_masks = gru_masks.to(self.device, torch.float32).contiguous()
             self._keep = (gru_masks, fc_mask)
         gd.drop_masks = gru_masks.data_ptr() if gru_masks is not None else None
-        gd.step_dev = self.dev_step.data_ptr() if (gru_masks is None and train and self.p_drop > 0) else None
+        if train and (gru_masks is None or fc_mask is None):
+            self.call("dpc_counter_advance", self.dev_draw)
+        gd.step_dev = self.dev_draw.data_ptr() if (gru_masks is None and train and self.p_drop > 0) else None
         self.call("dpc_gru_chain_fwd", C.byref(gd))
         if fc_mask is not None:
             fc_mask = fc_mask.to(self.device, torch.float32).contiguous()
             self._keep = (gru_masks, fc_mask)
         hd.train = int(train)
         hd.drop_mask = fc_mask.data_ptr() if fc_mask is not None else None
-        hd.step_dev = self.dev_step.data_ptr()
+        hd.step_dev = self.dev_draw.data_ptr()
         self.call("dpc_lc_head_fwd", C.byref(hd))
         return self.logits.view(B, 1, self.num_class), self.context.view(B, 1, D)
 
@@ -285,12 +288,25 @@ class LC(nn.Module):
         self.agg.cell_list = nn.ModuleList([self.agg.ConvGRUCell_00])
 
     def _ensure_engine(self, block):
+        """Parameters and BatchNorm buffers of the module ARE the engine's arenas (as in DPC_RNN): ``load_state_dict`` / an
+        optimizer writing through them reach the kernels, and what ``engine.train_step`` / a train-mode forward update (weights,
+        running statistics, num_batches_tracked) is what ``state_dict()`` / ``torch.save(model)`` return."""
         key = (block.shape[0], block.device, self.compute_dtype)
-        if self._engine is not None and self._engine_key == key:
+        first = self.backbone.conv1.weight
+        if self._engine is not None and self._engine_key == key and first.data_ptr() == self._engine.PRM["backbone.conv1.weight"].data_ptr():
             return
         eng = LCEngine(self.network, self.sample_size, self.num_seq, self.seq_len, block.shape[0], block.device, self.compute_dtype,
                        self.widths, self._simulator, dropout=self.dropout, num_class=self.num_class)
         eng.load_params({k: v.detach() for k, v in self.state_dict().items()})
+        named = dict(self.named_parameters())
+        for k, t in eng.PRM.items():
+            named[k].data = t  # re-point the Parameter at its slice of the flat arena
+        for k, t in eng.BUF.items():
+            mod = self
+            *path, leaf = k.split(".")
+            for p_ in path:
+                mod = getattr(mod, p_)
+            mod._buffers[leaf] = t  # same tensor object the kernels update
         self._engine, self._engine_key = eng, key
 
     @property
@@ -301,6 +317,7 @@ class LC(nn.Module):
         if block.device.type != "cuda" and self._simulator is None:
             raise L.DpcError("dpc_amd.LC runs on MI355X only: move the module and the input to a cuda (HIP) device")
         self._ensure_engine(block)
+        self._engine.packed_for_step = -1  # the parameters may have been changed through the module since the last forward
         if target is None:
             target = torch.zeros(block.shape[0], dtype=torch.int64)
         out, ctx = self._engine.forward(block.float(), target, train=self.training)

@@ -7,6 +7,14 @@ all-reduce as in dpc_amd.main); datasets, augmentation and tensorboard are outsi
 synthetic N(0,1) video with random labels in the dataset's tensor layout.  ``--pretrain`` loads a DPC-RNN checkpoint
 by key intersection (neq_load_customized, backbone/resnet_2d3d.py:310-333): backbone + ConvGRU weights are taken, the
 running buffers and the head stay at their initial values -- exactly what the reference does with its own checkpoints.
+
+Learning rate: the reference wraps Adam in ``LambdaLR(MultiStepLR_Restart_Multiplier)`` and calls ``scheduler.step(epoch)`` after
+every epoch (eval/test.py:93-100,197,408-423): epoch e > start runs at ``lr * multiplier(e - 1)``, the first epoch of a run at
+the constructor's ``lr * multiplier(0)`` (or the checkpoint's saved lr on ``--resume`` without ``--reset_lr``).  ``lr_multiplier``
+below restates the multiplier; the fused Adam takes ``eng.lr`` per step.
+``--train_what ft``: the reference gives parameters whose NAME contains 'resnet' or 'rnn' a 10x smaller lr
+(eval/test.py:76-84) -- but LC's parameters are called ``backbone.*`` / ``agg.*`` / ``final_*`` (model_3d_lc.py:29-45), so the
+filter never matches and every parameter trains at ``--lr``.  This entry does what the reference effectively does: one lr.
 """
 from __future__ import annotations
 
@@ -48,6 +56,24 @@ def build_parser() -> argparse.ArgumentParser:
     return parser
 
 
+def lr_multiplier(epoch: int, gamma: float, milestones, repeat: int) -> float:
+    """MultiStepLR_Restart_Multiplier (eval/test.py:408-423): gamma^(milestones passed) inside a cycle of max(milestones) epochs,
+    restarting `repeat` times, then pinned at the last decay level"""
+    period = max(milestones)
+    if epoch // period >= repeat:
+        return gamma ** (len(milestones) - 1)
+    return gamma ** sum(1 for m in milestones if epoch % period >= m)
+
+
+def lr_milestones(dataset: str, img_dim: int):
+    """eval/test.py:93-99"""
+    if dataset == 'hmdb51':
+        return [150, 250, 300]
+    if dataset == 'ucf101':
+        return [300, 400, 500] if img_dim == 224 else [60, 80, 100]
+    raise ValueError('no learning-rate schedule for dataset %r (eval/test.py:93-99 defines ucf101 and hmdb51)' % dataset)
+
+
 def _worker(rank: int, world: int, args, port: int):
     gpus = [int(g) for g in str(args.gpu).split(',') if g != '']
     dev = torch.device('cuda', gpus[rank] if world > 1 else gpus[0])
@@ -76,25 +102,39 @@ def _worker(rank: int, world: int, args, port: int):
     init = LC(args.img_dim, args.num_seq, args.seq_len, args.net, args.dropout, args.num_class, seed=0)
     eng.load_params({k: v.detach() for k, v in init.state_dict().items()})
     log = print if rank == 0 else (lambda *a, **k: None)
-    num_epoch = 0
+    if args.train_what == 'ft':
+        log("=> finetune backbone with smaller lr  [the reference's name filter ('resnet' / 'rnn') matches no LC parameter: one lr]")
+    num_epoch, best_acc, iteration = 0, 0.0, 0
+    base_lr = args.lr
+    milestones = lr_milestones(args.dataset, args.img_dim)
+    eng.lr = base_lr * lr_multiplier(0, 0.1, milestones, 1)  # LambdaLR's constructor step
     for path, what in ((args.test, 'test'), (args.resume, 'resume'), (args.pretrain, 'pretrain')):
         if not path or path == 'random' or (what == 'pretrain' and args.resume):
             continue
         if not os.path.isfile(path):
+            if what == 'test':
+                raise ValueError()  # eval/test.py:121-122
             log("=> no checkpoint found at '{}'".format(path))
             continue
         ck = torch.load(path, map_location='cpu', weights_only=False)
-        sd = {k[7:] if k.startswith('module.') else k: v for k, v in ck['state_dict'].items()}
-        known = {k: v for k, v in sd.items() if k in eng.PRM or k in eng.BUF or k.startswith('agg.cell_list.0.')}
-        if what == 'resume' and len(known) != len(sd):
-            raise RuntimeError('Unexpected key(s) in state_dict: {}'.format([k for k in sd if k not in known]))
-        eng.load_params(known)
-        log("=> loaded {} checkpoint '{}' ({} of {} tensors used)".format(what, path, len(known), len(sd)))
+        # --resume: nn.Module.load_state_dict, strict in both directions (eval/test.py:145); --test: strict, falling back to the
+        # key intersection with a warning (:113-116); --pretrain: key intersection (neq_load_customized, :160)
+        try:
+            missing, unexpected = ckpt.load_model_state(eng, ck['state_dict'], strict=what != 'pretrain')
+        except RuntimeError:
+            if what != 'test':
+                raise
+            log('=> [Warning]: weight structure is not equal to test model; Use non-equal load ==')
+            missing, unexpected = ckpt.load_model_state(eng, ck['state_dict'], strict=False)
+        log("=> loaded {} checkpoint '{}' (epoch {}; {} keys not in the file, {} keys of the file unused)".format(
+            what, path, ck.get('epoch', 0), len(missing), len(unexpected)))
         num_epoch = ck.get('epoch', 0)
         if what == 'resume':
             args.start_epoch = ck['epoch']
+            best_acc = float(ck.get('best_acc', 0.0))
+            iteration = int(ck.get('iteration', 0))
             if not args.reset_lr and 'optimizer' in ck:
-                ckpt.load_optimizer_state(eng, ck['optimizer'])
+                ckpt.load_optimizer_state(eng, ck['optimizer'])  # restores the group's lr as optimizer.load_state_dict does
     allreduce = make_allreduce(dist, world)
     gen = torch.Generator(dev).manual_seed(1000 + rank)
     shape = (per_gpu, args.num_seq, 3, args.seq_len, args.img_dim, args.img_dim)
@@ -130,7 +170,9 @@ def _worker(rank: int, world: int, args, port: int):
                 res = eng.train_step(x, y, allreduce=allreduce)
                 if idx % args.print_freq == 0:
                     loss, acc = reduce(res)
-                    log('Epoch: [{0}][{1}/{2}]\t Loss {3:.4f}\t Acc: {4:.4f}\t'.format(epoch, idx, args.synthetic, loss, acc), flush=True)
+                    log('Epoch: [{0}][{1}/{2}]\t Loss {3:.4f}\t Acc: {4:.4f}\t lr {5:g}'.format(epoch, idx, args.synthetic, loss, acc, eng.lr),
+                        flush=True)
+                    iteration += 1  # advanced on logged steps only, as the reference does (eval/test.py:262-270)
             vl = va = 0.0
             for idx in range(max(args.synthetic // 4, 1)):  # validate(): eval/test.py:273-304 (eval mode, running statistics)
                 x, y = batch()
@@ -139,12 +181,16 @@ def _worker(rank: int, world: int, args, port: int):
                 vl += loss
                 va += acc
             nv = max(args.synthetic // 4, 1)
-            log('Loss {:.4f}\t Acc: {:.4f} \t'.format(vl / nv, va / nv), flush=True)
+            val_acc = va / nv
+            log('Loss {:.4f}\t Acc: {:.4f} \t'.format(vl / nv, val_acc), flush=True)
+            eng.lr = base_lr * lr_multiplier(epoch, 0.1, milestones, 1)  # scheduler.step(epoch), eval/test.py:197
+            is_best = val_acc > best_acc  # eval/test.py:205-214
+            best_acc = max(val_acc, best_acc)
             if rank == 0 and args.save_dir:
                 os.makedirs(args.save_dir, exist_ok=True)
                 state = {'epoch': epoch + 1, 'net': args.net, 'state_dict': {'module.' + k: v.cpu() for k, v in eng.state_dict().items()},
-                         'best_acc': va / nv, 'optimizer': ckpt.optimizer_state_dict(eng), 'iteration': 0}
-                ckpt.save_checkpoint(state, False, filename=os.path.join(args.save_dir, 'epoch%s.pth.tar' % str(epoch + 1)))
+                         'best_acc': best_acc, 'optimizer': ckpt.optimizer_state_dict(eng), 'iteration': iteration}
+                ckpt.save_checkpoint(state, is_best, filename=os.path.join(args.save_dir, 'epoch%s.pth.tar' % str(epoch + 1)))
         log('Training from ep %d to ep %d finished' % (args.start_epoch, args.epochs))
     if dist is not None:
         dist.barrier()

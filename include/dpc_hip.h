@@ -208,11 +208,14 @@ int dpc_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr, 
 int dpc_step_advance(int32_t* step_dev, float* bias_corr_dev, double beta1, double beta2, dpc_stream_t stream);
 int dpc_adam_dev(float* p, const float* g, float* m, float* v, int64_t n, float lr, double beta1, double beta2, float eps,
                  float wd, const float* bias_corr_dev, float grad_scale, dpc_stream_t stream);
+/* counter_dev[0] += 1 on the stream: the dropout draw counter (one draw per train-mode forward; the `step_dev` the recurrence and
+ * the classifier head key their Philox masks on), graph-capturable like dpc_step_advance */
+int dpc_counter_advance(int32_t* counter_dev, dpc_stream_t stream);
 /* f32 [rows][cols] window copy between two leading dimensions (ConvGRU gate-gradient scatter) */
 int dpc_copy2d_f32(const float* src, int64_t src_ld, float* dst, int64_t dst_ld, int32_t rows, int32_t cols, dpc_stream_t stream);
 
 /* ---- ConvGRU dropout (nn.Dropout(p=0.1) on the carried hidden state, backbone/convrnn.py:39,59,78) ---------------
- * mask[i] = 1/(1-p) w.p. 1-p else 0: Philox4x32-10, key = seed, counter = (i/4, step_dev[0], 0, 0), word i%4,
+ * mask[i] = 1/(1-p) w.p. 1-p else 0: Philox4x32-10, key = seed, counter = (i/4, step_dev[0], stream id (0 here; 1 = the LC head's dropout), 0), word i%4,
  * keep iff (word >> 8) >= round(p * 2^24).  One launch draws the masks of all recurrence steps of one train step. */
 int dpc_dropout_mask(float* mask, int64_t n, float p, uint64_t seed, const int32_t* step_dev, dpc_stream_t stream);
 

@@ -86,7 +86,7 @@ def test_forward_bf16_smoke(emu):
 
 def test_fused_score_path_matches_materialised(emu):
     """throughput mode: forward(materialise=False) + fused loss + fused score backward (no [R][R] tensor) against the
-    materialised path of the same engine on the same step (same Philox dropout masks: the step counter has not moved)"""
+    materialised path of the same engine on the same step (same Philox dropout masks: new_draw=False repeats the draw)"""
     B, size = 1, 64
     eng = DPCEngine("resnet18", size, 8, 5, 3, B, "cpu", torch.bfloat16, WIDTHS, lib=emu, score_path="fused")
     assert eng.score_fusable
@@ -97,7 +97,7 @@ def test_fused_score_path_matches_materialised(emu):
     res_m = eng.loss_topk(True).clone()
     eng.backward()
     g_m, dp_m, df_m = eng.flat_g.clone(), eng.d_pred.clone(), eng.d_finf.clone()
-    assert eng.forward(x, train=True, materialise=False) is None and eng.score_mode == "fused"
+    assert eng.forward(x, train=True, materialise=False, new_draw=False) is None and eng.score_mode == "fused"
     res_f = eng.loss_topk(True).clone()
     eng.backward()
     assert abs(res_f[0].item() - res_m[0].item()) < 1e-4
@@ -107,3 +107,33 @@ def test_fused_score_path_matches_materialised(emu):
     assert ((eng.flat_g - g_m).norm() / g_m.norm()).item() < 3e-2
     with pytest.raises(L.DpcError):
         eng.backward(dscore_external=torch.zeros(eng.R, eng.R))
+
+
+def test_module_train_mode_draws_fresh_dropout_masks(emu):
+    """nn.Module boundary with an EXTERNAL optimizer (adam_step never runs): every train-mode forward must still draw new
+    ConvGRU dropout masks (backbone/convrnn.py:78 draws per call); eval forwards draw none and agree with each other."""
+    from dpc_amd.model import DPC_RNN
+    m = DPC_RNN(64, 8, 5, 3, "resnet18", widths=WIDTHS, _simulator=emu)
+    x = O.make_input_pcg(1, 8, 5, 64)
+    m.train()
+    s1 = m(x)[0].detach().clone()
+    k1 = m.engine.dropout_masks_of_step().clone()
+    s2 = m(x)[0].detach().clone()
+    k2 = m.engine.dropout_masks_of_step().clone()
+    assert int(m.engine.dev_draw.item()) == 2 and m.engine.step_count == 0
+    assert not torch.equal(k1, k2) and not torch.equal(s1, s2)
+    assert abs(k2.ne(0).float().mean().item() - 0.9) < 0.03
+    # the backward of a forward regenerates THAT forward's bits: gradient of the second call == injected-mask run of the same masks
+    s3 = m(x)[0]
+    k3 = m.engine.dropout_masks_of_step().clone()
+    s3.sum().backward()
+    g_philox = m.network_pred[2].weight.grad.clone() if hasattr(m.network_pred, "__getitem__") else dict(m.named_parameters())["network_pred.2.weight"].grad.clone()
+    eng = m.engine
+    sc = eng.forward(x, train=True, dropout_masks=k3)
+    assert torch.equal(sc.reshape(-1), s3.detach().reshape(-1))
+    eng.backward(dscore_external=torch.ones(eng.R, eng.R))
+    assert torch.equal(eng.G["network_pred.2.weight"], g_philox)
+    m.eval()
+    e1 = m(x)[0].detach().clone()
+    e2 = m(x)[0].detach().clone()
+    assert torch.equal(e1, e2) and int(m.engine.dev_draw.item()) == 3

@@ -227,7 +227,7 @@ def test_cfg5_full_shape_properties():
     assert torch.equal((mk == 1).sum(1), torch.ones(R, dtype=torch.long, device=DEV))
     assert int((mk == -3).sum().item()) == B * (P * 49) * (P * 49) - B * P * P * 49
     # (2) the fused path of the SAME step (same Philox masks): no [R][R] tensor is written
-    assert eng.forward(x, train=True, materialise=False) is None and eng.score_mode == "fused"
+    assert eng.forward(x, train=True, materialise=False, new_draw=False) is None and eng.score_mode == "fused"
     res_f = eng.loss_topk(True).clone().cpu()
     eng.backward()
     torch.cuda.synchronize()
@@ -268,7 +268,7 @@ def test_full_batch_properties(dtype):
     chk = eng.pred.float().view(R, -1)[:64] @ eng.feat_inf.float().view(R, -1).t()
     assert (chk - eng.score[:64]).abs().max().item() < 1e-2 * chk.abs().max().item()
     if dtype == torch.bfloat16:  # the fused score / loss / backward of the same step (what train_step runs in this mode)
-        assert eng.forward(x, train=True, materialise=False) is None and eng.score_mode == "fused"
+        assert eng.forward(x, train=True, materialise=False, new_draw=False) is None and eng.score_mode == "fused"
         res_f = eng.loss_topk(True).clone().cpu()
         eng.backward()
         torch.cuda.synchronize()

@@ -151,3 +151,44 @@ def test_engine_bf16_runs(emu):
         ro, _, _ = O.lc_forward(p, x, "resnet18", train=False)
     assert (out - ro).abs().max().item() < 0.15 * max(ro.abs().max().item(), 1.0)
     assert torch.isfinite(eng.result).all()
+
+
+def test_module_parameters_alias_the_engine(emu):
+    """LC module <-> engine: one storage.  load_state_dict after the first forward reaches the kernels; what the engine's
+    train step updates (weights, BatchNorm running buffers, num_batches_tracked) is what state_dict() returns."""
+    from dpc_amd.lc import LC
+    m = LC(64, 8, 5, "resnet18", 0.5, 11, widths=WIDTHS, _simulator=emu)
+    x = O.make_input_pcg(2, 8, 5, 64)
+    m.eval()
+    out0, _ = m(x)
+    eng = m.engine
+    sd = m.state_dict()
+    assert sd["backbone.conv1.weight"].data_ptr() == eng.PRM["backbone.conv1.weight"].data_ptr()
+    assert sd["backbone.bn1.running_mean"].data_ptr() == eng.BUF["backbone.bn1.running_mean"].data_ptr()
+    assert sd["agg.cell_list.0.out_gate.weight"].data_ptr() == eng.PRM["agg.ConvGRUCell_00.out_gate.weight"].data_ptr()
+    # (1) module -> engine: a new state_dict is seen by the next forward without rebuilding the engine
+    new = {k: (v * 0.5 if v.dtype.is_floating_point and k.endswith("final_fc.1.weight") else v.clone()) for k, v in sd.items()}
+    m.load_state_dict(new, strict=True)
+    out1, _ = m(x)
+    assert m.engine is eng and not torch.equal(out0, out1)
+    # (2) engine -> module: a train step moves the weights and the running statistics the module reports
+    before = {k: v.clone() for k, v in m.state_dict().items()}
+    eng.train_step(x, torch.tensor([1, 3]))
+    after = m.state_dict()
+    assert not torch.equal(before["backbone.layer1.0.conv1.weight"], after["backbone.layer1.0.conv1.weight"])
+    assert not torch.equal(before["backbone.bn1.running_mean"], after["backbone.bn1.running_mean"])
+    assert int(after["backbone.bn1.num_batches_tracked"]) == int(before["backbone.bn1.num_batches_tracked"]) + 1
+    assert int(after["final_bn.num_batches_tracked"]) == int(before["final_bn.num_batches_tracked"]) + 1
+
+
+def test_lr_schedule_and_train_what():
+    """MultiStepLR_Restart_Multiplier (eval/test.py:408-423): the docstring's own table for step=[10,15,20], repeat=3, and the
+    schedules main() selects (eval/test.py:93-99)"""
+    from dpc_amd.lc_main import lr_milestones, lr_multiplier
+    tab = {0: 1, 9: 1, 10: 0.1, 14: 0.1, 15: 0.01, 19: 0.01, 20: 1, 29: 1, 30: 0.1, 35: 0.01, 40: 1, 50: 0.1, 59: 0.01,
+           60: 0.01, 61: 0.01, 75: 0.01, 1000: 0.01}
+    for ep, want in tab.items():
+        assert lr_multiplier(ep, 0.1, [10, 15, 20], 3) == pytest.approx(want), ep
+    assert lr_milestones("ucf101", 128) == [60, 80, 100] and lr_milestones("ucf101", 224) == [300, 400, 500]
+    assert lr_milestones("hmdb51", 128) == [150, 250, 300]
+    assert [lr_multiplier(e, 0.1, [60, 80, 100], 1) for e in (0, 59, 60, 80, 99, 100, 500)] == pytest.approx([1, 1, .1, .01, .01, .01, .01])
