@@ -21,7 +21,11 @@ Prints ONE JSON line on rank 0, including
   hbm_family   -- BN / pool / pack kernels (HBM-bound): algorithmic bytes / time against 8 TB/s
   cpu_baseline -- the CPU oracle (torch-CPU port of the reference step) on configs[0] (batch 4),
                   rank 0, N=1 only, best of a thread-count sweep.
+  also         -- (default cfg2 run on one GPU only) the 224^2 configurations of BASELINE.json measured in the same process:
+                  the single-GPU shards of configs[3] (cfg4) and configs[4] (cfg5), a few hipGraph replays each, with the
+                  conv family's roofline fraction.  They never enter `value`.
 """
+import hashlib
 import argparse
 import json
 import os
@@ -42,6 +46,55 @@ CONFIGS = {  # BASELINE.json "configs" -> per-GPU shard
     "cfg4": dict(net="resnet34", img_dim=224, pred_step=3, batch=44),
     "cfg5": dict(net="resnet34", img_dim=224, pred_step=5, batch=64),
 }
+
+
+def csrc_sha16():
+    """fingerprint of the kernel sources: a PMC traffic file measured on other kernels is stale (no .git on the GPU box)"""
+    import glob
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "dpc_amd", "csrc", "*"))):
+        if f.endswith((".hip", ".h")):
+            h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def side_config(name, dev, steps=8, warmup=2, roof_steps=2):
+    """one of the 224^2 configurations, measured after the headline run in the same process (single GPU, no exchange)"""
+    from dpc_amd.engine import DPCEngine, KernelTimer
+    from dpc_amd.model import DPC_RNN
+    cfg = CONFIGS[name]
+    net, img, P, batch = cfg["net"], cfg["img_dim"], cfg["pred_step"], cfg["batch"]
+    eng = DPCEngine(net, img, 8, 5, P, batch, dev, torch.bfloat16, seed=233)
+    init = DPC_RNN(img, network=net, pred_step=P, seed=0)
+    eng.load_params({k: v.detach() for k, v in init.named_parameters()})
+    del init
+    block = torch.randn(batch, 8, 3, 5, img, img, device=dev, generator=torch.Generator(dev).manual_seed(1234))
+    step = eng.capture_train_step(block)
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        res = step()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    out = {"workload": f"{net} 2d3d, img_dim {img}, pred_step {P}, batch {batch}/GPU, bf16, full train step, hipGraph replay",
+           "value": round(batch * steps / dt, 2), "unit": "clips/s", "ms_per_step": round(1e3 * dt / steps, 3), "steps": steps,
+           "final_loss": round(res.cpu().tolist()[0], 4), "score_path": eng.score_mode}
+    timer = KernelTimer(["dpc_conv_igemm"])
+    eng.timer = timer
+    for _ in range(roof_steps):
+        eng.train_step(block)
+    torch.cuda.synchronize()
+    eng.timer = None
+    ig = timer.summary(roof_steps).get("dpc_conv_igemm")
+    if ig and ig["ms"] > 0:
+        ach = ig["flops"] / (ig["ms"] * 1e-3) / 1e12
+        out["roofline"] = {"kernel": "dpc_conv_igemm", "bound": "mfma", "achieved": round(ach, 2), "peak": MFMA_PEAK_BF16,
+                           "unit": "TFLOP/s", "frac": round(ach / MFMA_PEAK_BF16, 4), "ms_per_step": round(ig["ms"] / roof_steps, 3)}
+    del eng, step, block
+    torch.cuda.empty_cache()
+    return out
 
 
 def cpu_baseline(seconds_budget=24.0):
@@ -103,6 +156,7 @@ def main():
     ap.add_argument("--roofline-steps", type=int, default=4, help="steps of the separately instrumented pass")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-also", action="store_true", help="skip the 224^2 side measurements (cfg4 / cfg5) of the default run")
     ap.add_argument("--no-graph", action="store_true", help="launch the step kernel by kernel instead of replaying a hipGraph")
     ap.add_argument("--score-path", default="auto", choices=["auto", "fused", "materialised"],
                     help="contrastive score + loss: fused (no [R][R] tensor in HBM) or materialised; auto = fused for R >= 8192")
@@ -199,20 +253,26 @@ def main():
             s = timer.summary(rs)
             ig = s.get("dpc_conv_igemm")
             peak = MFMA_PEAK_BF16 if args.dtype == "bf16" else MFMA_PEAK_F32
-            traffic = None
+            traffic, traffic_src = None, None
             try:  # HBM bytes per launch from the rocprofv3 PMC passes (scripts/gpu_pmc_traffic.sh + scripts/pmc_traffic.py)
                 import glob
                 cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))
                 if cands and args.dtype == "bf16" and args.config == "cfg2" and batch == 128:
-                    traffic = round(json.load(open(cands[-1]))["dpc_conv_igemm"]["hbm_bytes_per_launch"] / 1e9, 4)
+                    tj = json.load(open(cands[-1]))
+                    traffic = round(tj["dpc_conv_igemm"]["hbm_bytes_per_launch"] / 1e9, 4)
+                    # the counters are a separate rocprofv3 session: the file says which kernel sources it was measured on
+                    traffic_src = {"file": os.path.basename(cands[-1]), "measured_on_csrc_sha16": tj.get("csrc_sha16"),
+                                   "measured_on_git_head": tj.get("git_head"), "this_build_csrc_sha16": csrc_sha16(),
+                                   "stale": tj.get("csrc_sha16") != csrc_sha16()}
             except Exception:
-                traffic = None
+                traffic, traffic_src = None, None
             if ig and ig["ms"] > 0:
                 ach = ig["flops"] / (ig["ms"] * 1e-3) / 1e12
                 out["roofline"] = {
                     "kernel": "dpc_conv_igemm (igemm_ws_kernel + conv_halo(_ws)_kernel + igemm_kernel: conv fwd + input-grad + 1x1 GEMMs)",
                     "bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
                     "traffic": traffic, "traffic_unit": "GB of HBM traffic per launch (rocprofv3 PMC, profiles/*_pmc_traffic.json)",
+                    "traffic_source": traffic_src,
                     "algorithmic_GB_per_launch": round(ig["bytes"] / ig["launches"] / 1e9, 4),
                     "launches_per_step": ig["launches"] // rs,
                     "avg_launch_us": round(1e3 * ig["ms"] / ig["launches"], 2),
@@ -251,6 +311,16 @@ def main():
                     "frac": round(by / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "ms_per_step": round(ms / rs, 3),
                     "algorithmic_GB_per_step": round(by / rs / 1e9, 3), "launches_per_step": sum(d["launches"] for d in hb) // rs,
                 }
+        if world == 1 and dist is None and args.config == "cfg2" and args.batch is None and args.dtype == "bf16" and not args.no_also:
+            del eng, step_fn, block
+            torch.cuda.empty_cache()
+            out["also"] = {}
+            for name in ("cfg4", "cfg5"):
+                try:
+                    out["also"][name] = side_config(name, dev)
+                except Exception as e:  # reported, never hidden
+                    out["also"][name] = {"error": f"{type(e).__name__}: {str(e)[:160]}"}
+                    torch.cuda.synchronize()
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
     if dist is not None:

@@ -71,6 +71,8 @@ _SIGS = {
     "dpc_conv_stats_rows": [C.POINTER(ConvDesc)],
     "dpc_conv_igemm": [C.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _vp],
     "dpc_conv_wgrad": [C.POINTER(ConvDesc), _vp, _vp, _i32, _vp, C.POINTER(_i32), _vp],
+    "dpc_conv_plan": [C.POINTER(ConvDesc), _i32, _i32, _i32, C.c_char_p, _i32],
+    "dpc_last_kernel": [C.c_char_p, _i32],
     "dpc_pack3d": [_vp, _vp, _i32, _i32, _i32, _i32, _i64, _i64, _i64, _vp],
     "dpc_pack3d_multi": [_vp, _i32, _i32, _i32, _vp],
     "dpc_reduce_unpack": [_vp, _i32, _vp, _i32, _i32, _i32, _i64, _i64, _i64, _i32, _vp],
@@ -157,6 +159,23 @@ class Lib:
         if rc < 0:
             raise DpcError(f"{name} failed with code {rc}")
         return rc
+
+
+PLAN_IGEMM, PLAN_WGRAD, PLAN_ADDEND, PLAN_STATS = 0, 1, 1, 2
+
+
+def conv_plan(lib: "Lib", desc: ConvDesc, op: int = PLAN_IGEMM, addend: bool = False, stats: bool = False, dy_ld: int = 0) -> str:
+    """name of the kernel dpc_conv_igemm / dpc_conv_wgrad would launch for `desc` (include/dpc_hip.h: dpc_conv_plan)"""
+    buf = C.create_string_buffer(192)
+    flags = (PLAN_ADDEND if addend else 0) | (PLAN_STATS if stats else 0)
+    lib.call("dpc_conv_plan", C.byref(desc), op, flags, dy_ld or desc.Co, buf, 192)
+    return buf.value.decode()
+
+
+def last_kernel(lib: "Lib") -> str:
+    buf = C.create_string_buffer(192)
+    lib.call("dpc_last_kernel", buf, 192)
+    return buf.value.decode()
 
 
 _HIP: Optional[Lib] = None

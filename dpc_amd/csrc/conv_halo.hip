@@ -657,6 +657,7 @@ int dpc_conv_halo_try(const dpc_conv_desc* d, const void* src, const void* wgt, 
         }
         return dpc_launch_status();
     }
+    dpc_plan_detail("ws_declined=%d", (int)(p.ws && !ws_go));
     if (d->KH == 3) {
         if (d->dtype_in == DPC_F32) {
             DPC_LAUNCH((conv_halo_kernel<float, float, 3, 3, 8>), grid, block, stream, p);

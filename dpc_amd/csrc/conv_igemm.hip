@@ -469,6 +469,7 @@ extern "C" int dpc_conv_stats_rows(const dpc_conv_desc* d) {
 template <class T, class TO, int BN>
 static int launch_igemm_bn(const IGemmParams& p, int gather, hipStream_t stream) {
     dim3 grid((unsigned)(p.gm * p.ntn)), block(256);
+    dpc_plan_detail("T=%s TO=%s BN=%d", sizeof(T) == 2 ? "bf16" : "f32", sizeof(TO) == 2 ? "bf16" : "f32", BN);
     if (gather == 3) {
         DPC_LAUNCH((igemm_kernel<T, TO, BN, 3>), grid, block, stream, p);
     } else if (gather == 1) {
@@ -568,7 +569,7 @@ extern "C" int dpc_conv_igemm(const dpc_conv_desc* d, const void* src, const voi
         const int promised = dpc_conv_stats_rows(d);
         if (promised > 0 && promised != p.gm) {
             p.gm = promised < p.ntm ? promised : p.ntm;
-            if (stats && p.gm < promised) {
+            if (stats && p.gm < promised && !dpc_tls_plan_only) {
                 if (hipMemsetAsync(stats + (size_t)p.gm * 2 * d->Co, 0, (size_t)(promised - p.gm) * 2 * d->Co * sizeof(float), stream) != hipSuccess)
                     return DPC_ERR_LAUNCH;
             }

@@ -528,6 +528,8 @@ __global__ __launch_bounds__(64 * NWM * NWN, 2) void wgrad2_kernel(Wgrad2Params 
 template <class T, int NWM, int NWN>
 static int launch_wgrad2_t(const Wgrad2Params& p, bool pu, hipStream_t stream) {
     dim3 grid((unsigned)(p.ntm * p.ntn * p.nks)), block(64 * NWM * NWN);
+    dpc_plan_detail("T=%s nwm=%d nwn=%d padded=%d", sizeof(T) == 2 ? "bf16" : "f32", NWM, NWN,
+                    (int)(((p.RWm + 1) != p.g.RW) || ((p.RHm + 1) != p.g.RH)));
     if (pu) {
         DPC_LAUNCH((wgrad2_kernel<T, NWM, NWN, true>), grid, block, stream, p);
     } else {
@@ -547,6 +549,7 @@ static int launch_wgrad2(const Wgrad2Params& p, int nwm, int nwn, bool pu, hipSt
 template <class T, bool RF>
 static int launch_wgrad_rf(const WgradParams& p, int tm, int tn, hipStream_t stream) {
     dim3 grid((unsigned)(p.ntm * p.ntn * p.nks)), block(256);
+    dpc_plan_detail("T=%s", sizeof(T) == 2 ? "bf16" : "f32");
     if (tm == 64 && tn == 64) {
         DPC_LAUNCH((wgrad_kernel<T, 64, 64, RF>), grid, block, stream, p);
     } else if (tm == 64 && tn == 128) {
@@ -634,7 +637,8 @@ extern "C" int dpc_conv_wgrad(const dpc_conv_desc* d, const void* src, const voi
         q.g = p.g; q.src = src; q.dy = dy; q.part = part; q.Co = d->Co; q.dy_ld = dy_ld;
         q.nks = p.nks; q.kcps = p.kcps; q.ntm = p.ntm; q.ntn = p.ntn; q.lRW = lrw; q.lRH = lrh;
         q.RWm = rwp - 1; q.RHm = rhp - 1; q.Mv = (int)mv;
-        { const char* e = getenv("DPC_WGRAD_XCD"); q.xcd_remap = (e && e[0] == '0') ? 0 : 1; }
+        static const int xcd_remap = (getenv("DPC_WGRAD_XCD") && getenv("DPC_WGRAD_XCD")[0] == '0') ? 0 : 1;  // read once
+        q.xcd_remap = xcd_remap;
         const bool pu = (rwp * rhp) % bkp == 0;  // a chunk never leaves its (n, t) plane
         if (d->dtype_in == DPC_F32) return launch_wgrad2<float>(q, nwm, nwn, pu, stream);
         return launch_wgrad2<bf16_t>(q, nwm, nwn, pu, stream);

@@ -8,21 +8,42 @@
 #include <stdint.h>
 #include <utility>
 
+// ---- kernel-selection trace (dpc_conv_plan / dpc_last_kernel, csrc/plan.hip) --------------------------------------------
+// Every launch site names the kernel it selected (the stringified kernel expression of DPC_LAUNCH, plus whatever the
+// dispatcher adds with dpc_plan_detail: element types, tile shape, padded grid ...).  In plan-only mode (set by dpc_conv_plan
+// around a call of the very same dispatch code with dummy pointers) the launch itself is skipped, so the query can never
+// disagree with what a real call does.  Thread-local: concurrent callers do not see each other's trace.
+extern thread_local int dpc_tls_plan_only;
+void dpc_plan_note(const char* kernel_expr);
+void dpc_plan_detail(const char* fmt, ...);
+
 #ifdef DPC_SIMT_EMU
 #include "simt_emu.h"
-#define DPC_LAUNCH(kernel, grid, block, stream, ...) \
-    simt::launch((grid), (block), [=]() { (kernel)(__VA_ARGS__); })
-#define DPC_LAUNCH_DYN(kernel, grid, block, lds, stream, ...) \
-    simt::launch_dyn((grid), (block), (lds), [=]() { (kernel)(__VA_ARGS__); })
+#define DPC_LAUNCH(kernel, grid, block, stream, ...)                                   \
+    do {                                                                               \
+        dpc_plan_note(#kernel);                                                        \
+        if (!dpc_tls_plan_only) simt::launch((grid), (block), [=]() { (kernel)(__VA_ARGS__); }); \
+    } while (0)
+#define DPC_LAUNCH_DYN(kernel, grid, block, lds, stream, ...)                          \
+    do {                                                                               \
+        dpc_plan_note(#kernel);                                                        \
+        if (!dpc_tls_plan_only) simt::launch_dyn((grid), (block), (lds), [=]() { (kernel)(__VA_ARGS__); }); \
+    } while (0)
 #define DPC_DYN_SMEM(name) unsigned char* name = simt::dyn_smem
 #define DPC_UNROLL
 #define DPC_NOUNROLL
 #else
 #include <hip/hip_runtime.h>
-#define DPC_LAUNCH(kernel, grid, block, stream, ...) \
-    hipLaunchKernelGGL(kernel, (grid), (block), 0, (stream), __VA_ARGS__)
-#define DPC_LAUNCH_DYN(kernel, grid, block, lds, stream, ...) \
-    hipLaunchKernelGGL(kernel, (grid), (block), (lds), (stream), __VA_ARGS__)
+#define DPC_LAUNCH(kernel, grid, block, stream, ...)                                   \
+    do {                                                                               \
+        dpc_plan_note(#kernel);                                                        \
+        if (!dpc_tls_plan_only) hipLaunchKernelGGL(kernel, (grid), (block), 0, (stream), __VA_ARGS__); \
+    } while (0)
+#define DPC_LAUNCH_DYN(kernel, grid, block, lds, stream, ...)                          \
+    do {                                                                               \
+        dpc_plan_note(#kernel);                                                        \
+        if (!dpc_tls_plan_only) hipLaunchKernelGGL(kernel, (grid), (block), (lds), (stream), __VA_ARGS__); \
+    } while (0)
 #define DPC_DYN_SMEM(name) extern __shared__ __attribute__((aligned(16))) unsigned char name[]
 #define DPC_UNROLL _Pragma("unroll")
 #define DPC_NOUNROLL _Pragma("unroll 1")
@@ -45,6 +66,7 @@ __device__ __forceinline__ float fast_rcp(float x) { return __frcp_rn(x); }
 #define DPC_ERR_UNSUPPORTED (-3)
 
 static inline int dpc_launch_status() {
+    if (dpc_tls_plan_only) return DPC_OK;  // nothing was launched (and the query must work without a device)
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? DPC_OK : DPC_ERR_LAUNCH;
 }

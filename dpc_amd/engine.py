@@ -32,9 +32,7 @@ from typing import Dict, List, Optional, Sequence, Tuple
 import torch
 
 from . import _lib as L
-
-LAYER_PLAN = {"resnet18": (2, 2, 2, 2), "resnet34": (3, 4, 6, 3)}  # backbone/resnet_2d3d.py:274-284
-LAYER_WIDTH = (64, 128, 256, 256)                                    # resnet_2d3d.py:217-223
+from .plan import LAYER_PLAN, LAYER_WIDTH, out_shape_of, unit_descs  # layer plan + descriptors shared with the plan query
 BN_EPS = 1e-5
 
 
@@ -191,21 +189,14 @@ class _ConvBN:
         self.Ci, self.Co, self.k, self.s, self.p, self.stem = Ci, Co, k, s, p, stem
         N, T, H, W = in_shape
         self.in_shape = in_shape
-        if stem:
-            self.out_shape = (N, T, H, W)  # s2d grid == output grid
-        else:
-            self.out_shape = (N, (T + 2 * p[0] - k[0]) // s[0] + 1, (H + 2 * p[1] - k[1]) // s[1] + 1,
-                              (W + 2 * p[2] - k[2]) // s[2] + 1)
+        self.out_shape = out_shape_of(in_shape, k, s, p, stem)
         self.taps = k[0] * k[1] * k[2]
         dt = eng.cdtype
         dc = L.dtype_code(dt)
         No, To, Ho, Wo = self.out_shape
         self.rows = No * To * Ho * Wo
         Kp = self.taps * Ci
-        self.desc_f = L.ConvDesc(dc, dc, 0, N, To, Ho, Wo, T, H, W, Ci, Ci, Co, Kp, Co, *k, *s, *p)
-        # input-gradient: rows enumerate the forward input grid, source is dy on the output grid
-        self.desc_d = L.ConvDesc(dc, dc, 1, N, T, H, W, To, Ho, Wo, Co, Co, Ci, self.taps * Co, Ci, *k, *s, *p)
-        self.desc_w = L.ConvDesc(dc, L.F32, 0, N, To, Ho, Wo, T, H, W, Ci, Ci, Co, Kp, Co, *k, *s, *p)
+        self.desc_f, self.desc_d, self.desc_w = unit_descs(Ci, Co, k, s, p, in_shape, dt, stem)
         self.wp = eng.empty((Co, Kp), dt)
         self.wd = None if stem else eng.empty((Ci, self.taps * Co), dt)
         self.raw = eng.empty((No, To, Ho, Wo, Co), dt)

@@ -73,6 +73,20 @@ int dpc_conv_igemm(const dpc_conv_desc* d, const void* src, const void* wgt, voi
 int dpc_conv_wgrad(const dpc_conv_desc* d, const void* src, const void* dy, int32_t dy_ld,
                    float* part, int32_t* nsplit, dpc_stream_t stream);
 
+/* ---- kernel selection, observable --------------------------------------------------------------------------------------------
+ * dpc_conv_igemm / dpc_conv_wgrad pick one of several gfx950 kernels per shape (role-specialised loader/compute kernels,
+ * staged-patch kernels, the generic implicit GEMM).  dpc_conv_plan returns the name of the kernel such a call WOULD launch
+ * (the same dispatch code runs with the launch skipped; pointers are assumed 16-byte aligned): op = DPC_PLAN_IGEMM with
+ * flags DPC_PLAN_ADDEND / DPC_PLAN_STATS for the optional operands, or DPC_PLAN_WGRAD with dy_ld.  dpc_last_kernel returns the
+ * kernel the calling thread's most recent C-ABI call launched last.  Both write a NUL-terminated string (e.g.
+ * "igemm_ws_kernel<true>", "wgrad2_kernel<T,NWM,NWN,true>[T=bf16 nwm=2 nwn=3 padded=1]") and return its length, or < 0. */
+#define DPC_PLAN_IGEMM 0
+#define DPC_PLAN_WGRAD 1
+#define DPC_PLAN_ADDEND 1
+#define DPC_PLAN_STATS 2
+int dpc_conv_plan(const dpc_conv_desc* d, int32_t op, int32_t flags, int32_t dy_ld, char* name, int32_t cap);
+int dpc_last_kernel(char* name, int32_t cap);
+
 /* ---- weight / operand repacking --------------------------------------------------
  * out[i0][i1][i2] (dtype_out, dense) = in[i0*s0 + i1*s1 + i2*s2] (f32).  Turns the
  * reference's [Co][Ci][kT][kH][kW] parameters (state_dict layout, §8b) into the

@@ -24,5 +24,13 @@ for fam, pat in (("dpc_conv_igemm", r"igemm_kernel|igemm_ws_kernel|igemm_wsp_ker
     res[fam] = {"launches": n, "fetch_KiB_raw": f, "write_KiB": w,
                 "hbm_bytes_per_launch": (2.0 * f + w) * 1024.0 / max(n, 1),
                 "note": "FETCH_SIZE x2 (gfx950 wide-load correction), WRITE_SIZE as reported; separate --pmc passes"}
+# stamp: which kernel sources the counters were collected on (bench.py prints it and flags a stale file)
+import glob, hashlib, os
+h = hashlib.sha256()
+for f in sorted(glob.glob("dpc_amd/csrc/*")):
+    if f.endswith((".hip", ".h")):
+        h.update(open(f, "rb").read())
+res["csrc_sha16"] = h.hexdigest()[:16]
+res["git_head"] = os.environ.get("DPC_GIT_HEAD") or (open(".git_head").read().strip() if os.path.exists(".git_head") else None)
 json.dump(res, open(f"profiles/{tag}_pmc_traffic.json", "w"), indent=1)
 print(json.dumps(res, indent=1))

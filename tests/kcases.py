@@ -63,13 +63,23 @@ class K:
             torch.cuda.synchronize()
 
 
+def check_kernel(k: K, expect):
+    """the kernel the last C-ABI call launched (dpc_last_kernel) is the variant the case is meant to cover.
+    expect: None, a name prefix, or "prefix|substring" (both must match)"""
+    if not expect:
+        return
+    got = L.last_kernel(k.lib)
+    pre, _, sub = expect.partition("|")
+    assert got.startswith(pre) and sub in got, f"case meant for {expect}, the library launched {got}"
+
+
 def conv_desc(dtype_in, dtype_out, mode, N, R, S, Ci, src_ld, Co, ldw, ldo, k, s, p):
     return L.ConvDesc(L.dtype_code(dtype_in), L.dtype_code(dtype_out), mode, N, R[0], R[1], R[2], S[0], S[1], S[2],
                       Ci, src_ld, Co, ldw, ldo, k[0], k[1], k[2], s[0], s[1], s[2], p[0], p[1], p[2])
 
 
 # ------------------------------------------------------------------ conv forward (+ BN partial sums)
-def case_conv_fwd(k: K, dtype, N, Ci, Co, T, H, W, ks, st, pd, seed=0):
+def case_conv_fwd(k: K, dtype, N, Ci, Co, T, H, W, ks, st, pd, seed=0, expect=None):
     g = torch.Generator().manual_seed(seed)
     x = q(torch.randn(N, Ci, T, H, W, generator=g), dtype)
     w = q(torch.randn(Co, Ci, *ks, generator=g) * 0.1, dtype)
@@ -83,6 +93,7 @@ def case_conv_fwd(k: K, dtype, N, Ci, Co, T, H, W, ks, st, pd, seed=0):
     rows = k.lib.call("dpc_conv_stats_rows", C.byref(d))
     stats = k.zeros(rows, 2, Co)
     k.call("dpc_conv_igemm", C.byref(d), src, wp, out, None, stats)
+    check_kernel(k, expect)
     k.sync()
     assert relerr(out, cl(y)) < tol(dtype)
     o = out.float().cpu().reshape(-1, Co).double()
@@ -91,7 +102,7 @@ def case_conv_fwd(k: K, dtype, N, Ci, Co, T, H, W, ks, st, pd, seed=0):
     assert (s[:, 1].sum(0) - (o * o).sum(0)).abs().max().item() < 1e-4 * (o * o).sum(0).max().item()
 
 
-def case_conv_dgrad(k: K, dtype, N, Ci, Co, T, H, W, ks, st, pd, seed=1):
+def case_conv_dgrad(k: K, dtype, N, Ci, Co, T, H, W, ks, st, pd, seed=1, expect=None):
     g = torch.Generator().manual_seed(seed)
     x = torch.randn(N, Ci, T, H, W, generator=g).requires_grad_()
     w = q(torch.randn(Co, Ci, *ks, generator=g) * 0.1, dtype)
@@ -105,11 +116,12 @@ def case_conv_dgrad(k: K, dtype, N, Ci, Co, T, H, W, ks, st, pd, seed=1):
     out = k.empty(N, T, H, W, Ci, dtype=dtype)
     wd = k.t(w.permute(1, 2, 3, 4, 0).reshape(Ci, taps * Co), dtype)
     k.call("dpc_conv_igemm", C.byref(d), k.t(cl(gy), dtype), wd, out, k.t(add, dtype), None)
+    check_kernel(k, expect)
     k.sync()
     assert relerr(out, cl(gx) + add) < tol(dtype)
 
 
-def case_conv_dgrad_inplace(k: K, dtype, N, Ci, Co, T, H, W, ks, st, pd, seed=5):
+def case_conv_dgrad_inplace(k: K, dtype, N, Ci, Co, T, H, W, ks, st, pd, seed=5, expect=None):
     """input-gradient accumulated IN PLACE (addend == out): the engine adds a strided 1x1 downsample's gradient onto the
     main path's dx; positions no tap reaches must keep their value exactly"""
     g = torch.Generator().manual_seed(seed)
@@ -125,13 +137,14 @@ def case_conv_dgrad_inplace(k: K, dtype, N, Ci, Co, T, H, W, ks, st, pd, seed=5)
     out = k.t(base.clone(), dtype)
     wd = k.t(w.permute(1, 2, 3, 4, 0).reshape(Ci, taps * Co), dtype)
     k.call("dpc_conv_igemm", C.byref(d), k.t(cl(gy), dtype), wd, out, out, None)
+    check_kernel(k, expect)
     k.sync()
     assert relerr(out, cl(gx) + base) < tol(dtype)
     untouched = cl(gx) == 0
     assert torch.equal(out.cpu().float()[untouched], base[untouched])
 
 
-def case_conv_wgrad(k: K, dtype, N, Ci, Co, T, H, W, ks, st, pd, seed=2):
+def case_conv_wgrad(k: K, dtype, N, Ci, Co, T, H, W, ks, st, pd, seed=2, expect=None):
     g = torch.Generator().manual_seed(seed)
     x = q(torch.randn(N, Ci, T, H, W, generator=g), dtype)
     w = (torch.randn(Co, Ci, *ks, generator=g) * 0.1).requires_grad_()
@@ -145,6 +158,7 @@ def case_conv_wgrad(k: K, dtype, N, Ci, Co, T, H, W, ks, st, pd, seed=2):
     k.call("dpc_conv_wgrad", C.byref(d), None, None, Co, None, C.byref(ns))
     part = k.zeros(ns.value, Co, taps * Ci)
     k.call("dpc_conv_wgrad", C.byref(d), k.t(cl(x), dtype), k.t(cl(gy), dtype), Co, part, C.byref(ns))
+    check_kernel(k, expect)
     dw = k.zeros(*gw.shape)
     k.call("dpc_reduce_unpack", part, ns.value, dw, Co, taps, Ci, Ci * taps, 1, taps, 0)
     k.sync()
@@ -162,7 +176,7 @@ def case_gemm_nt(k: K, dtype, M, N, Kd, seed=3):
     assert relerr(out, A.double() @ B.double().t()) < 1e-5
 
 
-def case_stem(k: K, dtype, BN, T, H, W, Co=64, seed=4):
+def case_stem(k: K, dtype, BN, T, H, W, Co=64, seed=4, expect=(None, None)):
     """Conv3d(3,Co,(1,7,7),s(1,2,2),p(0,3,3)) (resnet_2d3d.py:211) through the space-to-depth path."""
     g = torch.Generator().manual_seed(seed)
     x = torch.randn(BN, 3, T, H, W, generator=g)
@@ -178,6 +192,7 @@ def case_stem(k: K, dtype, BN, T, H, W, Co=64, seed=4):
     rows = k.lib.call("dpc_conv_stats_rows", C.byref(d))
     stats = k.zeros(rows, 2, Co)
     k.call("dpc_conv_igemm", C.byref(d), xs, wp, out, None, stats)
+    check_kernel(k, expect[0])
     k.sync()
     assert relerr(out, cl(y)) < tol(dtype)
     o = out.float().cpu().reshape(-1, Co).double()  # batch-norm partial sums are those of the STORED values
@@ -190,6 +205,7 @@ def case_stem(k: K, dtype, BN, T, H, W, Co=64, seed=4):
     k.call("dpc_conv_wgrad", C.byref(d), None, None, Co, None, C.byref(ns))
     part = k.zeros(ns.value, Co, 256)
     k.call("dpc_conv_wgrad", C.byref(d), xs, k.t(cl(gy), dtype), Co, part, C.byref(ns))
+    check_kernel(k, expect[1])
     dw = k.zeros(Co, 3, 1, 7, 7)
     k.call("dpc_unpack_stem_wgrad", part, ns.value, dw, Co)
     k.sync()

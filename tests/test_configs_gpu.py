@@ -45,3 +45,42 @@ def test_bf16_full_config4_shape_runs():
         r = eng.train_step(x).cpu()
     assert torch.isfinite(r).all() and torch.isfinite(eng.flat_g).all() and r[0] < r0[0]
     assert eng.R == B * 3 * 49
+
+
+def test_cfg4_full_shard_properties():
+    """BASELINE.json configs[3] on one GPU shard at its REAL batch (resnet34, 224^2, B = 44 -> 352 clips through the backbone:
+    14 x 14 / 7 x 7 planes straddling 256-row tiles, padded-grid weight gradients, R = 6 468 ragged score) in bf16:
+    size-independent invariants, as test_full_batch_properties does for cfg2."""
+    B = 44
+    eng = DPCEngine("resnet34", 224, 8, 5, 3, B, DEV, torch.bfloat16, score_path="fused")
+    eng.load_params(O.init_params_reference_style("resnet34", seed=0))
+    x = torch.randn(B, 8, 3, 5, 224, 224, device=DEV, generator=torch.Generator(DEV).manual_seed(4))
+    eng.forward(x, train=True, materialise=True)
+    res0 = eng.loss_topk(True).clone().cpu()
+    eng.backward()
+    torch.cuda.synchronize()
+    g_m = eng.flat_g.clone()
+    R = eng.R
+    assert R == 6468 and eng.SQ == 49 and torch.isfinite(res0).all() and torch.isfinite(g_m).all()
+    # BatchNorm invariant on a strided unit of the 224 family (28 x 28 planes) and on the last 14 x 14 unit
+    for u in (eng.blocks[3].c1, eng.blocks[12].c2):
+        z = u.raw.float().view(-1, u.Co) * u.scale + u.shift
+        assert z.mean(0).abs().max().item() < 2e-2 and (z.var(0, unbiased=False) - 1).abs().max().item() < 2e-2
+    # the score is the Gram matrix of its operands; CE gradient rows sum to zero
+    chk = eng.pred.float().view(R, -1)[:64] @ eng.feat_inf.float().view(R, -1).t()
+    assert (chk - eng.score[:64]).abs().max().item() < 1e-2 * chk.abs().max().item()
+    assert eng.dscore.float()[:, :R].sum(1).abs().max().item() < 1e-3
+    # fused path of the same step (what train_step runs): same loss / top-k, gradients within the bf16 dS rounding
+    assert eng.forward(x, train=True, materialise=False, new_draw=False) is None and eng.score_mode == "fused"
+    res_f = eng.loss_topk(True).clone().cpu()
+    eng.backward()
+    torch.cuda.synchronize()
+    assert abs(res_f[0].item() - res0[0].item()) < 1e-3
+    assert res_f[1:].tolist() == pytest.approx(res0[1:].tolist(), abs=3.0 / R)
+    assert ((eng.flat_g - g_m).norm() / g_m.norm()).item() < 3e-2
+    mk = eng.get_mask().view(R, R)
+    assert torch.equal((mk == 1).to(torch.int8).argmax(1), torch.arange(R, device=DEV))
+    r0 = eng.train_step(x).cpu()
+    for _ in range(3):
+        r = eng.train_step(x).cpu()
+    assert torch.isfinite(r).all() and r[0].item() < r0[0].item()
