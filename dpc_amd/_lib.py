@@ -55,6 +55,11 @@ class LcHeadDesc(C.Structure):
                                            "g_bn_bias", "dctx", "d_hlast")])
 
 
+class ConvEpilogue(C.Structure):
+    """struct dpc_conv_epilogue (include/dpc_hip.h)"""
+    _fields_ = [(n, C.c_void_p) for n in ("addend", "addend_mask", "bn_raw", "bn_mask", "bn_mean", "bn_invstd", "stats")]
+
+
 class PackEntry(C.Structure):
     """struct dpc_pack_entry (include/dpc_hip.h)"""
     _fields_ = [("in_", C.c_void_p), ("out", C.c_void_p), ("d0", C.c_int32), ("d1", C.c_int32), ("d2", C.c_int32), ("block0", C.c_int32),
@@ -70,6 +75,7 @@ _SIGS = {
     "dpc_abi_version": [],
     "dpc_conv_stats_rows": [C.POINTER(ConvDesc)],
     "dpc_conv_igemm": [C.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _vp],
+    "dpc_conv_igemm_ex": [C.POINTER(ConvDesc), _vp, _vp, _vp, C.POINTER(ConvEpilogue), _vp],
     "dpc_conv_wgrad": [C.POINTER(ConvDesc), _vp, _vp, _i32, _vp, C.POINTER(_i32), _vp],
     "dpc_conv_plan": [C.POINTER(ConvDesc), _i32, _i32, _i32, C.c_char_p, _i32],
     "dpc_last_kernel": [C.c_char_p, _i32],
@@ -161,14 +167,21 @@ class Lib:
         return rc
 
 
-PLAN_IGEMM, PLAN_WGRAD, PLAN_ADDEND, PLAN_STATS = 0, 1, 1, 2
+PLAN_IGEMM, PLAN_WGRAD, PLAN_ADDEND, PLAN_STATS, PLAN_ADDEND_MASK, PLAN_BNRED = 0, 1, 1, 2, 4, 8
 
 
-def conv_plan(lib: "Lib", desc: ConvDesc, op: int = PLAN_IGEMM, addend: bool = False, stats: bool = False, dy_ld: int = 0) -> str:
-    """name of the kernel dpc_conv_igemm / dpc_conv_wgrad would launch for `desc` (include/dpc_hip.h: dpc_conv_plan)"""
+def conv_plan(lib: "Lib", desc: ConvDesc, op: int = PLAN_IGEMM, addend: bool = False, stats: bool = False, dy_ld: int = 0,
+              addend_mask: bool = False, bnred: bool = False) -> str:
+    """name of the kernel dpc_conv_igemm(_ex) / dpc_conv_wgrad would launch for `desc` (include/dpc_hip.h: dpc_conv_plan);
+    "" when the combination is not supported (dpc_conv_igemm_ex returns DPC_ERR_UNSUPPORTED)"""
     buf = C.create_string_buffer(192)
-    flags = (PLAN_ADDEND if addend else 0) | (PLAN_STATS if stats else 0)
-    lib.call("dpc_conv_plan", C.byref(desc), op, flags, dy_ld or desc.Co, buf, 192)
+    flags = ((PLAN_ADDEND if addend else 0) | (PLAN_STATS if stats else 0) | (PLAN_ADDEND_MASK if addend_mask else 0) |
+             (PLAN_BNRED if bnred else 0))
+    rc = lib._fn("dpc_conv_plan")(C.byref(desc), op, flags, dy_ld or desc.Co, buf, 192)
+    if rc == -3:
+        return ""
+    if rc < 0:
+        raise DpcError(f"dpc_conv_plan failed with code {rc}")
     return buf.value.decode()
 
 

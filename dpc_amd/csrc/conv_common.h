@@ -135,16 +135,63 @@ __device__ __forceinline__ u32x4 mask_unit(u32x4 v, bool ok) {
     return v;
 }
 
+// ---- fused backward pieces of an input-gradient epilogue (dpc_conv_igemm_ex, include/dpc_hip.h) -----------------------------
+// addend_mask: the residual addend is the BLOCK's incoming gradient gated by the ReLU sign mask of the block output
+//   (out = conv + (bit ? addend : 0)): the masked gradient dz is never written as a tensor.
+// bn_raw / bn_mask / bn_mean / bn_invstd: the BatchNorm-backward reduction of the unit whose output gradient this launch produces,
+//   taken from the stored (rounded) outputs: dz = out (bit-gated when bn_mask), stats rows = (sum dz, sum dz * xhat).
+// Masks are dpc_bn_apply's: one byte per 16-byte unit of a DENSE [rows][Co] tensor (ldo == Co is required).
+struct EpiExtra {
+    const uint8_t* addend_mask;
+    const void* bn_raw;
+    const uint8_t* bn_mask;
+    const float* bn_mean;
+    const float* bn_invstd;
+};
+static inline EpiExtra epi_none() {
+    EpiExtra e = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    return e;
+}
+static inline bool epi_any(const EpiExtra& e) { return e.addend_mask || e.bn_raw; }
+
+// one 16-byte output unit: o = conv (+ gated addend), then either the forward statistics (sum, sum of squares of the stored
+// values) or the BatchNorm-backward partial sums.  mu / is: the unit's EPO channel statistics (registers of the caller).
+template <class TO, int EPO>
+__device__ __forceinline__ void epi_unit(u32x4& o, bool has_add, const u32x4& add, unsigned addbits, bool bnred, const u32x4& raw,
+                                         unsigned bnbits, const float (&mu)[EPO], const float (&is)[EPO], float (&s1)[EPO], float (&s2)[EPO]) {
+    if (has_add) {
+        float sv[EPO];
+        DPC_UNROLL
+        for (int e = 0; e < EPO; ++e) sv[e] = unit_get<TO>(o, e) + (((addbits >> e) & 1u) ? unit_get<TO>(add, e) : 0.f);
+        o = unit_pack<TO>(sv);
+    }
+    if (bnred) {
+        DPC_UNROLL
+        for (int e = 0; e < EPO; ++e) {
+            const float dz = ((bnbits >> e) & 1u) ? unit_get<TO>(o, e) : 0.f;
+            s1[e] += dz;
+            s2[e] += dz * ((unit_get<TO>(raw, e) - mu[e]) * is[e]);
+        }
+    } else {
+        DPC_UNROLL
+        for (int e = 0; e < EPO; ++e) {
+            const float v = unit_get<TO>(o, e);
+            s1[e] += v;
+            s2[e] += v * v;
+        }
+    }
+}
+
 // conv_halo.hip: LDS-staged-patch kernel for 1xKHxKW stride-1 same-size convs.  _try returns 1 when
 // the shape is not served (the caller then runs the generic implicit-GEMM path); _rows returns the
 // number of batch-norm partial rows that kernel would write (0 = not served).
 int dpc_conv_halo_try(const dpc_conv_desc* d, const void* src, const void* wgt, void* out, const void* addend, float* stats,
-                      hipStream_t stream);
+                      const EpiExtra& epi, hipStream_t stream);
 int dpc_conv_halo_rows(const dpc_conv_desc* d);
 
 // conv_igemm_ws.hip: loader/compute wave-specialised implicit GEMM for Co >= 128 (bf16); same contract.
 int dpc_conv_ws_try(const dpc_conv_desc* d, const void* src, const void* wgt, void* out, const void* addend, float* stats,
-                    hipStream_t stream);
+                    const EpiExtra& epi, hipStream_t stream);
 int dpc_conv_ws_rows(const dpc_conv_desc* d);
 
 // conv_wgrad_patch.hip: weight gradient of 1x3x3 stride-1 convs from one staged source patch (bf16).

@@ -37,6 +37,7 @@ struct HaloParams {
     void* out;
     const void* addend;
     float* stats;
+    EpiExtra epi;
     int NF, H, W, C, Co, ldw, ldo;
     int ph, pw, flip;
     int TR, TW, lTW, HR, HWd;
@@ -211,18 +212,33 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(HaloParams p) {
         const int cu = tid % UPR;
         const int col0 = cu * EPO;
         if (p.vec_out) {
+          const bool bnred = p.epi.bn_raw != nullptr;
+          float mu[EPO], is[EPO];
+          DPC_UNROLL
+          for (int e = 0; e < EPO; ++e) {
+              const bool okc = bnred && col0 + e < p.Co;
+              mu[e] = okc ? p.epi.bn_mean[col0 + e] : 0.f;
+              is[e] = okc ? p.epi.bn_invstd[col0 + e] : 0.f;
+          }
           DPC_UNROLL
           for (int hb = 0; hb < OIT; hb += 2) {  // two units at a time: the B operand owns most of the register file
-            u32x4 ov[2], av[2];
+            u32x4 ov[2], av[2], rv[2];
+            unsigned ab[2], bb[2];
             DPC_UNROLL
             for (int it = 0; it < 2; ++it) {
                 const int row_l = (tid + 256 * (hb + it)) / UPR;
                 ov[it] = *(const u32x4*)(lds + (row_l * BN + cu * EPO) * (int)sizeof(TO));
                 const int row = rowmap[row_l];
                 const bool ok = row >= 0 && col0 < p.Co;
+                const long long eo = (long long)row * p.ldo + col0;
+                ab[it] = ~0u; bb[it] = ~0u;
                 if (p.addend) {
-                    const char* a = (const char*)p.addend + ((long long)row * p.ldo + col0) * (int)sizeof(TO);
-                    av[it] = *(const u32x4*)(ok ? a : zero);
+                    av[it] = *(const u32x4*)(ok ? (const char*)p.addend + eo * (int)sizeof(TO) : zero);
+                    if (p.epi.addend_mask) ab[it] = ok ? (unsigned)p.epi.addend_mask[eo / EPO] : 0u;
+                }
+                if (bnred) {
+                    rv[it] = *(const u32x4*)(ok ? (const char*)p.epi.bn_raw + eo * (int)sizeof(TO) : zero);
+                    if (p.epi.bn_mask) bb[it] = ok ? (unsigned)p.epi.bn_mask[eo / EPO] : 0u;
                 }
             }
             DPC_UNROLL
@@ -230,19 +246,8 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(HaloParams p) {
                 const int row = rowmap[(tid + 256 * (hb + it)) / UPR];
                 if (row >= 0 && col0 < p.Co) {
                     u32x4 o = ov[it];
-                    if (p.addend) {
-                        float sv[EPO];
-                        DPC_UNROLL
-                        for (int e = 0; e < EPO; ++e) sv[e] = unit_get<TO>(o, e) + unit_get<TO>(av[it], e);
-                        o = unit_pack<TO>(sv);
-                    }
+                    epi_unit<TO, EPO>(o, p.addend != nullptr, av[it], ab[it], bnred, rv[it], bb[it], mu, is, s1, s2);
                     *(u32x4*)((char*)p.out + ((long long)row * p.ldo + col0) * (int)sizeof(TO)) = o;
-                    DPC_UNROLL
-                    for (int e = 0; e < EPO; ++e) {
-                        const float v = unit_get<TO>(o, e);
-                        s1[e] += v;
-                        s2[e] += v * v;
-                    }
                 }
             }
           }
@@ -316,7 +321,9 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(HaloParams p) {
 // 32-byte positions (one K chunk = the four kw taps of a kernel row = four neighbouring positions).
 // BM = output positions per tile: 128, or 256 for the stem (its MFMA phase is only 16 steps, so the fixed cost of a
 // tile -- two workgroup barriers, staging, address arithmetic: ~0.5 us -- was 40 % of its 1.35 us tile period).
-template <bool HAS_ADD, int UPP, int BM>
+// EPI: the fused backward pieces of dpc_conv_igemm_ex (gated residual addend, BatchNorm-backward partial sums); like the addend
+// they belong to the helper waves: the mask bytes and the raw unit of tile j are requested one interval before its epilogue.
+template <bool HAS_ADD, int UPP, int BM, bool EPI = false>
 __global__ __launch_bounds__(512, 2) void conv_halo_ws_kernel(HaloParams p) {
     typedef bf16_t T;
     typedef bf16_t TO;
@@ -469,9 +476,20 @@ __global__ __launch_bounds__(512, 2) void conv_halo_ws_kernel(HaloParams p) {
         // The residual addend of tile j is requested one interval before it is consumed: with the loads issued
         // inside the epilogue only 4 x 16 B per lane were in flight and the extra 0.67 GB of an input-gradient
         // with residual cost +270 us (the kernel then moves 2 GB and is HBM-bound).
-        u32x4 av[NQ];
+        struct Pre {             // what the epilogue of one tile needs from HBM besides the staged tile
+            u32x4 add[NQ], raw[NQ];
+            unsigned ab[NQ], bb[NQ];
+        };
+        Pre cur;
         DPC_UNROLL
-        for (int q = 0; q < NQ; ++q) av[q] = u32x4{0u, 0u, 0u, 0u};
+        for (int q = 0; q < NQ; ++q) { cur.add[q] = u32x4{0u, 0u, 0u, 0u}; cur.raw[q] = u32x4{0u, 0u, 0u, 0u}; cur.ab[q] = ~0u; cur.bb[q] = ~0u; }
+        const bool bnred = EPI && p.epi.bn_raw != nullptr;
+        float mu[EPO], is[EPO];
+        DPC_UNROLL
+        for (int e = 0; e < EPO; ++e) {
+            mu[e] = bnred ? p.epi.bn_mean[col0 + e] : 0.f;
+            is[e] = bnred ? p.epi.bn_invstd[col0 + e] : 0.f;
+        }
         auto tile_rows = [&](int j, int (&rows)[NQ]) {
             int frame, h0, w0;
             tile_origin(m_prog + j * p.gm, frame, h0, w0);
@@ -483,16 +501,24 @@ __global__ __launch_bounds__(512, 2) void conv_halo_ws_kernel(HaloParams p) {
                 rows[q] = ok ? (frame * p.H + h) * p.W + w : -1;
             }
         };
-        auto fetch_addend = [&](int j, u32x4 (&dst)[NQ]) {
+        auto prefetch = [&](int j, Pre& d) {
             int rows[NQ];
             tile_rows(j, rows);
             DPC_UNROLL
             for (int q = 0; q < NQ; ++q) {
-                const char* a = (const char*)p.addend + ((long long)rows[q] * p.ldo + col0) * 2;
-                dst[q] = *(const u32x4*)(rows[q] >= 0 ? a : zero);
+                const bool ok = rows[q] >= 0;
+                const long long eo = (long long)rows[q] * p.ldo + col0;
+                if (HAS_ADD) {
+                    d.add[q] = *(const u32x4*)(ok ? (const char*)p.addend + eo * 2 : zero);
+                    if (EPI && p.epi.addend_mask) d.ab[q] = ok ? (unsigned)p.epi.addend_mask[eo >> 3] : 0u;
+                }
+                if (bnred) {
+                    d.raw[q] = *(const u32x4*)(ok ? (const char*)p.epi.bn_raw + eo * 2 : zero);
+                    if (p.epi.bn_mask) d.bb[q] = ok ? (unsigned)p.epi.bn_mask[eo >> 3] : 0u;
+                }
             }
         };
-        auto epilogue = [&](int j, const u32x4 (&add)[NQ]) {
+        auto epilogue = [&](int j, const Pre& d) {
             int rows[NQ];
             tile_rows(j, rows);
             const unsigned char* stg = lds + NPB * PATCH + (j & 1) * STG;
@@ -503,47 +529,35 @@ __global__ __launch_bounds__(512, 2) void conv_halo_ws_kernel(HaloParams p) {
             for (int q = 0; q < NQ; ++q) {
                 if (rows[q] >= 0) {
                     u32x4 o = ov[q];
-                    if (HAS_ADD) {
-                        float sv[EPO];
-                        DPC_UNROLL
-                        for (int e = 0; e < EPO; ++e) sv[e] = unit_get<TO>(o, e) + unit_get<TO>(add[q], e);
-                        o = unit_pack<TO>(sv);
-                    }
+                    epi_unit<TO, EPO>(o, HAS_ADD, d.add[q], d.ab[q], bnred, d.raw[q], d.bb[q], mu, is, s1, s2);
                     *(u32x4*)((char*)p.out + ((long long)rows[q] * p.ldo + col0) * 2) = o;
-                    DPC_UNROLL
-                    for (int e = 0; e < EPO; ++e) {
-                        const float v = unit_get<TO>(o, e);
-                        s1[e] += v;
-                        s2[e] += v * v;
-                    }
                 }
             }
         };
+        constexpr bool PRE = HAS_ADD || EPI;   // anything to request ahead of the epilogue
         issue(0);
         DPC_UNROLL
         for (int a = 1; a < NPB - 1; ++a)
             if (ntiles > a) issue(a);
-        if (HAS_ADD) fetch_addend(0, av);
+        if (PRE) prefetch(0, cur);
         for (int j = 0; j <= ntiles; ++j) {
             // patch j must have landed.  Newer than its pieces are: this wave's stores of older tiles and the LIT pieces of each
             // of the patches j+1 .. j+NPB-2.  Loads (LDS-DMA included) complete in order among themselves, so "at most that many
-            // outstanding" implies every piece of patch j is done whatever the stores do.  (The addend loads of the residual
-            // variant are requested between two patches: counting them as absent only makes the wait stricter.)
+            // outstanding" implies every piece of patch j is done whatever the stores do.  (The addend / raw / mask loads of the
+            // residual and fused-reduction variants are requested between two patches: counting them as absent only makes the
+            // wait stricter.)
             if (j < ntiles) {
                 const int newer = ntiles - 1 - j < NPB - 2 ? ntiles - 1 - j : NPB - 2;
                 if (newer >= 2) wait_vmcnt<2 * LIT>(); else if (newer == 1) wait_vmcnt<LIT>(); else wait_vmcnt<0>();
             }
             barrier_lds_only();  // B1(j)
-            if (HAS_ADD) {
-                u32x4 avn[NQ];
-                DPC_UNROLL
-                for (int q = 0; q < NQ; ++q) avn[q] = av[q];
-                if (j < ntiles && j >= 1) fetch_addend(j, avn);
-                if (j >= 1 && !HP_DBG(8)) epilogue(j - 1, av);
-                DPC_UNROLL
-                for (int q = 0; q < NQ; ++q) av[q] = avn[q];
+            if (PRE) {
+                Pre nxt = cur;
+                if (j < ntiles && j >= 1) prefetch(j, nxt);
+                if (j >= 1 && !HP_DBG(8)) epilogue(j - 1, cur);
+                cur = nxt;
             } else if (j >= 1 && !HP_DBG(8)) {
-                epilogue(j - 1, av);
+                epilogue(j - 1, cur);
             }
             if (j + NPB - 1 < ntiles) issue(j + NPB - 1);  // into the buffer of patch j-1, released at B2(j-1)
             barrier_lds_only();  // B2(j)
@@ -627,10 +641,10 @@ int dpc_conv_halo_rows(const dpc_conv_desc* d) {
 
 // returns 1 when the shape is not served by this kernel (caller falls back to dpc_conv_igemm's generic path)
 int dpc_conv_halo_try(const dpc_conv_desc* d, const void* src, const void* wgt, void* out, const void* addend, float* stats,
-                      hipStream_t stream) {
+                      const EpiExtra& epi, hipStream_t stream) {
     HaloParams p;
     if (!halo_plan(d, &p)) return 1;
-    p.src = src; p.wgt = wgt; p.out = out; p.addend = addend; p.stats = stats;
+    p.src = src; p.wgt = wgt; p.out = out; p.addend = addend; p.stats = stats; p.epi = epi;
 #ifdef DPC_WS_PROBE
     p.dbg = getenv("DPC_WS_DBG") ? atoi(getenv("DPC_WS_DBG")) : 0;
 #else
@@ -642,14 +656,21 @@ int dpc_conv_halo_try(const dpc_conv_desc* d, const void* src, const void* wgt, 
     if (p.ws && !ws_go) {  // the specialised kernel declined at launch: generic patch kernel, same number of stats rows as promised
         const int promised = p.gm, vo = p.vec_out;
         if (!halo_plan(d, &p, false)) return 1;
-        p.src = src; p.wgt = wgt; p.out = out; p.addend = addend; p.stats = stats;
+        p.src = src; p.wgt = wgt; p.out = out; p.addend = addend; p.stats = stats; p.epi = epi;
         p.vec_out = vo;
         if (p.gm > promised) p.gm = promised;
     }
     dim3 grid((unsigned)p.gm), block(256);
     if (ws_go) {
         if (d->KH == 4) {
+            if (epi_any(epi)) return DPC_ERR_UNSUPPORTED;  // the stem has no input-gradient
             DPC_LAUNCH((conv_halo_ws_kernel<false, 2, 256>), grid, dim3(512), stream, p);
+        } else if (epi_any(epi)) {
+            if (addend) {
+                DPC_LAUNCH((conv_halo_ws_kernel<true, 8, 128, true>), grid, dim3(512), stream, p);
+            } else {
+                DPC_LAUNCH((conv_halo_ws_kernel<false, 8, 128, true>), grid, dim3(512), stream, p);
+            }
         } else if (addend) {
             DPC_LAUNCH((conv_halo_ws_kernel<true, 8, 128>), grid, dim3(512), stream, p);
         } else {

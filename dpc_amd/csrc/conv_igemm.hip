@@ -52,6 +52,7 @@ struct IGemmParams {
     void* out;
     const void* addend;
     float* stats;
+    EpiExtra epi;
     int Ncol, ldw, ldo;
     int gm, ntn, ntm;
     int vec_out;  // Ncol and ldo are multiples of the 16-byte output unit
@@ -363,16 +364,31 @@ __global__ __launch_bounds__(256, (BN == 64 ? 3 : 2)) void igemm_kernel(IGemmPar
             return (m0 + row_l < g.M) ? m0 + row_l : -1;
         };
         if (p.vec_out) {
-            u32x4 ov[OIT], av[OIT];
+            const bool bnred = p.epi.bn_raw != nullptr;
+            float mu[EPO], is[EPO];
+            DPC_UNROLL
+            for (int e = 0; e < EPO; ++e) {
+                const bool okc = bnred && col0 + e < p.Ncol;
+                mu[e] = okc ? p.epi.bn_mean[col0 + e] : 0.f;
+                is[e] = okc ? p.epi.bn_invstd[col0 + e] : 0.f;
+            }
+            u32x4 ov[OIT], av[OIT], rv[OIT];
+            unsigned ab[OIT], bb[OIT];
             DPC_UNROLL
             for (int it = 0; it < OIT; ++it) {
                 const int row_l = (tid + 256 * it) / UPR;
                 ov[it] = *(const u32x4*)(lds + (row_l * BN + cu * EPO) * (int)sizeof(TO));
                 const int row = out_row(row_l);
                 const bool ok = row >= 0 && col0 < p.Ncol;
+                const long long eo = (long long)row * p.ldo + col0;  // element offset of the unit (dense tensors: ldo == Ncol with masks)
+                ab[it] = ~0u; bb[it] = ~0u;
                 if (p.addend) {
-                    const char* a = (const char*)p.addend + ((long long)row * p.ldo + col0) * (int)sizeof(TO);
-                    av[it] = *(const u32x4*)(ok ? a : zero);
+                    av[it] = *(const u32x4*)(ok ? (const char*)p.addend + eo * (int)sizeof(TO) : zero);
+                    if (p.epi.addend_mask) ab[it] = ok ? (unsigned)p.epi.addend_mask[eo / EPO] : 0u;
+                }
+                if (bnred) {
+                    rv[it] = *(const u32x4*)(ok ? (const char*)p.epi.bn_raw + eo * (int)sizeof(TO) : zero);
+                    if (p.epi.bn_mask) bb[it] = ok ? (unsigned)p.epi.bn_mask[eo / EPO] : 0u;
                 }
             }
             DPC_UNROLL
@@ -380,19 +396,8 @@ __global__ __launch_bounds__(256, (BN == 64 ? 3 : 2)) void igemm_kernel(IGemmPar
                 const int row = out_row((tid + 256 * it) / UPR);
                 if (row >= 0 && col0 < p.Ncol) {
                     u32x4 o = ov[it];
-                    if (p.addend) {
-                        float sv[EPO];
-                        DPC_UNROLL
-                        for (int e = 0; e < EPO; ++e) sv[e] = unit_get<TO>(o, e) + unit_get<TO>(av[it], e);
-                        o = unit_pack<TO>(sv);
-                    }
+                    epi_unit<TO, EPO>(o, p.addend != nullptr, av[it], ab[it], bnred, rv[it], bb[it], mu, is, s1, s2);
                     *(u32x4*)((char*)p.out + ((long long)row * p.ldo + col0) * (int)sizeof(TO)) = o;
-                    DPC_UNROLL
-                    for (int e = 0; e < EPO; ++e) {
-                        const float v = unit_get<TO>(o, e);
-                        s1[e] += v;
-                        s2[e] += v * v;
-                    }
                 }
             }
         } else {  // ragged output width: element-wise tail path
@@ -542,9 +547,32 @@ static int launch_igemm(IGemmParams& p, int bn, hipStream_t stream) {
     return launch_igemm_bn<T, TO, 128>(p, gather, stream);
 }
 
+static int conv_igemm_impl(const dpc_conv_desc* d, const void* src, const void* wgt, void* out, const void* addend, float* stats,
+                           const EpiExtra& epi, hipStream_t stream);
+
 extern "C" int dpc_conv_igemm(const dpc_conv_desc* d, const void* src, const void* wgt, void* out,
                               const void* addend, float* stats, dpc_stream_t stream_) {
-    hipStream_t stream = (hipStream_t)stream_;
+    return conv_igemm_impl(d, src, wgt, out, addend, stats, epi_none(), (hipStream_t)stream_);
+}
+
+extern "C" int dpc_conv_igemm_ex(const dpc_conv_desc* d, const void* src, const void* wgt, void* out, const dpc_conv_epilogue* e,
+                                 dpc_stream_t stream_) {
+    if (!d || !e) return DPC_ERR_ARG;
+    EpiExtra x = {e->addend_mask, e->bn_raw, e->bn_mask, e->bn_mean, e->bn_invstd};
+    if (x.addend_mask && !e->addend) return DPC_ERR_ARG;
+    if (x.bn_raw && (!x.bn_mean || !x.bn_invstd || !e->stats)) return DPC_ERR_ARG;
+    if (x.bn_mask && !x.bn_raw) return DPC_ERR_ARG;
+    if (epi_any(x)) {
+        // masks index dense [rows][Co] tensors by 16-byte unit; the fused pieces live in the vectorised epilogue only
+        const int epo = d->dtype_out == DPC_BF16 ? 8 : 4;
+        if (d->ldo != d->Co || d->Co % epo || d->dtype_in != d->dtype_out) return DPC_ERR_UNSUPPORTED;
+        if (((uintptr_t)out % 16) || ((uintptr_t)e->addend % 16) || ((uintptr_t)x.bn_raw % 16)) return DPC_ERR_UNSUPPORTED;
+    }
+    return conv_igemm_impl(d, src, wgt, out, e->addend, e->stats, x, (hipStream_t)stream_);
+}
+
+static int conv_igemm_impl(const dpc_conv_desc* d, const void* src, const void* wgt, void* out, const void* addend, float* stats,
+                           const EpiExtra& epi, hipStream_t stream) {
     IGemmParams p;
     int rc = make_gather_geom(d, &p.g);
     if (rc) return rc;
@@ -552,11 +580,11 @@ extern "C" int dpc_conv_igemm(const dpc_conv_desc* d, const void* src, const voi
     const int per16 = d->dtype_in == DPC_BF16 ? 8 : 4;
     if (d->ldw % per16) return DPC_ERR_UNSUPPORTED;
     if (d->ldo < d->Co || d->ldw < p.g.Kp) return DPC_ERR_ARG;
-    rc = dpc_conv_halo_try(d, src, wgt, out, addend, stats, stream);  // LDS-staged patch kernel when the shape allows
+    rc = dpc_conv_halo_try(d, src, wgt, out, addend, stats, epi, stream);  // LDS-staged patch kernel when the shape allows
     if (rc != 1) return rc;
-    rc = dpc_conv_ws_try(d, src, wgt, out, addend, stats, stream);    // loader/compute specialised kernel for the wide layers
+    rc = dpc_conv_ws_try(d, src, wgt, out, addend, stats, epi, stream);    // loader/compute specialised kernel for the wide layers
     if (rc != 1) return rc;
-    p.src = src; p.wgt = wgt; p.out = out; p.addend = addend; p.stats = stats;
+    p.src = src; p.wgt = wgt; p.out = out; p.addend = addend; p.stats = stats; p.epi = epi;
     p.Ncol = d->Co; p.ldw = d->ldw; p.ldo = d->ldo;
     const int epo = d->dtype_out == DPC_BF16 ? 8 : 4;
     p.vec_out = (d->Co % epo == 0 && d->ldo % epo == 0 && ((uintptr_t)out % 16 == 0) && ((uintptr_t)addend % 16 == 0)) ? 1 : 0;

@@ -844,9 +844,10 @@ int dpc_conv_ws_rows(const dpc_conv_desc* d) {
 
 // returns 1 when the shape is not served by this kernel
 int dpc_conv_ws_try(const dpc_conv_desc* d, const void* src, const void* wgt, void* out, const void* addend, float* stats,
-                    hipStream_t stream) {
+                    const EpiExtra& epi, hipStream_t stream) {
     WsParams p;
     if (!ws_plan(d, &p)) return 1;
+    if (epi_any(epi)) return 1;  // the fused backward pieces of dpc_conv_igemm_ex are not built into these kernels (yet)
     if (addend && stats) return 1;  // not a combination of this path: the generic kernel serves it
     if (((uintptr_t)out % 16) || ((uintptr_t)addend % 16) || ((uintptr_t)src % 16) || ((uintptr_t)wgt % 16)) return 1;
     p.src = src; p.wgt = wgt; p.out = out; p.addend = addend; p.stats = stats;

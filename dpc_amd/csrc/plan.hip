@@ -57,7 +57,17 @@ extern "C" int dpc_conv_plan(const dpc_conv_desc* d, int32_t op, int32_t flags, 
     tls_detail[0] = 0;
     dpc_tls_plan_only = 1;
     int rc;
-    if (op == DPC_PLAN_IGEMM) {
+    if (op == DPC_PLAN_IGEMM && (flags & (DPC_PLAN_ADDEND_MASK | DPC_PLAN_BNRED))) {
+        dpc_conv_epilogue e = {};
+        const bool red = flags & DPC_PLAN_BNRED;
+        e.addend = (flags & (DPC_PLAN_ADDEND | DPC_PLAN_ADDEND_MASK)) ? dummy : nullptr;
+        e.addend_mask = (flags & DPC_PLAN_ADDEND_MASK) ? (const uint8_t*)dummy : nullptr;
+        e.bn_raw = red ? dummy : nullptr;
+        e.bn_mask = red ? (const uint8_t*)dummy : nullptr;
+        e.bn_mean = e.bn_invstd = red ? (const float*)dummy : nullptr;
+        e.stats = (red || (flags & DPC_PLAN_STATS)) ? (float*)dummy : nullptr;
+        rc = dpc_conv_igemm_ex(d, dummy, dummy, dummy, &e, nullptr);
+    } else if (op == DPC_PLAN_IGEMM) {
         rc = dpc_conv_igemm(d, dummy, dummy, dummy, (flags & DPC_PLAN_ADDEND) ? dummy : nullptr,
                             (flags & DPC_PLAN_STATS) ? (float*)dummy : nullptr, nullptr);
     } else {

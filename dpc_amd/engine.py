@@ -32,7 +32,7 @@ from typing import Dict, List, Optional, Sequence, Tuple
 import torch
 
 from . import _lib as L
-from .plan import LAYER_PLAN, LAYER_WIDTH, out_shape_of, unit_descs  # layer plan + descriptors shared with the plan query
+from .plan import LAYER_PLAN, LAYER_WIDTH, ex_supported, out_shape_of, unit_descs  # layer plan + descriptors shared with the plan query
 BN_EPS = 1e-5
 
 
@@ -94,7 +94,7 @@ class KernelTimer:
         rc = eng.lib.call(name, *args, eng.lib.stream())
         b.record()
         fl, by = algorithmic_cost(name, args)
-        self.records.append((name, eng._tag, a, b, fl, by))
+        self.records.append((TIMER_FAMILY.get(name, name), eng._tag, a, b, fl, by))
         return rc
 
     def summary(self, steps: int = 1):
@@ -125,6 +125,7 @@ class KernelTimer:
         return out
 
 
+TIMER_FAMILY = {"dpc_conv_igemm_ex": "dpc_conv_igemm"}  # same kernels, fused backward pieces in the epilogue
 HBM_FAMILY = ("dpc_bn_apply", "dpc_bn_bwd_reduce", "dpc_bn_bwd_apply", "dpc_bn_relu_maxpool_fwd", "dpc_pool_bn_bwd_apply",
               "dpc_pooled_bn_bwd_reduce", "dpc_pack_input_s2d")
 
@@ -159,7 +160,7 @@ def algorithmic_cost(name, args):
         return 2.0 * args[2] * args[2] * args[3], float(2 * args[2] * args[3] * 2)
     if name == "dpc_score_bwd":            # own, oth, othT, ldT, R, D, ...: one R x R x D contraction (the recompute is not counted)
         return 2.0 * args[4] * args[4] * args[5], float(2 * args[4] * args[5] * 2 + args[4] * args[5] * 4)
-    if name not in ("dpc_conv_igemm", "dpc_conv_wgrad"):
+    if name not in ("dpc_conv_igemm", "dpc_conv_igemm_ex", "dpc_conv_wgrad"):
         return 0.0, 0.0
     d = args[0]._obj
     esz = 2 if d.dtype_in == L.BF16 else 4
@@ -167,7 +168,7 @@ def algorithmic_cost(name, args):
     taps = d.KT * d.KH * d.KW
     rows_out = d.N * d.RT * d.RH * d.RW
     rows_src = d.N * d.ST * d.SH * d.SW
-    if name == "dpc_conv_igemm" and d.mode == 1:
+    if name in ("dpc_conv_igemm", "dpc_conv_igemm_ex") and d.mode == 1:
         # input-gradient: same MACs as the forward conv it differentiates (rows_src = forward output positions)
         macs = rows_src * d.Ci * d.Co * taps
     else:
@@ -176,6 +177,12 @@ def algorithmic_cost(name, args):
         macs = macs * 147 // 256
     if name == "dpc_conv_igemm":
         by = rows_src * d.Ci * esz + d.Co * d.Ci * taps * esz + rows_out * d.Co * osz
+    elif name == "dpc_conv_igemm_ex":  # + residual addend, the reduced unit's raw output, their byte masks
+        ep = args[4]._obj
+        n = rows_out * d.Co * osz
+        by = rows_src * d.Ci * esz + d.Co * d.Ci * taps * esz + n
+        by += (n if ep.addend else 0) + (n // 16 if ep.addend_mask else 0) + (n if ep.bn_raw else 0) + (n // 16 if ep.bn_mask else 0)
+        name = "dpc_conv_igemm"
     else:
         by = rows_src * d.Ci * esz + rows_out * d.Co * esz + d.Co * d.Ci * taps * 4
     return 2.0 * macs, float(by)
@@ -214,6 +221,10 @@ class _ConvBN:
         pr = C.c_int32(0)
         eng.lib.call("dpc_bn_bwd_reduce", None, None, None, None, dc, self.rows, Co, None, None, 0, None, C.byref(pr), eng.lib.stream())
         eng.need_stats(pr.value * 2 * Co)
+        # the input-gradient launch can carry the BatchNorm-backward reduction of the unit upstream (dpc_conv_igemm_ex)
+        self.stat_rows_d = 0 if stem else eng.lib.call("dpc_conv_stats_rows", C.byref(self.desc_d))
+        eng.need_stats(self.stat_rows_d * 2 * Ci)
+        self.reduced_rows = 0  # > 0: the partial sums of THIS unit's backward reduction are already in eng.stats (that many rows)
 
     # ---- per-optimizer-step repack of the f32 parameter into MFMA operand layouts
     def pack_entries(self):
@@ -249,18 +260,34 @@ class _ConvBN:
                self.mask if relu else None)
 
     # ---- backward pieces
+    def supports(self, addend: bool, gate: bool, bnred: bool) -> bool:
+        """dpc_conv_igemm_ex serves this unit's input-gradient with the given fused pieces WITHOUT demoting it from a
+        specialised kernel to the generic implicit GEMM (the plan query runs the library's own dispatch, include/dpc_hip.h)"""
+        e = self.eng
+        if self.stem or not e.fold:
+            return False
+        return ex_supported(e.lib, self.desc_d, addend, gate, bnred)
+
     def bn_backward(self, dy: torch.Tensor, y: Optional[torch.Tensor], relu: bool, dx: torch.Tensor,
-                    dz: Optional[torch.Tensor]):
+                    dz: Optional[torch.Tensor] = None, ext_mask: Optional[torch.Tensor] = None):
+        """BatchNorm backward of this unit: dz = dy gated by the ReLU that follows it (its own sign mask, or `ext_mask`: the
+        downsample branch sees the block output's gate) -> partial sums -> coefficients -> dx (and dz, when a caller still
+        wants it as a tensor).  The reduction pass is skipped when the launch that produced dy already took the sums."""
         e = self.eng
         dc = L.dtype_code(e.cdtype)
-        pr = C.c_int32(0)
-        mask = self.mask if relu else None
-        e.call("dpc_bn_bwd_reduce", dy, None if mask is not None else y, mask, self.raw, dc, self.rows, self.Co, self.mean,
-               self.invstd, int(relu), e.stats, C.byref(pr))
-        e.call("dpc_bn_bwd_finalize", e.stats, pr.value, self.Co, float(self.rows), e.G[self.bnname + ".weight"],
+        mask = ext_mask if ext_mask is not None else (self.mask if relu else None)
+        gated = int(relu or ext_mask is not None)
+        if self.reduced_rows:
+            prow, self.reduced_rows = self.reduced_rows, 0
+        else:
+            pr = C.c_int32(0)
+            e.call("dpc_bn_bwd_reduce", dy, None if mask is not None else y, mask, self.raw, dc, self.rows, self.Co, self.mean,
+                   self.invstd, gated, e.stats, C.byref(pr))
+            prow = pr.value
+        e.call("dpc_bn_bwd_finalize", e.stats, prow, self.Co, float(self.rows), e.G[self.bnname + ".weight"],
                e.G[self.bnname + ".bias"], e.coef)
         e.call("dpc_bn_bwd_apply", dy, None if mask is not None else y, mask, self.raw, dc, self.rows, self.Co, self.mean,
-               self.invstd, e.PRM[self.bnname + ".weight"], e.coef, int(relu), dx, dz)
+               self.invstd, e.PRM[self.bnname + ".weight"], e.coef, gated, dx, dz)
 
     def wgrad(self, x: torch.Tensor, draw: torch.Tensor):
         e = self.eng
@@ -273,8 +300,25 @@ class _ConvBN:
             Ci, t = self.Ci, self.taps
             e.call("dpc_reduce_unpack", e.part, ns.value, g, self.Co, t, Ci, Ci * t, 1, t, 0)
 
-    def dgrad(self, draw: torch.Tensor, dx: torch.Tensor, addend: Optional[torch.Tensor]):
-        self.eng.call("dpc_conv_igemm", C.byref(self.desc_d), draw, self.wd, dx, addend, None)
+    def dgrad(self, draw: torch.Tensor, dx: torch.Tensor, addend: Optional[torch.Tensor], addend_mask: Optional[torch.Tensor] = None,
+              red: "Optional[_ConvBN]" = None):
+        """input-gradient (+ residual addend).  addend_mask: the addend is gated by that ReLU sign mask (the block's dz is never
+        a tensor).  red: the unit whose output gradient dx is -- its BatchNorm-backward partial sums are taken in this launch's
+        epilogue and `red.bn_backward` skips its reduction pass."""
+        e = self.eng
+        if addend_mask is None and red is None:
+            e.call("dpc_conv_igemm", C.byref(self.desc_d), draw, self.wd, dx, addend, None)
+            return
+        ep = L.ConvEpilogue()
+        ep.addend = addend.data_ptr() if addend is not None else None
+        ep.addend_mask = addend_mask.data_ptr() if addend_mask is not None else None
+        if red is not None:
+            ep.bn_raw, ep.bn_mean, ep.bn_invstd = red.raw.data_ptr(), red.mean.data_ptr(), red.invstd.data_ptr()
+            ep.bn_mask = red.mask.data_ptr() if red.mask is not None else None
+            ep.stats = e.stats.data_ptr()
+        e.call("dpc_conv_igemm_ex", C.byref(self.desc_d), draw, self.wd, dx, C.byref(ep))
+        if red is not None:
+            red.reduced_rows = self.stat_rows_d
 
 
 class _Block:
@@ -311,24 +355,37 @@ class _Block:
             self.c2.apply(self.out, relu=self.final_relu, res=x)
         return self.out
 
+    def plan_backward(self, prev: "Optional[_Block]"):
+        """which backward pieces ride in input-gradient epilogues (decided once; dpc_conv_igemm_ex + the plan query):
+        fold_c1   conv2's input-gradient takes bn1's backward reduction;
+        gate      conv1's input-gradient adds the block's incoming gradient gated by the output ReLU mask (no dz tensor);
+        fold_prev ... and takes the backward reduction of the PREVIOUS block's bn2, whose output gradient it writes."""
+        self.fold_c1 = self.c2.supports(False, False, True)
+        self.gate = self.ds is None and self.c1.supports(True, self.final_relu, False)
+        self.fold_prev = bool(prev is not None and self.gate and self.c1.supports(True, self.final_relu, True))
+        self.prev = prev
+
     def backward(self, dout: torch.Tensor, need_dx: bool = True) -> Optional[torch.Tensor]:
         e = self.eng
         oshape = tuple(self.out.shape)
         ishape = tuple(self.x_in.shape)
+        omask = self.c2.mask if self.final_relu else None  # gate of everything behind the block output: dz = dout * (out > 0)
         draw2 = e.scratch(oshape, exclude=[dout])
-        dz = e.scratch(oshape, exclude=[dout, draw2])
+        # the masked gradient dz as a tensor only when a consumer cannot gate on the fly
+        dz = None
+        if self.ds is None and not self.gate and need_dx:
+            dz = e.scratch(oshape, exclude=[dout, draw2])
         self.c2.bn_backward(dout, self.out if self.final_relu else None, self.final_relu, draw2, dz)
-        # dout is dead from here on
         draw_d = None
         if self.ds is not None:
-            draw_d = e.scratch(oshape, exclude=[dout, draw2, dz])  # lives until the block's last input-gradient
-            self.ds.bn_backward(dz, None, False, draw_d, None)
+            draw_d = e.scratch(oshape, exclude=[dout, draw2])  # lives until the block's last input-gradient
+            self.ds.bn_backward(dout, None, False, draw_d, ext_mask=omask)
             self.ds.wgrad(self.x_in, draw_d)
         self.c2.wgrad(self.act1, draw2)
-        dact1 = dout  # out-shape buffer, free again
-        self.c2.dgrad(draw2, dact1, None)
+        dact1 = e.scratch(oshape, exclude=[dout, draw2, draw_d, dz])
+        self.c2.dgrad(draw2, dact1, None, red=self.c1 if self.fold_c1 else None)
         draw1 = draw2  # in place over the consumed draw2
-        self.c1.bn_backward(dact1, self.act1, True, draw1, None)
+        self.c1.bn_backward(dact1, self.act1, True, draw1)
         self.c1.wgrad(self.x_in, draw1)
         if not need_dx:
             return None
@@ -338,6 +395,10 @@ class _Block:
             dx = e.scratch(ishape, exclude=[])
             self.c1.dgrad(draw1, dx, None)
             self.ds.dgrad(draw_d, dx, dx)
+        elif self.gate:
+            # in place over dout: every lane reads its addend unit before it stores the same unit (all kernels behind the entry)
+            dx = dout
+            self.c1.dgrad(draw1, dx, dout, addend_mask=omask, red=self.prev.c2 if self.fold_prev else None)
         else:
             dx = dact1  # same shape as the input; dact1 is dead
             self.c1.dgrad(draw1, dx, dz)
@@ -351,7 +412,8 @@ class DPCEngine:
     def __init__(self, network: str = "resnet18", sample_size: int = 128, num_seq: int = 8, seq_len: int = 5,
                  pred_step: int = 3, batch: int = 4, device="cuda", compute_dtype=torch.float32,
                  widths: Sequence[int] = LAYER_WIDTH, lib: Optional[L.Lib] = None,
-                 lr: float = 1e-3, wd: float = 1e-5, dropout: float = 0.1, seed: int = 233, score_path: str = "auto", stem_fused: bool | None = None):
+                 lr: float = 1e-3, wd: float = 1e-5, dropout: float = 0.1, seed: int = 233, score_path: str = "auto", stem_fused: bool | None = None,
+                 fold: bool | None = None):
         self.device = torch.device(device)
         self.lib = L.lib_for(self.device, lib)  # raises unless HIP device (or an explicit simulator handle in tests)
         self.cdtype = compute_dtype
@@ -379,6 +441,9 @@ class DPCEngine:
         # MI355X (2.14 ms against 1.22 + 0.67 ms, profiles/r02_sweeps.txt) -- its per-chunk gathers are not covered by one chunk of
         # MFMA work -- so it is opt-in: it saves 2.7 GB (cfg2) / 8.2 GB (cfg5) of HBM, not time.
         self._want_stem_fused = bool(int(os.environ.get("DPC_STEM_FUSED", "0"))) if stem_fused is None else bool(stem_fused)
+        # backward pieces fused into input-gradient epilogues (dz never written, BatchNorm-backward reductions in the producing
+        # launch): on by default, DPC_FOLD=0 / fold=False runs the separate kernels (A/B, and the reference for the fused form)
+        self.fold = bool(int(os.environ.get("DPC_FOLD", "1"))) if fold is None else bool(fold)
         self._pack_table = None
         self.bn_running = type(self).BN_RUNNING  # BatchNorm3d with running statistics (the LC classifier's backbone)
         self.train_mode = True       # only matters when bn_running: eval uses the running buffers
@@ -421,6 +486,8 @@ class DPCEngine:
                              shape, has_ds, final_relu=not last)
                 self.blocks.append(blk)
                 shape, inplanes = blk.out_shape, planes
+        for i, blk in enumerate(self.blocks):
+            blk.plan_backward(self.blocks[i - 1] if i > 0 else None)
         # gradient-arena split for the overlapped all-reduce: the head = stem + layer1 (finished last by the backward)
         self.n_head_blocks = plan[0]
         self.grad_split = self.offsets["backbone.layer2.0.conv1.weight"][0]

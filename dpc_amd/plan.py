@@ -73,6 +73,41 @@ def backbone_units(network: str, size: int, batch: int, num_seq: int = 8, seq_le
     return units
 
 
+def ex_supported(lib: L.Lib, desc_d, addend: bool, gate: bool, bnred: bool) -> bool:
+    """dpc_conv_igemm_ex serves this input-gradient with the given fused pieces WITHOUT demoting it from a specialised kernel
+    to the generic implicit GEMM (the query runs the library's own dispatch code)"""
+    ex = L.conv_plan(lib, desc_d, L.PLAN_IGEMM, addend=addend, addend_mask=gate, bnred=bnred)
+    plain = L.conv_plan(lib, desc_d, L.PLAN_IGEMM, addend=addend)
+    return bool(ex) and (not ex.startswith("igemm_kernel") or plain.startswith("igemm_kernel"))
+
+
+def fold_table(lib: L.Lib, network: str, size: int, batch: int, dtype: torch.dtype, **kw) -> "List[Tuple[str, bool, bool, bool]]":
+    """per BasicBlock: (block, fold_c1, gate, fold_prev) as DPCEngine decides them (engine._Block.plan_backward):
+    conv2's input-gradient carries bn1's backward reduction / conv1's input-gradient gates the residual gradient on the fly /
+    ... and carries the previous block's bn2 reduction"""
+    units = backbone_units(network, size, batch, **kw)
+    nblocks = sum(LAYER_PLAN[network])
+    rows = []
+    last = f"layer4.{LAYER_PLAN[network][3] - 1}."
+    first = True
+    for u in units:
+        if not u["name"].endswith("conv1") or u["name"] == "conv1":
+            continue
+        pre = u["name"][:-len("conv1")]
+        c2 = next(v for v in units if v["name"] == pre + "conv2")
+        has_ds = any(v["name"] == pre + "downsample.0" for v in units)
+        final_relu = pre != last
+        d1 = unit_descs(u["Ci"], u["Co"], u["k"], u["s"], u["p"], u["in_shape"], dtype)[1]
+        d2 = unit_descs(c2["Ci"], c2["Co"], c2["k"], c2["s"], c2["p"], c2["in_shape"], dtype)[1]
+        fold_c1 = ex_supported(lib, d2, False, False, True)
+        gate = (not has_ds) and ex_supported(lib, d1, True, final_relu, False)
+        fold_prev = (not first) and gate and ex_supported(lib, d1, True, final_relu, True)
+        rows.append((pre[:-1], fold_c1, gate, fold_prev))
+        first = False
+    assert len(rows) == nblocks
+    return rows
+
+
 def plan_table(lib: L.Lib, network: str, size: int, batch: int, dtype: torch.dtype, **kw) -> "List[Tuple[str, str, str]]":
     """(unit, op, kernel) for every conv launch of one train step's backbone"""
     rows = []
@@ -98,3 +133,6 @@ if __name__ == "__main__":
             print(f"# {cfg}: {net} {size}^2 batch {batch} {dt}")
             for name, op, kern in plan_table(lib, net, size, batch, dt):
                 print(f"{name:24s} {op:14s} {kern}")
+            for name, a, b, c in fold_table(lib, net, size, batch, dt):
+                print(f"{name:24s} fused epilogues: bn1 reduction in conv2's input-gradient {int(a)}, gated residual {int(b)}, "
+                      f"previous bn2 reduction {int(c)}")

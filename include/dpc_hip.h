@@ -66,6 +66,28 @@ int dpc_conv_stats_rows(const dpc_conv_desc* d);
 int dpc_conv_igemm(const dpc_conv_desc* d, const void* src, const void* wgt, void* out,
                    const void* addend, float* stats, dpc_stream_t stream);
 
+/* dpc_conv_igemm with backward pieces of the BasicBlock fused into the epilogue of an INPUT-GRADIENT launch (autograd of
+ * backbone/resnet_2d3d.py:67-80,105-116), so that they stop being separate passes over HBM:
+ *  - addend_mask: out = conv + (bit ? addend : 0), addend = the gradient arriving at the block output, bit = that output's
+ *    ReLU sign mask (the byte-per-16-byte-unit mask dpc_bn_apply writes): the masked gradient dz is never materialised;
+ *  - bn_raw (+ bn_mask, bn_mean, bn_invstd): the reduction of dpc_bn_bwd_reduce for the unit whose output gradient `out` is --
+ *    dz = out gated by bn_mask, stats rows [dpc_conv_stats_rows(d)][2][Co] = (sum dz, sum dz * xhat), xhat = (bn_raw-mean)*invstd,
+ *    taken from the stored (rounded) values; finish with dpc_bn_bwd_finalize, then dpc_bn_bwd_apply as before.
+ * Without bn_raw `stats` means what it means for dpc_conv_igemm.  Requires ldo == Co, dtype_in == dtype_out, 16-byte aligned
+ * tensors; DPC_ERR_UNSUPPORTED otherwise (run the separate kernels).  dpc_conv_plan with DPC_PLAN_ADDEND_MASK / DPC_PLAN_BNRED
+ * tells which kernel serves the combination. */
+typedef struct dpc_conv_epilogue {
+    const void* addend;          /* optional [rows][ldo], dtype_out */
+    const uint8_t* addend_mask;  /* optional, needs addend */
+    const void* bn_raw;          /* optional [rows][ldo], dtype_out: raw conv output of the unit being differentiated */
+    const uint8_t* bn_mask;      /* optional, needs bn_raw: ReLU mask of that unit's activation */
+    const float* bn_mean;
+    const float* bn_invstd;
+    float* stats;
+} dpc_conv_epilogue;
+int dpc_conv_igemm_ex(const dpc_conv_desc* d, const void* src, const void* wgt, void* out, const dpc_conv_epilogue* epi,
+                      dpc_stream_t stream);
+
 /* Weight gradient: part[ks][co][tap*Ci+ci] = sum_{m in split ks} dy[m][co]*src[gather(m,tap)][ci]
  * (autograd of the same convs / 1x1 convs / matmul; f32 partials, reduced by
  * dpc_reduce_unpack).  Returns the number of K-splits through *nsplit; capacity in
@@ -84,6 +106,8 @@ int dpc_conv_wgrad(const dpc_conv_desc* d, const void* src, const void* dy, int3
 #define DPC_PLAN_WGRAD 1
 #define DPC_PLAN_ADDEND 1
 #define DPC_PLAN_STATS 2
+#define DPC_PLAN_ADDEND_MASK 4 /* dpc_conv_igemm_ex: gated addend */
+#define DPC_PLAN_BNRED 8       /* dpc_conv_igemm_ex: fused BatchNorm-backward reduction */
 int dpc_conv_plan(const dpc_conv_desc* d, int32_t op, int32_t flags, int32_t dy_ld, char* name, int32_t cap);
 int dpc_last_kernel(char* name, int32_t cap);
 

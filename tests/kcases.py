@@ -121,6 +121,52 @@ def case_conv_dgrad(k: K, dtype, N, Ci, Co, T, H, W, ks, st, pd, seed=1, expect=
     assert relerr(out, cl(gx) + add) < tol(dtype)
 
 
+def case_conv_dgrad_ex(k: K, dtype, N, Ci, Co, T, H, W, ks, st, pd, gate=True, bnred=True, bn_relu=True, seed=7, expect=None, with_add=True):
+    """dpc_conv_igemm_ex: input-gradient + (ReLU-gated residual addend) + (BatchNorm-backward partial sums of the unit whose
+    output gradient it produces) in one launch == autograd's input-gradient, the addend masked by the sign mask, and the sums
+    dpc_bn_bwd_reduce takes from the stored result (torch expectations, f64 sums)"""
+    g = torch.Generator().manual_seed(seed)
+    E = 8 if dtype == torch.bfloat16 else 4
+    x = torch.randn(N, Ci, T, H, W, generator=g).requires_grad_()
+    w = q(torch.randn(Co, Ci, *ks, generator=g) * 0.1, dtype)
+    y = F.conv3d(x, w, None, st, pd)
+    gy = q(torch.randn(y.shape, generator=g), dtype)
+    gx = cl(torch.autograd.grad(y, x, gy)[0])                      # [N,T,H,W,Ci]
+    To, Ho, Wo = y.shape[2:]
+    taps = ks[0] * ks[1] * ks[2]
+    d = conv_desc(dtype, dtype, 1, N, (T, H, W), (To, Ho, Wo), Co, Co, Ci, taps * Co, Ci, ks, st, pd)
+    rows = N * T * H * W
+    add = q(torch.randn(N, T, H, W, Ci, generator=g), dtype)
+    act_out = q(torch.randn(rows, Ci, generator=g), dtype)          # the block output whose sign gates the addend
+    raw = q(torch.randn(rows, Ci, generator=g) * 1.5 + 0.3, dtype)  # raw conv output of the unit being differentiated
+    act_in = q(torch.randn(rows, Ci, generator=g), dtype)           # its activation (sign mask of the ReLU that follows it)
+    mean, invstd = torch.randn(Ci, generator=g) * 0.2, torch.rand(Ci, generator=g) + 0.5
+    amask, bmask = bits_of(act_out, E).to(torch.uint8), bits_of(act_in, E).to(torch.uint8)
+    gate = gate and with_add
+    want = gx + (add * (act_out.reshape(add.shape) > 0).float() if gate else add) if with_add else gx
+    e = L.ConvEpilogue()
+    keep = [k.t(add, dtype), k.t(amask), k.t(raw, dtype), k.t(bmask), k.t(mean), k.t(invstd)]
+    nrows = k.lib.call("dpc_conv_stats_rows", C.byref(d))
+    stats = k.zeros(nrows, 2, Ci)
+    e.addend, e.addend_mask = (keep[0].data_ptr() if with_add else None), (keep[1].data_ptr() if gate else None)
+    if bnred:
+        e.bn_raw, e.bn_mask, e.bn_mean, e.bn_invstd = keep[2].data_ptr(), (keep[3].data_ptr() if bn_relu else None), keep[4].data_ptr(), keep[5].data_ptr()
+        e.stats = stats.data_ptr()
+    out = k.empty(N, T, H, W, Ci, dtype=dtype)
+    wd = k.t(w.permute(1, 2, 3, 4, 0).reshape(Ci, taps * Co), dtype)
+    k.call("dpc_conv_igemm_ex", C.byref(d), k.t(cl(gy), dtype), wd, out, C.byref(e))
+    check_kernel(k, expect)
+    k.sync()
+    assert relerr(out, want) < tol(dtype)
+    if bnred:
+        o = out.float().cpu().reshape(rows, Ci).double()            # sums are those of the STORED gradient
+        dz = o * (act_in > 0).double() if bn_relu else o
+        xh = (raw.double() - mean.double()) * invstd.double()
+        sgot = stats.cpu().double()
+        for got, exp in ((sgot[:, 0].sum(0), dz.sum(0)), (sgot[:, 1].sum(0), (dz * xh).sum(0))):
+            assert (got - exp).abs().max().item() < 2e-4 * max(1.0, dz.abs().sum(0).max().item())
+
+
 def case_conv_dgrad_inplace(k: K, dtype, N, Ci, Co, T, H, W, ks, st, pd, seed=5, expect=None):
     """input-gradient accumulated IN PLACE (addend == out): the engine adds a strided 1x1 downsample's gradient onto the
     main path's dx; positions no tap reaches must keep their value exactly"""

@@ -48,7 +48,7 @@ def test_save_resume_is_bit_identical_to_an_uninterrupted_run(tmp_path, dtype):
     assert (checkpoint["epoch"], checkpoint["iteration"], checkpoint["best_acc"], checkpoint["net"]) == (1, 2, 0.125, "resnet18")
     model.load_state_dict(checkpoint["state_dict"])
     optimizer.load_state_dict(checkpoint["optimizer"])
-    named = dict(model.module.named_parameters())
+    named = dict(model.module.named_parameters())  # (DataParallel moves a single-device module to cuda:0)
     assert int(optimizer.state[named["backbone.conv1.weight"]]["step"]) == 2
 
     # ---- resumed engine: third step bit-identical to the uninterrupted one
@@ -57,9 +57,9 @@ def test_save_resume_is_bit_identical_to_an_uninterrupted_run(tmp_path, dtype):
     info = ckpt.resume(b, fn)
     assert info == {"epoch": 1, "iteration": 2, "best_acc": 0.125} and b.step_count == 2
     for k in b.PRM:  # what the reference loader holds == what the resumed engine holds
-        assert torch.equal(named[k].detach(), b.PRM[k].cpu()), k
+        assert torch.equal(named[k].detach().cpu(), b.PRM[k].cpu()), k
         o, n = b.offsets[k]
-        assert torch.equal(optimizer.state[named[k]]["exp_avg"].flatten(), b.flat_m[o:o + n].cpu()), k
+        assert torch.equal(optimizer.state[named[k]]["exp_avg"].flatten().cpu(), b.flat_m[o:o + n].cpu()), k
     res_b = b.train_step(xs[2]).clone()
     torch.cuda.synchronize()
     assert torch.equal(res_a, res_b)

@@ -137,3 +137,26 @@ def test_module_train_mode_draws_fresh_dropout_masks(emu):
     e1 = m(x)[0].detach().clone()
     e2 = m(x)[0].detach().clone()
     assert torch.equal(e1, e2) and int(m.engine.dev_draw.item()) == 3
+
+
+def test_fused_backward_epilogues_match_the_separate_kernels(emu):
+    """fold=True (default): BatchNorm-backward reductions ride in the producing input-gradient's epilogue and the residual
+    branch is gated on the fly (no dz tensor) -- against fold=False, the separate-kernel schedule, on the same step."""
+    B, size = 1, 64
+    x = O.make_input_pcg(B, 8, 5, size)
+    out = []
+    for fold in (False, True):
+        eng = DPCEngine("resnet18", size, 8, 5, 3, B, "cpu", torch.float32, WIDTHS, lib=emu, fold=fold)
+        eng.load_params(O.make_params_pcg("resnet18", WIDTHS))
+        flags = [(b.fold_c1, b.gate, b.fold_prev) for b in eng.blocks]
+        assert all(f[0] == fold for f in flags)                                 # conv2's input-gradient always folds bn1
+        assert [f[1] for f in flags] == [fold and b.ds is None for b in eng.blocks]   # downsample blocks accumulate in place instead
+        assert [f[2] for f in flags] == [fold and b.ds is None and i > 0 for i, b in enumerate(eng.blocks)]
+        eng.forward(x, train=False)
+        eng.loss_topk(True)
+        eng.backward()
+        out.append(eng.flat_g.clone())
+    # same arithmetic on the same stored values; only the summation order of the partial sums differs
+    for k, (o, n) in eng.offsets.items():
+        a, b = out[0][o:o + n], out[1][o:o + n]
+        assert (a - b).abs().max().item() <= 2e-5 * max(b.abs().max().item(), 1e-6), k

@@ -21,6 +21,21 @@ def k():
 
 
 @pytest.mark.parametrize("dtype", [F32, BF16])
+@pytest.mark.parametrize("shape,gate,bnred,bn_relu", [
+    ((1, 32, 32, 3, 6, 6, (3, 3, 3), (1, 1, 1), (1, 1, 1)), True, True, True),     # generic kernel, 3x3x3
+    ((2, 8, 64, 2, 6, 5, (1, 3, 3), (1, 1, 1), (0, 1, 1)), True, True, True),      # bf16: role-specialised patch kernel (EPI), residual
+    ((2, 64, 64, 2, 9, 33, (1, 3, 3), (1, 1, 1), (0, 1, 1)), True, True, False),   # several tiles per workgroup, no ReLU on the reduced unit
+    ((2, 64, 64, 2, 9, 33, (1, 3, 3), (1, 1, 1), (0, 1, 1)), False, True, True),   # plain addend + fused reduction
+    ((2, 64, 64, 1, 12, 20, (1, 3, 3), (1, 1, 1), (0, 1, 1)), True, False, False), # gated addend only
+    ((1, 128, 128, 1, 10, 16, (1, 3, 3), (1, 1, 1), (0, 1, 1)), True, True, True),
+])
+def test_conv_dgrad_ex(k, dtype, shape, gate, bnred, bn_relu):
+    kc.case_conv_dgrad_ex(k, dtype, *shape, gate=gate, bnred=bnred, bn_relu=bn_relu)
+    if bnred:  # the block's second conv: no residual, only the fused reduction
+        kc.case_conv_dgrad_ex(k, dtype, *shape, bnred=True, bn_relu=bn_relu, with_add=False)
+
+
+@pytest.mark.parametrize("dtype", [F32, BF16])
 @pytest.mark.parametrize("shape", [
     (2, 16, 64, 2, 9, 9, (1, 3, 3), (1, 1, 1), (0, 1, 1)),
     (2, 64, 72, 3, 8, 8, (3, 3, 3), (2, 2, 2), (1, 1, 1)),

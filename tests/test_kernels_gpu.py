@@ -84,6 +84,22 @@ def test_conv_wgrad(k, dtype, shape):
 
 
 @pytest.mark.parametrize("dtype", [F32, BF16])
+@pytest.mark.parametrize("shape,gate,bn_relu,kern", [
+    ((66, 64, 64, 1, 32, 32, (1, 3, 3), (1, 1, 1), (0, 1, 1)), True, True, "conv_halo_ws_kernel<%s,8,128,true>"),   # layer1, 528 tiles
+    ((3, 64, 64, 2, 56, 56, (1, 3, 3), (1, 1, 1), (0, 1, 1)), True, False, "conv_halo_ws_kernel<%s,8,128,true>"),   # 224-pixel family, ragged tiles
+    ((16, 256, 256, 3, 8, 8, (3, 3, 3), (1, 1, 1), (1, 1, 1)), True, True, "igemm_kernel<T,TO,BN,1>"),              # generic kernel
+    ((66, 128, 128, 1, 16, 16, (1, 3, 3), (1, 1, 1), (0, 1, 1)), True, True, None),
+    ((87, 256, 256, 3, 8, 8, (3, 3, 3), (1, 1, 1), (1, 1, 1)), True, True, None),
+])
+def test_conv_dgrad_ex(k, dtype, shape, gate, bn_relu, kern):
+    """dpc_conv_igemm_ex: gated residual addend + fused BatchNorm-backward sums (residual form and the plain form of conv2)"""
+    ex = lambda add: (kern % add if "%s" in kern else kern) if (kern and dtype == BF16) else None  # noqa: E731
+    kc.case_conv_dgrad_ex(k, dtype, *shape, gate=gate, bnred=True, bn_relu=bn_relu, expect=ex("true"))
+    kc.case_conv_dgrad_ex(k, dtype, *shape, bnred=True, bn_relu=bn_relu, with_add=False, expect=ex("false"))
+    kc.case_conv_dgrad_ex(k, dtype, *shape, gate=True, bnred=False, expect=ex("true"))
+
+
+@pytest.mark.parametrize("dtype", [F32, BF16])
 @pytest.mark.parametrize("mnk", [(6144, 6144, 256), (6468, 6468, 256), (15680, 15680, 256), (2048, 768, 256), (192, 192, 256), (130, 70, 64)])
 def test_gemm_nt(k, dtype, mnk):
     kc.case_gemm_nt(k, dtype, *mnk)
