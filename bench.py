@@ -81,7 +81,7 @@ def side_config(name, dev, steps=8, warmup=2, roof_steps=2):
     out = {"workload": f"{net} 2d3d, img_dim {img}, pred_step {P}, batch {batch}/GPU, bf16, full train step, hipGraph replay",
            "value": round(batch * steps / dt, 2), "unit": "clips/s", "ms_per_step": round(1e3 * dt / steps, 3), "steps": steps,
            "final_loss": round(res.cpu().tolist()[0], 4), "score_path": eng.score_mode}
-    timer = KernelTimer(["dpc_conv_igemm"])
+    timer = KernelTimer(["dpc_conv_igemm", "dpc_conv_igemm_ex"])
     eng.timer = timer
     for _ in range(roof_steps):
         eng.train_step(block)
@@ -228,7 +228,7 @@ def main():
     # ---- separately instrumented pass (never part of `value`): HIP events around the selected launches
     timer = None
     if not args.no_roofline and rank == 0:
-        timer = KernelTimer(["dpc_conv_igemm", "dpc_conv_wgrad", "dpc_score_fwd", "dpc_score_bwd"] + list(HBM_FAMILY))
+        timer = KernelTimer(["dpc_conv_igemm", "dpc_conv_igemm_ex", "dpc_conv_wgrad", "dpc_score_fwd", "dpc_score_bwd"] + list(HBM_FAMILY))
         eng.timer = timer
         for _ in range(args.roofline_steps):
             eng.train_step(block, allreduce=None)

@@ -62,7 +62,9 @@ struct IGemmParams {
 #define DPC_IGEMM_DMA 1
 #endif
 
-template <class T, class TO, int BN, int GATHER>
+// EPI: the fused backward pieces of dpc_conv_igemm_ex in the epilogue (their registers cost the plain instantiation occupancy /
+// spills when they are merely run-time options: +50 % on the strided input-gradients, measured)
+template <class T, class TO, int BN, int GATHER, bool EPI = false>
 __global__ __launch_bounds__(256, (BN == 64 ? 3 : 2)) void igemm_kernel(IGemmParams p) {
     // DMA: operand units go global -> LDS directly (global_load_lds_dwordx4), no VGPR staging and no
     // ds_write.  The LDS destination of a wave is lane-linear (8 rows x 8 slots), so the XOR swizzle
@@ -363,7 +365,8 @@ __global__ __launch_bounds__(256, (BN == 64 ? 3 : 2)) void igemm_kernel(IGemmPar
             if (GATHER == 3) return rowmap[row_l];
             return (m0 + row_l < g.M) ? m0 + row_l : -1;
         };
-        if (p.vec_out) {
+        if (EPI && p.vec_out) {
+            if constexpr (EPI) {
             const bool bnred = p.epi.bn_raw != nullptr;
             float mu[EPO], is[EPO];
             DPC_UNROLL
@@ -398,6 +401,40 @@ __global__ __launch_bounds__(256, (BN == 64 ? 3 : 2)) void igemm_kernel(IGemmPar
                     u32x4 o = ov[it];
                     epi_unit<TO, EPO>(o, p.addend != nullptr, av[it], ab[it], bnred, rv[it], bb[it], mu, is, s1, s2);
                     *(u32x4*)((char*)p.out + ((long long)row * p.ldo + col0) * (int)sizeof(TO)) = o;
+                }
+            }
+            }
+        } else if (p.vec_out) {
+            u32x4 ov[OIT], av[OIT];
+            DPC_UNROLL
+            for (int it = 0; it < OIT; ++it) {
+                const int row_l = (tid + 256 * it) / UPR;
+                ov[it] = *(const u32x4*)(lds + (row_l * BN + cu * EPO) * (int)sizeof(TO));
+                const int row = out_row(row_l);
+                const bool ok = row >= 0 && col0 < p.Ncol;
+                if (p.addend) {
+                    const char* a = (const char*)p.addend + ((long long)row * p.ldo + col0) * (int)sizeof(TO);
+                    av[it] = *(const u32x4*)(ok ? a : zero);
+                }
+            }
+            DPC_UNROLL
+            for (int it = 0; it < OIT; ++it) {
+                const int row = out_row((tid + 256 * it) / UPR);
+                if (row >= 0 && col0 < p.Ncol) {
+                    u32x4 o = ov[it];
+                    if (p.addend) {
+                        float sv[EPO];
+                        DPC_UNROLL
+                        for (int e = 0; e < EPO; ++e) sv[e] = unit_get<TO>(o, e) + unit_get<TO>(av[it], e);
+                        o = unit_pack<TO>(sv);
+                    }
+                    *(u32x4*)((char*)p.out + ((long long)row * p.ldo + col0) * (int)sizeof(TO)) = o;
+                    DPC_UNROLL
+                    for (int e = 0; e < EPO; ++e) {
+                        const float v = unit_get<TO>(o, e);
+                        s1[e] += v;
+                        s2[e] += v * v;
+                    }
                 }
             }
         } else {  // ragged output width: element-wise tail path
@@ -475,6 +512,20 @@ template <class T, class TO, int BN>
 static int launch_igemm_bn(const IGemmParams& p, int gather, hipStream_t stream) {
     dim3 grid((unsigned)(p.gm * p.ntn)), block(256);
     dpc_plan_detail("T=%s TO=%s BN=%d", sizeof(T) == 2 ? "bf16" : "f32", sizeof(TO) == 2 ? "bf16" : "f32", BN);
+    if (epi_any(p.epi)) {  // dpc_conv_igemm_ex (T == TO, vectorised output: checked by the entry)
+        if constexpr (sizeof(T) == sizeof(TO)) {
+            if (gather == 1) {
+                DPC_LAUNCH((igemm_kernel<T, TO, BN, 1, true>), grid, block, stream, p);
+            } else if (gather == 2) {
+                DPC_LAUNCH((igemm_kernel<T, TO, BN, 2, true>), grid, block, stream, p);
+            } else {
+                DPC_LAUNCH((igemm_kernel<T, TO, BN, 0, true>), grid, block, stream, p);
+            }
+            return dpc_launch_status();
+        } else {
+            return DPC_ERR_UNSUPPORTED;
+        }
+    }
     if (gather == 3) {
         DPC_LAUNCH((igemm_kernel<T, TO, BN, 3>), grid, block, stream, p);
     } else if (gather == 1) {
@@ -542,7 +593,7 @@ static int launch_igemm(IGemmParams& p, int bn, hipStream_t stream) {
     const bool fits32 = (long long)(g.M / (g.RT * g.RH * g.RW)) * g.ST * g.SH * g.SW * g.src_ld < (1ll << 31);
     const bool affine = fits32 && (g.mode == 0 || unit_strides) && (g.KT + g.KH + g.KW <= 32);
     int gather = !affine ? 0 : ((g.taps == 1 || g.Ci >= bke) ? 1 : 2);
-    if (gather == 0 && fits32 && g.mode == 1 && !p.stats && plan_parity(p, bke)) gather = 3;
+    if (gather == 0 && fits32 && g.mode == 1 && !p.stats && !epi_any(p.epi) && plan_parity(p, bke)) gather = 3;
     if (bn == 64) return launch_igemm_bn<T, TO, 64>(p, gather, stream);
     return launch_igemm_bn<T, TO, 128>(p, gather, stream);
 }

@@ -35,18 +35,7 @@ struct WgradStemParams {
     int Ho, Wo;
 };
 
-// FUSED = true: the [64 positions][64 co] dy sub-tile is not DMA'd but COMPUTED by the workgroup from the pooled gradient
-// (routed through the saved argmax bytes), the raw conv output and the BatchNorm-backward coefficients -- what
-// dpc_pool_bn_bwd_apply wrote to a 2.7 GB tensor (1.2 ms) that this kernel then read back.  The loads of chunk c+1 are in
-// flight during the MFMAs of chunk c; the values are transformed and ds_written after them.
-// MEASURED (MI355X, batch 128, 128 x 128): 2.14 ms per launch against 1.22 ms (pool_bn_bwd_apply) + 0.67 ms (FUSED = false), i.e.
-// slower by 0.25 ms per step: a chunk's register gathers (2 x raw + up to 8 window loads per lane) see HBM latency that one chunk
-// of MFMA work (~0.5 us) does not cover, and the registers that hold them cost the third workgroup per CU.  Re-mapping lanes to
-// an even/odd column pair (4 shared gathers, compile-time taps) at 3 workgroups/CU spilled and ran 3.8 ms.  The engine therefore
-// keeps this variant opt-in (DPCEngine(stem_fused=True) / DPC_STEM_FUSED=1): it removes the 2.7 GB dz tensor, not time.  Making it
-// pay needs the gathers staged by LDS-DMA two chunks ahead (~21 KB of staging per stage) -- not built.
-template <bool FUSED>
-__global__ __launch_bounds__(256, FUSED ? 2 : 3) void wgrad_stem_kernel(WgradStemParams p) {
+__global__ __launch_bounds__(256, 3) void wgrad_stem_kernel(WgradStemParams p) {
     constexpr int PW = 68, NPOS = 4 * PW;       // patch: 4 rows x (64 + 3, padded to 68) positions of 32 bytes
     constexpr int NPB = (NPOS + 31) / 32;        // 9 pieces of 32 positions
     constexpr int NIB = (NPB + 3) / 4;
@@ -117,71 +106,6 @@ __global__ __launch_bounds__(256, FUSED ? 2 : 3) void wgrad_stem_kernel(WgradSte
         DPC_UNROLL
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
-    // ---- FUSED producer state: this lane makes logical unit (lane & 7) of positions a_pos[0], a_pos[1]
-    const int fu = lane & 7;                    // 8 output channels tile_m*64 + 8*fu ..
-    float f_mu[8], f_is[8], f_ga[8], f_c1[8], f_c2[8];
-    if (FUSED) {
-        DPC_UNROLL
-        for (int e = 0; e < 8; ++e) {
-            const int c = tile_m * 64 + fu * 8 + e;
-            f_mu[e] = p.mean[c]; f_is[e] = p.invstd[c]; f_ga[e] = p.gamma[c] * f_is[e]; f_c1[e] = p.coef[c]; f_c2[e] = p.coef[p.Co + c];
-        }
-    }
-    u32x4 f_raw[2], f_g[2][2][2];
-    u32x2 f_am[2][2][2];
-    int f_want[2][2][2];   // tap index the position is inside window (a, b), or -1
-    bool f_ok[2];
-    auto fused_load = [&](int chunk) {
-        const unsigned frame = fdiv((unsigned)chunk, p.d_cpf);
-        const int rem = chunk - (int)frame * p.cpf;
-        const int h = (int)fdiv((unsigned)rem, p.d_nseg);
-        const int w0 = (rem - h * p.nseg) * 64;
-        const u32x4 z4 = {0u, 0u, 0u, 0u};
-        DPC_UNROLL
-        for (int i = 0; i < 2; ++i) {
-            const int w = w0 + a_pos[i];
-            f_ok[i] = w < p.W;
-            f_raw[i] = z4;
-            if (f_ok[i]) f_raw[i] = *(const u32x4*)((const char*)p.raw + ((((long long)frame * p.H + h) * p.W + w) * p.dy_ld + tile_m * 64 + fu * 8) * 2);
-            DPC_UNROLL
-            for (int a = 0; a < 2; ++a)
-                DPC_UNROLL
-                for (int b = 0; b < 2; ++b) {
-                    const int oh = (h >> 1) + a, ow = (w >> 1) + b;
-                    const bool use = f_ok[i] && (a == 0 || (h & 1)) && (b == 0 || (w & 1)) && oh < p.Ho && ow < p.Wo;
-                    f_want[i][a][b] = use ? (h - (2 * oh - 1)) * 3 + (w - (2 * ow - 1)) : -1;
-                    f_g[i][a][b] = z4;
-                    f_am[i][a][b] = u32x2{0x09090909u, 0x09090909u};
-                    if (use) {
-                        const unsigned ui = (unsigned)(((int)frame * p.Ho + oh) * p.Wo + ow) * (unsigned)p.Co + (unsigned)(tile_m * 64 + fu * 8);
-                        f_g[i][a][b] = *(const u32x4*)((const bf16_t*)p.dpool + ui);
-                        f_am[i][a][b] = *(const u32x2*)(p.argmax + ui);
-                    }
-                }
-        }
-    };
-    auto fused_store = [&](int buf) {
-        unsigned char* stage = lds + buf * STAGE;
-        DPC_UNROLL
-        for (int i = 0; i < 2; ++i) {
-            float ov[8];
-            DPC_UNROLL
-            for (int e = 0; e < 8; ++e) {
-                float g = 0.f;
-                DPC_UNROLL
-                for (int a = 0; a < 2; ++a)
-                    DPC_UNROLL
-                    for (int b = 0; b < 2; ++b) {
-                        const int am = (int)((f_am[i][a][b][e >> 2] >> (8 * (e & 3))) & 0xffu);
-                        if (am == f_want[i][a][b]) g += unit_get<bf16_t>(f_g[i][a][b], e);
-                    }
-                const float xh = (unit_get<bf16_t>(f_raw[i], e) - f_mu[e]) * f_is[e];
-                ov[e] = f_ok[i] ? f_ga[e] * (g - f_c1[e] - xh * f_c2[e]) : 0.f;
-            }
-            *(u32x4*)(stage + (wv + 4 * i) * 1024 + pl * 128 + (((fu ^ (2 * (pl & 3))) & 7) << 4)) = unit_pack<bf16_t>(ov);
-        }
-    };
-
     auto issue = [&](int chunk, int buf) {
         unsigned char* stage = lds + buf * STAGE;
         const unsigned frame = fdiv((unsigned)chunk, p.d_cpf);
@@ -192,12 +116,10 @@ __global__ __launch_bounds__(256, FUSED ? 2 : 3) void wgrad_stem_kernel(WgradSte
         const unsigned a_base = (unsigned)(pos * p.dy_ld * 2 - a_lo);
         // patch origin = image (h - ph, w0 - pw); offsets may wrap below zero for border positions (those lanes are masked)
         const unsigned b_base = (unsigned)((pos - (long long)p.ph * p.W - p.pw) * 32 - b_lo);
-        if (!FUSED) {
-            DPC_UNROLL
-            for (int i = 0; i < 2; ++i) {
-                const bool ok = w0 + a_pos[i] < p.W;
-                glds16_buf(rs_a, ok ? a_base + a_off[i] : DPC_BUF_OOB, 0u, stage + (wv + 4 * i) * 1024, lane);
-            }
+        DPC_UNROLL
+        for (int i = 0; i < 2; ++i) {
+            const bool ok = w0 + a_pos[i] < p.W;
+            glds16_buf(rs_a, ok ? a_base + a_off[i] : DPC_BUF_OOB, 0u, stage + (wv + 4 * i) * 1024, lane);
         }
         DPC_UNROLL
         for (int i = 0; i < NIB; ++i) {
@@ -281,19 +203,12 @@ __global__ __launch_bounds__(256, FUSED ? 2 : 3) void wgrad_stem_kernel(WgradSte
     };
 #endif
 
-    if (c_begin < c_end) {
-        issue(c_begin, 0);
-        if (FUSED) { fused_load(c_begin); fused_store(0); }
-    }
+    if (c_begin < c_end) issue(c_begin, 0);
     __syncthreads();
     for (int ch = c_begin; ch < c_end; ++ch) {
         const int buf = (ch - c_begin) & 1;
-        if (ch + 1 < c_end) {
-            issue(ch + 1, buf ^ 1);
-            if (FUSED) fused_load(ch + 1);   // in flight during the MFMAs below
-        }
+        if (ch + 1 < c_end) issue(ch + 1, buf ^ 1);
         compute(buf);
-        if (FUSED && ch + 1 < c_end) fused_store(buf ^ 1);
         __syncthreads();
     }
 
@@ -301,6 +216,243 @@ __global__ __launch_bounds__(256, FUSED ? 2 : 3) void wgrad_stem_kernel(WgradSte
     DPC_UNROLL
     for (int c = 0; c < 4; ++c) {
         const int col = (2 * wj + (c >> 1)) * 64 + (c & 1) * 32 + l31;
+        DPC_UNROLL
+        for (int r = 0; r < 16; ++r) {
+            const int co = tile_m * 64 + wi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+            p.part[((long long)ks * p.Co + co) * 256 + col] = acc[c][r];
+        }
+    }
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Fused form (dpc_stem_wgrad_fused): the [64 positions][64 co] gradient sub-tile is not read from a tensor but BUILT in LDS
+// from the stem's raw output, the gradient at the pooled output (routed through the saved argmax bytes) and the BatchNorm-
+// backward coefficients -- what dpc_pool_bn_bwd_apply wrote to a 2.7 GB dz tensor (1.2 ms at batch 128) that the plain
+// kernel then read back (0.66 ms).  Round 2 built this with per-lane register gathers one chunk ahead: 2.14 ms, slower than the
+// two kernels (the gathers saw HBM latency that one chunk of MFMA work -- 0.5 us -- does not cover).  Here EVERY input of a
+// chunk arrives by LDS-DMA three chunks ahead (ring of four 33 KB stages, one workgroup of eight waves per CU):
+//     raw tile 8 KB (8 pieces) | source patch 9 pieces | pooled gradient, 2 rows x 33 positions (10 pieces) | argmax bytes (6)
+// and all eight waves first turn the raw tile of chunk c+1 into the gradient tile IN PLACE (one 16-byte unit per lane; the
+// pooling windows of a position are read from the staged pooled rows; position parity = wave parity and the image row is
+// chunk-uniform, so the tap a window must point at is a wave-uniform constant), then run the 64 MFMAs of chunk c
+// (wave = co half x ONE kernel row: two accumulators).  One barrier per chunk.  Same chunking, same K order per accumulator
+// and the same arithmetic on the same bf16 values as the two-kernel form: bit-identical results (case_stem_wgrad_fused).
+constexpr int SF_PW = 68, SF_NPOS = 4 * SF_PW;
+constexpr int SF_A = 0, SF_X = 8192, SF_P = SF_X + 9 * 1024, SF_M = SF_P + 10 * 1024, SF_STAGE = SF_M + 6 * 1024, SF_NS = 4;
+constexpr int SF_SLOTS = 33;  // DMA pieces per chunk: 8 raw + 9 patch + 10 pooled gradient + 6 argmax
+
+__global__ __launch_bounds__(512) void wgrad_stem_fused_kernel(WgradStemParams p) {
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[SF_NS * SF_STAGE];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+#ifdef DPC_SIMT_EMU
+    const int wv = tid >> 6;
+#else
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+#endif
+    int id = blockIdx.x;
+    {
+        const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, x = id & 7;
+        id = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (id >> 3);
+    }
+    const int tile_m = id % p.ntm;
+    const int ks = id / p.ntm;
+    const int nchunks = p.NF * p.cpf;
+    const int c_begin = ks * p.kcps;
+    const int c_end = (c_begin + p.kcps < nchunks) ? c_begin + p.kcps : nchunks;
+    const int nck = c_end > c_begin ? c_end - c_begin : 0;
+
+    // 32-bit buffer offsets: the raw tensor (2.7 GB) and the source are addressed through per-workgroup windows (as in the plain
+    // kernel); the pooled tensors are below 2 GB (checked on the host)
+    long long a_lo, b_lo;
+    {
+        const unsigned frame = fdiv((unsigned)c_begin, p.d_cpf);
+        const int rem = c_begin - (int)frame * p.cpf;
+        const unsigned h = fdiv((unsigned)rem, p.d_nseg);
+        const int w0 = (rem - (int)h * p.nseg) * 64;
+        const long long pos = ((long long)frame * p.H + (int)h) * p.W + w0;
+        a_lo = pos * p.dy_ld * 2;
+        b_lo = (pos - (long long)p.ph * p.W - p.pw) * 32;
+        if (b_lo < 0) b_lo = 0;
+    }
+    const long long a_len = p.dy_bytes - a_lo, b_len = p.src_bytes - b_lo;
+    const long long pooled_elems = (long long)p.NF * p.Ho * p.Wo * p.Co;
+    const BufRsrc rs_a = make_buf_rsrc((const char*)p.raw + a_lo, (unsigned)(a_len < 0x7fffffffll ? a_len : 0x7fffffffll));
+    const BufRsrc rs_b = make_buf_rsrc((const char*)p.src + b_lo, (unsigned)(b_len < 0x7fffffffll ? b_len : 0x7fffffffll));
+    const BufRsrc rs_p = make_buf_rsrc(p.dpool, (unsigned)(pooled_elems * 2));
+    const BufRsrc rs_m = make_buf_rsrc(p.argmax, (unsigned)pooled_elems);
+
+    // ---- this wave's DMA slots s = wv + 8 i (kind and lane constants are fixed for the whole kernel)
+    //   [0, 8)   raw piece s: positions 8s .. 8s+7, slot = logical unit ^ 2 (position & 3)       (the dy tile image of the plain kernel)
+    //   [8, 17)  source patch piece s - 8: 32 positions x 32 bytes
+    //   [17, 27) pooled gradient: row r = (s-17) / 5, positions 8 ((s-17) % 5) + (lane >> 3), unit lane & 7 of this co tile
+    //   [27, 33) argmax bytes:    row r = (s-27) / 3, positions 16 ((s-27) % 3) + (lane >> 2), 16 bytes (lane & 3) of this co tile
+    constexpr int NSL = (SF_SLOTS + 7) / 8;  // 5
+    unsigned rel[NSL];
+    int aux[NSL];   // raw: position in the chunk | patch: (row << 8) | column (row = 255: no position) | pooled: (r << 8) | pooled column offset
+    DPC_UNROLL
+    for (int i = 0; i < NSL; ++i) {
+        const int sl = wv + 8 * i;
+        rel[i] = 0u; aux[i] = 0;
+        if (sl < 8) {
+            const int pl = lane >> 3, pos = 8 * sl + pl;
+            const int lslot = (lane & 7) ^ (2 * (pl & 3));
+            rel[i] = (unsigned)(pos * p.dy_ld + tile_m * 64 + lslot * 8) * 2u;
+            aux[i] = pos;
+        } else if (sl < 17) {
+            const int pp = 32 * (sl - 8) + (lane >> 1);
+            const int prow = pp / SF_PW, pcol = pp % SF_PW;
+            rel[i] = (unsigned)((prow * p.W + pcol) * 32 + (lane & 1) * 16);
+            aux[i] = ((pp < SF_NPOS ? prow : 255) << 8) | pcol;
+        } else if (sl < 27) {
+            const int k = sl - 17, r = k / 5, oc = 8 * (k % 5) + (lane >> 3);
+            rel[i] = (unsigned)(oc * p.Co + tile_m * 64 + (lane & 7) * 8) * 2u;
+            aux[i] = (r << 8) | oc;
+        } else if (sl < SF_SLOTS) {
+            const int k = sl - 27, r = k / 3, oc = 16 * (k % 3) + (lane >> 2);
+            rel[i] = (unsigned)(oc * p.Co + tile_m * 64 + (lane & 3) * 16);
+            aux[i] = (r << 8) | oc;
+        }
+    }
+    const int n_mine = (SF_SLOTS - wv + 7) / 8;   // DMA instructions this wave issues per chunk
+
+    auto chunk_pos = [&](int chunk, int& frame, int& h, int& w0) {
+        const unsigned f = fdiv((unsigned)chunk, p.d_cpf);
+        const int rem = chunk - (int)f * p.cpf;
+        const unsigned hh = fdiv((unsigned)rem, p.d_nseg);
+        frame = (int)f; h = (int)hh; w0 = (rem - (int)hh * p.nseg) * 64;
+    };
+    auto issue = [&](int chunk, int st) {
+        unsigned char* stage = lds + st * SF_STAGE;
+        int frame, h, w0;
+        chunk_pos(chunk, frame, h, w0);
+        const long long pos = ((long long)frame * p.H + h) * p.W + w0;
+        const unsigned a_base = (unsigned)(pos * p.dy_ld * 2 - a_lo);
+        const unsigned b_base = (unsigned)((pos - (long long)p.ph * p.W - p.pw) * 32 - b_lo);
+        const int oh0 = h >> 1, ow0 = w0 >> 1;
+        DPC_UNROLL
+        for (int i = 0; i < NSL; ++i) {
+            const int sl = wv + 8 * i;   // wave-uniform: the branches below are scalar
+            if (sl < 8) {
+                const bool ok = w0 + aux[i] < p.W;
+                glds16_buf(rs_a, ok ? a_base + rel[i] : DPC_BUF_OOB, 0u, stage + SF_A + sl * 1024, lane);
+            } else if (sl < 17) {
+                const int prow = aux[i] >> 8, pcol = aux[i] & 255;
+                const bool ok = ((unsigned)(h - p.ph + prow) < (unsigned)p.H) & ((unsigned)(w0 - p.pw + pcol) < (unsigned)p.W);
+                glds16_buf(rs_b, ok ? b_base + rel[i] : DPC_BUF_OOB, 0u, stage + SF_X + (sl - 8) * 1024, lane);
+            } else if (sl < SF_SLOTS) {
+                const int r = aux[i] >> 8, oc = aux[i] & 255;
+                const int oh = oh0 + r;
+                // row 1 of the pooled pair is only looked at from odd image rows; positions beyond the 33 a chunk can touch,
+                // beyond the pooled row or the pooled image are out-of-range lanes (zero fill, no memory traffic)
+                const bool ok = (r == 0 || (h & 1)) && oh < p.Ho && oc < 33 && ow0 + oc < p.Wo;
+                const unsigned pbase = (unsigned)(((frame * p.Ho + oh) * p.Wo + ow0) * p.Co);
+                if (sl < 27) glds16_buf(rs_p, ok ? pbase * 2u + rel[i] : DPC_BUF_OOB, 0u, stage + SF_P + (sl - 17) * 1024, lane);
+                else glds16_buf(rs_m, ok ? pbase + rel[i] : DPC_BUF_OOB, 0u, stage + SF_M + (sl - 27) * 1024, lane);
+            }
+        }
+    };
+
+    // ---- builder constants: this lane makes logical unit fu of position pos = 2 idx + parity of every chunk
+    const int parity = wv & 1, idx = (lane >> 3) + 8 * (wv >> 1), pos = 2 * idx + parity, fu = lane & 7;
+    const int a_unit = SF_A + pos * 128 + (((fu ^ (2 * (pos & 3))) & 7) << 4);
+    float f_mu[8], f_is[8], f_ga[8], f_c1[8], f_c2[8];
+    DPC_UNROLL
+    for (int e = 0; e < 8; ++e) {
+        const int c = tile_m * 64 + fu * 8 + e;
+        f_mu[e] = p.mean[c]; f_is[e] = p.invstd[c]; f_ga[e] = p.gamma[c] * f_is[e]; f_c1[e] = p.coef[c]; f_c2[e] = p.coef[p.Co + c];
+    }
+    auto build = [&](int chunk, int st) {
+        unsigned char* stage = lds + st * SF_STAGE;
+        int frame, h, w0;
+        chunk_pos(chunk, frame, h, w0);
+        const int w = w0 + pos;
+        const bool ok = w < p.W;
+        const u32x4 rv = *(const u32x4*)(stage + a_unit);
+        float g[8];
+        DPC_UNROLL
+        for (int e = 0; e < 8; ++e) g[e] = 0.f;
+        DPC_UNROLL
+        for (int a = 0; a < 2; ++a) {
+            if (a == 1 && !(h & 1)) continue;            // chunk-uniform
+            if ((h >> 1) + a >= p.Ho) continue;
+            const int kh = a == 0 ? (h & 1) + 1 : 0;
+            DPC_UNROLL
+            for (int b = 0; b < 2; ++b) {
+                if (b == 1 && !parity) continue;          // wave-uniform
+                const int kw = b == 0 ? parity + 1 : 0;
+                const unsigned want = (unsigned)(kh * 3 + kw);
+                const int oc = idx + b;
+                const bool use = ok && (w >> 1) + b < p.Wo;
+                const u32x4 gv = *(const u32x4*)(stage + SF_P + a * 5120 + oc * 128 + fu * 16);
+                const u32x2 am = *(const u32x2*)(stage + SF_M + a * 3072 + oc * 64 + fu * 8);
+                DPC_UNROLL
+                for (int e = 0; e < 8; ++e)
+                    if (use && ((am[e >> 2] >> (8 * (e & 3))) & 0xffu) == want) g[e] += unit_get<bf16_t>(gv, e);
+            }
+        }
+        float ov[8];
+        DPC_UNROLL
+        for (int e = 0; e < 8; ++e) {
+            const float xh = (unit_get<bf16_t>(rv, e) - f_mu[e]) * f_is[e];
+            ov[e] = ok ? f_ga[e] * (g[e] - f_c1[e] - xh * f_c2[e]) : 0.f;
+        }
+        *(u32x4*)(stage + a_unit) = unit_pack<bf16_t>(ov);
+    };
+
+    // ---- MFMA: wave = (co half wi, kernel row wr); accumulator c = taps kw = 2c, 2c+1 of that row x 16 channels
+    const int wi = wv >> 2, wr = wv & 3;
+    const int l31 = lane & 31, lhi = lane >> 5;
+    const int gq = lane >> 4, s16 = lane & 15, ph4 = s16 >> 2;
+    int fa;
+    {
+        const int colb = (wi * 32 + (gq & 1) * 16 + 4 * (s16 & 3)) * 2;
+        fa = SF_A + ((gq >> 1) * 8 + ph4) * 128 + ((((colb >> 4) ^ (2 * ph4)) & 7) << 4) + (colb & 15);
+    }
+    const int fb = SF_X + ((gq >> 1) * 8 + ph4 + (gq & 1) + wr * SF_PW) * 32 + 8 * (s16 & 3);
+    f32x16 acc[2];
+    DPC_UNROLL
+    for (int c = 0; c < 2; ++c)
+        DPC_UNROLL
+        for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
+    auto compute = [&](int st) {
+        const unsigned char* sp = lds + st * SF_STAGE;
+        DPC_UNROLL
+        for (int kk = 0; kk < 4; ++kk) {
+            const u32x2 a0 = lds_read_tr16(sp + fa + (kk * 16) * 128);
+            const u32x2 a1 = lds_read_tr16(sp + fa + (kk * 16 + 4) * 128);
+            const u32x4 av = {a0[0], a0[1], a1[0], a1[1]};
+            DPC_UNROLL
+            for (int c = 0; c < 2; ++c) {
+                const unsigned char* bp = sp + fb + (kk * 16 + 2 * c) * 32;
+                const u32x2 b0 = lds_read_tr16(bp);
+                const u32x2 b1 = lds_read_tr16(bp + 4 * 32);
+                const u32x4 bv = {b0[0], b0[1], b1[0], b1[1]};
+                acc[c] = mfma_32x32x16_bf16(av, bv, acc[c]);
+            }
+        }
+    };
+
+    // ---- pipeline: DMA three chunks ahead, build one chunk ahead, one barrier per chunk
+    for (int j = 0; j < 3 && j < nck; ++j) issue(c_begin + j, j);
+    if (nck > 0) {
+        wait_vmcnt_upto((nck - 1 < 2 ? nck - 1 : 2) * n_mine);
+        __syncthreads();
+        build(c_begin, 0);
+    }
+    for (int j = 0; j < nck; ++j) {
+        if (j + 1 < nck) wait_vmcnt_upto((nck - 2 - j < 1 ? nck - 2 - j : 1) * n_mine);   // chunk j+1 landed (only j+2 may be newer)
+        __syncthreads();   // tile j built and published; stage (j-1) % 4 free; every wave's pieces of chunk j+1 have landed
+        if (j + 3 < nck) issue(c_begin + j + 3, (j + 3) % SF_NS);
+        if (j + 1 < nck) build(c_begin + j + 1, (j + 1) % SF_NS);
+        compute(j % SF_NS);
+    }
+
+    // partial slab rows = co, columns = tap*16 + ch = (kernel row)*64 + c*32 + lane column
+    DPC_UNROLL
+    for (int c = 0; c < 2; ++c) {
+        const int col = wr * 64 + c * 32 + l31;
         DPC_UNROLL
         for (int r = 0; r < 16; ++r) {
             const int co = tile_m * 64 + wi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
@@ -343,7 +495,7 @@ int dpc_wgrad_stem_try(const dpc_conv_desc* d, const void* src, const void* dy, 
     if (!src || !dy) return DPC_ERR_ARG;
     if (((uintptr_t)src % 16) || ((uintptr_t)dy % 16)) return DPC_ERR_UNSUPPORTED;
     p.src = src; p.dy = dy; p.part = part;
-    DPC_LAUNCH((wgrad_stem_kernel<false>), dim3((unsigned)(p.ntm * p.nks)), dim3(256), stream, p);
+    DPC_LAUNCH(wgrad_stem_kernel, dim3((unsigned)(p.ntm * p.nks)), dim3(256), stream, p);
     return dpc_launch_status();
 }
 
@@ -368,6 +520,6 @@ extern "C" int dpc_stem_wgrad_fused(const dpc_conv_desc* d, const void* src_s2d,
     p.src = src_s2d; p.dy = raw; p.part = part;  // p.dy only sizes the (unused) dy window
     p.raw = raw; p.dpool = dpool; p.argmax = argmax; p.mean = mean; p.invstd = invstd; p.gamma = gamma; p.coef = coef;
     p.Ho = (p.H - 1) / 2 + 1; p.Wo = (p.W - 1) / 2 + 1;
-    DPC_LAUNCH((wgrad_stem_kernel<true>), dim3((unsigned)(p.ntm * p.nks)), dim3(256), stream, p);
+    DPC_LAUNCH(wgrad_stem_fused_kernel, dim3((unsigned)(p.ntm * p.nks)), dim3(512), stream, p);
     return dpc_launch_status();
 }

@@ -19,13 +19,14 @@ __global__ void bn_relu_maxpool_fwd_kernel(const T* x, int NT, int H, int W, int
     constexpr int E = Elt<T>::PER16;
     const int upr = C / E;
     const long long units = (long long)NT * Ho * Wo * upr;
-    // One contiguous span of pooled units per workgroup: vertically adjacent pooled rows share an input row (2*oh+1 == 2*(oh+1)-1).
-    // With a grid-stride walk the two rows were handled by different workgroups at the same time -- on different XCDs, i.e.
-    // different L2s -- and every odd input row came from HBM twice (1.5x the input traffic: 878 us for 3.7 GB algorithmic).
-    const long long span = (units + (long long)gridDim.x * 256 - 1) / ((long long)gridDim.x * 256) * 256;
-    const long long sb = (long long)blockIdx.x * span;
-    const long long se = sb + span < units ? sb + span : units;
-    for (long long i = sb + threadIdx.x; i < se; i += 256) {
+    // Vertically adjacent pooled rows share an input row (2*oh+1 == 2*(oh+1)-1) and, at 32 pooled positions per 256-thread chunk,
+    // sit in neighbouring chunks.  Workgroup b runs on XCD b & 7: with chunk = workgroup index the two readers of every odd input
+    // row had different L2s (the second read came over the fabric from the Infinity Cache: 4.2 TB/s where the other kernels of
+    // the family run 5.5).  Here every XCD owns a contiguous eighth of each sweep of the grid.  (A contiguous span per WORKGROUP
+    // -- 2 048 independent streams -- measured slower: 1 132 us against 878.)
+    unsigned blk = blockIdx.x;
+    if ((gridDim.x & 7u) == 0u) blk = (blk & 7u) * (gridDim.x >> 3) + (blk >> 3);
+    for (long long i = (long long)blk * blockDim.x + threadIdx.x; i < units; i += (long long)gridDim.x * blockDim.x) {
         const unsigned pidx = (unsigned)(i / upr);  // pooled position < 2^31: 32-bit index math from here on
         const int cu = (int)(i - (long long)pidx * upr);
         const unsigned q1 = pidx / (unsigned)Wo;
@@ -82,9 +83,9 @@ extern "C" int dpc_bn_relu_maxpool_fwd(const void* x, int32_t dtype, int32_t NT,
     const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
     const long long units = (long long)NT * Ho * Wo * (C / E);
     if (dtype == DPC_F32) {
-        DPC_LAUNCH((bn_relu_maxpool_fwd_kernel<float>), dim3(grid_for(units, 256, 2048)), dim3(256), stream, (const float*)x, NT, H, W, C, Ho, Wo, scale, shift, (float*)y, argmax);
+        DPC_LAUNCH((bn_relu_maxpool_fwd_kernel<float>), dim3(grid_for(units)), dim3(256), stream, (const float*)x, NT, H, W, C, Ho, Wo, scale, shift, (float*)y, argmax);
     } else if (dtype == DPC_BF16) {
-        DPC_LAUNCH((bn_relu_maxpool_fwd_kernel<bf16_t>), dim3(grid_for(units, 256, 2048)), dim3(256), stream, (const bf16_t*)x, NT, H, W, C, Ho, Wo, scale, shift, (bf16_t*)y, argmax);
+        DPC_LAUNCH((bn_relu_maxpool_fwd_kernel<bf16_t>), dim3(grid_for(units)), dim3(256), stream, (const bf16_t*)x, NT, H, W, C, Ho, Wo, scale, shift, (bf16_t*)y, argmax);
     } else {
         return DPC_ERR_ARG;
     }

@@ -87,7 +87,7 @@ def test_conv_wgrad(k, dtype, shape):
 @pytest.mark.parametrize("shape,gate,bn_relu,kern", [
     ((66, 64, 64, 1, 32, 32, (1, 3, 3), (1, 1, 1), (0, 1, 1)), True, True, "conv_halo_ws_kernel<%s,8,128,true>"),   # layer1, 528 tiles
     ((3, 64, 64, 2, 56, 56, (1, 3, 3), (1, 1, 1), (0, 1, 1)), True, False, "conv_halo_ws_kernel<%s,8,128,true>"),   # 224-pixel family, ragged tiles
-    ((16, 256, 256, 3, 8, 8, (3, 3, 3), (1, 1, 1), (1, 1, 1)), True, True, "igemm_kernel<T,TO,BN,1>"),              # generic kernel
+    ((16, 256, 256, 3, 8, 8, (3, 3, 3), (1, 1, 1), (1, 1, 1)), True, True, "igemm_kernel<T,TO,BN,1,true>"),         # generic kernel
     ((66, 128, 128, 1, 16, 16, (1, 3, 3), (1, 1, 1), (0, 1, 1)), True, True, None),
     ((87, 256, 256, 3, 8, 8, (3, 3, 3), (1, 1, 1), (1, 1, 1)), True, True, None),
 ])
@@ -110,8 +110,8 @@ def test_stem_s2d(k, dtype):
     ws = "conv_halo_ws_kernel<false,2,256>" if dtype == BF16 else None
     kc.case_stem(k, dtype, 4, 5, 64, 64, expect=(ws, ws and "wgrad2_kernel|padded=0"))
     kc.case_stem(k, dtype, 2, 2, 16, 20, expect=(ws, ws and "wgrad2_kernel|padded=1"))
-    kc.case_stem(k, dtype, 3, 2, 128, 128, expect=(ws, ws and "wgrad_stem_kernel<false>"))  # the real stem geometry: staged-patch weight gradient (bf16)
-    kc.case_stem(k, dtype, 1, 2, 32, 224, expect=(ws, ws and "wgrad_stem_kernel<false>"))   # two 64-column segments per row
+    kc.case_stem(k, dtype, 3, 2, 128, 128, expect=(ws, ws and "wgrad_stem_kernel"))  # the real stem geometry: staged-patch weight gradient (bf16)
+    kc.case_stem(k, dtype, 1, 2, 32, 224, expect=(ws, ws and "wgrad_stem_kernel"))   # two 64-column segments per row
 
 
 @pytest.mark.parametrize("dtype", [F32, BF16])
