@@ -228,7 +228,8 @@ def main():
     # ---- separately instrumented pass (never part of `value`): HIP events around the selected launches
     timer = None
     if not args.no_roofline and rank == 0:
-        timer = KernelTimer(["dpc_conv_igemm", "dpc_conv_igemm_ex", "dpc_conv_wgrad", "dpc_score_fwd", "dpc_score_bwd"] + list(HBM_FAMILY))
+        timer = KernelTimer(["dpc_conv_igemm", "dpc_conv_igemm_ex", "dpc_conv_wgrad", "dpc_score_fwd", "dpc_score_bwd", "dpc_gemm_nt_splitk",
+                             "dpc_reduce_unpack"] + list(HBM_FAMILY))
         eng.timer = timer
         for _ in range(args.roofline_steps):
             eng.train_step(block, allreduce=None)
@@ -299,7 +300,7 @@ def main():
                     "flops_per_step": round(sc["flops"] / rs / 1e9, 2), "flops_unit": "GFLOP (algorithmic: 3 x 2 R^2 D)",
                     "score_bytes_f32": R * R * 4,
                     "includes": ("the softmax statistics / loss and the recomputation of dS inside the backward (no [R][R] tensor is "
-                                 "written)" if eng.score_mode == "fused" else "the three GEMMs only (CE/top-k and dS are a separate kernel)"),
+                                 "written)" if eng.score_mode == "fused" else "the three GEMMs with the reductions of their split-K slabs (CE/top-k and dS are a separate kernel)"),
                 }
             hb = [s[n] for n in HBM_FAMILY if n in s]
             if hb:

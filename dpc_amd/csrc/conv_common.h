@@ -194,6 +194,9 @@ int dpc_conv_ws_try(const dpc_conv_desc* d, const void* src, const void* wgt, vo
                     const EpiExtra& epi, hipStream_t stream);
 int dpc_conv_ws_rows(const dpc_conv_desc* d);
 
+// score_fused.hip: plain NT GEMM with bf16 operands, f32 output and a short reduction (the materialised contrastive score).
+int dpc_score_gemm_try(const dpc_conv_desc* d, const void* src, const void* wgt, void* out, hipStream_t stream);
+
 // conv_wgrad_patch.hip: weight gradient of 1x3x3 stride-1 convs from one staged source patch (bf16).
 int dpc_wgrad_patch_try(const dpc_conv_desc* d, const void* src, const void* dy, int dy_ld, float* part, int32_t* nsplit,
                         hipStream_t stream);

@@ -56,6 +56,9 @@ struct IGemmParams {
     int Ncol, ldw, ldo;
     int gm, ntn, ntm;
     int vec_out;  // Ncol and ldo are multiples of the 16-byte output unit
+    // split-K (dpc_gemm_nt_splitk): workgroup group ks reduces K chunks [ks*kcps, (ks+1)*kcps) into slab ks of `out`
+    int nks, kcps;
+    long long slab;  // elements of TO between slabs
 };
 
 #ifndef DPC_IGEMM_DMA
@@ -90,8 +93,12 @@ __global__ __launch_bounds__(256, (BN == 64 ? 3 : 2)) void igemm_kernel(IGemmPar
     const int wm = wv >> 1, wn = wv & 1;
     const int l31 = lane & 31, lhi = lane >> 5;
     const int n_tile = blockIdx.x % p.ntn;
-    const int m_prog = blockIdx.x / p.ntn;
-    const int nkc = (g.Kp + BKE - 1) / BKE;
+    const int ks = (blockIdx.x / p.ntn) / p.gm;        // 0 unless the reduction is split over workgroups
+    const int m_prog = (blockIdx.x / p.ntn) - ks * p.gm;
+    const int kc0 = ks * p.kcps;
+    const int nkc_all = (g.Kp + BKE - 1) / BKE;
+    const int nkc = (kc0 + p.kcps < nkc_all ? kc0 + p.kcps : nkc_all) - kc0;
+    char* const outp = (char*)p.out + (long long)ks * p.slab * (int)sizeof(TO);
     const int esz = (int)sizeof(T);
     const char* const zero = (const char*)dpc_zero16;
     __shared__ int rowmap[GATHER == 3 ? BM : 1];      // tile row -> output row (parity classes permute rows)
@@ -209,7 +216,8 @@ __global__ __launch_bounds__(256, (BN == 64 ? 3 : 2)) void igemm_kernel(IGemmPar
                 for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
         u32x4 ra[4], rb[BROWS];
-        auto load_chunk = [&](int kc, int dma_buf) {
+        auto load_chunk = [&](int kc_rel, int dma_buf) {
+            const int kc = kc_rel + (GATHER == 3 ? 0 : kc0);
             int k = kc * BKE + u * EPU;
             bool kok = k < g.Kp;
             if (GATHER == 3) {
@@ -400,7 +408,7 @@ __global__ __launch_bounds__(256, (BN == 64 ? 3 : 2)) void igemm_kernel(IGemmPar
                 if (row >= 0 && col0 < p.Ncol) {
                     u32x4 o = ov[it];
                     epi_unit<TO, EPO>(o, p.addend != nullptr, av[it], ab[it], bnred, rv[it], bb[it], mu, is, s1, s2);
-                    *(u32x4*)((char*)p.out + ((long long)row * p.ldo + col0) * (int)sizeof(TO)) = o;
+                    *(u32x4*)(outp + ((long long)row * p.ldo + col0) * (int)sizeof(TO)) = o;
                 }
             }
             }
@@ -428,7 +436,7 @@ __global__ __launch_bounds__(256, (BN == 64 ? 3 : 2)) void igemm_kernel(IGemmPar
                         for (int e = 0; e < EPO; ++e) sv[e] = unit_get<TO>(o, e) + unit_get<TO>(av[it], e);
                         o = unit_pack<TO>(sv);
                     }
-                    *(u32x4*)((char*)p.out + ((long long)row * p.ldo + col0) * (int)sizeof(TO)) = o;
+                    *(u32x4*)(outp + ((long long)row * p.ldo + col0) * (int)sizeof(TO)) = o;
                     DPC_UNROLL
                     for (int e = 0; e < EPO; ++e) {
                         const float v = unit_get<TO>(o, e);
@@ -450,7 +458,7 @@ __global__ __launch_bounds__(256, (BN == 64 ? 3 : 2)) void igemm_kernel(IGemmPar
                         float v = Elt<TO>::to_f32(tile[row_l * BN + cu * EPO + e]);
                         if (p.addend) v += Elt<TO>::to_f32(((const TO*)p.addend)[o]);
                         const TO q = Elt<TO>::from_f32(v);
-                        ((TO*)p.out)[o] = q;
+                        ((TO*)outp)[o] = q;
                         const float vq = Elt<TO>::to_f32(q);
                         s1[e] += vq;
                         s2[e] += vq * vq;
@@ -510,7 +518,7 @@ extern "C" int dpc_conv_stats_rows(const dpc_conv_desc* d) {
 
 template <class T, class TO, int BN>
 static int launch_igemm_bn(const IGemmParams& p, int gather, hipStream_t stream) {
-    dim3 grid((unsigned)(p.gm * p.ntn)), block(256);
+    dim3 grid((unsigned)(p.gm * p.ntn * p.nks)), block(256);
     dpc_plan_detail("T=%s TO=%s BN=%d", sizeof(T) == 2 ? "bf16" : "f32", sizeof(TO) == 2 ? "bf16" : "f32", BN);
     if (epi_any(p.epi)) {  // dpc_conv_igemm_ex (T == TO, vectorised output: checked by the entry)
         if constexpr (sizeof(T) == sizeof(TO)) {
@@ -631,11 +639,16 @@ static int conv_igemm_impl(const dpc_conv_desc* d, const void* src, const void* 
     const int per16 = d->dtype_in == DPC_BF16 ? 8 : 4;
     if (d->ldw % per16) return DPC_ERR_UNSUPPORTED;
     if (d->ldo < d->Co || d->ldw < p.g.Kp) return DPC_ERR_ARG;
+    if (!addend && !stats && !epi_any(epi)) {
+        rc = dpc_score_gemm_try(d, src, wgt, out, stream);                  // large bf16 -> f32 NT GEMM with K = 256: the materialised score
+        if (rc != 1) return rc;
+    }
     rc = dpc_conv_halo_try(d, src, wgt, out, addend, stats, epi, stream);  // LDS-staged patch kernel when the shape allows
     if (rc != 1) return rc;
     rc = dpc_conv_ws_try(d, src, wgt, out, addend, stats, epi, stream);    // loader/compute specialised kernel for the wide layers
     if (rc != 1) return rc;
     p.src = src; p.wgt = wgt; p.out = out; p.addend = addend; p.stats = stats; p.epi = epi;
+    p.nks = 1; p.kcps = 1 << 28; p.slab = 0;
     p.Ncol = d->Co; p.ldw = d->ldw; p.ldo = d->ldo;
     const int epo = d->dtype_out == DPC_BF16 ? 8 : 4;
     p.vec_out = (d->Co % epo == 0 && d->ldo % epo == 0 && ((uintptr_t)out % 16 == 0) && ((uintptr_t)addend % 16 == 0)) ? 1 : 0;
@@ -658,6 +671,40 @@ static int conv_igemm_impl(const dpc_conv_desc* d, const void* src, const void* 
     if (d->dtype_in == DPC_BF16 && d->dtype_out == DPC_BF16) return launch_igemm<bf16_t, bf16_t>(p, bn, stream);
     if (d->dtype_in == DPC_BF16 && d->dtype_out == DPC_F32) return launch_igemm<bf16_t, float>(p, bn, stream);
     return DPC_ERR_UNSUPPORTED;
+}
+
+// NT GEMM with the reduction split over workgroups (f32 partial slabs): products whose [M][N] output has too few 128 x BN tiles to
+// fill 256 CUs while K is long -- d_pred = dS @ feature_inf of the contrastive loss: M = R = 6 144, N = 256, K = R (96 tiles;
+// through dpc_conv_igemm it ran 89 us = 217 TFLOP/s on a third of the chip).
+extern "C" int dpc_gemm_nt_splitk(int32_t dtype, int32_t M, int32_t N, int32_t K, const void* A, int32_t lda, const void* B, int32_t ldb,
+                                  float* part, int32_t* nsplit, dpc_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (M <= 0 || N <= 0 || K <= 0 || (dtype != DPC_F32 && dtype != DPC_BF16)) return DPC_ERR_ARG;
+    const int per16 = dtype == DPC_BF16 ? 8 : 4;
+    if (K % per16 || lda % per16 || ldb % per16 || lda < K || ldb < K) return DPC_ERR_UNSUPPORTED;
+    dpc_conv_desc d = {dtype, DPC_F32, 0, M, 1, 1, 1, 1, 1, 1, K, lda, N, ldb, N, 1, 1, 1, 1, 1, 1, 0, 0, 0};
+    IGemmParams p;
+    int rc = make_gather_geom(&d, &p.g);
+    if (rc) return rc;
+    int bn;
+    igemm_grid(&d, p.g.M, &p.ntm, &p.ntn, &p.gm, &bn);
+    p.gm = p.ntm;  // one m-tile per workgroup: the split supplies the parallelism
+    const int bke = 8 * per16;
+    const int nchunks = (K + bke - 1) / bke;
+    int want = 512 / (p.ntm * p.ntn);           // two resident workgroups per CU
+    if (want > nchunks / 8) want = nchunks / 8;  // every split amortises its f32 slab over >= 8 chunks
+    if (want < 1) want = 1;
+    p.kcps = (nchunks + want - 1) / want;
+    p.nks = (nchunks + p.kcps - 1) / p.kcps;
+    if (nsplit) *nsplit = p.nks;
+    if (!part) return DPC_OK;  // size query: nsplit * M * N floats
+    if (!A || !B) return DPC_ERR_ARG;
+    p.src = A; p.wgt = B; p.out = part; p.addend = nullptr; p.stats = nullptr; p.epi = epi_none();
+    p.Ncol = N; p.ldw = ldb; p.ldo = N; p.slab = (long long)M * N;
+    p.vec_out = (N % 4 == 0 && ((uintptr_t)part % 16 == 0)) ? 1 : 0;
+    dpc_plan_detail("splitk=%d", p.nks);
+    if (dtype == DPC_F32) return launch_igemm<float, float>(p, bn, stream);
+    return launch_igemm<bf16_t, float>(p, bn, stream);
 }
 
 extern "C" int dpc_abi_version(void) { return 1; }

@@ -438,12 +438,12 @@ __global__ __launch_bounds__(512) void wgrad_stem_fused_kernel(WgradStemParams p
     for (int j = 0; j < 3 && j < nck; ++j) issue(c_begin + j, j);
     if (nck > 0) {
         wait_vmcnt_upto((nck - 1 < 2 ? nck - 1 : 2) * n_mine);
-        __syncthreads();
+        barrier_lds_only();   // NOT __syncthreads(): that waits vmcnt(0), i.e. for the DMA issued two and three chunks ahead
         build(c_begin, 0);
     }
     for (int j = 0; j < nck; ++j) {
         if (j + 1 < nck) wait_vmcnt_upto((nck - 2 - j < 1 ? nck - 2 - j : 1) * n_mine);   // chunk j+1 landed (only j+2 may be newer)
-        __syncthreads();   // tile j built and published; stage (j-1) % 4 free; every wave's pieces of chunk j+1 have landed
+        barrier_lds_only();   // tile j built and published; stage (j-1) % 4 free; every wave's pieces of chunk j+1 have landed
         if (j + 3 < nck) issue(c_begin + j + 3, (j + 3) % SF_NS);
         if (j + 1 < nck) build(c_begin + j + 1, (j + 1) % SF_NS);
         compute(j % SF_NS);

@@ -20,6 +20,7 @@
 // statistics / f32 output slabs are merged by small follow-up kernels.
 #include "dpc_rt.h"
 #include "../../include/dpc_hip.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -66,21 +67,27 @@ __device__ __forceinline__ void dma_rows(unsigned char* tile, const bf16_t* src,
 }
 
 template <int KS>
-__device__ __forceinline__ void load_own(u32x4 (&own)[KS], const ScoreP& p, int r0, int lane) {
+__device__ __forceinline__ void load_own_ld(u32x4 (&own)[KS], const bf16_t* base, long long ld, int nrows, int r0, int lane) {
     const int row = r0 + (lane & 31), kg = lane >> 5;
     DPC_UNROLL
     for (int ks = 0; ks < KS; ++ks) {
         u32x4 v = {0u, 0u, 0u, 0u};
-        if (row < p.R) v = *(const u32x4*)(p.own + (long long)row * p.D + (ks * 2 + kg) * 8);
+        if (row < nrows) v = *(const u32x4*)(base + (long long)row * ld + (ks * 2 + kg) * 8);
         own[ks] = v;
     }
+}
+template <int KS>
+__device__ __forceinline__ void load_own(u32x4 (&own)[KS], const ScoreP& p, int r0, int lane) {
+    load_own_ld<KS>(own, p.own, p.D, p.R, r0, lane);
 }
 
 // S[32 rows of the wave][64 columns of the tile] from the register-resident own fragments and the LDS tile.
 // The B fragments of K step ks + PF are requested before the MFMAs of step ks are issued: hipcc otherwise emits
 // ds_read -> s_waitcnt lgkmcnt(0) -> v_mfma per step and every MFMA eats a full LDS round trip (measured: 37 % of
 // the wave's cycles parked in s_waitcnt).
-template <int KS>
+// SWAP: the streamed operand goes first, so a lane holds ONE row of the wave (lane & 31) and quads of four consecutive streamed
+// columns (8 (r >> 2) + 4 (lane >> 5) + (r & 3)): what a 16-byte row store wants (score_gemm_kernel).
+template <int KS, bool SWAP = false>
 __device__ __forceinline__ void s_tile(f32x16 (&s)[2], const u32x4 (&own)[KS], const unsigned char* tile, int lane) {
     constexpr int PF = KS >= 4 ? 3 : (KS - 1 > 0 ? KS - 1 : 1);  // K steps in flight ahead of the MFMAs
     const int j = lane & 31, kg = lane >> 5;
@@ -104,7 +111,7 @@ __device__ __forceinline__ void s_tile(f32x16 (&s)[2], const u32x4 (&own)[KS], c
         constexpr int later = (KS - 1 - ks) < PF ? (KS - 1 - ks) : PF;  // K steps requested after this one
         lds_wait_tie_n(2 * later, b[ks][0], b[ks][1]);
         DPC_UNROLL
-        for (int t = 0; t < 2; ++t) s[t] = mfma_32x32x16_bf16(own[ks], b[ks][t], s[t]);
+        for (int t = 0; t < 2; ++t) s[t] = SWAP ? mfma_32x32x16_bf16(b[ks][t], own[ks], s[t]) : mfma_32x32x16_bf16(own[ks], b[ks][t], s[t]);
     });
 }
 
@@ -344,9 +351,69 @@ __global__ __launch_bounds__(256) void score_bwd_kernel(ScoreP p) {
         }
 }
 
+
+// ---------------------------------------------------------------- plain NT GEMM with a short reduction (K = D <= 256)
+// out[M][N] (f32) = a[M][D] @ b[N][D]^T and nothing else: the MATERIALISED score (dpc/model_3d.py:83 -- what the module boundary
+// returns, the f32 parity mode's loss reads, and the bf16 train step below R = 8 192 uses).  The generic implicit-GEMM kernel ran
+// this 6 144 x 6 144 x 256 product in 89 us (217 TFLOP/s): four 64-wide K chunks with a barrier each, the f32 tile staged through
+// LDS, 151 MB written at 1.7 TB/s.  Same structure as score_fwd_kernel instead: a wave's 32 rows stay in registers for all of K,
+// 64-column tiles of b stream through LDS (double-buffered LDS-DMA), two workgroups per CU so that one's stores overlap the
+// other's MFMAs; the MFMAs run with the operands swapped, so a lane owns one output row and quads of consecutive columns and the
+// tile leaves as 16-byte row stores straight from the accumulators (no LDS staging, a quarter of the store instructions).
+struct GemmKP {
+    const bf16_t* a;
+    const bf16_t* b;
+    float* out;
+    int M, N, D, lda, ldb, ldo;
+    int ntiles, tiles_per_split, nsplit;
+    int vec;  // 16-byte stores: ldo % 4 == 0 and out 16-byte aligned
+};
+
+template <int KS>
+__global__ __launch_bounds__(256, 2) void score_gemm_kernel(GemmKP p) {
+    DPC_DYN_SMEM(smem);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int rb = blockIdx.x, split = blockIdx.y;
+    const int r0 = rb * BM + wave * 32;
+    const int tile_bytes = ((KS * 32 + 127) / 128) * BN * 128;
+    u32x4 own[KS];
+    load_own_ld<KS>(own, p.a, p.lda, p.M, r0, lane);
+    const int jt0 = split * p.tiles_per_split;
+    int jt1 = jt0 + p.tiles_per_split;
+    if (jt1 > p.ntiles) jt1 = p.ntiles;
+    if (jt0 < jt1) dma_rows(smem, p.b, p.ldb, jt0 * BN, BN, p.N, 0, p.D, p.D, wave, lane);
+    const int row = r0 + (lane & 31), lhi = lane >> 5;
+    float* const orow = p.out + (long long)row * p.ldo;
+    for (int jt = jt0; jt < jt1; ++jt) {
+        const int buf = (jt - jt0) & 1;
+        wait_vmcnt<0>();
+        __syncthreads();  // tile jt has landed; every wave is done with the buffer the next DMA overwrites
+        if (jt + 1 < jt1) dma_rows(smem + (buf ^ 1) * tile_bytes, p.b, p.ldb, (jt + 1) * BN, BN, p.N, 0, p.D, p.D, wave, lane);
+        f32x16 s[2];
+        s_tile<KS, true>(s, own, smem + buf * tile_bytes, lane);
+        if (row < p.M) {
+            DPC_UNROLL
+            for (int t = 0; t < 2; ++t)
+                DPC_UNROLL
+                for (int k = 0; k < 4; ++k) {
+                    const int c = jt * BN + t * 32 + 8 * k + 4 * lhi;
+                    if (p.vec && c + 3 < p.N) {
+                        const f32x4 v = {s[t][4 * k], s[t][4 * k + 1], s[t][4 * k + 2], s[t][4 * k + 3]};
+                        *(f32x4*)(orow + c) = v;
+                    } else {
+                        DPC_UNROLL
+                        for (int e = 0; e < 4; ++e)
+                            if (c + e < p.N) orow[c + e] = s[t][4 * k + e];
+                    }
+                }
+        }
+    }
+}
+
 template <class K> int allow_lds(K kernel, size_t bytes) {
 #ifndef DPC_SIMT_EMU
     if (bytes > 160 * 1024) return DPC_ERR_UNSUPPORTED;
+    if (dpc_tls_plan_only) return DPC_OK;  // the plan query launches nothing (and must work without a device)
     if (hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess) return DPC_ERR_LAUNCH;
 #else
     (void)kernel; (void)bytes;
@@ -368,6 +435,39 @@ void plan_splits(int R, int target_wgs, int* ntiles, int* tps, int* nsplit) {
 }
 
 }  // namespace
+
+// dpc_conv_igemm hands plain NT GEMMs with bf16 operands, f32 output and K = 256 (or 32: the width-reduced test networks) to
+// score_gemm_kernel when the output is large; returns 1 when the shape is not served (the generic kernel runs it)
+int dpc_score_gemm_try(const dpc_conv_desc* d, const void* src, const void* wgt, void* out, hipStream_t stream) {
+    if (d->dtype_in != DPC_BF16 || d->dtype_out != DPC_F32 || d->mode != 0) return 1;
+    if (d->KT * d->KH * d->KW != 1 || d->RT * d->RH * d->RW != 1 || d->ST * d->SH * d->SW != 1) return 1;
+    if (d->st != 1 || d->sh != 1 || d->sw != 1 || d->pt || d->ph || d->pw) return 1;
+    if (d->Ci != 256 && d->Ci != 32) return 1;
+    static const int on = getenv("DPC_SCORE_GEMM") ? atoi(getenv("DPC_SCORE_GEMM")) : 1;
+    if (!on || (long long)d->N * d->Co < (1ll << 20) || d->N < 512 || d->Co < 512) return 1;  // small products: launch-bound either way
+    if (d->src_ld % 8 || d->ldw % 8 || ((uintptr_t)src % 16) || ((uintptr_t)wgt % 16)) return 1;
+    GemmKP p = {};
+    p.a = (const bf16_t*)src; p.b = (const bf16_t*)wgt; p.out = (float*)out;
+    p.M = d->N; p.N = d->Co; p.D = d->Ci; p.lda = d->src_ld; p.ldb = d->ldw; p.ldo = d->ldo;
+    p.vec = (d->ldo % 4 == 0 && ((uintptr_t)out % 16) == 0) ? 1 : 0;
+    const int nrb = (p.M + BM - 1) / BM;
+    p.ntiles = (p.N + BN - 1) / BN;
+    int sp = (512 + nrb - 1) / nrb;   // two workgroups per CU
+    if (sp > p.ntiles / 4) sp = p.ntiles / 4 > 0 ? p.ntiles / 4 : 1;
+    if (sp < 1) sp = 1;
+    p.tiles_per_split = (p.ntiles + sp - 1) / sp;
+    p.nsplit = (p.ntiles + p.tiles_per_split - 1) / p.tiles_per_split;
+    const dim3 grid(nrb, p.nsplit);
+    const size_t lds = 2 * (size_t)((p.D * 2 + 127) / 128) * BN * 128;
+    if (p.D == 256) {
+        if (int e = allow_lds(score_gemm_kernel<16>, lds)) return e;
+        DPC_LAUNCH_DYN((score_gemm_kernel<16>), grid, dim3(256), lds, stream, p);
+    } else {
+        if (int e = allow_lds(score_gemm_kernel<2>, lds)) return e;
+        DPC_LAUNCH_DYN((score_gemm_kernel<2>), grid, dim3(256), lds, stream, p);
+    }
+    return dpc_launch_status();
+}
 
 // workspace query: floats needed for `ws` of dpc_score_fwd / dpc_score_bwd (max of both)
 extern "C" int dpc_score_ws_floats(int32_t R, int32_t D, int64_t* fwd_floats, int64_t* bwd_floats) {

@@ -160,6 +160,9 @@ def algorithmic_cost(name, args):
         return 2.0 * args[2] * args[2] * args[3], float(2 * args[2] * args[3] * 2)
     if name == "dpc_score_bwd":            # own, oth, othT, ldT, R, D, ...: one R x R x D contraction (the recompute is not counted)
         return 2.0 * args[4] * args[4] * args[5], float(2 * args[4] * args[5] * 2 + args[4] * args[5] * 4)
+    if name == "dpc_gemm_nt_splitk":       # dtype, M, N, K, A, lda, B, ldb, part, nsplit
+        e = _esz(args[0])
+        return 2.0 * args[1] * args[2] * args[3], float((args[1] + args[2]) * args[3] * e + args[1] * args[2] * 4)
     if name not in ("dpc_conv_igemm", "dpc_conv_igemm_ex", "dpc_conv_wgrad"):
         return 0.0, 0.0
     d = args[0]._obj
@@ -580,6 +583,9 @@ class DPCEngine:
             self._need_wgrad(ns * M, co, kk)
         self.need_part(64 * 3 * D)  # dpc_colsum workspace
         self._need_wgrad(R, R, D)
+        nsk = C.c_int32(0)  # d_pred = dS @ feature_inf: f32 slabs of the split reduction
+        self.lib.call("dpc_gemm_nt_splitk", L.dtype_code(dt), R, D, self.ld_d, None, self.ld_d, None, self.ld_d, None, C.byref(nsk), self.lib.stream())
+        self.need_part(nsk.value * R * D)
         gd, Pm = self.gru_desc, self.PRM
         gd.dtype, gd.M, gd.D, gd.SQ, gd.P, gd.n_agg, gd.n_steps = L.dtype_code(dt), M, D, SQ, P, self.n_agg, ns
         gd.p_drop, gd.seed = float(self.p_drop), self.seed
@@ -667,6 +673,12 @@ class DPCEngine:
         """out[M][N] = A[M][K] @ Bm[N][K]^T (+ addend) on the matrix cores"""
         d = self._gemm_desc(M, N, K, lda or K, ldb or K, ldo or N, out_f32)
         self.call("dpc_conv_igemm", C.byref(d), A, Bm, out, addend, None)
+
+    def gemm_splitk(self, A, Bm, out, M, N, K, lda, ldb):
+        """out[M][N] (f32) = A[M][K] @ Bm[N][K]^T with the reduction split over workgroups (small output, long K)"""
+        ns = C.c_int32(0)
+        self.call("dpc_gemm_nt_splitk", L.dtype_code(self.cdtype), M, N, K, A, lda, Bm, ldb, self.part, C.byref(ns))
+        self.call("dpc_reduce_unpack", self.part, ns.value, out, M, 1, N, N, 0, 1, 0)
 
     def gemm_tn(self, dy, dy_ld, X, x_ld, out, M, Co, K):
         """out[Co][K] = dy[M][Co]^T @ X[M][K] (f32), split-K + deterministic reduce"""
@@ -862,7 +874,7 @@ class DPCEngine:
             if self._score_fused:
                 raise L.DpcError("backward(dscore_external=...) needs a materialised score: call forward(materialise=True)")
             with self.tag("score"):
-                self.gemm(self.dscore, self.finfT, self.d_pred, R, D, self.ld_d, lda=self.ld_d, ldb=self.ld_d)
+                self.gemm_splitk(self.dscore, self.finfT, self.d_pred, R, D, self.ld_d, self.ld_d, self.ld_d)
                 self.gemm_tn(self.dscore, self.ld_d, self.pred, D, self.d_finf, R, R, D)
         # ---- predict loop + aggregation, reversed: one launch (G_all, dP1, dP2, d_featrelu come back)
         ns = self.n_steps

@@ -88,6 +88,13 @@ typedef struct dpc_conv_epilogue {
 int dpc_conv_igemm_ex(const dpc_conv_desc* d, const void* src, const void* wgt, void* out, const dpc_conv_epilogue* epi,
                       dpc_stream_t stream);
 
+/* NT GEMM with the reduction split over workgroups: part[ks][M][N] (f32) = A[M][K range ks] @ B[N][K range ks]^T, A / B row-major
+ * with leading dimensions lda / ldb (dtype elements).  For products with a small output and a long reduction -- d_pred = dS @
+ * feature_inf of the contrastive loss (dpc/main.py:217 backward: M = R, N = 256, K = R).  *nsplit = number of slabs (query with
+ * part == NULL: capacity nsplit*M*N floats); sum them with dpc_reduce_unpack(part, nsplit, out, M, 1, N, N, 0, 1, 0). */
+int dpc_gemm_nt_splitk(int32_t dtype, int32_t M, int32_t N, int32_t K, const void* A, int32_t lda, const void* B, int32_t ldb,
+                       float* part, int32_t* nsplit, dpc_stream_t stream);
+
 /* Weight gradient: part[ks][co][tap*Ci+ci] = sum_{m in split ks} dy[m][co]*src[gather(m,tap)][ci]
  * (autograd of the same convs / 1x1 convs / matmul; f32 partials, reduced by
  * dpc_reduce_unpack).  Returns the number of K-splits through *nsplit; capacity in

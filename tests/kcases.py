@@ -211,15 +211,35 @@ def case_conv_wgrad(k: K, dtype, N, Ci, Co, T, H, W, ks, st, pd, seed=2, expect=
     assert relerr(dw, gw) < 1e-4  # f32 accumulation in both modes
 
 
-def case_gemm_nt(k: K, dtype, M, N, Kd, seed=3):
+def case_gemm_nt(k: K, dtype, M, N, Kd, seed=3, expect=None):
     g = torch.Generator().manual_seed(seed)
     A = q(torch.randn(M, Kd, generator=g), dtype)
     B = q(torch.randn(N, Kd, generator=g), dtype)
     d = conv_desc(dtype, torch.float32, 0, M, (1, 1, 1), (1, 1, 1), Kd, Kd, N, Kd, N, (1, 1, 1), (1, 1, 1), (0, 0, 0))
     out = k.empty(M, N)
     k.call("dpc_conv_igemm", C.byref(d), k.t(A, dtype), k.t(B, dtype), out, None, None)
+    check_kernel(k, expect)
     k.sync()
     assert relerr(out, A.double() @ B.double().t()) < 1e-5
+
+
+def case_gemm_nt_splitk(k: K, dtype, M, N, Kd, pad=0, seed=13):
+    """dpc_gemm_nt_splitk: f32 partial slabs of A @ B^T over K ranges, summed by dpc_reduce_unpack (d_pred = dS @ feature_inf);
+    leading dimensions Kd + pad, the padding columns hold garbage that must not be read"""
+    g = torch.Generator().manual_seed(seed)
+    A = q(torch.randn(M, Kd, generator=g), dtype)
+    B = q(torch.randn(N, Kd, generator=g), dtype)
+    Ap = torch.full((M, Kd + pad), 77.0).to(dtype); Ap[:, :Kd] = A.to(dtype)
+    Bp = torch.full((N, Kd + pad), -55.0).to(dtype); Bp[:, :Kd] = B.to(dtype)
+    ns = C.c_int32(0)
+    k.call("dpc_gemm_nt_splitk", L.dtype_code(dtype), M, N, Kd, None, Kd + pad, None, Kd + pad, None, C.byref(ns))
+    part = k.zeros(ns.value, M, N)
+    k.call("dpc_gemm_nt_splitk", L.dtype_code(dtype), M, N, Kd, k.t(Ap), Kd + pad, k.t(Bp), Kd + pad, part, C.byref(ns))
+    out = k.zeros(M, N)
+    k.call("dpc_reduce_unpack", part, ns.value, out, M, 1, N, N, 0, 1, 0)
+    k.sync()
+    assert relerr(out, A.double() @ B.double().t()) < 1e-5
+    return ns.value
 
 
 def case_stem(k: K, dtype, BN, T, H, W, Co=64, seed=4, expect=(None, None)):

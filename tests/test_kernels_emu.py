@@ -21,6 +21,13 @@ def k():
 
 
 @pytest.mark.parametrize("dtype", [F32, BF16])
+def test_gemm_nt_splitk(k, dtype):
+    assert kc.case_gemm_nt_splitk(k, dtype, 130, 64, 1024, pad=8) > 1   # ragged rows, several K splits, padded leading dimensions
+    kc.case_gemm_nt_splitk(k, dtype, 200, 72, 520)                       # ragged columns (element-wise tail path), K not a multiple of a chunk
+    assert kc.case_gemm_nt_splitk(k, dtype, 64, 32, 64) == 1             # nothing to split
+
+
+@pytest.mark.parametrize("dtype", [F32, BF16])
 @pytest.mark.parametrize("shape,gate,bnred,bn_relu", [
     ((1, 32, 32, 3, 6, 6, (3, 3, 3), (1, 1, 1), (1, 1, 1)), True, True, True),     # generic kernel, 3x3x3
     ((2, 8, 64, 2, 6, 5, (1, 3, 3), (1, 1, 1), (0, 1, 1)), True, True, True),      # bf16: role-specialised patch kernel (EPI), residual
@@ -101,6 +108,13 @@ def test_gemm_nt(k, dtype, mnk):
     kc.case_gemm_nt(k, dtype, *mnk)
 
 
+@pytest.mark.parametrize("mn", [(1100, 1028), (1027, 1027)])
+def test_score_gemm(k, mn):
+    """large bf16 -> f32 NT GEMM with a short reduction (the materialised score): register-resident rows, streamed column tiles,
+    16-byte row stores (1028: ragged last tile; 1027: odd leading dimension -> element-wise stores)"""
+    kc.case_gemm_nt(k, BF16, mn[0], mn[1], 32, expect="score_gemm_kernel<2>")
+
+
 @pytest.mark.parametrize("dtype", [F32, BF16])
 def test_stem_s2d(k, dtype):
     kc.case_stem(k, dtype, 2, 2, 16, 20)
@@ -136,7 +150,8 @@ def test_mask(k, bps):
 def test_ce_topk(k, dtype_d):
     kc.case_ce_topk(k, 24, 24, dtype_d)
     kc.case_ce_topk(k, 300, 300, dtype_d)
-    kc.case_ce_topk(k, 37, 37, dtype_d)
+    kc.case_ce_topk(k, 37, 37, dtype_d)      # odd width: the three-sweep kernel
+    kc.case_ce_topk(k, 1100, 1100, dtype_d)  # register-resident rows, NV = 8, more than one float4 per thread
 
 
 def test_adam(k):

@@ -102,7 +102,17 @@ def test_conv_dgrad_ex(k, dtype, shape, gate, bn_relu, kern):
 @pytest.mark.parametrize("dtype", [F32, BF16])
 @pytest.mark.parametrize("mnk", [(6144, 6144, 256), (6468, 6468, 256), (15680, 15680, 256), (2048, 768, 256), (192, 192, 256), (130, 70, 64)])
 def test_gemm_nt(k, dtype, mnk):
-    kc.case_gemm_nt(k, dtype, *mnk)
+    big = dtype == BF16 and mnk[2] == 256 and mnk[0] >= 1024 and mnk[1] >= 512   # the materialised score: dedicated kernel
+    kc.case_gemm_nt(k, dtype, *mnk, expect="score_gemm_kernel<16>" if big else ("igemm_kernel" if dtype == BF16 else None))
+
+
+@pytest.mark.parametrize("dtype", [F32, BF16])
+@pytest.mark.parametrize("mnk", [(6144, 256, 6144), (6468, 256, 6472), (15680, 256, 15680), (2048, 256, 256)])
+def test_gemm_nt_splitk(k, dtype, mnk):
+    """d_pred = dS @ feature_inf at cfg2 / cfg4 (leading dimension 6 472 = R rounded up to the 16-byte unit) / cfg5 size:
+    reduction split over workgroups, f32 slabs"""
+    ns = kc.case_gemm_nt_splitk(k, dtype, *mnk, pad=8)
+    assert ns >= (4 if mnk[0] > 4096 else 1)
 
 
 @pytest.mark.parametrize("dtype", [F32, BF16])
