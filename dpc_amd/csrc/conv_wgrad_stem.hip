@@ -240,7 +240,6 @@ __global__ __launch_bounds__(256, 3) void wgrad_stem_kernel(WgradStemParams p) {
 // and the same arithmetic on the same bf16 values as the two-kernel form: bit-identical results (case_stem_wgrad_fused).
 constexpr int SF_PW = 68, SF_NPOS = 4 * SF_PW;
 constexpr int SF_A = 0, SF_X = 8192, SF_P = SF_X + 9 * 1024, SF_M = SF_P + 10 * 1024, SF_STAGE = SF_M + 6 * 1024, SF_NS = 4;
-constexpr int SF_SLOTS = 33;  // DMA pieces per chunk: 8 raw + 9 patch + 10 pooled gradient + 6 argmax
 
 __global__ __launch_bounds__(512) void wgrad_stem_fused_kernel(WgradStemParams p) {
     __shared__ __attribute__((aligned(1024))) unsigned char lds[SF_NS * SF_STAGE];
@@ -283,39 +282,33 @@ __global__ __launch_bounds__(512) void wgrad_stem_fused_kernel(WgradStemParams p
     const BufRsrc rs_p = make_buf_rsrc(p.dpool, (unsigned)(pooled_elems * 2));
     const BufRsrc rs_m = make_buf_rsrc(p.argmax, (unsigned)pooled_elems);
 
-    // ---- this wave's DMA slots s = wv + 8 i (kind and lane constants are fixed for the whole kernel)
-    //   [0, 8)   raw piece s: positions 8s .. 8s+7, slot = logical unit ^ 2 (position & 3)       (the dy tile image of the plain kernel)
-    //   [8, 17)  source patch piece s - 8: 32 positions x 32 bytes
-    //   [17, 27) pooled gradient: row r = (s-17) / 5, positions 8 ((s-17) % 5) + (lane >> 3), unit lane & 7 of this co tile
-    //   [27, 33) argmax bytes:    row r = (s-27) / 3, positions 16 ((s-27) % 3) + (lane >> 2), 16 bytes (lane & 3) of this co tile
-    constexpr int NSL = (SF_SLOTS + 7) / 8;  // 5
-    unsigned rel[NSL];
-    int aux[NSL];   // raw: position in the chunk | patch: (row << 8) | column (row = 255: no position) | pooled: (r << 8) | pooled column offset
-    DPC_UNROLL
-    for (int i = 0; i < NSL; ++i) {
-        const int sl = wv + 8 * i;
-        rel[i] = 0u; aux[i] = 0;
-        if (sl < 8) {
-            const int pl = lane >> 3, pos = 8 * sl + pl;
-            const int lslot = (lane & 7) ^ (2 * (pl & 3));
-            rel[i] = (unsigned)(pos * p.dy_ld + tile_m * 64 + lslot * 8) * 2u;
-            aux[i] = pos;
-        } else if (sl < 17) {
-            const int pp = 32 * (sl - 8) + (lane >> 1);
-            const int prow = pp / SF_PW, pcol = pp % SF_PW;
-            rel[i] = (unsigned)((prow * p.W + pcol) * 32 + (lane & 1) * 16);
-            aux[i] = ((pp < SF_NPOS ? prow : 255) << 8) | pcol;
-        } else if (sl < 27) {
-            const int k = sl - 17, r = k / 5, oc = 8 * (k % 5) + (lane >> 3);
-            rel[i] = (unsigned)(oc * p.Co + tile_m * 64 + (lane & 7) * 8) * 2u;
-            aux[i] = (r << 8) | oc;
-        } else if (sl < SF_SLOTS) {
-            const int k = sl - 27, r = k / 3, oc = 16 * (k % 3) + (lane >> 2);
-            rel[i] = (unsigned)(oc * p.Co + tile_m * 64 + (lane & 3) * 16);
-            aux[i] = (r << 8) | oc;
-        }
-    }
-    const int n_mine = (SF_SLOTS - wv + 7) / 8;   // DMA instructions this wave issues per chunk
+    // ---- this wave's DMA pieces (33 per chunk over 8 waves; straight-line code with named per-lane constants: a loop over a
+    //      table of slots was not unrolled by hipcc, the table went to scratch, the LDS destination into a waterfall loop --
+    //      and a scratch load waits for every LDS-DMA piece issued before it)
+    //   A  raw piece wv: positions 8 wv .. 8 wv + 7, slot = logical unit ^ 2 (position & 3)     (the dy tile image of the plain kernel)
+    //   B  source patch piece wv (32 positions x 32 bytes); wave 0 also piece 8 (E)
+    //   C  pooled gradient piece wv: row wv / 5, positions 8 (wv % 5) + (lane >> 3), unit lane & 7 of this co tile
+    //   D  waves 0-1: pooled gradient pieces 8, 9 (row 1); waves 2-7: argmax piece wv - 2: row (wv-2) / 3, positions
+    //      16 ((wv-2) % 3) + (lane >> 2), 16 bytes (lane & 3) of this co tile
+    const int posA = 8 * wv + (lane >> 3);
+    const unsigned relA = (unsigned)(posA * p.dy_ld + tile_m * 64 + ((lane & 7) ^ (2 * ((lane >> 3) & 3))) * 8) * 2u;
+    auto patch_consts = [&](int piece, unsigned& rel, int& prow, int& pcol) {
+        const int pp = 32 * piece + (lane >> 1);
+        prow = pp < SF_NPOS ? pp / SF_PW : (1 << 20);
+        pcol = pp % SF_PW;
+        rel = (unsigned)(((pp / SF_PW) * p.W + pcol) * 32 + (lane & 1) * 16);
+    };
+    unsigned relB, relE;
+    int prowB, pcolB, prowE, pcolE;
+    patch_consts(wv, relB, prowB, pcolB);
+    patch_consts(8, relE, prowE, pcolE);
+    const int rC = wv / 5, ocC = 8 * (wv % 5) + (lane >> 3);
+    const unsigned relC = (unsigned)(ocC * p.Co + tile_m * 64 + (lane & 7) * 8) * 2u;
+    const bool dIsP = wv < 2;
+    const int rD = dIsP ? 1 : (wv - 2) / 3;
+    const int ocD = dIsP ? 8 * (3 + wv) + (lane >> 3) : 16 * ((wv - 2) % 3) + (lane >> 2);
+    const unsigned relD = dIsP ? (unsigned)(ocD * p.Co + tile_m * 64 + (lane & 7) * 8) * 2u : (unsigned)(ocD * p.Co + tile_m * 64 + (lane & 3) * 16);
+    const int n_mine = wv == 0 ? 5 : 4;   // DMA instructions this wave issues per chunk
 
     auto chunk_pos = [&](int chunk, int& frame, int& h, int& w0) {
         const unsigned f = fdiv((unsigned)chunk, p.d_cpf);
@@ -331,26 +324,26 @@ __global__ __launch_bounds__(512) void wgrad_stem_fused_kernel(WgradStemParams p
         const unsigned a_base = (unsigned)(pos * p.dy_ld * 2 - a_lo);
         const unsigned b_base = (unsigned)((pos - (long long)p.ph * p.W - p.pw) * 32 - b_lo);
         const int oh0 = h >> 1, ow0 = w0 >> 1;
-        DPC_UNROLL
-        for (int i = 0; i < NSL; ++i) {
-            const int sl = wv + 8 * i;   // wave-uniform: the branches below are scalar
-            if (sl < 8) {
-                const bool ok = w0 + aux[i] < p.W;
-                glds16_buf(rs_a, ok ? a_base + rel[i] : DPC_BUF_OOB, 0u, stage + SF_A + sl * 1024, lane);
-            } else if (sl < 17) {
-                const int prow = aux[i] >> 8, pcol = aux[i] & 255;
-                const bool ok = ((unsigned)(h - p.ph + prow) < (unsigned)p.H) & ((unsigned)(w0 - p.pw + pcol) < (unsigned)p.W);
-                glds16_buf(rs_b, ok ? b_base + rel[i] : DPC_BUF_OOB, 0u, stage + SF_X + (sl - 8) * 1024, lane);
-            } else if (sl < SF_SLOTS) {
-                const int r = aux[i] >> 8, oc = aux[i] & 255;
-                const int oh = oh0 + r;
-                // row 1 of the pooled pair is only looked at from odd image rows; positions beyond the 33 a chunk can touch,
-                // beyond the pooled row or the pooled image are out-of-range lanes (zero fill, no memory traffic)
-                const bool ok = (r == 0 || (h & 1)) && oh < p.Ho && oc < 33 && ow0 + oc < p.Wo;
-                const unsigned pbase = (unsigned)(((frame * p.Ho + oh) * p.Wo + ow0) * p.Co);
-                if (sl < 27) glds16_buf(rs_p, ok ? pbase * 2u + rel[i] : DPC_BUF_OOB, 0u, stage + SF_P + (sl - 17) * 1024, lane);
-                else glds16_buf(rs_m, ok ? pbase + rel[i] : DPC_BUF_OOB, 0u, stage + SF_M + (sl - 27) * 1024, lane);
-            }
+        // A
+        glds16_buf(rs_a, (w0 + posA < p.W) ? a_base + relA : DPC_BUF_OOB, 0u, stage + SF_A + wv * 1024, lane);
+        // B
+        {
+            const bool ok = ((unsigned)(h - p.ph + prowB) < (unsigned)p.H) & ((unsigned)(w0 - p.pw + pcolB) < (unsigned)p.W);
+            glds16_buf(rs_b, ok ? b_base + relB : DPC_BUF_OOB, 0u, stage + SF_X + wv * 1024, lane);
+        }
+        // pooled rows: row 1 of the pair is only looked at from odd image rows; positions beyond the 33 a chunk can touch, beyond
+        // the pooled row or the pooled image are out-of-range lanes (zero fill, no memory traffic)
+        auto pooled_ok = [&](int r, int oc) { return (r == 0 || (h & 1)) && oh0 + r < p.Ho && oc < 33 && ow0 + oc < p.Wo; };
+        auto pooled_base = [&](int r) { return (unsigned)(((frame * p.Ho + oh0 + r) * p.Wo + ow0) * p.Co); };
+        // C
+        glds16_buf(rs_p, pooled_ok(rC, ocC) ? pooled_base(rC) * 2u + relC : DPC_BUF_OOB, 0u, stage + SF_P + wv * 1024, lane);
+        // D
+        if (dIsP) glds16_buf(rs_p, pooled_ok(1, ocD) ? pooled_base(1) * 2u + relD : DPC_BUF_OOB, 0u, stage + SF_P + (8 + wv) * 1024, lane);
+        else glds16_buf(rs_m, pooled_ok(rD, ocD) ? pooled_base(rD) + relD : DPC_BUF_OOB, 0u, stage + SF_M + (wv - 2) * 1024, lane);
+        // E
+        if (wv == 0) {
+            const bool ok = ((unsigned)(h - p.ph + prowE) < (unsigned)p.H) & ((unsigned)(w0 - p.pw + pcolE) < (unsigned)p.W);
+            glds16_buf(rs_b, ok ? b_base + relE : DPC_BUF_OOB, 0u, stage + SF_X + 8 * 1024, lane);
         }
     };
 
@@ -363,42 +356,60 @@ __global__ __launch_bounds__(512) void wgrad_stem_fused_kernel(WgradStemParams p
         const int c = tile_m * 64 + fu * 8 + e;
         f_mu[e] = p.mean[c]; f_is[e] = p.invstd[c]; f_ga[e] = p.gamma[c] * f_is[e]; f_c1[e] = p.coef[c]; f_c2[e] = p.coef[p.Co + c];
     }
+    // All LDS traffic of build / compute goes through the raw accessors of dpc_rt.h: hipcc would put s_waitcnt vmcnt(0) in front of
+    // every LDS access it can see (it may alias an LDS-DMA destination) and so wait for the pieces issued for chunk j+3 -- the first
+    // build of this kernel ran 4.2 ms that way, 3.3 us per chunk of exposed memory latency.
     auto build = [&](int chunk, int st) {
         unsigned char* stage = lds + st * SF_STAGE;
         int frame, h, w0;
         chunk_pos(chunk, frame, h, w0);
         const int w = w0 + pos;
         const bool ok = w < p.W;
-        const u32x4 rv = *(const u32x4*)(stage + a_unit);
+        const bool odd_h = h & 1;
+        // window (a, b): pooled row (h >> 1) + a, pooled column idx + b; rows / columns the position is not inside are skipped
+        // (chunk- / wave-uniform), so the gathers are 1, 2, 2 or 4 per unit
+        const bool ua[2] = {(h >> 1) < p.Ho, odd_h && (h >> 1) + 1 < p.Ho};
+        const bool ub[2] = {true, parity != 0};
+        // the four windows are read unconditionally (inside the stage; what a position is not part of is masked below): named
+        // registers, no conditional inline asm -- an array of asm outputs behind run-time conditions went to SCRATCH, and a scratch
+        // load is a vector-memory operation whose wait drains the LDS-DMA queue just like vmcnt(0)
+        u32x4 rv, g00, g01, g10, g11;
+        u32x2 m00, m01, m10, m11;
+        const unsigned char* pg = stage + SF_P + idx * 128 + fu * 16;
+        const unsigned char* pm = stage + SF_M + idx * 64 + fu * 8;
+        lds_read_b128_raw(rv, stage + a_unit);
+        lds_read_b128_raw(g00, pg);
+        lds_read_b128_raw(g01, pg + 128);
+        lds_read_b128_raw(g10, pg + 5120);
+        lds_read_b128_raw(g11, pg + 5120 + 128);
+        lds_read_b64_raw(m00, pm);
+        lds_read_b64_raw(m01, pm + 64);
+        lds_read_b64_raw(m10, pm + 3072);
+        lds_read_b64_raw(m11, pm + 3072 + 64);
+        lds_wait0_5(rv, g00, g01, g10, g11);
+        lds_wait0_4x2(m00, m01, m10, m11);
         float g[8];
         DPC_UNROLL
         for (int e = 0; e < 8; ++e) g[e] = 0.f;
-        DPC_UNROLL
-        for (int a = 0; a < 2; ++a) {
-            if (a == 1 && !(h & 1)) continue;            // chunk-uniform
-            if ((h >> 1) + a >= p.Ho) continue;
-            const int kh = a == 0 ? (h & 1) + 1 : 0;
+        auto route = [&](const u32x4& gv, const u32x2& am, int a, int b) {   // summation order (a, b) = (0,0) (0,1) (1,0) (1,1): pool_routed_grad's
+            const int kh = a == 0 ? (h & 1) + 1 : 0, kw = b == 0 ? parity + 1 : 0;
+            const unsigned want = (unsigned)(kh * 3 + kw);
+            const bool use = ua[a] && ub[b] && ok && (w >> 1) + b < p.Wo;
             DPC_UNROLL
-            for (int b = 0; b < 2; ++b) {
-                if (b == 1 && !parity) continue;          // wave-uniform
-                const int kw = b == 0 ? parity + 1 : 0;
-                const unsigned want = (unsigned)(kh * 3 + kw);
-                const int oc = idx + b;
-                const bool use = ok && (w >> 1) + b < p.Wo;
-                const u32x4 gv = *(const u32x4*)(stage + SF_P + a * 5120 + oc * 128 + fu * 16);
-                const u32x2 am = *(const u32x2*)(stage + SF_M + a * 3072 + oc * 64 + fu * 8);
-                DPC_UNROLL
-                for (int e = 0; e < 8; ++e)
-                    if (use && ((am[e >> 2] >> (8 * (e & 3))) & 0xffu) == want) g[e] += unit_get<bf16_t>(gv, e);
-            }
-        }
+            for (int e = 0; e < 8; ++e)
+                if (use && ((am[e >> 2] >> (8 * (e & 3))) & 0xffu) == want) g[e] += unit_get<bf16_t>(gv, e);
+        };
+        route(g00, m00, 0, 0);
+        route(g01, m01, 0, 1);
+        route(g10, m10, 1, 0);
+        route(g11, m11, 1, 1);
         float ov[8];
         DPC_UNROLL
         for (int e = 0; e < 8; ++e) {
             const float xh = (unit_get<bf16_t>(rv, e) - f_mu[e]) * f_is[e];
             ov[e] = ok ? f_ga[e] * (g[e] - f_c1[e] - xh * f_c2[e]) : 0.f;
         }
-        *(u32x4*)(stage + a_unit) = unit_pack<bf16_t>(ov);
+        lds_write_b128_raw(stage + a_unit, unit_pack<bf16_t>(ov));
     };
 
     // ---- MFMA: wave = (co half wi, kernel row wr); accumulator c = taps kw = 2c, 2c+1 of that row x 16 channels
@@ -420,15 +431,20 @@ __global__ __launch_bounds__(512) void wgrad_stem_fused_kernel(WgradStemParams p
         const unsigned char* sp = lds + st * SF_STAGE;
         DPC_UNROLL
         for (int kk = 0; kk < 4; ++kk) {
-            const u32x2 a0 = lds_read_tr16(sp + fa + (kk * 16) * 128);
-            const u32x2 a1 = lds_read_tr16(sp + fa + (kk * 16 + 4) * 128);
-            const u32x4 av = {a0[0], a0[1], a1[0], a1[1]};
+            u32x2 a0, a1, b[2][2];
+            lds_read_tr16_raw(a0, sp + fa + (kk * 16) * 128);
+            lds_read_tr16_raw(a1, sp + fa + (kk * 16 + 4) * 128);
             DPC_UNROLL
             for (int c = 0; c < 2; ++c) {
                 const unsigned char* bp = sp + fb + (kk * 16 + 2 * c) * 32;
-                const u32x2 b0 = lds_read_tr16(bp);
-                const u32x2 b1 = lds_read_tr16(bp + 4 * 32);
-                const u32x4 bv = {b0[0], b0[1], b1[0], b1[1]};
+                lds_read_tr16_raw(b[c][0], bp);
+                lds_read_tr16_raw(b[c][1], bp + 4 * 32);
+            }
+            lds_wait0_6x2(a0, a1, b[0][0], b[0][1], b[1][0], b[1][1]);
+            const u32x4 av = {a0[0], a0[1], a1[0], a1[1]};
+            DPC_UNROLL
+            for (int c = 0; c < 2; ++c) {
+                const u32x4 bv = {b[c][0][0], b[c][0][1], b[c][1][0], b[c][1][1]};
                 acc[c] = mfma_32x32x16_bf16(av, bv, acc[c]);
             }
         }

@@ -348,6 +348,42 @@ template <int N> __device__ __forceinline__ void lds_wait_tie(u32x4& a, u32x4& b
 // instruction-scheduler fence: nothing is moved across it (no instruction is emitted)
 __device__ __forceinline__ void sched_fence() { __builtin_amdgcn_sched_barrier(0); }
 #endif
+// LDS accesses the compiler must not see as such: hipcc orders every LDS access it knows about after ALL outstanding LDS-DMA
+// (s_waitcnt vmcnt(0) in front of it -- it cannot tell the DMA's destination from the address it reads), which drains a prefetch
+// that is meant to stay in flight for several chunks.  The caller guarantees (counted vmcnt + barrier) that what it touches has
+// landed.  lds_wait0_*: s_waitcnt lgkmcnt(0) tied to the registers the preceding raw reads wrote.
+#ifdef DPC_SIMT_EMU
+__device__ __forceinline__ void lds_read_b64_raw(u32x2& d, const unsigned char* p) { d = *(const u32x2*)p; }
+__device__ __forceinline__ void lds_read_b128_raw(u32x4& d, const unsigned char* p) { d = *(const u32x4*)p; }
+__device__ __forceinline__ void lds_write_b128_raw(unsigned char* p, const u32x4& v) { *(u32x4*)p = v; }
+__device__ __forceinline__ void lds_read_tr16_raw(u32x2& d, const unsigned char* p) { d = lds_read_tr16(p); }
+__device__ __forceinline__ void lds_wait0_5(u32x4&, u32x4&, u32x4&, u32x4&, u32x4&) {}
+__device__ __forceinline__ void lds_wait0_4x2(u32x2&, u32x2&, u32x2&, u32x2&) {}
+__device__ __forceinline__ void lds_wait0_6x2(u32x2&, u32x2&, u32x2&, u32x2&, u32x2&, u32x2&) {}
+#else
+__device__ __forceinline__ void lds_read_b64_raw(u32x2& d, const unsigned char* p) {
+    const uint32_t a = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const unsigned char*)p;
+    asm volatile("ds_read_b64 %0, %1" : "=&v"(d) : "v"(a) : "memory");
+}
+__device__ __forceinline__ void lds_read_b128_raw(u32x4& d, const unsigned char* p) { lds_read_b128_async(d, p); }
+__device__ __forceinline__ void lds_write_b128_raw(unsigned char* p, const u32x4& v) {
+    const uint32_t a = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)p;
+    asm volatile("ds_write_b128 %0, %1" ::"v"(a), "v"(v) : "memory");
+}
+__device__ __forceinline__ void lds_read_tr16_raw(u32x2& d, const unsigned char* p) {
+    const uint32_t a = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const unsigned char*)p;
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=&v"(d) : "v"(a) : "memory");
+}
+__device__ __forceinline__ void lds_wait0_5(u32x4& a, u32x4& b, u32x4& c, u32x4& d, u32x4& e) {
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e)::"memory");
+}
+__device__ __forceinline__ void lds_wait0_4x2(u32x2& a, u32x2& b, u32x2& c, u32x2& d) {
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d)::"memory");
+}
+__device__ __forceinline__ void lds_wait0_6x2(u32x2& a, u32x2& b, u32x2& c, u32x2& d, u32x2& e, u32x2& f) {
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f)::"memory");
+}
+#endif
 __device__ __forceinline__ void lds_wait_tie_n(int n, u32x4& a, u32x4& b) {  // n is a compile-time value after unrolling
     if (n >= 6) lds_wait_tie<6>(a, b);
     else if (n == 4) lds_wait_tie<4>(a, b);

@@ -150,6 +150,34 @@ def basic_block(x: torch.Tensor, p: Params, pre: str, is3d: bool, stride: int,
     return F.relu(out) if final_relu else out
 
 
+def ste_round_bf16(x: torch.Tensor) -> torch.Tensor:
+    """round to bf16 in the forward, identity in the backward: how a tensor the engine STORES in bf16 enters the next op while the
+    gradient flows through unchanged (the engine's backward kernels differentiate the unrounded op at the stored values)"""
+    return x + (x.to(torch.bfloat16).to(x.dtype) - x).detach()
+
+
+def basic_block_rounded(x: torch.Tensor, p: Params, pre: str, is3d: bool, stride: int, final_relu: bool = True) -> torch.Tensor:
+    """basic_block with the engine's throughput-mode storage points: weights, raw conv outputs and activations pass through
+    ste_round_bf16; BatchNorm statistics are those of the STORED raw outputs, accumulation stays full precision.  The block-local
+    gradient checks of the bf16 mode (tests/test_block_grads_gpu.py) differentiate this, not the fp32 block."""
+    r = ste_round_bf16
+    if is3d:
+        s1, pad = (stride,) * 3, (1, 1, 1)
+    else:
+        s1, pad = (1, stride, stride), (0, 1, 1)
+    raw1 = r(F.conv3d(x, r(p[pre + "conv1.weight"]), None, s1, pad))
+    act1 = r(F.relu(bn_batch(raw1, p[pre + "bn1.weight"], p[pre + "bn1.bias"])))
+    raw2 = r(F.conv3d(act1, r(p[pre + "conv2.weight"]), None, 1, pad))
+    out = bn_batch(raw2, p[pre + "bn2.weight"], p[pre + "bn2.bias"])
+    if (pre + "downsample.0.weight") in p:
+        rawd = r(F.conv3d(x, r(p[pre + "downsample.0.weight"]), None, s1, 0))
+        res = bn_batch(rawd, p[pre + "downsample.1.weight"], p[pre + "downsample.1.bias"])
+    else:
+        res = x
+    out = out + res
+    return r(F.relu(out) if final_relu else out)
+
+
 def backbone_forward(p: Params, x: torch.Tensor, network: str = "resnet18") -> torch.Tensor:
     """ResNet2d3d_full.forward (resnet_2d3d.py:259-270); x is [BN,3,T,H,W]."""
     plan = LAYER_PLAN[network]

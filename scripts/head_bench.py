@@ -36,6 +36,40 @@ for R in (6144, 15680):
     timeit(lambda: k.lib.call("dpc_score_bwd", pred, finf, finfT, ld, R, D, lse2, 1, ws, k.lib.stream()), f"score_bwd d_pred R={R}", fl)
     timeit(lambda: k.lib.call("dpc_score_bwd", finf, pred, predT, ld, R, D, lse2, 0, ws, k.lib.stream()), f"score_bwd d_finf R={R}", fl)
 
+# ---- materialised path: score GEMM (dpc_conv_igemm), CE / top-k + dS, d_pred (split-K NT GEMM), d_finf (transpose-read TN GEMM)
+for R in (6144, 6468, 15680):
+    D = 256
+    g = torch.Generator(device="cuda").manual_seed(2)
+    pred = (torch.randn(R, D, device="cuda", generator=g) * 0.1).to(bf)
+    finf = (torch.randn(R, D, device="cuda", generator=g) * 0.1).to(bf)
+    ld = (R + 7) // 8 * 8
+    finfT = torch.zeros(D, ld, dtype=bf, device="cuda"); finfT[:, :R] = finf.t()
+    score = k.empty(R, R)
+    dS = k.empty(R, ld, dtype=bf)
+    row_ws, res = k.empty(R, 2), k.empty(4)
+    d = kc.conv_desc(bf, torch.float32, 0, R, (1, 1, 1), (1, 1, 1), D, D, R, D, R, (1, 1, 1), (1, 1, 1), (0, 0, 0))
+    fl = 2.0 * R * R * D
+    timeit(lambda: k.call("dpc_conv_igemm", C.byref(d), pred, finf, score, None, None), f"score GEMM R={R} [{L.conv_plan(k.lib, d)}]", fl)
+    timeit(lambda: k.call("dpc_ce_topk", score, R, R, R, row_ws, res, dS, 1, ld), f"CE/top-k + dS R={R}")
+    nsk = C.c_int32(0)
+    k.call("dpc_gemm_nt_splitk", 1, R, D, ld, None, ld, None, ld, None, C.byref(nsk))
+    part = k.empty(max(nsk.value, 1) * R * D)
+    dp = k.empty(R, D)
+    def dpred():
+        k.call("dpc_gemm_nt_splitk", 1, R, D, ld, dS, ld, finfT, ld, part, C.byref(nsk))
+        k.call("dpc_reduce_unpack", part, nsk.value, dp, R, 1, D, D, 0, 1, 0)
+    timeit(dpred, f"d_pred split-K x{nsk.value} + reduce R={R}", fl)
+    dw = kc.conv_desc(bf, torch.float32, 0, R, (1, 1, 1), (1, 1, 1), D, D, R, D, R, (1, 1, 1), (1, 1, 1), (0, 0, 0))
+    nsw = C.c_int32(0)
+    k.call("dpc_conv_wgrad", C.byref(dw), None, None, ld, None, C.byref(nsw))
+    part2 = k.empty(max(nsw.value, 1) * R * D)
+    df = k.empty(R, D)
+    def dfinf():
+        k.call("dpc_conv_wgrad", C.byref(dw), pred, dS, ld, part2, C.byref(nsw))
+        k.call("dpc_reduce_unpack", part2, nsw.value, df, R, 1, D, D, 0, 1, 0)
+    timeit(dfinf, f"d_finf wgrad2 x{nsw.value} + reduce R={R}", fl)
+    del score, dS, part, part2
+
 for (B, SQ, P) in ((128, 16, 3), (64, 49, 5)):
     d, dev, *_ = kc._chain_setup(k, bf, B, SQ, 256, P, 8 - P, seed=3)
     step = torch.tensor([1], dtype=torch.int32, device="cuda")

@@ -1,0 +1,100 @@
+"""GPU tier: the bf16 (throughput) mode's backward, block by block, against an oracle that rounds where the engine rounds.
+
+The end-to-end bf16 gradients can only be held to the rounding noise of 17 stacked layers (30-46 % rel-L2 in layer1 / stem,
+tests/golden/anchor_r18_128_b16.npz) -- a dropped tap in one weight gradient (+33 %) would pass.  Here every BasicBlock type is
+differentiated in isolation: the engine's own saved block input (bf16) and a random incoming gradient go through
+``_Block.backward`` -- the specialised kernels the benchmark runs: role-specialised patch kernel with fused epilogues, plane and
+loader/compute implicit GEMMs, staged-patch / transpose-read weight gradients, parity-class strided input-gradients -- and
+through torch autograd of ``oracle.basic_block_rounded`` (f32 accumulation, bf16 storage points, straight-through rounding) on
+the CPU.  What differs is the rounding of the backward intermediates only: every gradient is held to 2 % rel-L2, and a mutation
+that drops one tap of a weight gradient is shown to fail the same check."""
+import pytest
+import torch
+
+from dpc_amd.engine import DPCEngine
+from oracle import dpc_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+TOL = 0.02
+
+
+def rel(a, b):
+    return ((a.float().cpu() - b.float()).norm() / b.float().norm().clamp_min(1e-20)).item()
+
+
+def nchw(t):  # engine activation [N,T,H,W,C] -> [N,C,T,H,W]
+    return t.permute(0, 4, 1, 2, 3).contiguous()
+
+
+@pytest.fixture(scope="module")
+def eng():
+    # B = 16: the batch at which every specialised bf16 kernel of cfg2 is selected (tests/test_plan.py pins the plan)
+    e = DPCEngine("resnet18", 128, 8, 5, 3, 16, DEV, torch.bfloat16)
+    e.load_params(O.init_params_reference_style("resnet18", seed=0))
+    x = O.make_input_pcg(16, 8, 5, 128).to(DEV)
+    e.forward(x, train=False)   # fills every block's saved tensors (x_in, raw, act1, masks, statistics)
+    torch.cuda.synchronize()
+    return e
+
+
+@pytest.mark.parametrize("bi", [0, 1, 2, 3, 4, 5, 6, 7])
+def test_block_backward_vs_rounding_oracle(eng, bi):
+    blk = eng.blocks[bi]
+    li, bj = bi // 2, bi % 2
+    pre = f"backbone.layer{li + 1}.{bj}."
+    g = torch.Generator().manual_seed(100 + bi)
+    dout = (torch.randn(tuple(blk.out.shape), generator=g) * 0.05).to(torch.bfloat16)
+    # ---- oracle: autograd of the rounded block at the engine's saved input and the same weights
+    p = {k: v.detach().cpu().clone().requires_grad_() for k, v in eng.PRM.items() if k.startswith(pre)}
+    x = nchw(blk.x_in.float().cpu()).requires_grad_()
+    out = O.basic_block_rounded(x, p, pre, li >= 2, 2 if (li > 0 and bj == 0) else 1, final_relu=blk.final_relu)
+    assert rel(nchw(blk.out), out.detach()) < 5e-3        # same forward (the engine's stored output is the oracle's, bf16 rounding aside)
+    out.backward(nchw(dout.float()))
+    # ---- engine: the block's backward kernels on its own saved tensors
+    for k in p:
+        eng.G[k].zero_()
+    if blk.prev is not None:
+        blk.prev.c2.reduced_rows = 0
+    dx = blk.backward(dout.to(DEV).clone(), need_dx=True)
+    if blk.prev is not None:
+        blk.prev.c2.reduced_rows = 0   # the fused reduction of the previous block's bn2 is not consumed here
+    torch.cuda.synchronize()
+    errs = {"dx": rel(nchw(dx), x.grad)}
+    for k, v in p.items():
+        errs[k[len(pre):]] = rel(eng.G[k], v.grad)
+    worst = max(errs, key=errs.get)
+    print(f"{pre} fold_c1={blk.fold_c1} gate={blk.gate} fold_prev={blk.fold_prev}: worst {worst} {errs[worst]:.4f}; dx {errs['dx']:.4f}")
+    for k, e in errs.items():
+        assert e < TOL, (pre + k, e)
+    # ---- the check has teeth: one dropped tap of conv2's weight gradient is far outside the tolerance
+    w = p[pre + "conv2.weight"].grad.clone()
+    mut = eng.G[pre + "conv2.weight"].cpu().clone()
+    mut[..., -1, -1] = 0
+    assert rel(mut, w) > 5 * TOL
+
+
+def test_fused_reduction_of_the_previous_block_is_what_the_standalone_pass_computes(eng):
+    """layer1.1's first input-gradient carries the BatchNorm-backward partial sums of layer1.0's bn2 (dpc_conv_igemm_ex): finalised,
+    they give the dgamma / dbeta the standalone reduction gives for the same gradient tensor"""
+    import ctypes as C
+    from dpc_amd import _lib as L
+    blk, prev = eng.blocks[1], eng.blocks[0]
+    if not blk.fold_prev:
+        pytest.skip("the plan does not fold this reduction")
+    g = torch.Generator().manual_seed(5)
+    dout = (torch.randn(tuple(blk.out.shape), generator=g) * 0.05).to(torch.bfloat16).to(DEV)
+    dx = blk.backward(dout.clone(), need_dx=True)
+    rows = prev.c2.reduced_rows
+    assert rows > 0
+    u = prev.c2
+    dgam, dbet, coef = (torch.empty(n, device=DEV) for n in (u.Co, u.Co, 2 * u.Co))
+    eng.call("dpc_bn_bwd_finalize", eng.stats, rows, u.Co, float(u.rows), dgam, dbet, coef)
+    pr = C.c_int32(0)
+    part = torch.empty_like(eng.stats)
+    eng.call("dpc_bn_bwd_reduce", dx, None, u.mask, u.raw, L.BF16, u.rows, u.Co, u.mean, u.invstd, 1, part, C.byref(pr))
+    dgam2, dbet2, coef2 = (torch.empty(n, device=DEV) for n in (u.Co, u.Co, 2 * u.Co))
+    eng.call("dpc_bn_bwd_finalize", part, pr.value, u.Co, float(u.rows), dgam2, dbet2, coef2)
+    torch.cuda.synchronize()
+    u.reduced_rows = 0
+    assert rel(dgam, dgam2.cpu()) < 1e-5 and rel(dbet, dbet2.cpu()) < 1e-5
