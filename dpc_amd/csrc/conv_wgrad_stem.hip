@@ -359,54 +359,62 @@ __global__ __launch_bounds__(512) void wgrad_stem_fused_kernel(WgradStemParams p
     // All LDS traffic of build / compute goes through the raw accessors of dpc_rt.h: hipcc would put s_waitcnt vmcnt(0) in front of
     // every LDS access it can see (it may alias an LDS-DMA destination) and so wait for the pieces issued for chunk j+3 -- the first
     // build of this kernel ran 4.2 ms that way, 3.3 us per chunk of exposed memory latency.
-    auto build = [&](int chunk, int st) {
+    // build(chunk j+1) and compute(chunk j) of an iteration are independent: all their LDS reads are issued first (one round trip
+    // instead of five), then the eight MFMAs and the builder's VALU work are left to hipcc's scheduler to interleave
+    u32x4 b_rv, b_g00, b_g01, b_g10, b_g11;
+    u32x2 b_m00, b_m01, b_m10, b_m11;
+    auto build_reads = [&](int st) {
+        // the four windows are read unconditionally (inside the stage; what a position is not part of is skipped below): named
+        // registers, no conditional inline asm -- an array of asm outputs behind run-time conditions went to SCRATCH, and a scratch
+        // load is a vector-memory operation whose wait drains the LDS-DMA queue just like vmcnt(0)
+        unsigned char* stage = lds + st * SF_STAGE;
+        const unsigned char* pg = stage + SF_P + idx * 128 + fu * 16;
+        const unsigned char* pm = stage + SF_M + idx * 64 + fu * 8;
+        lds_read_b128_raw(b_rv, stage + a_unit);
+        lds_read_b128_raw(b_g00, pg);
+        lds_read_b128_raw(b_g01, pg + 128);
+        lds_read_b128_raw(b_g10, pg + 5120);
+        lds_read_b128_raw(b_g11, pg + 5120 + 128);
+        lds_read_b64_raw(b_m00, pm);
+        lds_read_b64_raw(b_m01, pm + 64);
+        lds_read_b64_raw(b_m10, pm + 3072);
+        lds_read_b64_raw(b_m11, pm + 3072 + 64);
+    };
+    auto build_wait = [&]() {
+        lds_wait0_5(b_rv, b_g00, b_g01, b_g10, b_g11);
+        lds_wait0_4x2(b_m00, b_m01, b_m10, b_m11);
+    };
+    auto build_math = [&](int chunk, int st) {
         unsigned char* stage = lds + st * SF_STAGE;
         int frame, h, w0;
         chunk_pos(chunk, frame, h, w0);
         const int w = w0 + pos;
         const bool ok = w < p.W;
-        const bool odd_h = h & 1;
-        // window (a, b): pooled row (h >> 1) + a, pooled column idx + b; rows / columns the position is not inside are skipped
-        // (chunk- / wave-uniform), so the gathers are 1, 2, 2 or 4 per unit
-        const bool ua[2] = {(h >> 1) < p.Ho, odd_h && (h >> 1) + 1 < p.Ho};
-        const bool ub[2] = {true, parity != 0};
-        // the four windows are read unconditionally (inside the stage; what a position is not part of is masked below): named
-        // registers, no conditional inline asm -- an array of asm outputs behind run-time conditions went to SCRATCH, and a scratch
-        // load is a vector-memory operation whose wait drains the LDS-DMA queue just like vmcnt(0)
-        u32x4 rv, g00, g01, g10, g11;
-        u32x2 m00, m01, m10, m11;
-        const unsigned char* pg = stage + SF_P + idx * 128 + fu * 16;
-        const unsigned char* pm = stage + SF_M + idx * 64 + fu * 8;
-        lds_read_b128_raw(rv, stage + a_unit);
-        lds_read_b128_raw(g00, pg);
-        lds_read_b128_raw(g01, pg + 128);
-        lds_read_b128_raw(g10, pg + 5120);
-        lds_read_b128_raw(g11, pg + 5120 + 128);
-        lds_read_b64_raw(m00, pm);
-        lds_read_b64_raw(m01, pm + 64);
-        lds_read_b64_raw(m10, pm + 3072);
-        lds_read_b64_raw(m11, pm + 3072 + 64);
-        lds_wait0_5(rv, g00, g01, g10, g11);
-        lds_wait0_4x2(m00, m01, m10, m11);
         float g[8];
         DPC_UNROLL
         for (int e = 0; e < 8; ++e) g[e] = 0.f;
-        auto route = [&](const u32x4& gv, const u32x2& am, int a, int b) {   // summation order (a, b) = (0,0) (0,1) (1,0) (1,1): pool_routed_grad's
+        // window (a, b) = pooled row (h >> 1) + a, pooled column idx + b; it holds this position at tap (kh, kw) -- constants of the
+        // chunk (h) and of the wave (column parity).  Summation order (0,0) (0,1) (1,0) (1,1): pool_routed_grad's.
+        auto route = [&](const u32x4& gv, const u32x2& am, int a, int b) {
             const int kh = a == 0 ? (h & 1) + 1 : 0, kw = b == 0 ? parity + 1 : 0;
             const unsigned want = (unsigned)(kh * 3 + kw);
-            const bool use = ua[a] && ub[b] && ok && (w >> 1) + b < p.Wo;
+            const bool use = ok && (w >> 1) + b < p.Wo;
             DPC_UNROLL
             for (int e = 0; e < 8; ++e)
                 if (use && ((am[e >> 2] >> (8 * (e & 3))) & 0xffu) == want) g[e] += unit_get<bf16_t>(gv, e);
         };
-        route(g00, m00, 0, 0);
-        route(g01, m01, 0, 1);
-        route(g10, m10, 1, 0);
-        route(g11, m11, 1, 1);
+        if ((h >> 1) < p.Ho) {                               // chunk-uniform
+            route(b_g00, b_m00, 0, 0);
+            if (parity) route(b_g01, b_m01, 0, 1);           // wave-uniform
+        }
+        if ((h & 1) && (h >> 1) + 1 < p.Ho) {
+            route(b_g10, b_m10, 1, 0);
+            if (parity) route(b_g11, b_m11, 1, 1);
+        }
         float ov[8];
         DPC_UNROLL
         for (int e = 0; e < 8; ++e) {
-            const float xh = (unit_get<bf16_t>(rv, e) - f_mu[e]) * f_is[e];
+            const float xh = (unit_get<bf16_t>(b_rv, e) - f_mu[e]) * f_is[e];
             ov[e] = ok ? f_ga[e] * (g[e] - f_c1[e] - xh * f_c2[e]) : 0.f;
         }
         lds_write_b128_raw(stage + a_unit, unit_pack<bf16_t>(ov));
@@ -427,27 +435,35 @@ __global__ __launch_bounds__(512) void wgrad_stem_fused_kernel(WgradStemParams p
     for (int c = 0; c < 2; ++c)
         DPC_UNROLL
         for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
-    auto compute = [&](int st) {
+    u32x2 c_a[4][2], c_b[4][2][2];
+    auto compute_reads = [&](int st) {
         const unsigned char* sp = lds + st * SF_STAGE;
-        DPC_UNROLL
-        for (int kk = 0; kk < 4; ++kk) {
-            u32x2 a0, a1, b[2][2];
-            lds_read_tr16_raw(a0, sp + fa + (kk * 16) * 128);
-            lds_read_tr16_raw(a1, sp + fa + (kk * 16 + 4) * 128);
+        static_for<4>([&](auto Kc) {
+            constexpr int kk = decltype(Kc)::value;
+            lds_read_tr16_raw(c_a[kk][0], sp + fa + (kk * 16) * 128);
+            lds_read_tr16_raw(c_a[kk][1], sp + fa + (kk * 16 + 4) * 128);
+            lds_read_tr16_raw(c_b[kk][0][0], sp + fb + (kk * 16) * 32);
+            lds_read_tr16_raw(c_b[kk][0][1], sp + fb + (kk * 16) * 32 + 4 * 32);
+            lds_read_tr16_raw(c_b[kk][1][0], sp + fb + (kk * 16 + 2) * 32);
+            lds_read_tr16_raw(c_b[kk][1][1], sp + fb + (kk * 16 + 2) * 32 + 4 * 32);
+        });
+    };
+    auto compute_wait = [&]() {
+        static_for<4>([&](auto Kc) {
+            constexpr int kk = decltype(Kc)::value;
+            lds_wait0_6x2(c_a[kk][0], c_a[kk][1], c_b[kk][0][0], c_b[kk][0][1], c_b[kk][1][0], c_b[kk][1][1]);
+        });
+    };
+    auto compute_mma = [&]() {
+        static_for<4>([&](auto Kc) {
+            constexpr int kk = decltype(Kc)::value;
+            const u32x4 av = {c_a[kk][0][0], c_a[kk][0][1], c_a[kk][1][0], c_a[kk][1][1]};
             DPC_UNROLL
             for (int c = 0; c < 2; ++c) {
-                const unsigned char* bp = sp + fb + (kk * 16 + 2 * c) * 32;
-                lds_read_tr16_raw(b[c][0], bp);
-                lds_read_tr16_raw(b[c][1], bp + 4 * 32);
-            }
-            lds_wait0_6x2(a0, a1, b[0][0], b[0][1], b[1][0], b[1][1]);
-            const u32x4 av = {a0[0], a0[1], a1[0], a1[1]};
-            DPC_UNROLL
-            for (int c = 0; c < 2; ++c) {
-                const u32x4 bv = {b[c][0][0], b[c][0][1], b[c][1][0], b[c][1][1]};
+                const u32x4 bv = {c_b[kk][c][0][0], c_b[kk][c][0][1], c_b[kk][c][1][0], c_b[kk][c][1][1]};
                 acc[c] = mfma_32x32x16_bf16(av, bv, acc[c]);
             }
-        }
+        });
     };
 
     // ---- pipeline: DMA three chunks ahead, build one chunk ahead, one barrier per chunk
@@ -455,14 +471,20 @@ __global__ __launch_bounds__(512) void wgrad_stem_fused_kernel(WgradStemParams p
     if (nck > 0) {
         wait_vmcnt_upto((nck - 1 < 2 ? nck - 1 : 2) * n_mine);
         barrier_lds_only();   // NOT __syncthreads(): that waits vmcnt(0), i.e. for the DMA issued two and three chunks ahead
-        build(c_begin, 0);
+        build_reads(0);
+        build_wait();
+        build_math(c_begin, 0);
     }
     for (int j = 0; j < nck; ++j) {
         if (j + 1 < nck) wait_vmcnt_upto((nck - 2 - j < 1 ? nck - 2 - j : 1) * n_mine);   // chunk j+1 landed (only j+2 may be newer)
         barrier_lds_only();   // tile j built and published; stage (j-1) % 4 free; every wave's pieces of chunk j+1 have landed
         if (j + 3 < nck) issue(c_begin + j + 3, (j + 3) % SF_NS);
-        if (j + 1 < nck) build(c_begin + j + 1, (j + 1) % SF_NS);
-        compute(j % SF_NS);
+        compute_reads(j % SF_NS);
+        if (j + 1 < nck) build_reads((j + 1) % SF_NS);
+        compute_wait();
+        if (j + 1 < nck) build_wait();
+        compute_mma();
+        if (j + 1 < nck) build_math(c_begin + j + 1, (j + 1) % SF_NS);
     }
 
     // partial slab rows = co, columns = tap*16 + ch = (kernel row)*64 + c*32 + lane column

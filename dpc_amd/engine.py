@@ -440,10 +440,10 @@ class DPCEngine:
 
         # ---- flat f32 arenas: parameters, gradients, Adam moments
         self._score_path = score_path
-        # Fused stem weight gradient (no full-resolution dz tensor).  Bit-identical to the two-kernel form but measured SLOWER on
-        # MI355X (2.14 ms against 1.22 + 0.67 ms, profiles/r02_sweeps.txt) -- its per-chunk gathers are not covered by one chunk of
-        # MFMA work -- so it is opt-in: it saves 2.7 GB (cfg2) / 8.2 GB (cfg5) of HBM, not time.
-        self._want_stem_fused = bool(int(os.environ.get("DPC_STEM_FUSED", "0"))) if stem_fused is None else bool(stem_fused)
+        # Fused stem weight gradient (csrc/conv_wgrad_stem.hip: no full-resolution dz tensor, bit-identical to the two-kernel form).
+        # Round 2's register-gather version was slower than the two kernels and opt-in; the LDS-DMA rebuild of round 3 is faster in
+        # the step (4 667 against 4 617 clips/s at cfg2) and the default; DPC_STEM_FUSED=0 / stem_fused=False run the two kernels.
+        self._want_stem_fused = bool(int(os.environ.get("DPC_STEM_FUSED", "1"))) if stem_fused is None else bool(stem_fused)
         # backward pieces fused into input-gradient epilogues (dz never written, BatchNorm-backward reductions in the producing
         # launch): on by default, DPC_FOLD=0 / fold=False runs the separate kernels (A/B, and the reference for the fused form)
         self.fold = bool(int(os.environ.get("DPC_FOLD", "1"))) if fold is None else bool(fold)
