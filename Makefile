@@ -34,7 +34,7 @@ build/emu/simt_emu.o: $(EMU)/simt_emu.cpp $(EMU)/simt_emu.h
 
 # timing probes only (scripts/probes/*.py): the two loader/compute kernels rebuilt with -DDPC_WS_PROBE (phases can be left out
 # through DPC_WS_DBG; results are then wrong by design), linked with the product objects
-PROBE_SRCS := conv_igemm_ws conv_wgrad_patch conv_halo
+PROBE_SRCS := conv_igemm_ws conv_wgrad_patch conv_halo conv_wgrad_stem
 probe: all
 	@mkdir -p build/probe
 	for f in $(PROBE_SRCS); do $(HIPCC) --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -Iinclude -DDPC_WS_PROBE -c $(CSRC)/$$f.hip -o build/probe/$$f.o || exit 1; done

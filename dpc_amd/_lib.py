@@ -60,6 +60,11 @@ class ConvEpilogue(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("addend", "addend_mask", "bn_raw", "bn_mask", "bn_mean", "bn_invstd", "stats")]
 
 
+class Resample(C.Structure):
+    """struct dpc_resample (include/dpc_hip.h)"""
+    _fields_ = [("xb", C.c_void_p), ("xk", C.c_void_p), ("yb", C.c_void_p), ("yk", C.c_void_p), ("ksx", C.c_int32), ("ksy", C.c_int32)]
+
+
 class PackEntry(C.Structure):
     """struct dpc_pack_entry (include/dpc_hip.h)"""
     _fields_ = [("in_", C.c_void_p), ("out", C.c_void_p), ("d0", C.c_int32), ("d1", C.c_int32), ("d2", C.c_int32), ("block0", C.c_int32),
@@ -122,6 +127,8 @@ _SIGS = {
     "dpc_lc_head_bwd": [C.POINTER(LcHeadDesc), _vp],
     "dpc_frames_to_input": [_vp, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _i32,
                             C.POINTER(C.c_float), C.POINTER(C.c_float), _vp, _vp, _i32, _vp],
+    "dpc_frames_to_input_ex": [_vp, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _i32, _i32, _i32, _i32, C.POINTER(Resample), _vp, _vp, _vp,
+                               C.POINTER(C.c_float), C.POINTER(C.c_float), _vp, _vp, _i32, _vp],
     "dpc_stem_wgrad_fused": [C.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(_i32), _vp],
     "dpc_adam": [_vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _f32, _f32, _f32, _f32, _vp],
 }

@@ -33,7 +33,13 @@ struct WgradStemParams {
     const uint8_t* argmax;
     const float *mean, *invstd, *gamma, *coef;
     int Ho, Wo;
+    int dbg;              // DPC_WS_PROBE builds only (scripts/stem_bench.py --probe): phases to leave out, for timing
 };
+#ifdef DPC_WS_PROBE
+#define SF_DBG(bit) (p.dbg & (bit))
+#else
+#define SF_DBG(bit) 0
+#endif
 
 __global__ __launch_bounds__(256, 3) void wgrad_stem_kernel(WgradStemParams p) {
     constexpr int PW = 68, NPOS = 4 * PW;       // patch: 4 rows x (64 + 3, padded to 68) positions of 32 bytes
@@ -324,16 +330,18 @@ __global__ __launch_bounds__(512) void wgrad_stem_fused_kernel(WgradStemParams p
         const unsigned a_base = (unsigned)(pos * p.dy_ld * 2 - a_lo);
         const unsigned b_base = (unsigned)((pos - (long long)p.ph * p.W - p.pw) * 32 - b_lo);
         const int oh0 = h >> 1, ow0 = w0 >> 1;
+        if (SF_DBG(64)) return;  // probe: no DMA instructions at all
         // A
-        glds16_buf(rs_a, (w0 + posA < p.W) ? a_base + relA : DPC_BUF_OOB, 0u, stage + SF_A + wv * 1024, lane);
+        glds16_buf(rs_a, (w0 + posA < p.W && !SF_DBG(1)) ? a_base + relA : DPC_BUF_OOB, 0u, stage + SF_A + wv * 1024, lane);
         // B
         {
-            const bool ok = ((unsigned)(h - p.ph + prowB) < (unsigned)p.H) & ((unsigned)(w0 - p.pw + pcolB) < (unsigned)p.W);
+            const bool ok = ((unsigned)(h - p.ph + prowB) < (unsigned)p.H) & ((unsigned)(w0 - p.pw + pcolB) < (unsigned)p.W) & !SF_DBG(1);
             glds16_buf(rs_b, ok ? b_base + relB : DPC_BUF_OOB, 0u, stage + SF_X + wv * 1024, lane);
         }
         // pooled rows: row 1 of the pair is only looked at from odd image rows; positions beyond the 33 a chunk can touch, beyond
         // the pooled row or the pooled image are out-of-range lanes (zero fill, no memory traffic)
-        auto pooled_ok = [&](int r, int oc) { return (r == 0 || (h & 1)) && oh0 + r < p.Ho && oc < 33 && ow0 + oc < p.Wo; };
+        // probe bits 1 / 2: every piece / the pooled pieces out of range (same instruction stream, no memory traffic)
+        auto pooled_ok = [&](int r, int oc) { return !SF_DBG(1 | 2) && (r == 0 || (h & 1)) && oh0 + r < p.Ho && oc < 33 && ow0 + oc < p.Wo; };
         auto pooled_base = [&](int r) { return (unsigned)(((frame * p.Ho + oh0 + r) * p.Wo + ow0) * p.Co); };
         // C
         glds16_buf(rs_p, pooled_ok(rC, ocC) ? pooled_base(rC) * 2u + relC : DPC_BUF_OOB, 0u, stage + SF_P + wv * 1024, lane);
@@ -364,6 +372,7 @@ __global__ __launch_bounds__(512) void wgrad_stem_fused_kernel(WgradStemParams p
     u32x4 b_rv, b_g00, b_g01, b_g10, b_g11;
     u32x2 b_m00, b_m01, b_m10, b_m11;
     auto build_reads = [&](int st) {
+        if (SF_DBG(32)) return;  // probe: no builder reads (with 4)
         // the four windows are read unconditionally (inside the stage; what a position is not part of is skipped below): named
         // registers, no conditional inline asm -- an array of asm outputs behind run-time conditions went to SCRATCH, and a scratch
         // load is a vector-memory operation whose wait drains the LDS-DMA queue just like vmcnt(0)
@@ -385,6 +394,7 @@ __global__ __launch_bounds__(512) void wgrad_stem_fused_kernel(WgradStemParams p
         lds_wait0_4x2(b_m00, b_m01, b_m10, b_m11);
     };
     auto build_math = [&](int chunk, int st) {
+        if (SF_DBG(4)) return;   // probe: the raw tile stays what it is
         unsigned char* stage = lds + st * SF_STAGE;
         int frame, h, w0;
         chunk_pos(chunk, frame, h, w0);
@@ -437,6 +447,7 @@ __global__ __launch_bounds__(512) void wgrad_stem_fused_kernel(WgradStemParams p
         for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
     u32x2 c_a[4][2], c_b[4][2][2];
     auto compute_reads = [&](int st) {
+        if (SF_DBG(16)) return;  // probe: no fragment reads (with 8)
         const unsigned char* sp = lds + st * SF_STAGE;
         static_for<4>([&](auto Kc) {
             constexpr int kk = decltype(Kc)::value;
@@ -455,6 +466,7 @@ __global__ __launch_bounds__(512) void wgrad_stem_fused_kernel(WgradStemParams p
         });
     };
     auto compute_mma = [&]() {
+        if (SF_DBG(8)) return;   // probe: no MFMAs
         static_for<4>([&](auto Kc) {
             constexpr int kk = decltype(Kc)::value;
             const u32x4 av = {c_a[kk][0][0], c_a[kk][0][1], c_a[kk][1][0], c_a[kk][1][1]};
@@ -558,6 +570,9 @@ extern "C" int dpc_stem_wgrad_fused(const dpc_conv_desc* d, const void* src_s2d,
     p.src = src_s2d; p.dy = raw; p.part = part;  // p.dy only sizes the (unused) dy window
     p.raw = raw; p.dpool = dpool; p.argmax = argmax; p.mean = mean; p.invstd = invstd; p.gamma = gamma; p.coef = coef;
     p.Ho = (p.H - 1) / 2 + 1; p.Wo = (p.W - 1) / 2 + 1;
+#ifdef DPC_WS_PROBE
+    p.dbg = getenv("DPC_SF_DBG") ? atoi(getenv("DPC_SF_DBG")) : 0;
+#endif
     DPC_LAUNCH(wgrad_stem_fused_kernel, dim3((unsigned)(p.ntm * p.nks)), dim3(512), stream, p);
     return dpc_launch_status();
 }

@@ -352,7 +352,14 @@ int dpc_lc_head_bwd(const dpc_lc_head_desc* c, dpc_stream_t stream);
  * column / row -> column / row inside the crop_w x crop_h crop box, produced by PIL on the host; NULL = no scaling),
  * ToTensor (/255) and Normalize(mean3, std3; HOST arrays of 3 floats).  flip: 0 none, 1 after crop + scale (k400 recipe),
  * 2 of the full frame before the crop (ucf101 recipe, dpc/main.py:114-123).  The random draws stay on the host (a handful of
- * integers per clip); the BILINEAR resize of RandomSizedCrop and ColorJitter are not covered. */
+ * integers per clip; dpc_amd/data.py mirrors the reference's calls of `random` / `np.random`).
+ * dpc_frames_to_input_ex adds, bit-exact against PIL / torchvision's PIL path:
+ *  - dpc_resample: PIL's separable resampling (Image.resize BILINEAR / NEAREST / ..., 8 bits per channel) as per-clip tables --
+ *    output column x reads source columns x1 + xb[x][0] + [0, xb[x][1]) of the crop box with the 22-bit fixed-point coefficients
+ *    xk[x][.]; rows likewise; horizontal pass rounded to 8 bits first (RandomSizedCrop's resize, utils/augmentation.py:144-196);
+ *  - dpc_frame_jitter: ColorJitter (utils/augmentation.py:253-351), one draw per frame: order[k] = the k-th step of the shuffled
+ *    chain (0 brightness, 1 contrast, 2 saturation, 3 hue, 255 none), factor[0..2] = brightness / contrast / saturation factors,
+ *    hue_shift = np.uint8(hue_factor * 255).  Needs u8_ws (B*N*SL*H*W*3 bytes) and lsum_ws (B*N*SL uint64). */
 typedef struct dpc_clip_aug {
     int32_t start, x1, y1, flip;
 } dpc_clip_aug;
@@ -360,6 +367,20 @@ int dpc_frames_to_input(const uint8_t* frames, int32_t B, int32_t F, int32_t H0,
                         const int8_t* gray, int32_t N, int32_t SL, int32_t ds, int32_t H, int32_t W, const int32_t* xtab,
                         const int32_t* ytab, int32_t crop_w, int32_t crop_h, const float* mean3, const float* std3, float* block,
                         void* s2d, int32_t dtype_s2d, dpc_stream_t stream);
+typedef struct dpc_resample {
+    const int32_t *xb, *xk;   /* device: [B][W][2] (first source column, taps), [B][W][ksx] */
+    const int32_t *yb, *yk;   /* device: [B][H][2], [B][H][ksy] */
+    int32_t ksx, ksy;
+} dpc_resample;
+typedef struct dpc_frame_jitter {
+    float factor[3];
+    int32_t hue_shift;
+    uint8_t order[4];
+} dpc_frame_jitter;
+int dpc_frames_to_input_ex(const uint8_t* frames, int32_t B, int32_t F, int32_t H0, int32_t W0, const dpc_clip_aug* aug,
+                           const int8_t* gray, int32_t N, int32_t SL, int32_t ds, int32_t H, int32_t W, const dpc_resample* rs,
+                           const dpc_frame_jitter* jitter, uint8_t* u8_ws, uint64_t* lsum_ws, const float* mean3, const float* std3,
+                           float* block, void* s2d, int32_t dtype_s2d, dpc_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -18,8 +18,9 @@ def main():
     ap.add_argument("--bn", type=int, default=1024)
     ap.add_argument("--hw", type=int, default=64)
     ap.add_argument("--iters", type=int, default=10)
+    ap.add_argument("--probe", action="store_true", help="scripts/probes/libdpc_probe.so ('make probe'): DPC_SF_DBG leaves phases out")
     a = ap.parse_args()
-    lib = L.load_hip()
+    lib = L.Lib(os.path.join(os.path.dirname(os.path.abspath(__file__)), "probes", "libdpc_probe.so"), "hip") if a.probe else L.load_hip()
     dev = torch.device("cuda", 0)
     st = lib.stream()
     BN, T, H, Co = a.bn, 5, a.hw, 64
@@ -48,6 +49,8 @@ def main():
         ("conv_wgrad (reads dz)", lambda: lib.call("dpc_conv_wgrad", C.byref(d), xs, dz, Co, part, C.byref(ns), st)),
         ("stem_wgrad_fused", lambda: lib.call("dpc_stem_wgrad_fused", C.byref(d), xs, raw, gy, am, mean, invstd, gamma, coef, part2, C.byref(ns2), st)),
     ]
+    if a.probe:
+        cases = cases[-1:]
     for name, fn in cases:
         fn()
         torch.cuda.synchronize()
@@ -58,7 +61,8 @@ def main():
         e1.record()
         torch.cuda.synchronize()
         print(f"{name:34s} {1e3 * e0.elapsed_time(e1) / a.iters:9.1f} us  [{L.last_kernel(lib)}]", flush=True)
-    print("fused == two-kernel:", torch.equal(part, part2))
+    if not a.probe:
+        print("fused == two-kernel:", torch.equal(part, part2))
 
 
 if __name__ == "__main__":

@@ -109,3 +109,87 @@ def test_engine_consumes_frames_directly():
     eng.load_frames(frames, au, gr, ds=3)
     s_frames = eng.forward(None, train=False)
     assert torch.equal(s_block, s_frames)
+
+
+# ---- the full training recipes, pinned to the REFERENCE'S OWN classes (tests/golden/aug.npz, make_aug_golden.py) ---------------
+def _golden_recipe_case(lib, dev, golden_dir, name, seed):
+    """random.seed(s); np.random.seed(s); the reference's Compose([...]) of dpc/main.py:114-132 produced the stored clip.  The
+    same seeds through dpc_amd.data.draw_* (same calls of `random` / `np.random`, same order) + the kernel must give the same
+    float32 tensor bit for bit: crop box, BILINEAR / NEAREST resize, flip, RandomGray, ColorJitter, ToTensor, Normalize, layout."""
+    import random
+    from dpc_amd.data import draw_k400, draw_ucf101, recipe_to_input
+    g = np.load(os.path.join(golden_dir, "aug.npz"))
+    F, H0, W0, N, SL, ds, size, crop, start = (int(v) for v in g["params"])
+    random.seed(seed)
+    np.random.seed(seed)
+    jit = None if name.endswith("_geo") else dict(brightness=0.5, contrast=0.5, saturation=0.5, hue=0.25, p=1.0)
+    if name.startswith("k400"):
+        clip = draw_k400(W0, H0, size, N * SL, jitter=jit)
+    else:
+        clip = draw_ucf101(W0, H0, crop, size, N * SL, jitter=jit)
+    frames = torch.from_numpy(g["frames"]).unsqueeze(0).to(dev)
+    block = torch.empty(1, N, 3, SL, size, size, device=dev)
+    s2d = torch.empty(N, SL, size // 2, size // 2, 16, device=dev)
+    recipe_to_input(lib, frames, [start], [clip], N, SL, ds, size, block, s2d)
+    want = torch.from_numpy(g[f"{name}::{seed}"])
+    got = block[0].cpu()
+    assert torch.equal(got, want), f"{name} seed {seed}: {(got != want).sum().item()} of {want.numel()} values differ, max {(got - want).abs().max().item():.3g}"
+    chk = torch.empty_like(s2d)
+    lib.call("dpc_pack_input_s2d", block, chk, L.F32, N, SL, size, size, lib.stream())
+    assert torch.equal(s2d.cpu(), chk.cpu())
+    return clip
+
+
+@pytest.mark.parametrize("name", ["k400_geo", "ucf101_geo", "k400", "ucf101"])
+def test_recipes_match_the_reference_classes_emu(golden_dir, name):
+    subprocess.run(["make", "-s", "-j8", "emu"], cwd=ROOT, check=True)
+    seen = set()
+    for seed in (1, 2, 3, 4, 5, 6):
+        clip = _golden_recipe_case(L.load_emulator(), "cpu", golden_dir, name, seed)
+        seen.add((clip["flip"] != 0, bool((clip["gray"] >= 0).any()), tuple(clip["jitter"][0].order)))
+    assert len({s[0] for s in seen}) == 2 and len({s[2] for s in seen}) >= (1 if name.endswith("_geo") else 3)   # both flip states, several jitter orders
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["k400_geo", "ucf101_geo", "k400", "ucf101"])
+def test_recipes_match_the_reference_classes_gpu(golden_dir, name):
+    for seed in (1, 2, 3, 4, 5, 6):
+        _golden_recipe_case(L.load_hip(), "cuda:0", golden_dir, name, seed)
+
+
+def test_resample_tables_match_pil():
+    """dpc_amd.data.resample_tables + the kernel's two-pass fixed-point resampling == PIL's Image.resize(BILINEAR) on random images
+    (up- and down-scaling, odd sizes), through a crop box"""
+    from dpc_amd.data import FrameJitter, recipe_to_input, resample_tables
+    subprocess.run(["make", "-s", "-j8", "emu"], cwd=ROOT, check=True)
+    lib = L.load_emulator()
+    rng = np.random.default_rng(9)
+    for (H0, W0, x1, y1, w, h, size) in ((60, 80, 7, 3, 51, 44, 24), (40, 50, 0, 0, 50, 40, 32), (30, 30, 5, 6, 11, 13, 28)):
+        fr = rng.integers(0, 256, (1, 2, H0, W0, 3), dtype=np.uint8)
+        xb, xk = resample_tables(w, size)
+        yb, yk = resample_tables(h, size)
+        jit = (FrameJitter * 2)()
+        for j in jit:
+            j.order[:] = [255] * 4
+        clip = dict(x1=x1, y1=y1, flip=0, xb=xb, xk=xk, yb=yb, yk=yk, gray=np.full(2, -1, np.int8), jitter=jit)
+        block = torch.empty(1, 2, 3, 1, size, size)
+        recipe_to_input(lib, torch.from_numpy(fr), [0], [clip], 2, 1, 1, size, block, None)
+        for n in range(2):
+            ref = np.array(Image.fromarray(fr[0, n]).crop((x1, y1, x1 + w, y1 + h)).resize((size, size), Image.BILINEAR))
+            t = torch.from_numpy(ref).permute(2, 0, 1).float().div(255)
+            t = (t - torch.tensor(MEAN).view(3, 1, 1)) / torch.tensor(STD).view(3, 1, 1)
+            assert torch.equal(block[0, n, :, 0], t)
+
+
+def test_bad_draws_are_rejected_on_the_host():
+    """the kernel trusts the per-clip draws; frames_to_input / recipe_to_input validate them (a short clip or a box
+    outside the frame read out of bounds silently)"""
+    subprocess.run(["make", "-s", "-j8", "emu"], cwd=ROOT, check=True)
+    lib = L.load_emulator()
+    fr = torch.zeros(1, 10, 20, 24, 3, dtype=torch.uint8)
+    block = torch.empty(1, 2, 3, 2, 16, 16)
+    ok = torch.tensor([[0, 8, 4, 0]], dtype=torch.int32)
+    frames_to_input(lib, fr, ok, None, 2, 2, 3, 16, block, None)
+    for bad in ([[1, 8, 4, 0]], [[0, 9, 4, 0]], [[0, 8, 5, 0]], [[-1, 0, 0, 0]]):   # last frame 1 + 9 = 10 >= F; box leaves the frame
+        with pytest.raises(ValueError):
+            frames_to_input(lib, fr, torch.tensor(bad, dtype=torch.int32), None, 2, 2, 3, 16, block, None)
