@@ -239,11 +239,19 @@ __global__ __launch_bounds__(256, 3) void wgrad_stem_kernel(WgradStemParams p) {
 // two kernels (the gathers saw HBM latency that one chunk of MFMA work -- 0.5 us -- does not cover).  Here EVERY input of a
 // chunk arrives by LDS-DMA three chunks ahead (ring of four 33 KB stages, one workgroup of eight waves per CU):
 //     raw tile 8 KB (8 pieces) | source patch 9 pieces | pooled gradient, 2 rows x 33 positions (10 pieces) | argmax bytes (6)
-// and all eight waves first turn the raw tile of chunk c+1 into the gradient tile IN PLACE (one 16-byte unit per lane; the
-// pooling windows of a position are read from the staged pooled rows; position parity = wave parity and the image row is
-// chunk-uniform, so the tap a window must point at is a wave-uniform constant), then run the 64 MFMAs of chunk c
-// (wave = co half x ONE kernel row: two accumulators).  One barrier per chunk.  Same chunking, same K order per accumulator
-// and the same arithmetic on the same bf16 values as the two-kernel form: bit-identical results (case_stem_wgrad_fused).
+// and the waves have ROLES (one of each per SIMD): waves 4-7 turn the raw tile of chunk c+1 into the gradient tile IN PLACE (two
+// 16-byte units per lane; the pooling windows of a position are read from the staged pooled rows; position parity = wave parity
+// and the image row is chunk-uniform, so the tap a window must point at is a wave-uniform constant) while waves 0-3 run the 64
+// MFMAs of chunk c exactly as the plain kernel does (co half x kernel-row pair, hand-pipelined transpose reads); all eight
+// issue the DMA.  One barrier per chunk.  Same chunking, same K order per accumulator and the same arithmetic on the same bf16
+// values as the two-kernel form: bit-identical results (case_stem_wgrad_fused).
+// History (MI355X, batch 128, 2.7 GB raw tensor; the two kernels: 1.23 + 0.65 ms):
+//   4.2 ms  first build: a table-driven DMA loop hipcc did not unroll (table in scratch, LDS destination in a waterfall loop) and
+//           __syncthreads -- both wait for EVERY outstanding LDS-DMA piece, i.e. expose the memory latency of chunk c+3 per chunk;
+//   2.19 ms straight-line DMA issue, LDS-only barriers, raw LDS accessors.  Phase ablation (scripts/stem_bench.py --probe): loop +
+//           barriers 0.34, DMA issue 0.34, memory traffic 0.26, LDS reads 0.40, builder VALU 0.67, MFMAs 0.35 ms -- they ADD UP
+//           (2.36): with all eight waves doing the same phase at the same time nothing overlaps;
+//   roles:  builder VALU / LDS reads under the other waves' MFMAs (this version).
 constexpr int SF_PW = 68, SF_NPOS = 4 * SF_PW;
 constexpr int SF_A = 0, SF_X = 8192, SF_P = SF_X + 9 * 1024, SF_M = SF_P + 10 * 1024, SF_STAGE = SF_M + 6 * 1024, SF_NS = 4;
 
@@ -355,83 +363,107 @@ __global__ __launch_bounds__(512) void wgrad_stem_fused_kernel(WgradStemParams p
         }
     };
 
-    // ---- builder constants: this lane makes logical unit fu of position pos = 2 idx + parity of every chunk
-    const int parity = wv & 1, idx = (lane >> 3) + 8 * (wv >> 1), pos = 2 * idx + parity, fu = lane & 7;
-    const int a_unit = SF_A + pos * 128 + (((fu ^ (2 * (pos & 3))) & 7) << 4);
-    float f_mu[8], f_is[8], f_ga[8], f_c1[8], f_c2[8];
-    DPC_UNROLL
-    for (int e = 0; e < 8; ++e) {
-        const int c = tile_m * 64 + fu * 8 + e;
-        f_mu[e] = p.mean[c]; f_is[e] = p.invstd[c]; f_ga[e] = p.gamma[c] * f_is[e]; f_c1[e] = p.coef[c]; f_c2[e] = p.coef[p.Co + c];
-    }
-    // All LDS traffic of build / compute goes through the raw accessors of dpc_rt.h: hipcc would put s_waitcnt vmcnt(0) in front of
-    // every LDS access it can see (it may alias an LDS-DMA destination) and so wait for the pieces issued for chunk j+3 -- the first
-    // build of this kernel ran 4.2 ms that way, 3.3 us per chunk of exposed memory latency.
-    // build(chunk j+1) and compute(chunk j) of an iteration are independent: all their LDS reads are issued first (one round trip
-    // instead of five), then the eight MFMAs and the builder's VALU work are left to hipcc's scheduler to interleave
-    u32x4 b_rv, b_g00, b_g01, b_g10, b_g11;
-    u32x2 b_m00, b_m01, b_m10, b_m11;
-    auto build_reads = [&](int st) {
-        if (SF_DBG(32)) return;  // probe: no builder reads (with 4)
-        // the four windows are read unconditionally (inside the stage; what a position is not part of is skipped below): named
-        // registers, no conditional inline asm -- an array of asm outputs behind run-time conditions went to SCRATCH, and a scratch
-        // load is a vector-memory operation whose wait drains the LDS-DMA queue just like vmcnt(0)
-        unsigned char* stage = lds + st * SF_STAGE;
-        const unsigned char* pg = stage + SF_P + idx * 128 + fu * 16;
-        const unsigned char* pm = stage + SF_M + idx * 64 + fu * 8;
-        lds_read_b128_raw(b_rv, stage + a_unit);
-        lds_read_b128_raw(b_g00, pg);
-        lds_read_b128_raw(b_g01, pg + 128);
-        lds_read_b128_raw(b_g10, pg + 5120);
-        lds_read_b128_raw(b_g11, pg + 5120 + 128);
-        lds_read_b64_raw(b_m00, pm);
-        lds_read_b64_raw(b_m01, pm + 64);
-        lds_read_b64_raw(b_m10, pm + 3072);
-        lds_read_b64_raw(b_m11, pm + 3072 + 64);
-    };
-    auto build_wait = [&]() {
-        lds_wait0_5(b_rv, b_g00, b_g01, b_g10, b_g11);
-        lds_wait0_4x2(b_m00, b_m01, b_m10, b_m11);
-    };
-    auto build_math = [&](int chunk, int st) {
-        if (SF_DBG(4)) return;   // probe: the raw tile stays what it is
-        unsigned char* stage = lds + st * SF_STAGE;
-        int frame, h, w0;
-        chunk_pos(chunk, frame, h, w0);
-        const int w = w0 + pos;
-        const bool ok = w < p.W;
-        float g[8];
+    const auto wait_landed = [&](int newer_chunks) { wait_vmcnt_upto(newer_chunks * n_mine); };
+
+    if (wv >= 4) {
+        // ------------------------------------------------------------------ builder waves
+        // lane makes logical unit fu of positions pos_i = 2 idx_i + parity, i = 0, 1, of every chunk
+        const int bw = wv - 4, parity = bw & 1, fu = lane & 7;
+        int idx[2], a_unit[2];
         DPC_UNROLL
-        for (int e = 0; e < 8; ++e) g[e] = 0.f;
-        // window (a, b) = pooled row (h >> 1) + a, pooled column idx + b; it holds this position at tap (kh, kw) -- constants of the
-        // chunk (h) and of the wave (column parity).  Summation order (0,0) (0,1) (1,0) (1,1): pool_routed_grad's.
-        auto route = [&](const u32x4& gv, const u32x2& am, int a, int b) {
-            const int kh = a == 0 ? (h & 1) + 1 : 0, kw = b == 0 ? parity + 1 : 0;
-            const unsigned want = (unsigned)(kh * 3 + kw);
-            const bool use = ok && (w >> 1) + b < p.Wo;
-            DPC_UNROLL
-            for (int e = 0; e < 8; ++e)
-                if (use && ((am[e >> 2] >> (8 * (e & 3))) & 0xffu) == want) g[e] += unit_get<bf16_t>(gv, e);
-        };
-        if ((h >> 1) < p.Ho) {                               // chunk-uniform
-            route(b_g00, b_m00, 0, 0);
-            if (parity) route(b_g01, b_m01, 0, 1);           // wave-uniform
+        for (int i = 0; i < 2; ++i) {
+            idx[i] = (lane >> 3) + 8 * ((bw >> 1) + 2 * i);
+            const int pos = 2 * idx[i] + parity;
+            a_unit[i] = SF_A + pos * 128 + (((fu ^ (2 * (pos & 3))) & 7) << 4);
         }
-        if ((h & 1) && (h >> 1) + 1 < p.Ho) {
-            route(b_g10, b_m10, 1, 0);
-            if (parity) route(b_g11, b_m11, 1, 1);
-        }
-        float ov[8];
+        float f_mu[8], f_is[8], f_ga[8], f_c1[8], f_c2[8];
         DPC_UNROLL
         for (int e = 0; e < 8; ++e) {
-            const float xh = (unit_get<bf16_t>(b_rv, e) - f_mu[e]) * f_is[e];
-            ov[e] = ok ? f_ga[e] * (g[e] - f_c1[e] - xh * f_c2[e]) : 0.f;
+            const int c = tile_m * 64 + fu * 8 + e;
+            f_mu[e] = p.mean[c]; f_is[e] = p.invstd[c]; f_ga[e] = p.gamma[c] * f_is[e]; f_c1[e] = p.coef[c]; f_c2[e] = p.coef[p.Co + c];
         }
-        lds_write_b128_raw(stage + a_unit, unit_pack<bf16_t>(ov));
-    };
+        // All LDS traffic goes through the raw accessors of dpc_rt.h (hipcc may order an LDS access it can see after every
+        // outstanding LDS-DMA piece); the four windows of a unit are read unconditionally into NAMED registers -- an array of asm
+        // outputs behind run-time conditions went to scratch, and a scratch load waits like vmcnt(0).
+        auto build = [&](int chunk, int st) {
+            unsigned char* stage = lds + st * SF_STAGE;
+            int frame, h, w0;
+            chunk_pos(chunk, frame, h, w0);
+            u32x4 rv[2], g00[2], g01[2], g10[2], g11[2];
+            u32x2 m00[2], m01[2], m10[2], m11[2];
+            if (!SF_DBG(32)) {
+                static_for<2>([&](auto Ic) {
+                    constexpr int i = decltype(Ic)::value;
+                    const unsigned char* pg = stage + SF_P + idx[i] * 128 + fu * 16;
+                    const unsigned char* pm = stage + SF_M + idx[i] * 64 + fu * 8;
+                    lds_read_b128_raw(rv[i], stage + a_unit[i]);
+                    lds_read_b128_raw(g00[i], pg);
+                    lds_read_b128_raw(g01[i], pg + 128);
+                    lds_read_b128_raw(g10[i], pg + 5120);
+                    lds_read_b128_raw(g11[i], pg + 5120 + 128);
+                    lds_read_b64_raw(m00[i], pm);
+                    lds_read_b64_raw(m01[i], pm + 64);
+                    lds_read_b64_raw(m10[i], pm + 3072);
+                    lds_read_b64_raw(m11[i], pm + 3072 + 64);
+                });
+                static_for<2>([&](auto Ic) {
+                    constexpr int i = decltype(Ic)::value;
+                    lds_wait0_5(rv[i], g00[i], g01[i], g10[i], g11[i]);
+                    lds_wait0_4x2(m00[i], m01[i], m10[i], m11[i]);
+                });
+            }
+            if (SF_DBG(4)) return;
+            static_for<2>([&](auto Ic) {
+                constexpr int i = decltype(Ic)::value;
+                const int w = w0 + 2 * idx[i] + parity;
+                const bool ok = w < p.W;
+                float g[8];
+                DPC_UNROLL
+                for (int e = 0; e < 8; ++e) g[e] = 0.f;
+                // window (a, b) = pooled row (h >> 1) + a, pooled column idx + b; it holds this position at tap (kh, kw) -- constants
+                // of the chunk (h) and of the wave (column parity).  Summation order (0,0) (0,1) (1,0) (1,1): pool_routed_grad's.
+                auto route = [&](const u32x4& gv, const u32x2& am, int a, int b) {
+                    const int kh = a == 0 ? (h & 1) + 1 : 0, kw = b == 0 ? parity + 1 : 0;
+                    const unsigned want = (unsigned)(kh * 3 + kw);
+                    const bool use = ok && (w >> 1) + b < p.Wo;
+                    DPC_UNROLL
+                    for (int e = 0; e < 8; ++e)
+                        if (use && ((am[e >> 2] >> (8 * (e & 3))) & 0xffu) == want) g[e] += unit_get<bf16_t>(gv, e);
+                };
+                if ((h >> 1) < p.Ho) {                               // chunk-uniform
+                    route(g00[i], m00[i], 0, 0);
+                    if (parity) route(g01[i], m01[i], 0, 1);         // wave-uniform
+                }
+                if ((h & 1) && (h >> 1) + 1 < p.Ho) {
+                    route(g10[i], m10[i], 1, 0);
+                    if (parity) route(g11[i], m11[i], 1, 1);
+                }
+                float ov[8];
+                DPC_UNROLL
+                for (int e = 0; e < 8; ++e) {
+                    const float xh = (unit_get<bf16_t>(rv[i], e) - f_mu[e]) * f_is[e];
+                    ov[e] = ok ? f_ga[e] * (g[e] - f_c1[e] - xh * f_c2[e]) : 0.f;
+                }
+                lds_write_b128_raw(stage + a_unit[i], unit_pack<bf16_t>(ov));
+            });
+        };
+        for (int j = 0; j < 3 && j < nck; ++j) issue(c_begin + j, j);
+        if (nck > 0) {
+            wait_landed(nck - 1 < 2 ? nck - 1 : 2);
+            barrier_lds_only();   // P: chunk 0 landed.  (LDS-only barriers: __syncthreads would wait for the pieces issued two and three chunks ahead)
+            build(c_begin, 0);
+        }
+        for (int j = 0; j < nck; ++j) {
+            if (j + 1 < nck) wait_landed(nck - 2 - j < 1 ? nck - 2 - j : 1);   // own pieces of chunk j+1 landed (only j+2 may be newer)
+            barrier_lds_only();   // B(j): tile j built and published; stage (j-1) % 4 free; chunk j+1 complete
+            if (j + 3 < nck) issue(c_begin + j + 3, (j + 3) % SF_NS);
+            if (j + 1 < nck) build(c_begin + j + 1, (j + 1) % SF_NS);
+        }
+        return;
+    }
 
-    // ---- MFMA: wave = (co half wi, kernel row wr); accumulator c = taps kw = 2c, 2c+1 of that row x 16 channels
-    const int wi = wv >> 2, wr = wv & 3;
+    // ---------------------------------------------------------------------- MFMA waves (the plain kernel's wave tile and read pipeline)
+    const int wi = wv >> 1, wj = wv & 1;
     const int l31 = lane & 31, lhi = lane >> 5;
     const int gq = lane >> 4, s16 = lane & 15, ph4 = s16 >> 2;
     int fa;
@@ -439,70 +471,88 @@ __global__ __launch_bounds__(512) void wgrad_stem_fused_kernel(WgradStemParams p
         const int colb = (wi * 32 + (gq & 1) * 16 + 4 * (s16 & 3)) * 2;
         fa = SF_A + ((gq >> 1) * 8 + ph4) * 128 + ((((colb >> 4) ^ (2 * ph4)) & 7) << 4) + (colb & 15);
     }
-    const int fb = SF_X + ((gq >> 1) * 8 + ph4 + (gq & 1) + wr * SF_PW) * 32 + 8 * (s16 & 3);
-    f32x16 acc[2];
+    const int fb = SF_X + ((gq >> 1) * 8 + ph4 + (gq & 1)) * 32 + 8 * (s16 & 3) + wj * (2 * SF_PW * 32);
+    f32x16 acc[4];
     DPC_UNROLL
-    for (int c = 0; c < 2; ++c)
+    for (int t = 0; t < 4; ++t)
         DPC_UNROLL
-        for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
-    u32x2 c_a[4][2], c_b[4][2][2];
-    auto compute_reads = [&](int st) {
-        if (SF_DBG(16)) return;  // probe: no fragment reads (with 8)
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+#ifdef DPC_SIMT_EMU
+    auto compute = [&](int st) {
         const unsigned char* sp = lds + st * SF_STAGE;
-        static_for<4>([&](auto Kc) {
-            constexpr int kk = decltype(Kc)::value;
-            lds_read_tr16_raw(c_a[kk][0], sp + fa + (kk * 16) * 128);
-            lds_read_tr16_raw(c_a[kk][1], sp + fa + (kk * 16 + 4) * 128);
-            lds_read_tr16_raw(c_b[kk][0][0], sp + fb + (kk * 16) * 32);
-            lds_read_tr16_raw(c_b[kk][0][1], sp + fb + (kk * 16) * 32 + 4 * 32);
-            lds_read_tr16_raw(c_b[kk][1][0], sp + fb + (kk * 16 + 2) * 32);
-            lds_read_tr16_raw(c_b[kk][1][1], sp + fb + (kk * 16 + 2) * 32 + 4 * 32);
-        });
-    };
-    auto compute_wait = [&]() {
-        static_for<4>([&](auto Kc) {
-            constexpr int kk = decltype(Kc)::value;
-            lds_wait0_6x2(c_a[kk][0], c_a[kk][1], c_b[kk][0][0], c_b[kk][0][1], c_b[kk][1][0], c_b[kk][1][1]);
-        });
-    };
-    auto compute_mma = [&]() {
-        if (SF_DBG(8)) return;   // probe: no MFMAs
-        static_for<4>([&](auto Kc) {
-            constexpr int kk = decltype(Kc)::value;
-            const u32x4 av = {c_a[kk][0][0], c_a[kk][0][1], c_a[kk][1][0], c_a[kk][1][1]};
+        DPC_UNROLL
+        for (int kk = 0; kk < 4; ++kk) {
+            const u32x2 a0 = lds_read_tr16(sp + fa + (kk * 16) * 128);
+            const u32x2 a1 = lds_read_tr16(sp + fa + (kk * 16 + 4) * 128);
+            const u32x4 av = {a0[0], a0[1], a1[0], a1[1]};
             DPC_UNROLL
-            for (int c = 0; c < 2; ++c) {
-                const u32x4 bv = {c_b[kk][c][0][0], c_b[kk][c][0][1], c_b[kk][c][1][0], c_b[kk][c][1][1]};
+            for (int c = 0; c < 4; ++c) {
+                const unsigned char* bp = sp + fb + (((c >> 1) * SF_PW + kk * 16 + 2 * (c & 1)) * 32);
+                const u32x2 b0 = lds_read_tr16(bp);
+                const u32x2 b1 = lds_read_tr16(bp + 4 * 32);
+                const u32x4 bv = {b0[0], b0[1], b1[0], b1[1]};
                 acc[c] = mfma_32x32x16_bf16(av, bv, acc[c]);
             }
+        }
+    };
+#else
+    constexpr int LOOKAHEAD = 4, RB = 8;
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)lds;
+    auto compute = [&](int st) {
+        if (SF_DBG(8)) return;
+        const uint32_t sa = lds0 + st * SF_STAGE + fa;
+        const uint32_t sb = lds0 + st * SF_STAGE + fb;
+        u32x2 alo[2], ahi[2], blo[RB], bhi[RB];
+        auto load = [&](auto Ic) {
+            constexpr int I = decltype(Ic)::value;
+            constexpr int kk = I / 5, r5 = I % 5;
+            if constexpr (r5 == 0) {
+                asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(alo[kk & 1]) : "v"(sa), "n"((kk * 16) * 128) : "memory");
+                __builtin_amdgcn_sched_barrier(0);
+                asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(ahi[kk & 1]) : "v"(sa), "n"((kk * 16 + 4) * 128) : "memory");
+                __builtin_amdgcn_sched_barrier(0);
+            } else {
+                constexpr int c = r5 - 1, jx = 4 * kk + c;
+                constexpr int off = ((c >> 1) * SF_PW + kk * 16 + 2 * (c & 1)) * 32;
+                asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(blo[jx % RB]) : "v"(sb), "n"(off) : "memory");
+                __builtin_amdgcn_sched_barrier(0);
+                asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(bhi[jx % RB]) : "v"(sb), "n"(off + 4 * 32) : "memory");
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+        __builtin_amdgcn_sched_barrier(0);
+        static_for<16>([&](auto Mc) {
+            constexpr int m = decltype(Mc)::value;
+            constexpr int kk = m / 4, c = m % 4, ix = 5 * kk + 1 + c;
+            constexpr int ix_prev = ix - 1 + (c == 0 ? -1 : 0);
+            constexpr int f_prev = m == 0 ? 0 : (ix_prev + 1 + LOOKAHEAD < 20 ? ix_prev + 1 + LOOKAHEAD : 20);
+            constexpr int f_now = ix + 1 + LOOKAHEAD < 20 ? ix + 1 + LOOKAHEAD : 20;
+            static_for<f_now - f_prev>([&](auto Dc) { load(std::integral_constant<int, f_prev + decltype(Dc)::value>{}); });
+            asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(2 * (f_now - ix - 1)) : "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            const u32x4 av = {alo[kk & 1][0], alo[kk & 1][1], ahi[kk & 1][0], ahi[kk & 1][1]};
+            const u32x4 bv = {blo[m % RB][0], blo[m % RB][1], bhi[m % RB][0], bhi[m % RB][1]};
+            acc[c] = mfma_32x32x16_bf16(av, bv, acc[c]);
+            __builtin_amdgcn_sched_barrier(0);
         });
     };
-
-    // ---- pipeline: DMA three chunks ahead, build one chunk ahead, one barrier per chunk
+#endif
     for (int j = 0; j < 3 && j < nck; ++j) issue(c_begin + j, j);
     if (nck > 0) {
-        wait_vmcnt_upto((nck - 1 < 2 ? nck - 1 : 2) * n_mine);
-        barrier_lds_only();   // NOT __syncthreads(): that waits vmcnt(0), i.e. for the DMA issued two and three chunks ahead
-        build_reads(0);
-        build_wait();
-        build_math(c_begin, 0);
+        wait_landed(nck - 1 < 2 ? nck - 1 : 2);
+        barrier_lds_only();   // P
     }
     for (int j = 0; j < nck; ++j) {
-        if (j + 1 < nck) wait_vmcnt_upto((nck - 2 - j < 1 ? nck - 2 - j : 1) * n_mine);   // chunk j+1 landed (only j+2 may be newer)
-        barrier_lds_only();   // tile j built and published; stage (j-1) % 4 free; every wave's pieces of chunk j+1 have landed
+        if (j + 1 < nck) wait_landed(nck - 2 - j < 1 ? nck - 2 - j : 1);
+        barrier_lds_only();   // B(j)
         if (j + 3 < nck) issue(c_begin + j + 3, (j + 3) % SF_NS);
-        compute_reads(j % SF_NS);
-        if (j + 1 < nck) build_reads((j + 1) % SF_NS);
-        compute_wait();
-        if (j + 1 < nck) build_wait();
-        compute_mma();
-        if (j + 1 < nck) build_math(c_begin + j + 1, (j + 1) % SF_NS);
+        compute(j % SF_NS);
     }
 
-    // partial slab rows = co, columns = tap*16 + ch = (kernel row)*64 + c*32 + lane column
+    // partial slab rows = co, columns = tap*16 + ch = (kernel row)*64 + (c&1)*32 + lane column
     DPC_UNROLL
-    for (int c = 0; c < 2; ++c) {
-        const int col = wr * 64 + c * 32 + l31;
+    for (int c = 0; c < 4; ++c) {
+        const int col = (2 * wj + (c >> 1)) * 64 + (c & 1) * 32 + l31;
         DPC_UNROLL
         for (int r = 0; r < 16; ++r) {
             const int co = tile_m * 64 + wi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
