@@ -176,8 +176,11 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
+    rccl_knobs = {}
     if world > 1 or "RANK" in os.environ:  # under a launcher the RCCL path is exercised even with one rank
         import torch.distributed as dist_
+        from dpc_amd.parallel import configure_rccl
+        rccl_knobs = configure_rccl()  # DPC_RCCL_CHANNELS / DPC_RESERVE_CUS: documented A/B knobs, nothing set by default
         dist = dist_
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
@@ -220,7 +223,11 @@ def main():
     sync()
     dt = time.perf_counter() - t0
     tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+    rank_ms = [1e3 * dt / args.steps]
     if dist is not None:
+        every = [torch.zeros_like(tmax) for _ in range(world)]
+        dist.all_gather(every, tmax)          # per-rank wall time of the same K steps: stragglers show as a spread
+        rank_ms = [1e3 * t.item() / args.steps for t in every]
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = tmax.item()
     loss = res.cpu().tolist()
@@ -250,6 +257,9 @@ def main():
                        "launch": "hipGraph replay" if use_graph else "kernel by kernel" + graph_note},
             "final_loss": round(loss[0], 4),
         }
+        if dist is not None:
+            out["per_rank_ms_per_step"] = {"min": round(min(rank_ms), 3), "max": round(max(rank_ms), 3), "all": [round(v, 3) for v in rank_ms]}
+            out["config"]["rccl_knobs"] = rccl_knobs
         if timer is not None:
             s = timer.summary(rs)
             ig = s.get("dpc_conv_igemm")

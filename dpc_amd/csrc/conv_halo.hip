@@ -626,7 +626,10 @@ static bool halo_plan(const dpc_conv_desc* d, HaloParams* p, bool allow_ws = tru
     p->ws = ws_ok && p->src_bytes > 0 && ((k33 && p->HR * p->HWd * 9 <= 8 * 256) || (k44 && p->HR * p->HWd * 3 <= 5 * 256));
     if (bm == 256 && !p->ws) return halo_plan(d, p, false);
     static const int ws_gm = getenv("DPC_HALO_WS_GM") ? atoi(getenv("DPC_HALO_WS_GM")) : 256;  // test tiers shrink it
-    if (p->ws) p->gm = p->ntm < ws_gm ? p->ntm : ws_gm;  // one resident workgroup per CU
+    if (p->ws) {  // one resident workgroup per CU (minus the CUs reserved for a concurrent collective)
+        const int cap = dpc_persistent_grid(ws_gm);
+        p->gm = p->ntm < cap ? p->ntm : cap;
+    }
     p->d_tpf = make_fastdiv(p->tiles_per_frame);
     p->d_tw = make_fastdiv(p->tiles_w);
     p->d_hwd = make_fastdiv(p->HWd);

@@ -828,7 +828,7 @@ static bool ws_plan(const dpc_conv_desc* d, WsParams* p) {
     }
     // one resident workgroup per CU (144 KB of LDS); XCD x gets workgroups x, x+8, ...: keep gm a multiple
     // of 8 so that the ntn column tiles of one row tile (blockIdx differing by gm) share an L2
-    int gm = ws_max_programs() / p->ntn;
+    int gm = dpc_persistent_grid(ws_max_programs()) / p->ntn;
     if (gm < 1) gm = 1;
     if (gm > p->ntm) gm = p->ntm;
     if (gm >= 8) gm &= ~7;

@@ -239,11 +239,11 @@ __global__ __launch_bounds__(256, 3) void wgrad_stem_kernel(WgradStemParams p) {
 // two kernels (the gathers saw HBM latency that one chunk of MFMA work -- 0.5 us -- does not cover).  Here EVERY input of a
 // chunk arrives by LDS-DMA three chunks ahead (ring of four 33 KB stages, one workgroup of eight waves per CU):
 //     raw tile 8 KB (8 pieces) | source patch 9 pieces | pooled gradient, 2 rows x 33 positions (10 pieces) | argmax bytes (6)
-// and the waves have ROLES (one of each per SIMD): waves 4-7 turn the raw tile of chunk c+1 into the gradient tile IN PLACE (two
-// 16-byte units per lane; the pooling windows of a position are read from the staged pooled rows; position parity = wave parity
-// and the image row is chunk-uniform, so the tap a window must point at is a wave-uniform constant) while waves 0-3 run the 64
-// MFMAs of chunk c exactly as the plain kernel does (co half x kernel-row pair, hand-pipelined transpose reads); all eight
-// issue the DMA.  One barrier per chunk.  Same chunking, same K order per accumulator and the same arithmetic on the same bf16
+// and the TWELVE waves have roles: waves 4-11 (two per SIMD) issue the DMA and turn the raw tile of chunk c+1 into the gradient
+// tile IN PLACE (one 16-byte unit per lane; the pooling windows of a position are read from the staged pooled rows; position
+// parity = wave parity and the image row is chunk-uniform, so the tap a window must point at is a wave-uniform constant) while
+// waves 0-3 (one per SIMD) run the 64 MFMAs of chunk c exactly as the plain kernel does (co half x kernel-row pair,
+// hand-pipelined transpose reads).  One barrier per chunk.  Same chunking, same K order per accumulator and the same arithmetic on the same bf16
 // values as the two-kernel form: bit-identical results (case_stem_wgrad_fused).
 // History (MI355X, batch 128, 2.7 GB raw tensor; the two kernels: 1.23 + 0.65 ms):
 //   4.2 ms  first build: a table-driven DMA loop hipcc did not unroll (table in scratch, LDS destination in a waterfall loop) and
@@ -251,11 +251,13 @@ __global__ __launch_bounds__(256, 3) void wgrad_stem_kernel(WgradStemParams p) {
 //   2.19 ms straight-line DMA issue, LDS-only barriers, raw LDS accessors.  Phase ablation (scripts/stem_bench.py --probe): loop +
 //           barriers 0.34, DMA issue 0.34, memory traffic 0.26, LDS reads 0.40, builder VALU 0.67, MFMAs 0.35 ms -- they ADD UP
 //           (2.36): with all eight waves doing the same phase at the same time nothing overlaps;
-//   roles:  builder VALU / LDS reads under the other waves' MFMAs (this version).
+//   2.39 ms roles with ONE builder wave per SIMD (two units per lane): slower -- a lone wave cannot hide its own VALU dependency
+//           and LDS latencies (builder math alone 1.03 ms);
+//   roles with two builder waves + one MFMA wave per SIMD (this version).
 constexpr int SF_PW = 68, SF_NPOS = 4 * SF_PW;
 constexpr int SF_A = 0, SF_X = 8192, SF_P = SF_X + 9 * 1024, SF_M = SF_P + 10 * 1024, SF_STAGE = SF_M + 6 * 1024, SF_NS = 4;
 
-__global__ __launch_bounds__(512) void wgrad_stem_fused_kernel(WgradStemParams p) {
+__global__ __launch_bounds__(768) void wgrad_stem_fused_kernel(WgradStemParams p) {
     __shared__ __attribute__((aligned(1024))) unsigned char lds[SF_NS * SF_STAGE];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -304,7 +306,9 @@ __global__ __launch_bounds__(512) void wgrad_stem_fused_kernel(WgradStemParams p
     //   C  pooled gradient piece wv: row wv / 5, positions 8 (wv % 5) + (lane >> 3), unit lane & 7 of this co tile
     //   D  waves 0-1: pooled gradient pieces 8, 9 (row 1); waves 2-7: argmax piece wv - 2: row (wv-2) / 3, positions
     //      16 ((wv-2) % 3) + (lane >> 2), 16 bytes (lane & 3) of this co tile
-    const int posA = 8 * wv + (lane >> 3);
+    // waves 0-3 run the MFMAs, waves 4-11 (bw = 0..7, two per SIMD) issue the DMA and build the gradient tiles
+    const int bw = wv >= 4 ? wv - 4 : 0;
+    const int posA = 8 * bw + (lane >> 3);
     const unsigned relA = (unsigned)(posA * p.dy_ld + tile_m * 64 + ((lane & 7) ^ (2 * ((lane >> 3) & 3))) * 8) * 2u;
     auto patch_consts = [&](int piece, unsigned& rel, int& prow, int& pcol) {
         const int pp = 32 * piece + (lane >> 1);
@@ -314,15 +318,15 @@ __global__ __launch_bounds__(512) void wgrad_stem_fused_kernel(WgradStemParams p
     };
     unsigned relB, relE;
     int prowB, pcolB, prowE, pcolE;
-    patch_consts(wv, relB, prowB, pcolB);
+    patch_consts(bw, relB, prowB, pcolB);
     patch_consts(8, relE, prowE, pcolE);
-    const int rC = wv / 5, ocC = 8 * (wv % 5) + (lane >> 3);
+    const int rC = bw / 5, ocC = 8 * (bw % 5) + (lane >> 3);
     const unsigned relC = (unsigned)(ocC * p.Co + tile_m * 64 + (lane & 7) * 8) * 2u;
-    const bool dIsP = wv < 2;
-    const int rD = dIsP ? 1 : (wv - 2) / 3;
-    const int ocD = dIsP ? 8 * (3 + wv) + (lane >> 3) : 16 * ((wv - 2) % 3) + (lane >> 2);
+    const bool dIsP = bw < 2;
+    const int rD = dIsP ? 1 : (bw - 2) / 3;
+    const int ocD = dIsP ? 8 * (3 + bw) + (lane >> 3) : 16 * ((bw - 2) % 3) + (lane >> 2);
     const unsigned relD = dIsP ? (unsigned)(ocD * p.Co + tile_m * 64 + (lane & 7) * 8) * 2u : (unsigned)(ocD * p.Co + tile_m * 64 + (lane & 3) * 16);
-    const int n_mine = wv == 0 ? 5 : 4;   // DMA instructions this wave issues per chunk
+    const int n_mine = bw == 0 ? 5 : 4;   // DMA instructions this wave issues per chunk
 
     auto chunk_pos = [&](int chunk, int& frame, int& h, int& w0) {
         const unsigned f = fdiv((unsigned)chunk, p.d_cpf);
@@ -340,11 +344,11 @@ __global__ __launch_bounds__(512) void wgrad_stem_fused_kernel(WgradStemParams p
         const int oh0 = h >> 1, ow0 = w0 >> 1;
         if (SF_DBG(64)) return;  // probe: no DMA instructions at all
         // A
-        glds16_buf(rs_a, (w0 + posA < p.W && !SF_DBG(1)) ? a_base + relA : DPC_BUF_OOB, 0u, stage + SF_A + wv * 1024, lane);
+        glds16_buf(rs_a, (w0 + posA < p.W && !SF_DBG(1)) ? a_base + relA : DPC_BUF_OOB, 0u, stage + SF_A + bw * 1024, lane);
         // B
         {
             const bool ok = ((unsigned)(h - p.ph + prowB) < (unsigned)p.H) & ((unsigned)(w0 - p.pw + pcolB) < (unsigned)p.W) & !SF_DBG(1);
-            glds16_buf(rs_b, ok ? b_base + relB : DPC_BUF_OOB, 0u, stage + SF_X + wv * 1024, lane);
+            glds16_buf(rs_b, ok ? b_base + relB : DPC_BUF_OOB, 0u, stage + SF_X + bw * 1024, lane);
         }
         // pooled rows: row 1 of the pair is only looked at from odd image rows; positions beyond the 33 a chunk can touch, beyond
         // the pooled row or the pooled image are out-of-range lanes (zero fill, no memory traffic)
@@ -352,12 +356,12 @@ __global__ __launch_bounds__(512) void wgrad_stem_fused_kernel(WgradStemParams p
         auto pooled_ok = [&](int r, int oc) { return !SF_DBG(1 | 2) && (r == 0 || (h & 1)) && oh0 + r < p.Ho && oc < 33 && ow0 + oc < p.Wo; };
         auto pooled_base = [&](int r) { return (unsigned)(((frame * p.Ho + oh0 + r) * p.Wo + ow0) * p.Co); };
         // C
-        glds16_buf(rs_p, pooled_ok(rC, ocC) ? pooled_base(rC) * 2u + relC : DPC_BUF_OOB, 0u, stage + SF_P + wv * 1024, lane);
+        glds16_buf(rs_p, pooled_ok(rC, ocC) ? pooled_base(rC) * 2u + relC : DPC_BUF_OOB, 0u, stage + SF_P + bw * 1024, lane);
         // D
-        if (dIsP) glds16_buf(rs_p, pooled_ok(1, ocD) ? pooled_base(1) * 2u + relD : DPC_BUF_OOB, 0u, stage + SF_P + (8 + wv) * 1024, lane);
-        else glds16_buf(rs_m, pooled_ok(rD, ocD) ? pooled_base(rD) + relD : DPC_BUF_OOB, 0u, stage + SF_M + (wv - 2) * 1024, lane);
+        if (dIsP) glds16_buf(rs_p, pooled_ok(1, ocD) ? pooled_base(1) * 2u + relD : DPC_BUF_OOB, 0u, stage + SF_P + (8 + bw) * 1024, lane);
+        else glds16_buf(rs_m, pooled_ok(rD, ocD) ? pooled_base(rD) + relD : DPC_BUF_OOB, 0u, stage + SF_M + (bw - 2) * 1024, lane);
         // E
-        if (wv == 0) {
+        if (bw == 0) {
             const bool ok = ((unsigned)(h - p.ph + prowE) < (unsigned)p.H) & ((unsigned)(w0 - p.pw + pcolE) < (unsigned)p.W);
             glds16_buf(rs_b, ok ? b_base + relE : DPC_BUF_OOB, 0u, stage + SF_X + 8 * 1024, lane);
         }
@@ -368,11 +372,12 @@ __global__ __launch_bounds__(512) void wgrad_stem_fused_kernel(WgradStemParams p
     if (wv >= 4) {
         // ------------------------------------------------------------------ builder waves
         // lane makes logical unit fu of positions pos_i = 2 idx_i + parity, i = 0, 1, of every chunk
-        const int bw = wv - 4, parity = bw & 1, fu = lane & 7;
-        int idx[2], a_unit[2];
+        const int parity = bw & 1, fu = lane & 7;
+        constexpr int NU = 1;   // units per lane and chunk: 512 units over eight builder waves
+        int idx[NU], a_unit[NU];
         DPC_UNROLL
-        for (int i = 0; i < 2; ++i) {
-            idx[i] = (lane >> 3) + 8 * ((bw >> 1) + 2 * i);
+        for (int i = 0; i < NU; ++i) {
+            idx[i] = (lane >> 3) + 8 * (bw >> 1);
             const int pos = 2 * idx[i] + parity;
             a_unit[i] = SF_A + pos * 128 + (((fu ^ (2 * (pos & 3))) & 7) << 4);
         }
@@ -389,10 +394,10 @@ __global__ __launch_bounds__(512) void wgrad_stem_fused_kernel(WgradStemParams p
             unsigned char* stage = lds + st * SF_STAGE;
             int frame, h, w0;
             chunk_pos(chunk, frame, h, w0);
-            u32x4 rv[2], g00[2], g01[2], g10[2], g11[2];
-            u32x2 m00[2], m01[2], m10[2], m11[2];
+            u32x4 rv[NU], g00[NU], g01[NU], g10[NU], g11[NU];
+            u32x2 m00[NU], m01[NU], m10[NU], m11[NU];
             if (!SF_DBG(32)) {
-                static_for<2>([&](auto Ic) {
+                static_for<NU>([&](auto Ic) {
                     constexpr int i = decltype(Ic)::value;
                     const unsigned char* pg = stage + SF_P + idx[i] * 128 + fu * 16;
                     const unsigned char* pm = stage + SF_M + idx[i] * 64 + fu * 8;
@@ -406,14 +411,14 @@ __global__ __launch_bounds__(512) void wgrad_stem_fused_kernel(WgradStemParams p
                     lds_read_b64_raw(m10[i], pm + 3072);
                     lds_read_b64_raw(m11[i], pm + 3072 + 64);
                 });
-                static_for<2>([&](auto Ic) {
+                static_for<NU>([&](auto Ic) {
                     constexpr int i = decltype(Ic)::value;
                     lds_wait0_5(rv[i], g00[i], g01[i], g10[i], g11[i]);
                     lds_wait0_4x2(m00[i], m01[i], m10[i], m11[i]);
                 });
             }
             if (SF_DBG(4)) return;
-            static_for<2>([&](auto Ic) {
+            static_for<NU>([&](auto Ic) {
                 constexpr int i = decltype(Ic)::value;
                 const int w = w0 + 2 * idx[i] + parity;
                 const bool ok = w < p.W;
@@ -537,15 +542,9 @@ __global__ __launch_bounds__(512) void wgrad_stem_fused_kernel(WgradStemParams p
         });
     };
 #endif
-    for (int j = 0; j < 3 && j < nck; ++j) issue(c_begin + j, j);
-    if (nck > 0) {
-        wait_landed(nck - 1 < 2 ? nck - 1 : 2);
-        barrier_lds_only();   // P
-    }
+    if (nck > 0) barrier_lds_only();   // P
     for (int j = 0; j < nck; ++j) {
-        if (j + 1 < nck) wait_landed(nck - 2 - j < 1 ? nck - 2 - j : 1);
-        barrier_lds_only();   // B(j)
-        if (j + 3 < nck) issue(c_begin + j + 3, (j + 3) % SF_NS);
+        barrier_lds_only();   // B(j): tile j is built (the builders waited for every piece of it and transformed it)
         compute(j % SF_NS);
     }
 
@@ -623,6 +622,6 @@ extern "C" int dpc_stem_wgrad_fused(const dpc_conv_desc* d, const void* src_s2d,
 #ifdef DPC_WS_PROBE
     p.dbg = getenv("DPC_SF_DBG") ? atoi(getenv("DPC_SF_DBG")) : 0;
 #endif
-    DPC_LAUNCH(wgrad_stem_fused_kernel, dim3((unsigned)(p.ntm * p.nks)), dim3(512), stream, p);
+    DPC_LAUNCH(wgrad_stem_fused_kernel, dim3((unsigned)(p.ntm * p.nks)), dim3(768), stream, p);
     return dpc_launch_status();
 }

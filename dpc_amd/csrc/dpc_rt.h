@@ -8,6 +8,16 @@
 #include <stdint.h>
 #include <utility>
 
+// ---- CU carve-out for a concurrent collective (dpc_set_reserved_cus, csrc/plan.hip): the kernels that launch exactly one
+// persistent workgroup per CU (conv_halo_ws, igemm_ws / igemm_wsp) shrink their grid by this many workgroups, so that RCCL's
+// channel kernels find free CUs while the gradient all-reduce overlaps the rest of the backward pass.  0 by default.
+int dpc_reserved_cus();
+static inline int dpc_persistent_grid(int base) {   // a multiple of 8 (XCD-grouped tile slots), at least 8
+    int g = base - dpc_reserved_cus();
+    if (g < 8) g = 8;
+    return base >= 8 ? (g & ~7) : base;
+}
+
 // ---- kernel-selection trace (dpc_conv_plan / dpc_last_kernel, csrc/plan.hip) --------------------------------------------
 // Every launch site names the kernel it selected (the stringified kernel expression of DPC_LAUNCH, plus whatever the
 // dispatcher adds with dpc_plan_detail: element types, tile shape, padded grid ...).  In plan-only mode (set by dpc_conv_plan

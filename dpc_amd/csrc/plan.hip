@@ -13,6 +13,17 @@
 #include <string.h>
 
 thread_local int dpc_tls_plan_only = 0;
+
+// process-wide (the engine sets it around the part of the backward pass that overlaps the gradient all-reduce); kernels read it at
+// plan time on the host, so a captured hipGraph keeps the grid it was captured with
+static int g_reserved_cus = 0;
+int dpc_reserved_cus() { return g_reserved_cus; }
+extern "C" int dpc_set_reserved_cus(int32_t n) {
+    if (n < 0 || n > 128) return DPC_ERR_ARG;
+    const int prev = g_reserved_cus;
+    g_reserved_cus = n;
+    return prev;
+}
 static thread_local char tls_name[192] = "";
 static thread_local char tls_detail[96] = "";
 

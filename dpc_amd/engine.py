@@ -320,8 +320,8 @@ class _ConvBN:
             ep.bn_mask = red.mask.data_ptr() if red.mask is not None else None
             ep.stats = e.stats.data_ptr()
         e.call("dpc_conv_igemm_ex", C.byref(self.desc_d), draw, self.wd, dx, C.byref(ep))
-        if red is not None:
-            red.reduced_rows = self.stat_rows_d
+        if red is not None:  # rows of THIS launch (a CU carve-out in force shrinks the persistent grid)
+            red.reduced_rows = self.stat_rows_d if not e.reserve_cus else e.lib.call("dpc_conv_stats_rows", C.byref(self.desc_d))
 
 
 class _Block:
@@ -447,6 +447,10 @@ class DPCEngine:
         # backward pieces fused into input-gradient epilogues (dz never written, BatchNorm-backward reductions in the producing
         # launch): on by default, DPC_FOLD=0 / fold=False runs the separate kernels (A/B, and the reference for the fused form)
         self.fold = bool(int(os.environ.get("DPC_FOLD", "1"))) if fold is None else bool(fold)
+        # CUs left to RCCL's channel kernels while the gradient tail is being all-reduced under layer1 + stem backward: the
+        # persistent one-workgroup-per-CU kernels of that phase shrink their grids (dpc_set_reserved_cus).  0 = off (default);
+        # an A/B knob for the first multi-GPU runs, only consulted when a two-bucket exchange is running.
+        self.reserve_cus = int(os.environ.get("DPC_RESERVE_CUS", "0"))
         self._pack_table = None
         self.bn_running = type(self).BN_RUNNING  # BatchNorm3d with running statistics (the LC classifier's backbone)
         self.train_mode = True       # only matters when bn_running: eval uses the running buffers
@@ -755,10 +759,16 @@ class DPCEngine:
     def _backbone_backward(self, d: torch.Tensor, on_tail_ready=None):
         """backward of _backbone_forward from d = d loss / d (last block output); fills the backbone's gradients"""
         dc = L.dtype_code(self.cdtype)
+        carved = False
         for bi in reversed(range(len(self.blocks))):
             if on_tail_ready is not None and bi == self.n_head_blocks - 1:
                 on_tail_ready(self.flat_g[self.grad_split:])
+                if self.reserve_cus:  # the all-reduce of the tail is in flight from here to the end of the backward pass
+                    self.lib.call("dpc_set_reserved_cus", self.reserve_cus)
+                    carved = True
             d = self.blocks[bi].backward(d, need_dx=True)
+        if carved:
+            self._carved = True
         # stem: max-pool routing (ReLU mask folded into the saved argmax) -> BN -> weight grad; the video has no grad
         st = self.stem.out_shape
         u, C0 = self.stem, self.widths[0]
@@ -773,10 +783,17 @@ class DPCEngine:
             self.call("dpc_stem_wgrad_fused", C.byref(u.desc_w), self.x_s2d, u.raw, d, self.pool_arg, u.mean, u.invstd,
                       self.PRM[u.bnname + ".weight"], self.coef, self.part, C.byref(ns))
             self.call("dpc_unpack_stem_wgrad", self.part, ns.value, self.G[u.wname], C0)
+            self._uncarve()
             return
         self.call("dpc_pool_bn_bwd_apply", d, self.pool_arg, u.raw, dc, st[0] * st[1], st[2], st[3], C0, u.mean, u.invstd,
                   self.PRM[u.bnname + ".weight"], self.coef, self.stem_dz)
         self.stem.wgrad(self.x_s2d, self.stem_dz)
+        self._uncarve()
+
+    def _uncarve(self):
+        if getattr(self, "_carved", False):
+            self.lib.call("dpc_set_reserved_cus", 0)
+            self._carved = False
 
     def forward(self, block: torch.Tensor, train: bool = False, dropout_masks: Optional[torch.Tensor] = None,
                 materialise: bool = True, new_draw: bool = True):

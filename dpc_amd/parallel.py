@@ -10,7 +10,33 @@ no parameter broadcast.  (mean over all rows == mean of equal-sized per-rank mea
 """
 from __future__ import annotations
 
+import os
+
 import torch
+
+
+def configure_rccl(environ=os.environ) -> dict:
+    """Knobs for the first multi-GPU runs, applied BEFORE init_process_group (RCCL reads its environment when the communicator
+    is created).  None is set unless asked for; what is set is returned (bench.py prints it in the JSON line).
+      DPC_RCCL_CHANNELS=n   NCCL_MIN_NCHANNELS = NCCL_MAX_NCHANNELS = n: the number of channel workgroups (one CU each) an
+                            all-reduce occupies.  The 58 / 132 MB gradient over 7 xGMI links wants few, long-lived channels next to
+                            the backward kernels; RCCL's default is sized for a collective that owns the chip.
+      DPC_RESERVE_CUS=n     (read by DPCEngine) the persistent one-workgroup-per-CU kernels of layer1 + stem backward launch
+                            256 - n workgroups while the tail all-reduce is in flight, so the channel kernels are not queued
+                            behind them.  A/B both against the defaults (0 / unset) on the first 8-GPU run: DESIGN.md section 7.
+      HSA_ENABLE_IPC_MODE_LEGACY=0 is kept (dmabuf IPC is what the host driver supports); set here if the launcher dropped it."""
+    applied = {}
+    ch = environ.get("DPC_RCCL_CHANNELS")
+    if ch:
+        for k in ("NCCL_MIN_NCHANNELS", "NCCL_MAX_NCHANNELS"):
+            environ[k] = str(int(ch))
+            applied[k] = int(ch)
+    if "HSA_ENABLE_IPC_MODE_LEGACY" not in environ:
+        environ["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+        applied["HSA_ENABLE_IPC_MODE_LEGACY"] = 0
+    if environ.get("DPC_RESERVE_CUS"):
+        applied["DPC_RESERVE_CUS"] = int(environ["DPC_RESERVE_CUS"])
+    return applied
 
 
 class GradAllReduce:

@@ -118,6 +118,13 @@ int dpc_conv_wgrad(const dpc_conv_desc* d, const void* src, const void* dy, int3
 int dpc_conv_plan(const dpc_conv_desc* d, int32_t op, int32_t flags, int32_t dy_ld, char* name, int32_t cap);
 int dpc_last_kernel(char* name, int32_t cap);
 
+/* CU carve-out for a concurrent collective: the kernels that launch one persistent workgroup per CU (layer1's patch kernel, the
+ * loader/compute implicit GEMMs) shrink their grids by n workgroups (multiples of 8 are kept) for launches planned while the
+ * setting is in force, so that RCCL's channel kernels find CUs during the overlapped gradient all-reduce (dpc/main.py:65's
+ * DataParallel reduce, here one all-reduce per step).  Process-wide host state; returns the previous value.  dpc_conv_stats_rows
+ * follows the setting: query it under the same value the launch sees. */
+int dpc_set_reserved_cus(int32_t n);
+
 /* ---- weight / operand repacking --------------------------------------------------
  * out[i0][i1][i2] (dtype_out, dense) = in[i0*s0 + i1*s1 + i2*s2] (f32).  Turns the
  * reference's [Co][Ci][kT][kH][kW] parameters (state_dict layout, §8b) into the
