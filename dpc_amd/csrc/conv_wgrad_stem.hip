@@ -328,19 +328,38 @@ __global__ __launch_bounds__(768) void wgrad_stem_fused_kernel(WgradStemParams p
     const unsigned relD = dIsP ? (unsigned)(ocD * p.Co + tile_m * 64 + (lane & 7) * 8) * 2u : (unsigned)(ocD * p.Co + tile_m * 64 + (lane & 3) * 16);
     const int n_mine = bw == 0 ? 5 : 4;   // DMA instructions this wave issues per chunk
 
-    auto chunk_pos = [&](int chunk, int& frame, int& h, int& w0) {
-        const unsigned f = fdiv((unsigned)chunk, p.d_cpf);
-        const int rem = chunk - (int)f * p.cpf;
+    // ---- chunk cursors.  A chunk's frame / row / segment and its position relative to the workgroup's first chunk are carried
+    //      along and advanced per iteration: the scalar ALU is shared by the whole CU, and the first role-specialised version
+    //      spent 1 266 scalar instructions per chunk (divisions, 64-bit offsets, stage multiplies, exec-mask juggling; rocprofv3
+    //      SQ_INSTS_SALU) -- a third of its run time.
+    struct Cur { int frame, h, seg, posrel; };
+    auto cur_at_begin = [&]() {
+        const unsigned f = fdiv((unsigned)c_begin, p.d_cpf);
+        const int rem = c_begin - (int)f * p.cpf;
         const unsigned hh = fdiv((unsigned)rem, p.d_nseg);
-        frame = (int)f; h = (int)hh; w0 = (rem - (int)hh * p.nseg) * 64;
+        Cur c = {(int)f, (int)hh, rem - (int)hh * p.nseg, 0};
+        return c;
     };
-    auto issue = [&](int chunk, int st) {
-        unsigned char* stage = lds + st * SF_STAGE;
-        int frame, h, w0;
-        chunk_pos(chunk, frame, h, w0);
-        const long long pos = ((long long)frame * p.H + h) * p.W + w0;
-        const unsigned a_base = (unsigned)(pos * p.dy_ld * 2 - a_lo);
-        const unsigned b_base = (unsigned)((pos - (long long)p.ph * p.W - p.pw) * 32 - b_lo);
+    auto advance = [&](Cur& c) {
+        if (c.seg + 1 < p.nseg) { ++c.seg; c.posrel += 64; }
+        else {
+            c.posrel += p.W - 64 * c.seg;
+            c.seg = 0;
+            if (++c.h == p.H) { c.h = 0; ++c.frame; }
+        }
+    };
+    int b_off0;   // (first position - patch margin) * 32 - b_lo: what the source offsets of the first chunk start from (may be negative: masked lanes)
+    {
+        const Cur c0 = cur_at_begin();
+        const long long pos0 = ((long long)c0.frame * p.H + c0.h) * p.W + c0.seg * 64;
+        b_off0 = (int)((pos0 - (long long)p.ph * p.W - p.pw) * 32 - b_lo);
+    }
+    const int a_step = p.dy_ld * 2;
+    auto issue = [&](const Cur& c, int so) {
+        unsigned char* stage = lds + so;
+        const int h = c.h, w0 = c.seg * 64;
+        const unsigned a_base = (unsigned)(c.posrel * a_step);
+        const unsigned b_base = (unsigned)(b_off0 + c.posrel * 32);
         const int oh0 = h >> 1, ow0 = w0 >> 1;
         if (SF_DBG(64)) return;  // probe: no DMA instructions at all
         // A
@@ -353,34 +372,36 @@ __global__ __launch_bounds__(768) void wgrad_stem_fused_kernel(WgradStemParams p
         // pooled rows: row 1 of the pair is only looked at from odd image rows; positions beyond the 33 a chunk can touch, beyond
         // the pooled row or the pooled image are out-of-range lanes (zero fill, no memory traffic)
         // probe bits 1 / 2: every piece / the pooled pieces out of range (same instruction stream, no memory traffic)
-        auto pooled_ok = [&](int r, int oc) { return !SF_DBG(1 | 2) && (r == 0 || (h & 1)) && oh0 + r < p.Ho && oc < 33 && ow0 + oc < p.Wo; };
-        auto pooled_base = [&](int r) { return (unsigned)(((frame * p.Ho + oh0 + r) * p.Wo + ow0) * p.Co); };
+        const unsigned pb0 = (unsigned)(((c.frame * p.Ho + oh0) * p.Wo + ow0) * p.Co), prow = (unsigned)(p.Wo * p.Co);
+        const bool r1 = (h & 1) && oh0 + 1 < p.Ho && !SF_DBG(1 | 2), r0 = oh0 < p.Ho && !SF_DBG(1 | 2);
+        auto pooled_ok = [&](int r, int oc) { return (r ? r1 : r0) && oc < 33 && ow0 + oc < p.Wo; };
         // C
-        glds16_buf(rs_p, pooled_ok(rC, ocC) ? pooled_base(rC) * 2u + relC : DPC_BUF_OOB, 0u, stage + SF_P + bw * 1024, lane);
+        glds16_buf(rs_p, pooled_ok(rC, ocC) ? (pb0 + (rC ? prow : 0u)) * 2u + relC : DPC_BUF_OOB, 0u, stage + SF_P + bw * 1024, lane);
         // D
-        if (dIsP) glds16_buf(rs_p, pooled_ok(1, ocD) ? pooled_base(1) * 2u + relD : DPC_BUF_OOB, 0u, stage + SF_P + (8 + bw) * 1024, lane);
-        else glds16_buf(rs_m, pooled_ok(rD, ocD) ? pooled_base(rD) + relD : DPC_BUF_OOB, 0u, stage + SF_M + (bw - 2) * 1024, lane);
+        if (dIsP) glds16_buf(rs_p, pooled_ok(1, ocD) ? (pb0 + prow) * 2u + relD : DPC_BUF_OOB, 0u, stage + SF_P + (8 + bw) * 1024, lane);
+        else glds16_buf(rs_m, pooled_ok(rD, ocD) ? pb0 + (rD ? prow : 0u) + relD : DPC_BUF_OOB, 0u, stage + SF_M + (bw - 2) * 1024, lane);
         // E
         if (bw == 0) {
             const bool ok = ((unsigned)(h - p.ph + prowE) < (unsigned)p.H) & ((unsigned)(w0 - p.pw + pcolE) < (unsigned)p.W);
             glds16_buf(rs_b, ok ? b_base + relE : DPC_BUF_OOB, 0u, stage + SF_X + 8 * 1024, lane);
         }
     };
-
-    const auto wait_landed = [&](int newer_chunks) { wait_vmcnt_upto(newer_chunks * n_mine); };
+    // own pieces of a chunk have landed when at most those of the `newer` (0, 1, 2) chunks issued after it are outstanding
+    const auto wait_landed = [&](int newer) {
+        if (newer <= 0) wait_vmcnt<0>();
+        else if (newer == 1) { if (bw == 0) wait_vmcnt<5>(); else wait_vmcnt<4>(); }
+        else { if (bw == 0) wait_vmcnt<10>(); else wait_vmcnt<8>(); }
+    };
+    constexpr int SF_RING = SF_NS * SF_STAGE;
+    auto next_stage = [](int so) { return so + SF_STAGE == SF_RING ? 0 : so + SF_STAGE; };
 
     if (wv >= 4) {
         // ------------------------------------------------------------------ builder waves
-        // lane makes logical unit fu of positions pos_i = 2 idx_i + parity, i = 0, 1, of every chunk
+        // lane makes logical unit fu of position pos = 2 idx + parity of every chunk
         const int parity = bw & 1, fu = lane & 7;
-        constexpr int NU = 1;   // units per lane and chunk: 512 units over eight builder waves
-        int idx[NU], a_unit[NU];
-        DPC_UNROLL
-        for (int i = 0; i < NU; ++i) {
-            idx[i] = (lane >> 3) + 8 * (bw >> 1);
-            const int pos = 2 * idx[i] + parity;
-            a_unit[i] = SF_A + pos * 128 + (((fu ^ (2 * (pos & 3))) & 7) << 4);
-        }
+        const int idx = (lane >> 3) + 8 * (bw >> 1);
+        const int a_unit = SF_A + (2 * idx + parity) * 128 + (((fu ^ (2 * ((2 * idx + parity) & 3))) & 7) << 4);
+        const int pg_off = SF_P + idx * 128 + fu * 16, pm_off = SF_M + idx * 64 + fu * 8;
         float f_mu[8], f_is[8], f_ga[8], f_c1[8], f_c2[8];
         DPC_UNROLL
         for (int e = 0; e < 8; ++e) {
@@ -390,79 +411,77 @@ __global__ __launch_bounds__(768) void wgrad_stem_fused_kernel(WgradStemParams p
         // All LDS traffic goes through the raw accessors of dpc_rt.h (hipcc may order an LDS access it can see after every
         // outstanding LDS-DMA piece); the four windows of a unit are read unconditionally into NAMED registers -- an array of asm
         // outputs behind run-time conditions went to scratch, and a scratch load waits like vmcnt(0).
-        auto build = [&](int chunk, int st) {
-            unsigned char* stage = lds + st * SF_STAGE;
-            int frame, h, w0;
-            chunk_pos(chunk, frame, h, w0);
-            u32x4 rv[NU], g00[NU], g01[NU], g10[NU], g11[NU];
-            u32x2 m00[NU], m01[NU], m10[NU], m11[NU];
+        auto build = [&](const Cur& c, int so) {
+            unsigned char* stage = lds + so;
+            const int h = c.h;
+            const int w = c.seg * 64 + 2 * idx + parity;
+            const bool ok = w < p.W;
+            u32x4 rv, g00, g01, g10, g11;
+            u32x2 m00, m01, m10, m11;
             if (!SF_DBG(32)) {
-                static_for<NU>([&](auto Ic) {
-                    constexpr int i = decltype(Ic)::value;
-                    const unsigned char* pg = stage + SF_P + idx[i] * 128 + fu * 16;
-                    const unsigned char* pm = stage + SF_M + idx[i] * 64 + fu * 8;
-                    lds_read_b128_raw(rv[i], stage + a_unit[i]);
-                    lds_read_b128_raw(g00[i], pg);
-                    lds_read_b128_raw(g01[i], pg + 128);
-                    lds_read_b128_raw(g10[i], pg + 5120);
-                    lds_read_b128_raw(g11[i], pg + 5120 + 128);
-                    lds_read_b64_raw(m00[i], pm);
-                    lds_read_b64_raw(m01[i], pm + 64);
-                    lds_read_b64_raw(m10[i], pm + 3072);
-                    lds_read_b64_raw(m11[i], pm + 3072 + 64);
-                });
-                static_for<NU>([&](auto Ic) {
-                    constexpr int i = decltype(Ic)::value;
-                    lds_wait0_5(rv[i], g00[i], g01[i], g10[i], g11[i]);
-                    lds_wait0_4x2(m00[i], m01[i], m10[i], m11[i]);
-                });
+                lds_read_b128_raw(rv, stage + a_unit);
+                lds_read_b128_raw(g00, stage + pg_off);
+                lds_read_b128_raw(g01, stage + pg_off + 128);
+                lds_read_b128_raw(g10, stage + pg_off + 5120);
+                lds_read_b128_raw(g11, stage + pg_off + 5120 + 128);
+                lds_read_b64_raw(m00, stage + pm_off);
+                lds_read_b64_raw(m01, stage + pm_off + 64);
+                lds_read_b64_raw(m10, stage + pm_off + 3072);
+                lds_read_b64_raw(m11, stage + pm_off + 3072 + 64);
+                lds_wait0_5(rv, g00, g01, g10, g11);
+                lds_wait0_4x2(m00, m01, m10, m11);
             }
             if (SF_DBG(4)) return;
-            static_for<NU>([&](auto Ic) {
-                constexpr int i = decltype(Ic)::value;
-                const int w = w0 + 2 * idx[i] + parity;
-                const bool ok = w < p.W;
-                float g[8];
-                DPC_UNROLL
-                for (int e = 0; e < 8; ++e) g[e] = 0.f;
-                // window (a, b) = pooled row (h >> 1) + a, pooled column idx + b; it holds this position at tap (kh, kw) -- constants
-                // of the chunk (h) and of the wave (column parity).  Summation order (0,0) (0,1) (1,0) (1,1): pool_routed_grad's.
-                auto route = [&](const u32x4& gv, const u32x2& am, int a, int b) {
-                    const int kh = a == 0 ? (h & 1) + 1 : 0, kw = b == 0 ? parity + 1 : 0;
-                    const unsigned want = (unsigned)(kh * 3 + kw);
-                    const bool use = ok && (w >> 1) + b < p.Wo;
-                    DPC_UNROLL
-                    for (int e = 0; e < 8; ++e)
-                        if (use && ((am[e >> 2] >> (8 * (e & 3))) & 0xffu) == want) g[e] += unit_get<bf16_t>(gv, e);
-                };
-                if ((h >> 1) < p.Ho) {                               // chunk-uniform
-                    route(g00[i], m00[i], 0, 0);
-                    if (parity) route(g01[i], m01[i], 0, 1);         // wave-uniform
-                }
-                if ((h & 1) && (h >> 1) + 1 < p.Ho) {
-                    route(g10[i], m10[i], 1, 0);
-                    if (parity) route(g11[i], m11[i], 1, 1);
-                }
-                float ov[8];
+            float g[8];
+            DPC_UNROLL
+            for (int e = 0; e < 8; ++e) g[e] = 0.f;
+            // window (a, b) = pooled row (h >> 1) + a, pooled column idx + b; it holds this position at tap (kh, kw) -- constants of the
+            // chunk (h) and of the wave (column parity).  Summation order (0,0) (0,1) (1,0) (1,1): pool_routed_grad's.  A position
+            // outside the image or a window outside the pooled image matches nothing: its argmax bytes are replaced by 9 ("no
+            // gradient") ONCE, so the per-element work is compare + select + add with no exec-mask / scalar-mask arithmetic.
+            const u32x2 nine = {0x09090909u, 0x09090909u};
+            auto route = [&](const u32x4& gv, const u32x2& am_in, int a, int b) {
+                const int kh = a == 0 ? (h & 1) + 1 : 0, kw = b == 0 ? parity + 1 : 0;
+                const unsigned want = (unsigned)(kh * 3 + kw);
+                const bool use = ok && (w >> 1) + b < p.Wo;
+                const u32x2 am = {use ? am_in[0] : nine[0], use ? am_in[1] : nine[1]};
                 DPC_UNROLL
                 for (int e = 0; e < 8; ++e) {
-                    const float xh = (unit_get<bf16_t>(rv[i], e) - f_mu[e]) * f_is[e];
-                    ov[e] = ok ? f_ga[e] * (g[e] - f_c1[e] - xh * f_c2[e]) : 0.f;
+                    const float v = unit_get<bf16_t>(gv, e);
+                    g[e] += (((am[e >> 2] >> (8 * (e & 3))) & 0xffu) == want) ? v : 0.f;
                 }
-                lds_write_b128_raw(stage + a_unit[i], unit_pack<bf16_t>(ov));
-            });
+            };
+            if ((h >> 1) < p.Ho) {                               // chunk-uniform
+                route(g00, m00, 0, 0);
+                if (parity) route(g01, m01, 0, 1);               // wave-uniform
+            }
+            if ((h & 1) && (h >> 1) + 1 < p.Ho) {
+                route(g10, m10, 1, 0);
+                if (parity) route(g11, m11, 1, 1);
+            }
+            float ov[8];
+            DPC_UNROLL
+            for (int e = 0; e < 8; ++e) {
+                const float xh = (unit_get<bf16_t>(rv, e) - f_mu[e]) * f_is[e];
+                ov[e] = f_ga[e] * (g[e] - f_c1[e] - xh * f_c2[e]);
+            }
+            u32x4 o = unit_pack<bf16_t>(ov);
+            if (!ok) o = u32x4{0u, 0u, 0u, 0u};
+            lds_write_b128_raw(stage + a_unit, o);
         };
-        for (int j = 0; j < 3 && j < nck; ++j) issue(c_begin + j, j);
+        Cur ci = cur_at_begin(), cb = ci;   // next chunk to issue / to build
+        int so_i = 0, so_b = 0;
+        for (int j = 0; j < 3 && j < nck; ++j) { issue(ci, so_i); advance(ci); so_i = next_stage(so_i); }
         if (nck > 0) {
             wait_landed(nck - 1 < 2 ? nck - 1 : 2);
             barrier_lds_only();   // P: chunk 0 landed.  (LDS-only barriers: __syncthreads would wait for the pieces issued two and three chunks ahead)
-            build(c_begin, 0);
+            build(cb, so_b); advance(cb); so_b = next_stage(so_b);
         }
         for (int j = 0; j < nck; ++j) {
             if (j + 1 < nck) wait_landed(nck - 2 - j < 1 ? nck - 2 - j : 1);   // own pieces of chunk j+1 landed (only j+2 may be newer)
             barrier_lds_only();   // B(j): tile j built and published; stage (j-1) % 4 free; chunk j+1 complete
-            if (j + 3 < nck) issue(c_begin + j + 3, (j + 3) % SF_NS);
-            if (j + 1 < nck) build(c_begin + j + 1, (j + 1) % SF_NS);
+            if (j + 3 < nck) { issue(ci, so_i); advance(ci); so_i = next_stage(so_i); }
+            if (j + 1 < nck) { build(cb, so_b); advance(cb); so_b = next_stage(so_b); }
         }
         return;
     }
@@ -483,8 +502,8 @@ __global__ __launch_bounds__(768) void wgrad_stem_fused_kernel(WgradStemParams p
         DPC_UNROLL
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 #ifdef DPC_SIMT_EMU
-    auto compute = [&](int st) {
-        const unsigned char* sp = lds + st * SF_STAGE;
+    auto compute = [&](int so) {
+        const unsigned char* sp = lds + so;
         DPC_UNROLL
         for (int kk = 0; kk < 4; ++kk) {
             const u32x2 a0 = lds_read_tr16(sp + fa + (kk * 16) * 128);
@@ -503,10 +522,10 @@ __global__ __launch_bounds__(768) void wgrad_stem_fused_kernel(WgradStemParams p
 #else
     constexpr int LOOKAHEAD = 4, RB = 8;
     const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)lds;
-    auto compute = [&](int st) {
+    auto compute = [&](int so) {
         if (SF_DBG(8)) return;
-        const uint32_t sa = lds0 + st * SF_STAGE + fa;
-        const uint32_t sb = lds0 + st * SF_STAGE + fb;
+        const uint32_t sa = lds0 + so + fa;
+        const uint32_t sb = lds0 + so + fb;
         u32x2 alo[2], ahi[2], blo[RB], bhi[RB];
         auto load = [&](auto Ic) {
             constexpr int I = decltype(Ic)::value;
@@ -543,9 +562,11 @@ __global__ __launch_bounds__(768) void wgrad_stem_fused_kernel(WgradStemParams p
     };
 #endif
     if (nck > 0) barrier_lds_only();   // P
+    int so_c = 0;
     for (int j = 0; j < nck; ++j) {
         barrier_lds_only();   // B(j): tile j is built (the builders waited for every piece of it and transformed it)
-        compute(j % SF_NS);
+        compute(so_c);
+        so_c = so_c + SF_STAGE == SF_NS * SF_STAGE ? 0 : so_c + SF_STAGE;
     }
 
     // partial slab rows = co, columns = tap*16 + ch = (kernel row)*64 + (c&1)*32 + lane column
