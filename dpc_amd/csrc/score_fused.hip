@@ -369,7 +369,11 @@ struct GemmKP {
     int vec;  // 16-byte stores: ldo % 4 == 0 and out 16-byte aligned
 };
 
-template <int KS>
+// SWAP: MFMA operands swapped -> a lane owns one output row and quads of consecutive columns -> 16-byte stores.  Fewer store
+// instructions (8 against 32 per tile and wave), but each touches 64 different cache lines with 32 bytes (the texture addresser
+// walks an instruction line by line); the plain form writes two whole 128-byte lines per instruction.  Both are kept for the A/B
+// (DPC_SCORE_GEMM_SWAP); the default is what measured faster.
+template <int KS, bool SWAP>
 __global__ __launch_bounds__(256, 2) void score_gemm_kernel(GemmKP p) {
     DPC_DYN_SMEM(smem);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -390,22 +394,34 @@ __global__ __launch_bounds__(256, 2) void score_gemm_kernel(GemmKP p) {
         __syncthreads();  // tile jt has landed; every wave is done with the buffer the next DMA overwrites
         if (jt + 1 < jt1) dma_rows(smem + (buf ^ 1) * tile_bytes, p.b, p.ldb, (jt + 1) * BN, BN, p.N, 0, p.D, p.D, wave, lane);
         f32x16 s[2];
-        s_tile<KS, true>(s, own, smem + buf * tile_bytes, lane);
-        if (row < p.M) {
-            DPC_UNROLL
-            for (int t = 0; t < 2; ++t)
+        s_tile<KS, SWAP>(s, own, smem + buf * tile_bytes, lane);
+        if (SWAP) {
+            if (row < p.M) {
                 DPC_UNROLL
-                for (int k = 0; k < 4; ++k) {
-                    const int c = jt * BN + t * 32 + 8 * k + 4 * lhi;
-                    if (p.vec && c + 3 < p.N) {
-                        const f32x4 v = {s[t][4 * k], s[t][4 * k + 1], s[t][4 * k + 2], s[t][4 * k + 3]};
-                        *(f32x4*)(orow + c) = v;
-                    } else {
-                        DPC_UNROLL
-                        for (int e = 0; e < 4; ++e)
-                            if (c + e < p.N) orow[c + e] = s[t][4 * k + e];
+                for (int t = 0; t < 2; ++t)
+                    DPC_UNROLL
+                    for (int k = 0; k < 4; ++k) {
+                        const int c = jt * BN + t * 32 + 8 * k + 4 * lhi;
+                        if (p.vec && c + 3 < p.N) {
+                            const f32x4 v = {s[t][4 * k], s[t][4 * k + 1], s[t][4 * k + 2], s[t][4 * k + 3]};
+                            *(f32x4*)(orow + c) = v;
+                        } else {
+                            DPC_UNROLL
+                            for (int e = 0; e < 4; ++e)
+                                if (c + e < p.N) orow[c + e] = s[t][4 * k + e];
+                        }
                     }
+            }
+        } else {   // lanes = 32 consecutive columns of one row (x 2 rows): every store instruction writes two full 128-byte lines
+            DPC_UNROLL
+            for (int t = 0; t < 2; ++t) {
+                const int c = jt * BN + t * 32 + (lane & 31);
+                DPC_UNROLL
+                for (int r = 0; r < 16; ++r) {
+                    const int grow = r0 + crow(r, lane);
+                    if (c < p.N && grow < p.M) p.out[(long long)grow * p.ldo + c] = s[t][r];
                 }
+            }
         }
     }
 }
@@ -459,12 +475,23 @@ int dpc_score_gemm_try(const dpc_conv_desc* d, const void* src, const void* wgt,
     p.nsplit = (p.ntiles + p.tiles_per_split - 1) / p.tiles_per_split;
     const dim3 grid(nrb, p.nsplit);
     const size_t lds = 2 * (size_t)((p.D * 2 + 127) / 128) * BN * 128;
+    static const int swap = getenv("DPC_SCORE_GEMM_SWAP") ? atoi(getenv("DPC_SCORE_GEMM_SWAP")) : 0;
     if (p.D == 256) {
-        if (int e = allow_lds(score_gemm_kernel<16>, lds)) return e;
-        DPC_LAUNCH_DYN((score_gemm_kernel<16>), grid, dim3(256), lds, stream, p);
+        if (swap) {
+            if (int e = allow_lds(score_gemm_kernel<16, true>, lds)) return e;
+            DPC_LAUNCH_DYN((score_gemm_kernel<16, true>), grid, dim3(256), lds, stream, p);
+        } else {
+            if (int e = allow_lds(score_gemm_kernel<16, false>, lds)) return e;
+            DPC_LAUNCH_DYN((score_gemm_kernel<16, false>), grid, dim3(256), lds, stream, p);
+        }
     } else {
-        if (int e = allow_lds(score_gemm_kernel<2>, lds)) return e;
-        DPC_LAUNCH_DYN((score_gemm_kernel<2>), grid, dim3(256), lds, stream, p);
+        if (swap) {
+            if (int e = allow_lds(score_gemm_kernel<2, true>, lds)) return e;
+            DPC_LAUNCH_DYN((score_gemm_kernel<2, true>), grid, dim3(256), lds, stream, p);
+        } else {
+            if (int e = allow_lds(score_gemm_kernel<2, false>, lds)) return e;
+            DPC_LAUNCH_DYN((score_gemm_kernel<2, false>), grid, dim3(256), lds, stream, p);
+        }
     }
     return dpc_launch_status();
 }

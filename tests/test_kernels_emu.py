@@ -112,7 +112,7 @@ def test_gemm_nt(k, dtype, mnk):
 def test_score_gemm(k, mn):
     """large bf16 -> f32 NT GEMM with a short reduction (the materialised score): register-resident rows, streamed column tiles,
     16-byte row stores (1028: ragged last tile; 1027: odd leading dimension -> element-wise stores)"""
-    kc.case_gemm_nt(k, BF16, mn[0], mn[1], 32, expect="score_gemm_kernel<2>")
+    kc.case_gemm_nt(k, BF16, mn[0], mn[1], 32, expect="score_gemm_kernel<2,")
 
 
 @pytest.mark.parametrize("dtype", [F32, BF16])
