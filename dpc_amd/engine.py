@@ -739,6 +739,13 @@ class DPCEngine:
         from .data import frames_to_input
         frames_to_input(self.lib, frames, aug, gray, self.N, self.SL, ds, self.size, None, self.x_s2d)
 
+    def load_recipe(self, frames: torch.Tensor, starts, clips, ds: int = 3):
+        """the reference's full training transform (dpc/main.py:114-132: crop / resized crop, flip, RandomGray, ColorJitter, ToTensor,
+        Normalize) on the GPU: decoded uint8 frames [B,F,H0,W0,3] + one data.draw_k400 / data.draw_ucf101 result per clip -> the
+        stem's operand.  Follow with forward(None, ...) / train_step(None, ...)."""
+        from .data import recipe_to_input
+        recipe_to_input(self.lib, frames, starts, clips, self.N, self.SL, ds, self.size, None, self.x_s2d)
+
     def _backbone_forward(self, block: Optional[torch.Tensor]) -> torch.Tensor:
         """2d3d-ResNet (backbone/resnet_2d3d.py:259-270) on block [B,N,3,SL,H,W] (None: the stem operand was filled by
         load_frames): returns the last block's output [B*N, T, ls, ls, D] (channels-last, no final ReLU)"""
