@@ -2,6 +2,7 @@
 // weight-gradient kernel: how GEMM row m and GEMM k' map onto the channels-last source.
 #pragma once
 #include "dpc_rt.h"
+#include <stdlib.h>
 #include "../../include/dpc_hip.h"
 
 struct GatherGeom {
@@ -134,6 +135,130 @@ __device__ __forceinline__ u32x4 mask_unit(u32x4 v, bool ok) {
     v[0] &= m; v[1] &= m; v[2] &= m; v[3] &= m;
     return v;
 }
+
+// ---- strided input-gradient by parity classes (conv_igemm.hip GATHER 3, conv_igemm_ws.hip PAR) -------------------------------------
+// Output positions with the same residues (t % st, h % sh, w % sw) see the same subset of taps, and inside a class the gather is
+// affine again (source = class coordinate + dl(tap)).  M-tiles are laid out class by class; taps that never hit a class are skipped
+// wholesale (7/8 of them for 3x3x3 stride 2) instead of being multiplied by zeros.
+struct ParityInfo {
+    int ncls, N;
+    int tile_start[9];  // first tile of class c = (ct * sh + ch) * sw + cw; [ncls..8] = number of tiles
+    int dimc[3][2];     // class extent per dim (t,h,w) and residue
+    FastDiv div[3][2];
+    int cnt[3][2];      // taps that hit the class, per dim and residue
+    int kl[3][2][4];    // their tap indices
+    int dl[3][2][4];    // their source offsets (rt + pt - kt) / st
+    // tile order inside one temporal class: the nsp = sh * sw spatial classes cover the same (clip, tq, hq, wq) ranges tile by tile
+    // and re-read the same source rows.  Class after class those re-reads come from HBM nsp times; interleaved in groups of 8
+    // tiles (tile l of the temporal class -> spatial class (l / 8) % nsp, tile-in-class (l / (8 nsp)) * 8 + l % 8) the nsp tiles of a
+    // region run at the same time on the same XCD (workgroup b sits on XCD b % 8) and share its L2.
+    int ilv, nsp;
+    int tpc[2];         // tiles per spatial class, per temporal residue
+    int tstart_t[2];    // first tile of the temporal class
+};
+
+static inline int dpc_floordiv(int a, int b) { return (a >= 0) ? a / b : -((-a + b - 1) / b); }
+
+// fills `par` for tiles of bm rows; false when the shape is outside the scheme.  skip_empty: classes no tap reaches get no tiles
+// (in-place accumulation: their positions keep their value).
+static inline bool dpc_plan_parity(const GatherGeom& g, ParityInfo& par, int bke, int bm, bool skip_empty, int* ntm) {
+    if (g.log2C < 0 || g.Ci < bke || g.Ci % bke) return false;
+    const int K[3] = {g.KT, g.KH, g.KW}, S[3] = {g.st, g.sh, g.sw}, P[3] = {g.pt, g.ph, g.pw}, R[3] = {g.RT, g.RH, g.RW};
+    for (int d = 0; d < 3; ++d) {
+        if (S[d] > 2) return false;
+        for (int r = 0; r < 2; ++r) {
+            par.cnt[d][r] = 0;
+            par.dimc[d][r] = r < S[d] ? (R[d] - r + S[d] - 1) / S[d] : 0;
+            par.div[d][r] = make_fastdiv(par.dimc[d][r] > 0 ? par.dimc[d][r] : 1);
+            for (int j = 0; j < 4; ++j) { par.kl[d][r][j] = 0; par.dl[d][r][j] = 0; }
+            if (r >= S[d]) continue;
+            for (int k = 0; k < K[d]; ++k) {
+                const int x = r + P[d] - k;
+                if (((x % S[d]) + S[d]) % S[d] != 0) continue;
+                if (par.cnt[d][r] >= 4) return false;
+                par.kl[d][r][par.cnt[d][r]] = k;
+                par.dl[d][r][par.cnt[d][r]] = dpc_floordiv(x, S[d]);
+                ++par.cnt[d][r];
+            }
+        }
+    }
+    par.ncls = g.st * g.sh * g.sw;
+    par.N = g.M / (g.RT * g.RH * g.RW);
+    par.nsp = g.sh * g.sw;
+    par.ilv = par.nsp > 1 ? 1 : 0;
+    par.tpc[0] = par.tpc[1] = 0;
+    int tiles = 0;
+    for (int c = 0; c < par.ncls; ++c) {
+        const int cw = c % g.sw, ch = (c / g.sw) % g.sh, ct = c / (g.sw * g.sh);
+        par.tile_start[c] = tiles;
+        if (par.cnt[0][ct] * par.cnt[1][ch] * par.cnt[2][cw] > 64) return false;
+        long long rows = (long long)par.N * par.dimc[0][ct] * par.dimc[1][ch] * par.dimc[2][cw];
+        if (skip_empty && par.cnt[0][ct] * par.cnt[1][ch] * par.cnt[2][cw] == 0) rows = 0;
+        const int tc = (int)((rows + bm - 1) / bm);
+        if (c % par.nsp == 0) par.tpc[ct] = tc;
+        else if (tc != par.tpc[ct]) par.ilv = 0;   // unequal spatial classes (odd extents, skipped classes): class after class
+        if (tc == 0) par.ilv = 0;
+        tiles += tc;
+    }
+    for (int c = par.ncls; c < 9; ++c) par.tile_start[c] = tiles;
+    par.tstart_t[0] = 0;
+    par.tstart_t[1] = par.tile_start[par.nsp];
+    {
+        static const int ilv_on = getenv("DPC_PARITY_ILV") ? atoi(getenv("DPC_PARITY_ILV")) : 1;
+        if (!ilv_on) par.ilv = 0;
+    }
+    *ntm = tiles;
+    return true;
+}
+
+// tile index -> (class, tile inside the class).  Every table access below has a compile-time index: a dynamic index into the
+// by-value kernel argument makes hipcc copy the whole struct to scratch in some kernels (712 bytes per lane in igemm_ws_kernel,
+// and a scratch load waits for every LDS-DMA piece in flight).
+__device__ __forceinline__ void parity_tile(const ParityInfo& par, int mt, int& c, int& j) {
+    if (!par.ilv) {
+        int start = 0;
+        c = 0;
+        DPC_UNROLL
+        for (int i = 1; i < 8; ++i) {
+            const bool in = i < par.ncls && mt >= par.tile_start[i];
+            c += in ? 1 : 0;
+            start = in ? par.tile_start[i] : start;
+        }
+        j = mt - start;
+        return;
+    }
+    const int ct = (par.ncls > par.nsp && mt >= par.tstart_t[1]) ? 1 : 0;
+    const int l = mt - (ct ? par.tstart_t[1] : 0);
+    const int tpc = ct ? par.tpc[1] : par.tpc[0];
+    const int full = tpc & ~7;
+    int cs;
+    if (l < full * par.nsp) {
+        const int blk = l / (8 * par.nsp), r = l - blk * 8 * par.nsp;
+        cs = r >> 3;
+        j = blk * 8 + (r & 7);
+    } else {
+        const int l2 = l - full * par.nsp, rem = tpc - full;
+        cs = l2 / rem;
+        j = full + (l2 - cs * rem);
+    }
+    c = ct * par.nsp + cs;
+}
+// class tables of one dimension for residue r (0 / 1), as values
+struct ParDim { int n, ext; FastDiv div; int kl[4], dl[4]; };
+template <int D>
+__device__ __forceinline__ ParDim parity_dim(const ParityInfo& par, int r) {
+    ParDim o;
+    o.n = r ? par.cnt[D][1] : par.cnt[D][0];
+    o.ext = r ? par.dimc[D][1] : par.dimc[D][0];
+    o.div = r ? par.div[D][1] : par.div[D][0];
+    DPC_UNROLL
+    for (int j = 0; j < 4; ++j) {
+        o.kl[j] = r ? par.kl[D][1][j] : par.kl[D][0][j];
+        o.dl[j] = r ? par.dl[D][1][j] : par.dl[D][0][j];
+    }
+    return o;
+}
+__device__ __forceinline__ int pick4(const int (&a)[4], int j) { return j == 0 ? a[0] : (j == 1 ? a[1] : (j == 2 ? a[2] : a[3])); }
 
 // ---- fused backward pieces of an input-gradient epilogue (dpc_conv_igemm_ex, include/dpc_hip.h) -----------------------------
 // addend_mask: the residual addend is the BLOCK's incoming gradient gated by the ReLU sign mask of the block output

@@ -30,20 +30,6 @@
 // sums accumulate in registers and leave as ONE row of `stats` per program: deterministic.
 #include "conv_common.h"
 
-// Strided input-gradient ("parity classes"): output positions with the same residues
-// (t%st, h%sh, w%sw) see the same subset of taps, and inside a class the gather is affine again
-// (source = class coordinate + dt(kt)).  M-tiles are laid out class by class, taps that never hit
-// the class are skipped wholesale (7/8 of them for 3x3x3 stride 2) instead of being multiplied by zeros.
-struct ParityInfo {
-    int ncls, N;
-    int tile_start[9];
-    int dimc[3][2];     // class extent per dim (t,h,w) and residue
-    FastDiv div[3][2];
-    int cnt[3][2];      // taps that hit the class, per dim and residue
-    int kl[3][2][4];    // their tap indices
-    int dl[3][2][4];    // their source offsets (rt + pt - kt) / st
-};
-
 struct IGemmParams {
     GatherGeom g;
     ParityInfo par;
@@ -134,12 +120,12 @@ __global__ __launch_bounds__(256, (BN == 64 ? 3 : 2)) void igemm_kernel(IGemmPar
         int nkc_t = nkc, lcpt = 0;
         if (GATHER == 3) {
             const ParityInfo& par = p.par;
-            int c = 0;
-            while (c + 1 < par.ncls && mt >= par.tile_start[c + 1]) ++c;
+            int c, jt_;
+            parity_tile(par, mt, c, jt_);
             const int cw_ = c % g.sw, ch_ = (c / g.sw) % g.sh, ct_ = c / (g.sw * g.sh);
             const int Tc = par.dimc[0][ct_], Hc = par.dimc[1][ch_], Wc = par.dimc[2][cw_];
             const int rows_c = par.N * Tc * Hc * Wc;
-            const int lr0 = (mt - par.tile_start[c]) * BM;
+            const int lr0 = jt_ * BM;
             const int ct_n = par.cnt[0][ct_], ch_n = par.cnt[1][ch_], cw_n = par.cnt[2][cw_];
             // the 8 lanes of a tile row need the same 4 rows (r0 + 32 i): each decodes one, the group exchanges
             // them by lane shuffles (the decode is per tile, and a parity-class tile has as few as 2 K chunks)
@@ -546,49 +532,14 @@ static int launch_igemm_bn(const IGemmParams& p, int gather, hipStream_t stream)
     return dpc_launch_status();
 }
 
-static inline int floordiv(int a, int b) { return (a >= 0) ? a / b : -((-a + b - 1) / b); }
-
 // fills p.par and re-plans the m-tiles class by class; false when the shape is outside the scheme
 static bool plan_parity(IGemmParams& p, int bke) {
-    const GatherGeom& g = p.g;
-    ParityInfo& par = p.par;
-    if (g.log2C < 0 || g.Ci < bke || g.Ci % bke) return false;
-    const int K[3] = {g.KT, g.KH, g.KW}, S[3] = {g.st, g.sh, g.sw}, P[3] = {g.pt, g.ph, g.pw}, R[3] = {g.RT, g.RH, g.RW};
-    for (int d = 0; d < 3; ++d) {
-        if (S[d] > 2) return false;
-        for (int r = 0; r < 2; ++r) {
-            par.cnt[d][r] = 0;
-            par.dimc[d][r] = r < S[d] ? (R[d] - r + S[d] - 1) / S[d] : 0;
-            par.div[d][r] = make_fastdiv(par.dimc[d][r] > 0 ? par.dimc[d][r] : 1);
-            for (int j = 0; j < 4; ++j) { par.kl[d][r][j] = 0; par.dl[d][r][j] = 0; }
-            if (r >= S[d]) continue;
-            for (int k = 0; k < K[d]; ++k) {
-                const int x = r + P[d] - k;
-                if (((x % S[d]) + S[d]) % S[d] != 0) continue;
-                if (par.cnt[d][r] >= 4) return false;
-                par.kl[d][r][par.cnt[d][r]] = k;
-                par.dl[d][r][par.cnt[d][r]] = floordiv(x, S[d]);
-                ++par.cnt[d][r];
-            }
-        }
-    }
-    par.ncls = g.st * g.sh * g.sw;
-    par.N = g.M / (g.RT * g.RH * g.RW);
-    int tiles = 0;
-    for (int c = 0; c < par.ncls; ++c) {
-        const int cw = c % g.sw, ch = (c / g.sw) % g.sh, ct = c / (g.sw * g.sh);
-        par.tile_start[c] = tiles;
-        if (par.cnt[0][ct] * par.cnt[1][ch] * par.cnt[2][cw] > 64) return false;
-        long long rows = (long long)par.N * par.dimc[0][ct] * par.dimc[1][ch] * par.dimc[2][cw];
-        // in-place accumulation (addend == out): positions no tap reaches keep their value, so their classes get no tiles --
-        // a 1x1 stride-2 downsample's input-gradient touches 1/4 (2D) or 1/8 (3D) of dx instead of rewriting all of it
-        if (p.addend && p.addend == p.out && par.cnt[0][ct] * par.cnt[1][ch] * par.cnt[2][cw] == 0) rows = 0;
-        tiles += (int)((rows + 127) / 128);
-    }
-    for (int c = par.ncls; c < 9; ++c) par.tile_start[c] = tiles;
-    p.ntm = tiles;
+    // in-place accumulation (addend == out): positions no tap reaches keep their value, so their classes get no tiles --
+    // a 1x1 stride-2 downsample's input-gradient touches 1/4 (2D) or 1/8 (3D) of dx instead of rewriting all of it
+    if (!dpc_plan_parity(p.g, p.par, bke, 128, p.addend && p.addend == p.out, &p.ntm)) return false;
     int cap = 2048 / p.ntn;
     if (cap < 1) cap = 1;
+    if (cap >= 8) cap &= ~7;  // interleaved class tiles rely on tile mt running on XCD mt % 8
     p.gm = p.ntm < cap ? p.ntm : cap;
     return true;
 }

@@ -44,6 +44,12 @@ struct WsParams {
     int tgroup, hw, nclip, tpt, cpkt;  // on/off, RH*RW, clips, tiles per t, chunks per temporal tap
     FastDiv d_hw;
     int plane;                        // 1: served by igemm_wsp_kernel (a tile is one 16 x 16 plane, staged as a patch)
+    // strided input-gradient (igemm_ws_kernel<., true>): tiles are 256 rows of ONE parity class (conv_common.h), whose K range is
+    // the class's own taps -- the generic kernel's scheme on this kernel's loaders.  There a tile of 4..32 chunks pays a decode, a
+    // first-chunk round trip and an epilogue with one chunk in flight (layer3.0: 390 us for 62 us of MFMA work); here the loaders
+    // run ahead across tile boundaries.
+    int parity;
+    ParityInfo par;
     int dbg;                          // DPC_WS_PROBE builds only (scripts/probes/ws_probe.py): phases to leave out, for timing
 };
 #ifdef DPC_WS_PROBE
@@ -183,7 +189,7 @@ __device__ __forceinline__ void stage_block(unsigned char* mine, const f32x16 (&
         }
 }
 
-template <bool HAS_ADD>
+template <bool HAS_ADD, bool PAR = false>
 __global__ __launch_bounds__(512, 2) void igemm_ws_kernel(WsParams p) {
     typedef bf16_t T;
     typedef bf16_t TO;
@@ -205,8 +211,36 @@ __global__ __launch_bounds__(512, 2) void igemm_ws_kernel(WsParams p) {
     const int m_prog = blockIdx.x % p.gm;
     const int nkc = g.Kp / BKE;
     const int my_tiles = (p.ntm - m_prog + p.gm - 1) / p.gm;
-    // tile row -> GEMM row (identity unless the tiles are grouped by output frame index)
+    // parity class of a tile (wave-uniform): residues, extents, row count, tile inside the class
+    struct ParCls { int j, rows; ParDim T, H, W; int ct, ch, cw; };
+    auto par_cls = [&](int mt) -> ParCls {
+        ParCls k;
+        int c;
+        parity_tile(p.par, mt, c, k.j);
+        k.cw = c & (g.sw - 1); k.ch = (c >> g.lsw) & (g.sh - 1); k.ct = c >> (g.lsw + g.lsh);   // strides are 1 or 2
+        k.T = parity_dim<0>(p.par, k.ct); k.H = parity_dim<1>(p.par, k.ch); k.W = parity_dim<2>(p.par, k.cw);
+        k.rows = p.par.N * k.T.ext * k.H.ext * k.W.ext;
+        return k;
+    };
+    auto par_decode = [&](const ParCls& k, int lr, int& n, int& tq, int& hq, int& wq) {
+        const unsigned q1 = fdiv((unsigned)lr, k.W.div);
+        wq = lr - (int)q1 * k.W.ext;
+        const unsigned q2 = fdiv(q1, k.H.div);
+        hq = (int)q1 - (int)q2 * k.H.ext;
+        const unsigned nn = fdiv(q2, k.T.div);
+        tq = (int)q2 - (int)nn * k.T.ext;
+        n = (int)nn;
+    };
+    // tile row -> GEMM row (identity unless the tiles are grouped by output frame index / parity class)
     auto tile_row = [&](int mt, int r) -> int {
+        if (PAR) {
+            const ParCls k = par_cls(mt);
+            const int lr = k.j * BM + r;
+            if (lr >= k.rows) return g.M;
+            int n, tq, hq, wq;
+            par_decode(k, lr, n, tq, hq, wq);
+            return (((n * g.RT + tq * g.st + k.ct) * g.RH + hq * g.sh + k.ch) * g.RW) + wq * g.sw + k.cw;
+        }
         if (!p.tgroup) return mt * BM + r;
         const int t = mt / p.tpt;
         const unsigned idx = (unsigned)((mt - t * p.tpt) * BM + r);   // pixel of frame t, counted across the clips
@@ -216,6 +250,11 @@ __global__ __launch_bounds__(512, 2) void igemm_ws_kernel(WsParams p) {
     // K chunks [lo, hi) of a tile: all of them, or those of the temporal taps that hit real frames
     auto tile_chunks = [&](int mt, int& lo, int& hi) {
         lo = 0; hi = nkc;
+        if (PAR) {
+            const ParCls k = par_cls(mt);
+            hi = k.T.n * k.H.n * k.W.n * (g.Ci >> 6);
+            return;
+        }
         if (!p.tgroup) return;
         const int t = mt / p.tpt;
         int klo, khi;
@@ -263,8 +302,35 @@ __global__ __launch_bounds__(512, 2) void igemm_ws_kernel(WsParams p) {
             if (hi > K - 1) hi = K - 1;
             return hi >= lo ? (((2u << hi) - 1u) & ~((1u << lo) - 1u)) : 0u;
         };
+        ParCls lk = {};                                 // PAR: class of the tile whose chunks are being issued,
+        int l_jt = 0, l_jh = 0, l_jw = 0, l_cc = 0;   // and the (tap, 64-channel group) cursor of its next chunk
         auto decode_tile = [&](int mt) {
             const int mine = lane & 7;  // which of the group's 8 rows this lane decodes
+            if (PAR) {
+                lk = par_cls(mt);
+                const ParCls& k = lk;
+                l_jt = l_jh = l_jw = l_cc = 0;
+                const int lr = k.j * BM + 8 * (lw + 4 * mine) + rl;
+                unsigned off = 0, m = 0;
+                if (lr < k.rows) {
+                    int n, tq, hq, wq;
+                    par_decode(k, lr, n, tq, hq, wq);
+                    off = (((((unsigned)(n * g.ST + tq) * (unsigned)g.SH + (unsigned)hq) * (unsigned)g.SW) + (unsigned)wq) * (unsigned)g.src_ld) * 2u;
+                    DPC_UNROLL
+                    for (int j = 0; j < 4; ++j) {
+                        m |= (j < k.T.n && (unsigned)(tq + k.T.dl[j]) < (unsigned)g.ST ? 1u : 0u) << j;
+                        m |= (j < k.H.n && (unsigned)(hq + k.H.dl[j]) < (unsigned)g.SH ? 1u : 0u) << (4 + j);
+                        m |= (j < k.W.n && (unsigned)(wq + k.W.dl[j]) < (unsigned)g.SW ? 1u : 0u) << (8 + j);
+                    }
+                }
+                DPC_UNROLL
+                for (int i = 0; i < 8; ++i) {
+                    const int from = (lane & ~7) | i;
+                    rowoff[i] = (unsigned)__shfl((int)off, from) + (unsigned)(u * 16);
+                    vmask[i] = (unsigned)__shfl((int)m, from);
+                }
+                return;
+            }
             const RowPos rp = decode_row(g, tile_row(mt, 8 * (lw + 4 * mine) + rl));
             const unsigned off = (((((unsigned)(rp.nbase + rp.t0) * (unsigned)g.SH + (unsigned)rp.h0) * (unsigned)g.SW) + (unsigned)rp.w0) *
                                   (unsigned)g.src_ld) * 2u;
@@ -279,6 +345,30 @@ __global__ __launch_bounds__(512, 2) void igemm_ws_kernel(WsParams p) {
             }
         };
         auto issue = [&](int kc, int stage) {
+            unsigned char* st = lds + stage * STAGE;
+            if (PAR) {   // chunks of a tile come in order: (tap of the class, 64-channel group) is a cursor, wave-uniform scalar work
+                const int jt = l_jt, jh = l_jh, jw = l_jw, cofs = l_cc * BKE;
+                if (++l_cc == (g.Ci >> 6)) {
+                    l_cc = 0;
+                    if (++l_jw == lk.W.n) {
+                        l_jw = 0;
+                        if (++l_jh == lk.H.n) { l_jh = 0; ++l_jt; }
+                    }
+                }
+                const int kt = pick4(lk.T.kl, jt), kh = pick4(lk.H.kl, jh), kw = pick4(lk.W.kl, jw);
+                const int dt = pick4(lk.T.dl, jt), dh = pick4(lk.H.dl, jh), dw = pick4(lk.W.dl, jw);
+                const unsigned sel = (1u << jt) | (1u << (4 + jh)) | (1u << (8 + jw));
+                const unsigned tapoff = (unsigned)(((dt * g.SH + dh) * g.SW + dw) * g.src_ld + cofs) * 2u;
+                const unsigned kd = (unsigned)(((kt * g.KH + kh) * g.KW + kw) * g.Ci + cofs);
+                DPC_UNROLL
+                for (int i = 0; i < 8; ++i) {
+                    const bool ok = (vmask[i] & sel) == sel;
+                    glds16_buf(rs_a, ok ? rowoff[i] + tapoff : DPC_BUF_OOB, 0u, st + (lw + 4 * i) * 1024, lane);
+                }
+                DPC_UNROLL
+                for (int i = 0; i < 4; ++i) glds16_buf(rs_b, wrow[i], kd * 2u, st + BM * 128 + (lw + 4 * i) * 1024, lane);
+                return;
+            }
             // one tap per chunk (Ci is a multiple of 64): the tap decode is wave-uniform scalar work
             const int kd = kc * BKE;
             const int tap = (g.taps == 1) ? 0 : (kd >> g.log2C);
@@ -290,7 +380,6 @@ __global__ __launch_bounds__(512, 2) void igemm_ws_kernel(WsParams p) {
             const int sgn = g.mode == 0 ? 1 : -1;
             const int cbase = (g.taps == 1) ? 0 : (tap << g.log2C);
             const unsigned tapoff = (unsigned)(sgn * ((((int)kt * g.SH + kh) * g.SW + kw) * g.src_ld) + (kd - cbase)) * 2u;
-            unsigned char* st = lds + stage * STAGE;
             DPC_UNROLL
             for (int i = 0; i < 8; ++i) {
                 const bool ok = (vmask[i] & sel) == sel;
@@ -800,7 +889,16 @@ static bool ws_plan(const dpc_conv_desc* d, WsParams* p) {
     const bool unit_strides = g.st == 1 && g.sh == 1 && g.sw == 1;
     // byte offsets stay below DPC_BUF_OOB (2 GB), which therefore is out of range for the buffer resource
     const bool fits32 = (long long)(g.M / (g.RT * g.RH * g.RW)) * g.ST * g.SH * g.SW * g.src_ld < (1ll << 30);
-    if (!fits32 || !(g.mode == 0 || unit_strides) || g.KT + g.KH + g.KW > 32) return false;
+    if (!fits32 || g.KT + g.KH + g.KW > 32) return false;
+    p->parity = 0;
+    int par_tiles = 0;
+    if (!(g.mode == 0 || unit_strides)) {   // strided input-gradient: parity classes on 256-row tiles
+        static const int par_on = env_int("DPC_IGEMM_WS_PAR", 1);
+        if (!par_on || g.taps == 1 || !dpc_plan_parity(g, p->par, 64, 256, false, &par_tiles)) return false;
+        for (int c = 0; c < p->par.ncls; ++c)   // a class without taps would be a tile without chunks: not a case of this kernel's barrier sequence
+            if (p->par.cnt[0][c / (g.sw * g.sh)] * p->par.cnt[1][(c / g.sw) % g.sh] * p->par.cnt[2][c % g.sw] == 0) return false;
+        p->parity = 1;
+    }
     if (g.M < ws_min_rows()) return false;  // too few 256-row tiles to feed 256 CUs: the 128-row kernel balances better
     p->Ncol = d->Co; p->ldw = d->ldw; p->ldo = d->ldo;
     const long long wbytes = ((long long)(d->Co - 1) * d->ldw + g.Kp) * 2;
@@ -808,17 +906,17 @@ static bool ws_plan(const dpc_conv_desc* d, WsParams* p) {
     p->src_bytes = (unsigned)((long long)(g.M / (g.RT * g.RH * g.RW)) * g.ST * g.SH * g.SW * g.src_ld * 2);
     p->wgt_bytes = (unsigned)wbytes;
     p->ntn = (d->Co + 127) / 128;
-    p->ntm = (g.M + 255) / 256;
+    p->ntm = p->parity ? par_tiles : (g.M + 255) / 256;
     p->tgroup = 0; p->hw = 1; p->nclip = 0; p->tpt = 1; p->cpkt = 1; p->d_hw = make_fastdiv(1);
     {
         static const int plane_on = env_int("DPC_IGEMM_WS_PLANE", 1);
-        p->plane = plane_on && g.KT == 1 && g.KH == 3 && g.KW == 3 && g.pt == 0 && g.ph == 1 && g.pw == 1 && unit_strides && g.RT == g.ST &&
+        p->plane = !p->parity && plane_on && g.KT == 1 && g.KH == 3 && g.KW == 3 && g.pt == 0 && g.ph == 1 && g.pw == 1 && unit_strides && g.RT == g.ST &&
                    g.RH == 16 && g.RW == 16 && g.SH == 16 && g.SW == 16 && g.Ci % 64 == 0;
     }
     {
         static const int tg_on = env_int("DPC_IGEMM_WS_TGROUP", 1);
         const int hw = g.RH * g.RW;
-        if (tg_on && g.KT > 1 && unit_strides && g.RT == g.ST && g.RT > 1) {
+        if (tg_on && !p->parity && g.KT > 1 && unit_strides && g.RT == g.ST && g.RT > 1) {
             p->tgroup = 1; p->hw = hw; p->d_hw = make_fastdiv((uint32_t)hw);
             p->nclip = g.M / (g.RT * hw);
             p->tpt = (int)(((long long)p->nclip * hw + 255) / 256);
@@ -849,6 +947,7 @@ int dpc_conv_ws_try(const dpc_conv_desc* d, const void* src, const void* wgt, vo
     if (!ws_plan(d, &p)) return 1;
     if (epi_any(epi)) return 1;  // the fused backward pieces of dpc_conv_igemm_ex are not built into these kernels (yet)
     if (addend && stats) return 1;  // not a combination of this path: the generic kernel serves it
+    if (p.parity && (addend || stats)) return 1;
     if (((uintptr_t)out % 16) || ((uintptr_t)addend % 16) || ((uintptr_t)src % 16) || ((uintptr_t)wgt % 16)) return 1;
     p.src = src; p.wgt = wgt; p.out = out; p.addend = addend; p.stats = stats;
 #ifdef DPC_WS_PROBE
@@ -857,7 +956,9 @@ int dpc_conv_ws_try(const dpc_conv_desc* d, const void* src, const void* wgt, vo
     p.dbg = 0;
 #endif
     dim3 grid((unsigned)(p.gm * p.ntn)), block(512);
-    if (p.plane) {
+    if (p.parity) {
+        DPC_LAUNCH((igemm_ws_kernel<false, true>), grid, block, stream, p);
+    } else if (p.plane) {
         if (addend) {
             DPC_LAUNCH((igemm_wsp_kernel<true>), grid, block, stream, p);
         } else {

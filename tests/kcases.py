@@ -102,7 +102,7 @@ def case_conv_fwd(k: K, dtype, N, Ci, Co, T, H, W, ks, st, pd, seed=0, expect=No
     assert (s[:, 1].sum(0) - (o * o).sum(0)).abs().max().item() < 1e-4 * (o * o).sum(0).max().item()
 
 
-def case_conv_dgrad(k: K, dtype, N, Ci, Co, T, H, W, ks, st, pd, seed=1, expect=None):
+def case_conv_dgrad(k: K, dtype, N, Ci, Co, T, H, W, ks, st, pd, seed=1, expect=None, with_add=True):
     g = torch.Generator().manual_seed(seed)
     x = torch.randn(N, Ci, T, H, W, generator=g).requires_grad_()
     w = q(torch.randn(Co, Ci, *ks, generator=g) * 0.1, dtype)
@@ -115,10 +115,10 @@ def case_conv_dgrad(k: K, dtype, N, Ci, Co, T, H, W, ks, st, pd, seed=1, expect=
     add = q(torch.randn(N, T, H, W, Ci, generator=g), dtype)
     out = k.empty(N, T, H, W, Ci, dtype=dtype)
     wd = k.t(w.permute(1, 2, 3, 4, 0).reshape(Ci, taps * Co), dtype)
-    k.call("dpc_conv_igemm", C.byref(d), k.t(cl(gy), dtype), wd, out, k.t(add, dtype), None)
+    k.call("dpc_conv_igemm", C.byref(d), k.t(cl(gy), dtype), wd, out, k.t(add, dtype) if with_add else None, None)
     check_kernel(k, expect)
     k.sync()
-    assert relerr(out, cl(gx) + add) < tol(dtype)
+    assert relerr(out, cl(gx) + add if with_add else cl(gx)) < tol(dtype)
 
 
 def case_conv_dgrad_ex(k: K, dtype, N, Ci, Co, T, H, W, ks, st, pd, gate=True, bnred=True, bn_relu=True, seed=7, expect=None, with_add=True):

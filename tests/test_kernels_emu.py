@@ -69,6 +69,8 @@ def test_conv_fwd(k, dtype, shape):
     (1, 8, 64, 5, 7, 9, (3, 3, 3), (2, 2, 2), (1, 1, 1)),       # odd extents: unequal classes
     (2, 8, 64, 2, 8, 8, (1, 1, 1), (1, 2, 2), (0, 0, 0)),       # strided 1x1x1: 3 of 4 classes see no tap
     (2, 8, 128, 3, 6, 6, (1, 3, 3), (1, 2, 2), (0, 1, 1)),
+    (1, 8, 64, 1, 64, 72, (1, 3, 3), (1, 2, 2), (0, 1, 1)),     # 9 tiles per class: interleaved class order (a block of 8 + a tail)
+    (1, 8, 64, 3, 32, 40, (3, 3, 3), (2, 2, 2), (1, 1, 1)),     # two temporal classes of different size, spatial classes interleaved
     (2, 64, 64, 2, 9, 33, (1, 3, 3), (1, 1, 1), (0, 1, 1)),    # patch kernel, flipped taps
     (1, 128, 128, 1, 10, 16, (1, 3, 3), (1, 1, 1), (0, 1, 1)),
 ])

@@ -44,6 +44,20 @@ def test_conv_fwd(k, dtype, shape):
 
 @pytest.mark.parametrize("dtype", [F32, BF16])
 @pytest.mark.parametrize("shape", [
+    (24, 128, 256, 3, 16, 16, (3, 3, 3), (2, 2, 2), (1, 1, 1), "igemm_ws_kernel<false,true>"),   # layer3.0.conv1 at 128^2: 12 tiles per class (8 interleaved + 4)
+    (130, 256, 256, 2, 8, 8, (3, 3, 3), (2, 2, 2), (1, 1, 1), "igemm_ws_kernel<false,true>"),    # layer4.0.conv1: T = 2, one frame per temporal class
+    (40, 128, 256, 3, 28, 28, (3, 3, 3), (2, 2, 2), (1, 1, 1), "igemm_ws_kernel<false,true>"),   # layer3.0.conv1 of the 224-pixel family
+    (8, 128, 128, 2, 32, 32, (1, 3, 3), (1, 2, 2), (0, 1, 1), "igemm_ws_kernel<false,true>"),    # 2D stride, two channel groups
+    (24, 128, 256, 3, 15, 17, (3, 3, 3), (2, 2, 2), (1, 1, 1), "igemm_ws_kernel<false,true>"),    # odd extents: unequal classes, class after class
+    (64, 64, 128, 1, 32, 32, (1, 3, 3), (1, 2, 2), (0, 1, 1), "igemm_kernel<T,TO,BN,3>"),        # layer2.0.conv1 (64 output columns): generic kernel, interleaved classes
+])
+def test_conv_dgrad_strided(k, dtype, shape):
+    """strided input-gradients without a residual (a layer's first conv): parity classes on the loader / compute kernel"""
+    kc.case_conv_dgrad(k, dtype, *shape[:9], expect=shape[9] if dtype == BF16 else None, with_add=False)
+
+
+@pytest.mark.parametrize("dtype", [F32, BF16])
+@pytest.mark.parametrize("shape", [
     (4, 64, 64, 3, 32, 32, (1, 3, 3), (1, 1, 1), (0, 1, 1), "conv_halo_ws_kernel<true,8,128>"),
     (4, 64, 128, 3, 32, 32, (1, 3, 3), (1, 2, 2), (0, 1, 1), "igemm_kernel<T,TO,BN,3>"),
     (6, 128, 256, 5, 16, 16, (3, 3, 3), (2, 2, 2), (1, 1, 1), "igemm_kernel<T,TO,BN,3>"),

@@ -41,6 +41,13 @@ def main():
     kc.case_conv_fwd(k, BF16, 9, 64, 128, 3, 8, 8, (3, 3, 3), (1, 1, 1), (1, 1, 1))         # T = 3: border frames skip a tap; ragged last tile (9 clips)
     kc.case_conv_fwd(k, BF16, 4, 128, 136, 2, 8, 8, (3, 3, 3), (1, 1, 1), (1, 1, 1))        # T = 2, two channel groups, ragged column tile
     kc.case_conv_dgrad(k, BF16, 5, 128, 128, 3, 8, 8, (3, 3, 3), (1, 1, 1), (1, 1, 1))      # flipped taps + residual addend
+    # strided input-gradients by parity classes on the loader / compute kernel (igemm_ws_kernel<false, true>): 256-row tiles of one
+    # class, K = the class's own taps; 2 programs walk the tiles of all classes (ring of stages across classes with 1..8 taps)
+    PAR = "igemm_ws_kernel<false,true>"
+    kc.case_conv_dgrad(k, BF16, 3, 128, 64, 3, 8, 8, (3, 3, 3), (2, 2, 2), (1, 1, 1), expect=PAR, with_add=False)      # 8 classes, temporal classes of 2 / 1 frames
+    kc.case_conv_dgrad(k, BF16, 2, 128, 128, 2, 16, 36, (1, 3, 3), (1, 2, 2), (0, 1, 1), expect=PAR, with_add=False)   # 2D stride, two channel groups, 3 tiles per class (tail order)
+    kc.case_conv_dgrad(k, BF16, 1, 136, 64, 1, 64, 144, (1, 3, 3), (1, 2, 2), (0, 1, 1), expect=PAR, with_add=False)   # 9 tiles per class: interleaved class order; ragged column tile
+    kc.case_conv_dgrad(k, BF16, 2, 128, 64, 3, 7, 9, (3, 3, 3), (2, 2, 2), (1, 1, 1), expect=PAR, with_add=False)      # odd extents: unequal classes, class after class
     # role-specialised patch kernel (conv_halo_ws_kernel): DPC_HALO_WS_GM = 3 workgroups walk 24 / 8 tiles each
     kc.case_conv_fwd(k, BF16, 2, 64, 64, 2, 9, 33, (1, 3, 3), (1, 1, 1), (0, 1, 1))
     kc.case_conv_fwd(k, BF16, 1, 64, 40, 1, 20, 12, (1, 3, 3), (1, 1, 1), (0, 1, 1))
