@@ -27,6 +27,9 @@ SHAPES = {
     "gru": (896, 256, 768, 1, 4, 4, (1, 1, 1), (1, 1, 1), (0, 0, 0)),         # ConvGRU gate GEMMs batched over 7 steps (weight gradient)
     "gru1": (128, 256, 768, 1, 4, 4, (1, 1, 1), (1, 1, 1), (0, 0, 0)),        # one step (forward / input gradient)
     "l4": (1024, 256, 256, 2, 4, 4, (3, 3, 3), (1, 1, 1), (1, 1, 1)),
+    "l4s": (1024, 256, 256, 3, 8, 8, (3, 3, 3), (2, 2, 2), (1, 1, 1)),
+    "l2s224": (1760, 64, 128, 1, 56, 56, (1, 3, 3), (1, 2, 2), (0, 1, 1)),   # cfg4 shard (44 x 8 clips x 5 frames)
+    "l3s224": (352, 128, 256, 5, 28, 28, (3, 3, 3), (2, 2, 2), (1, 1, 1)),
 }
 
 
