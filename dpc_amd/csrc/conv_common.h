@@ -152,15 +152,30 @@ struct ParityInfo {
     // and re-read the same source rows.  Class after class those re-reads come from HBM nsp times; interleaved in groups of 8
     // tiles (tile l of the temporal class -> spatial class (l / 8) % nsp, tile-in-class (l / (8 nsp)) * 8 + l % 8) the nsp tiles of a
     // region run at the same time on the same XCD (workgroup b sits on XCD b % 8) and share its L2.
-    int ilv, nsp;
+    // A program walks tiles mt, mt + gm, ...: with gm a multiple of 8 nsp it would meet the same spatial class every round and the
+    // programs of the 4-tap class would run 4x longer than those of the 1-tap class; the class is therefore rotated by the round
+    // (block index >> rot_sh, 2^rot_sh = blocks per round), so that every program sees every class.
+    int ilv, nsp, lnsp, rot_sh;
     int tpc[2];         // tiles per spatial class, per temporal residue
     int tstart_t[2];    // first tile of the temporal class
+    // cnt / kl / dl of one (dim, residue) in one word: n | kl_j << (3 + 6 j) | (dl_j + 4) << (6 + 6 j) -- tap j of a class is then
+    // shifts and masks on a scalar register instead of a table lookup; valid when pk_ok (k < 8, -4 <= dl < 4)
+    unsigned pk[3][2];
+    int pk_ok;
 };
+__host__ __device__ __forceinline__ int par_pk_n(unsigned pk) { return (int)(pk & 7u); }
+__host__ __device__ __forceinline__ int par_pk_kl(unsigned pk, int j) { return (int)((pk >> (3 + 6 * j)) & 7u); }
+__host__ __device__ __forceinline__ int par_pk_dl(unsigned pk, int j) { return (int)((pk >> (6 + 6 * j)) & 7u) - 4; }
 
 static inline int dpc_floordiv(int a, int b) { return (a >= 0) ? a / b : -((-a + b - 1) / b); }
 
 // fills `par` for tiles of bm rows; false when the shape is outside the scheme.  skip_empty: classes no tap reaches get no tiles
 // (in-place accumulation: their positions keep their value).
+static inline void dpc_parity_rounds(ParityInfo& par, int gm) {   // gm: programs that walk the m-tiles (tile mt -> program mt % gm)
+    int bpr = gm >> (3 + par.lnsp), sh = 0;
+    while ((2 << sh) <= bpr) ++sh;
+    par.rot_sh = bpr >= 1 ? sh : 30;
+}
 static inline bool dpc_plan_parity(const GatherGeom& g, ParityInfo& par, int bke, int bm, bool skip_empty, int* ntm) {
     if (g.log2C < 0 || g.Ci < bke || g.Ci % bke) return false;
     const int K[3] = {g.KT, g.KH, g.KW}, S[3] = {g.st, g.sh, g.sw}, P[3] = {g.pt, g.ph, g.pw}, R[3] = {g.RT, g.RH, g.RW};
@@ -182,9 +197,22 @@ static inline bool dpc_plan_parity(const GatherGeom& g, ParityInfo& par, int bke
             }
         }
     }
+    par.pk_ok = 1;
+    for (int d = 0; d < 3; ++d)
+        for (int r = 0; r < 2; ++r) {
+            unsigned w = (unsigned)par.cnt[d][r];
+            for (int j = 0; j < par.cnt[d][r]; ++j) {
+                if (par.kl[d][r][j] > 7 || par.dl[d][r][j] < -4 || par.dl[d][r][j] > 3) par.pk_ok = 0;
+                w |= ((unsigned)par.kl[d][r][j] & 7u) << (3 + 6 * j);
+                w |= ((unsigned)(par.dl[d][r][j] + 4) & 7u) << (6 + 6 * j);
+            }
+            par.pk[d][r] = w;
+        }
     par.ncls = g.st * g.sh * g.sw;
     par.N = g.M / (g.RT * g.RH * g.RW);
     par.nsp = g.sh * g.sw;
+    par.lnsp = g.lsh + g.lsw;
+    par.rot_sh = 30;
     par.ilv = par.nsp > 1 ? 1 : 0;
     par.tpc[0] = par.tpc[1] = 0;
     int tiles = 0;
@@ -233,8 +261,8 @@ __device__ __forceinline__ void parity_tile(const ParityInfo& par, int mt, int& 
     const int full = tpc & ~7;
     int cs;
     if (l < full * par.nsp) {
-        const int blk = l / (8 * par.nsp), r = l - blk * 8 * par.nsp;
-        cs = r >> 3;
+        const int blk = l >> (3 + par.lnsp), r = l & ((8 << par.lnsp) - 1);
+        cs = ((r >> 3) + (blk >> par.rot_sh)) & (par.nsp - 1);
         j = blk * 8 + (r & 7);
     } else {
         const int l2 = l - full * par.nsp, rem = tpc - full;
@@ -243,23 +271,6 @@ __device__ __forceinline__ void parity_tile(const ParityInfo& par, int mt, int& 
     }
     c = ct * par.nsp + cs;
 }
-// class tables of one dimension for residue r (0 / 1), as values
-struct ParDim { int n, ext; FastDiv div; int kl[4], dl[4]; };
-template <int D>
-__device__ __forceinline__ ParDim parity_dim(const ParityInfo& par, int r) {
-    ParDim o;
-    o.n = r ? par.cnt[D][1] : par.cnt[D][0];
-    o.ext = r ? par.dimc[D][1] : par.dimc[D][0];
-    o.div = r ? par.div[D][1] : par.div[D][0];
-    DPC_UNROLL
-    for (int j = 0; j < 4; ++j) {
-        o.kl[j] = r ? par.kl[D][1][j] : par.kl[D][0][j];
-        o.dl[j] = r ? par.dl[D][1][j] : par.dl[D][0][j];
-    }
-    return o;
-}
-__device__ __forceinline__ int pick4(const int (&a)[4], int j) { return j == 0 ? a[0] : (j == 1 ? a[1] : (j == 2 ? a[2] : a[3])); }
-
 // ---- fused backward pieces of an input-gradient epilogue (dpc_conv_igemm_ex, include/dpc_hip.h) -----------------------------
 // addend_mask: the residual addend is the BLOCK's incoming gradient gated by the ReLU sign mask of the block output
 //   (out = conv + (bit ? addend : 0)): the masked gradient dz is never written as a tensor.

@@ -537,10 +537,12 @@ static bool plan_parity(IGemmParams& p, int bke) {
     // in-place accumulation (addend == out): positions no tap reaches keep their value, so their classes get no tiles --
     // a 1x1 stride-2 downsample's input-gradient touches 1/4 (2D) or 1/8 (3D) of dx instead of rewriting all of it
     if (!dpc_plan_parity(p.g, p.par, bke, 128, p.addend && p.addend == p.out, &p.ntm)) return false;
-    int cap = 2048 / p.ntn;
+    static const int gm_cap = getenv("DPC_IGEMM_GM_CAP") ? atoi(getenv("DPC_IGEMM_GM_CAP")) : 2048;   // test tiers: several rounds on small shapes
+    int cap = gm_cap / p.ntn;
     if (cap < 1) cap = 1;
     if (cap >= 8) cap &= ~7;  // interleaved class tiles rely on tile mt running on XCD mt % 8
     p.gm = p.ntm < cap ? p.ntm : cap;
+    dpc_parity_rounds(p.par, p.gm);
     return true;
 }
 

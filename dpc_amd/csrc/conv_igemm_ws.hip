@@ -212,35 +212,41 @@ __global__ __launch_bounds__(512, 2) void igemm_ws_kernel(WsParams p) {
     const int nkc = g.Kp / BKE;
     const int my_tiles = (p.ntm - m_prog + p.gm - 1) / p.gm;
     // parity class of a tile (wave-uniform): residues, extents, row count, tile inside the class
-    struct ParCls { int j, rows; ParDim T, H, W; int ct, ch, cw; };
+    struct ParCls { int j, rows, ct, ch, cw, Tc, Hc, Wc; FastDiv dT, dH, dW; };
     auto par_cls = [&](int mt) -> ParCls {
         ParCls k;
         int c;
         parity_tile(p.par, mt, c, k.j);
         k.cw = c & (g.sw - 1); k.ch = (c >> g.lsw) & (g.sh - 1); k.ct = c >> (g.lsw + g.lsh);   // strides are 1 or 2
-        k.T = parity_dim<0>(p.par, k.ct); k.H = parity_dim<1>(p.par, k.ch); k.W = parity_dim<2>(p.par, k.cw);
-        k.rows = p.par.N * k.T.ext * k.H.ext * k.W.ext;
+        k.Tc = k.ct ? p.par.dimc[0][1] : p.par.dimc[0][0]; k.dT = k.ct ? p.par.div[0][1] : p.par.div[0][0];
+        k.Hc = k.ch ? p.par.dimc[1][1] : p.par.dimc[1][0]; k.dH = k.ch ? p.par.div[1][1] : p.par.div[1][0];
+        k.Wc = k.cw ? p.par.dimc[2][1] : p.par.dimc[2][0]; k.dW = k.cw ? p.par.div[2][1] : p.par.div[2][0];
+        k.rows = p.par.N * k.Tc * k.Hc * k.Wc;
         return k;
     };
     auto par_decode = [&](const ParCls& k, int lr, int& n, int& tq, int& hq, int& wq) {
-        const unsigned q1 = fdiv((unsigned)lr, k.W.div);
-        wq = lr - (int)q1 * k.W.ext;
-        const unsigned q2 = fdiv(q1, k.H.div);
-        hq = (int)q1 - (int)q2 * k.H.ext;
-        const unsigned nn = fdiv(q2, k.T.div);
-        tq = (int)q2 - (int)nn * k.T.ext;
+        const unsigned q1 = fdiv((unsigned)lr, k.dW);
+        wq = lr - (int)q1 * k.Wc;
+        const unsigned q2 = fdiv(q1, k.dH);
+        hq = (int)q1 - (int)q2 * k.Hc;
+        const unsigned nn = fdiv(q2, k.dT);
+        tq = (int)q2 - (int)nn * k.Tc;
         n = (int)nn;
+    };
+    auto par_row = [&](const ParCls& k, int r) -> int {   // tile row -> output row of the class tile (g.M: no such row)
+        const int lr = k.j * BM + r;
+        if (lr >= k.rows) return g.M;
+        int n, tq, hq, wq;
+        par_decode(k, lr, n, tq, hq, wq);
+        return (((n * g.RT + tq * g.st + k.ct) * g.RH + hq * g.sh + k.ch) * g.RW) + wq * g.sw + k.cw;
+    };
+    auto par_pk = [&](const ParCls& k, unsigned& pT, unsigned& pH, unsigned& pW) {
+        pT = k.ct ? p.par.pk[0][1] : p.par.pk[0][0];
+        pH = k.ch ? p.par.pk[1][1] : p.par.pk[1][0];
+        pW = k.cw ? p.par.pk[2][1] : p.par.pk[2][0];
     };
     // tile row -> GEMM row (identity unless the tiles are grouped by output frame index / parity class)
     auto tile_row = [&](int mt, int r) -> int {
-        if (PAR) {
-            const ParCls k = par_cls(mt);
-            const int lr = k.j * BM + r;
-            if (lr >= k.rows) return g.M;
-            int n, tq, hq, wq;
-            par_decode(k, lr, n, tq, hq, wq);
-            return (((n * g.RT + tq * g.st + k.ct) * g.RH + hq * g.sh + k.ch) * g.RW) + wq * g.sw + k.cw;
-        }
         if (!p.tgroup) return mt * BM + r;
         const int t = mt / p.tpt;
         const unsigned idx = (unsigned)((mt - t * p.tpt) * BM + r);   // pixel of frame t, counted across the clips
@@ -252,7 +258,9 @@ __global__ __launch_bounds__(512, 2) void igemm_ws_kernel(WsParams p) {
         lo = 0; hi = nkc;
         if (PAR) {
             const ParCls k = par_cls(mt);
-            hi = k.T.n * k.H.n * k.W.n * (g.Ci >> 6);
+            unsigned pT, pH, pW;
+            par_pk(k, pT, pH, pW);
+            hi = par_pk_n(pT) * par_pk_n(pH) * par_pk_n(pW) * (g.Ci >> 6);
             return;
         }
         if (!p.tgroup) return;
@@ -302,13 +310,13 @@ __global__ __launch_bounds__(512, 2) void igemm_ws_kernel(WsParams p) {
             if (hi > K - 1) hi = K - 1;
             return hi >= lo ? (((2u << hi) - 1u) & ~((1u << lo) - 1u)) : 0u;
         };
-        ParCls lk = {};                                 // PAR: class of the tile whose chunks are being issued,
+        unsigned l_pT = 0, l_pH = 0, l_pW = 0;          // PAR: packed tap tables of the class whose chunks are being issued,
         int l_jt = 0, l_jh = 0, l_jw = 0, l_cc = 0;   // and the (tap, 64-channel group) cursor of its next chunk
         auto decode_tile = [&](int mt) {
             const int mine = lane & 7;  // which of the group's 8 rows this lane decodes
             if (PAR) {
-                lk = par_cls(mt);
-                const ParCls& k = lk;
+                const ParCls k = par_cls(mt);
+                par_pk(k, l_pT, l_pH, l_pW);
                 l_jt = l_jh = l_jw = l_cc = 0;
                 const int lr = k.j * BM + 8 * (lw + 4 * mine) + rl;
                 unsigned off = 0, m = 0;
@@ -318,9 +326,9 @@ __global__ __launch_bounds__(512, 2) void igemm_ws_kernel(WsParams p) {
                     off = (((((unsigned)(n * g.ST + tq) * (unsigned)g.SH + (unsigned)hq) * (unsigned)g.SW) + (unsigned)wq) * (unsigned)g.src_ld) * 2u;
                     DPC_UNROLL
                     for (int j = 0; j < 4; ++j) {
-                        m |= (j < k.T.n && (unsigned)(tq + k.T.dl[j]) < (unsigned)g.ST ? 1u : 0u) << j;
-                        m |= (j < k.H.n && (unsigned)(hq + k.H.dl[j]) < (unsigned)g.SH ? 1u : 0u) << (4 + j);
-                        m |= (j < k.W.n && (unsigned)(wq + k.W.dl[j]) < (unsigned)g.SW ? 1u : 0u) << (8 + j);
+                        m |= (j < par_pk_n(l_pT) && (unsigned)(tq + par_pk_dl(l_pT, j)) < (unsigned)g.ST ? 1u : 0u) << j;
+                        m |= (j < par_pk_n(l_pH) && (unsigned)(hq + par_pk_dl(l_pH, j)) < (unsigned)g.SH ? 1u : 0u) << (4 + j);
+                        m |= (j < par_pk_n(l_pW) && (unsigned)(wq + par_pk_dl(l_pW, j)) < (unsigned)g.SW ? 1u : 0u) << (8 + j);
                     }
                 }
                 DPC_UNROLL
@@ -350,23 +358,24 @@ __global__ __launch_bounds__(512, 2) void igemm_ws_kernel(WsParams p) {
                 const int jt = l_jt, jh = l_jh, jw = l_jw, cofs = l_cc * BKE;
                 if (++l_cc == (g.Ci >> 6)) {
                     l_cc = 0;
-                    if (++l_jw == lk.W.n) {
+                    if (++l_jw == par_pk_n(l_pW)) {
                         l_jw = 0;
-                        if (++l_jh == lk.H.n) { l_jh = 0; ++l_jt; }
+                        if (++l_jh == par_pk_n(l_pH)) { l_jh = 0; ++l_jt; }
                     }
                 }
-                const int kt = pick4(lk.T.kl, jt), kh = pick4(lk.H.kl, jh), kw = pick4(lk.W.kl, jw);
-                const int dt = pick4(lk.T.dl, jt), dh = pick4(lk.H.dl, jh), dw = pick4(lk.W.dl, jw);
+                const int kt = par_pk_kl(l_pT, jt), kh = par_pk_kl(l_pH, jh), kw = par_pk_kl(l_pW, jw);
+                const int dt = par_pk_dl(l_pT, jt), dh = par_pk_dl(l_pH, jh), dw = par_pk_dl(l_pW, jw);
                 const unsigned sel = (1u << jt) | (1u << (4 + jh)) | (1u << (8 + jw));
                 const unsigned tapoff = (unsigned)(((dt * g.SH + dh) * g.SW + dw) * g.src_ld + cofs) * 2u;
                 const unsigned kd = (unsigned)(((kt * g.KH + kh) * g.KW + kw) * g.Ci + cofs);
                 DPC_UNROLL
                 for (int i = 0; i < 8; ++i) {
                     const bool ok = (vmask[i] & sel) == sel;
-                    glds16_buf(rs_a, ok ? rowoff[i] + tapoff : DPC_BUF_OOB, 0u, st + (lw + 4 * i) * 1024, lane);
+                    if (!WS_DBG(4 | 128)) glds16_buf(rs_a, ok ? rowoff[i] + tapoff : DPC_BUF_OOB, 0u, st + (lw + 4 * i) * 1024, lane);
                 }
                 DPC_UNROLL
-                for (int i = 0; i < 4; ++i) glds16_buf(rs_b, wrow[i], kd * 2u, st + BM * 128 + (lw + 4 * i) * 1024, lane);
+                for (int i = 0; i < 4; ++i)
+                    if (!WS_DBG(4 | 256)) glds16_buf(rs_b, wrow[i], kd * 2u, st + BM * 128 + (lw + 4 * i) * 1024, lane);
                 return;
             }
             // one tap per chunk (Ci is a multiple of 64): the tap decode is wave-uniform scalar work
@@ -445,6 +454,8 @@ __global__ __launch_bounds__(512, 2) void igemm_ws_kernel(WsParams p) {
 #endif
     for (int t = 0; wv < 4 && t < my_tiles; ++t) {
         const int mt = m_prog + t * p.gm;
+        ParCls ck = {};
+        if (PAR) ck = par_cls(mt);
         int kc_lo, kc_hi;
         tile_chunks(mt, kc_lo, kc_hi);
         const int nkc_t = kc_hi - kc_lo;
@@ -468,7 +479,7 @@ __global__ __launch_bounds__(512, 2) void igemm_ws_kernel(WsParams p) {
         auto fetch_addend = [&](int i, u32x4 (&dst)[8]) {
             DPC_UNROLL
             for (int it = 0; it < 8; ++it) {
-                const int row = tile_row(mt, wv * 64 + i * 32 + er + 4 * it);
+                const int row = PAR ? par_row(ck, wv * 64 + i * 32 + er + 4 * it) : tile_row(mt, wv * 64 + i * 32 + er + 4 * it);
                 const bool ok = row < g.M && col0 < p.Ncol;
                 const char* a = (const char*)p.addend + ((long long)row * p.ldo + col0) * 2;
                 dst[it] = *(const u32x4*)(ok ? a : zero);
@@ -517,7 +528,7 @@ __global__ __launch_bounds__(512, 2) void igemm_ws_kernel(WsParams p) {
             wave_lds_fence();  // the second pass overwrites what this one has just read
             DPC_UNROLL
             for (int it = 0; it < 8; ++it) {
-                const int row = tile_row(mt, wv * 64 + i * 32 + er + 4 * it);
+                const int row = PAR ? par_row(ck, wv * 64 + i * 32 + er + 4 * it) : tile_row(mt, wv * 64 + i * 32 + er + 4 * it);
                 if (row < g.M && col0 < p.Ncol) {
                     u32x4 o = ov[it];
                     if (HAS_ADD) {
@@ -882,7 +893,7 @@ static int ws_max_programs() { static int v = env_int("DPC_IGEMM_WS_GM", 256); r
 static bool ws_plan(const dpc_conv_desc* d, WsParams* p) {
     if (!ws_enabled()) return false;
     if (d->dtype_in != DPC_BF16 || d->dtype_out != DPC_BF16) return false;
-    if (d->Co < 128 || d->Co % 8 || d->ldo % 8 || d->ldw % 8) return false;
+    if (d->Co < 64 || d->Co % 8 || d->ldo % 8 || d->ldw % 8) return false;
     GatherGeom& g = p->g;
     if (make_gather_geom(d, &g)) return false;
     if (g.Kp % 64 || (g.taps > 1 && g.Ci % 64)) return false;
@@ -895,10 +906,15 @@ static bool ws_plan(const dpc_conv_desc* d, WsParams* p) {
     if (!(g.mode == 0 || unit_strides)) {   // strided input-gradient: parity classes on 256-row tiles
         static const int par_on = env_int("DPC_IGEMM_WS_PAR", 1);
         if (!par_on || g.taps == 1 || !dpc_plan_parity(g, p->par, 64, 256, false, &par_tiles)) return false;
+        if (!p->par.pk_ok) return false;
         for (int c = 0; c < p->par.ncls; ++c)   // a class without taps would be a tile without chunks: not a case of this kernel's barrier sequence
             if (p->par.cnt[0][c / (g.sw * g.sh)] * p->par.cnt[1][(c / g.sw) % g.sh] * p->par.cnt[2][c % g.sw] == 0) return false;
         p->parity = 1;
     }
+    // 64 output columns (layer2.0.conv1's input-gradient) run on the 128-column tile with the upper weight rows zero-filled by the
+    // buffer resource: half of the MFMA work is wasted and it is still 1.7x faster than the generic kernel's one-chunk-in-flight
+    // loop on tiles of 2..8 chunks (562 -> 330 us); forward / unit-stride shapes with Co < 128 have their own kernels (conv_halo)
+    if (!p->parity && d->Co < 128) return false;
     if (g.M < ws_min_rows()) return false;  // too few 256-row tiles to feed 256 CUs: the 128-row kernel balances better
     p->Ncol = d->Co; p->ldw = d->ldw; p->ldo = d->ldo;
     const long long wbytes = ((long long)(d->Co - 1) * d->ldw + g.Kp) * 2;
@@ -931,6 +947,7 @@ static bool ws_plan(const dpc_conv_desc* d, WsParams* p) {
     if (gm > p->ntm) gm = p->ntm;
     if (gm >= 8) gm &= ~7;
     p->gm = gm;
+    if (p->parity) dpc_parity_rounds(p->par, gm);
     return true;
 }
 

@@ -20,24 +20,34 @@ if SHAPE == "layer3":   # igemm_ws_kernel: 3x3x3, 8x8 planes, 256 -> 256 (two co
 else:                   # igemm_wsp_kernel: 1x3x3, 16x16 planes, 128 -> 128
     N, T, H, W, Ci, Co, KS, PD = 1024, 5, 16, 16, 128, 128, (1, 3, 3), (0, 1, 1)
 TAPS = KS[0] * KS[1] * KS[2]
-d = kc.conv_desc(BF, BF, 0, N, (T, H, W), (T, H, W), Ci, Ci, Co, TAPS * Ci, Co, KS, (1, 1, 1), PD)
-src = torch.randn(N, T, H, W, Ci, device=dev).to(BF)
-wgt = (torch.randn(Co, TAPS * Ci, device=dev) * 0.05).to(BF)
-out = torch.empty(N, T, H, W, Co, device=dev, dtype=BF)
-rows = lib.call("dpc_conv_stats_rows", C.byref(d))
-stats = torch.zeros(rows, 2, Co, device=dev)
-flops = 2.0 * N * T * H * W * Co * TAPS * Ci
+if SHAPE in ("l3s", "l4s"):   # igemm_ws_kernel<false,true>: strided input-gradient by parity classes (layer3.0 / layer4.0 conv1)
+    N, T, H, W, Ci, Co = (1024, 5, 16, 16, 128, 256) if SHAPE == "l3s" else (1024, 3, 8, 8, 256, 256)
+    R = tuple((i + 2 - 3) // 2 + 1 for i in (T, H, W))
+    d = kc.conv_desc(BF, BF, 1, N, (T, H, W), R, Co, Co, Ci, TAPS * Co, Ci, KS, (2, 2, 2), PD)
+    src = torch.randn(N, *R, Co, device=dev).to(BF)            # dy
+    wgt = (torch.randn(Ci, TAPS * Co, device=dev) * 0.05).to(BF)
+    out = torch.empty(N, T, H, W, Ci, device=dev, dtype=BF)
+    stats = None
+    flops = 2.0 * N * R[0] * R[1] * R[2] * Co * TAPS * Ci
+else:
+    d = kc.conv_desc(BF, BF, 0, N, (T, H, W), (T, H, W), Ci, Ci, Co, TAPS * Ci, Co, KS, (1, 1, 1), PD)
+    src = torch.randn(N, T, H, W, Ci, device=dev).to(BF)
+    wgt = (torch.randn(Co, TAPS * Ci, device=dev) * 0.05).to(BF)
+    out = torch.empty(N, T, H, W, Co, device=dev, dtype=BF)
+    rows = lib.call("dpc_conv_stats_rows", C.byref(d))
+    stats = torch.zeros(rows, 2, Co, device=dev)
+    flops = 2.0 * N * T * H * W * Co * TAPS * Ci
 
 
 def run(tag, dbg, plane=True, reps=20):
     os.environ["DPC_WS_DBG"] = str(dbg)
     for _ in range(3):
-        lib.call("dpc_conv_igemm", C.byref(d), src.data_ptr(), wgt.data_ptr(), out.data_ptr(), None, stats.data_ptr(), lib.stream())
+        lib.call("dpc_conv_igemm", C.byref(d), src.data_ptr(), wgt.data_ptr(), out.data_ptr(), None, stats.data_ptr() if stats is not None else None, lib.stream())
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(reps):
-        lib.call("dpc_conv_igemm", C.byref(d), src.data_ptr(), wgt.data_ptr(), out.data_ptr(), None, stats.data_ptr(), lib.stream())
+        lib.call("dpc_conv_igemm", C.byref(d), src.data_ptr(), wgt.data_ptr(), out.data_ptr(), None, stats.data_ptr() if stats is not None else None, lib.stream())
     e1.record()
     torch.cuda.synchronize()
     us = e0.elapsed_time(e1) * 1e3 / reps

@@ -48,6 +48,10 @@ def main():
     kc.case_conv_dgrad(k, BF16, 2, 128, 128, 2, 16, 36, (1, 3, 3), (1, 2, 2), (0, 1, 1), expect=PAR, with_add=False)   # 2D stride, two channel groups, 3 tiles per class (tail order)
     kc.case_conv_dgrad(k, BF16, 1, 136, 64, 1, 64, 144, (1, 3, 3), (1, 2, 2), (0, 1, 1), expect=PAR, with_add=False)   # 9 tiles per class: interleaved class order; ragged column tile
     kc.case_conv_dgrad(k, BF16, 2, 128, 64, 3, 7, 9, (3, 3, 3), (2, 2, 2), (1, 1, 1), expect=PAR, with_add=False)      # odd extents: unequal classes, class after class
+    kc.case_conv_dgrad(k, BF16, 2, 64, 128, 1, 16, 24, (1, 3, 3), (1, 2, 2), (0, 1, 1), expect=PAR, with_add=False)     # 64 output columns on the 128-column tile
+    # the generic kernel's class order with several rounds per program (DPC_IGEMM_GM_CAP = 32 programs, 72 tiles): the class of a
+    # block rotates with the round
+    kc.case_conv_dgrad(k, BF16, 1, 32, 64, 1, 64, 144, (1, 3, 3), (1, 2, 2), (0, 1, 1), expect="igemm_kernel<T,TO,BN,3>", with_add=False)
     # role-specialised patch kernel (conv_halo_ws_kernel): DPC_HALO_WS_GM = 3 workgroups walk 24 / 8 tiles each
     kc.case_conv_fwd(k, BF16, 2, 64, 64, 2, 9, 33, (1, 3, 3), (1, 1, 1), (0, 1, 1))
     kc.case_conv_fwd(k, BF16, 1, 64, 40, 1, 20, 12, (1, 3, 3), (1, 1, 1), (0, 1, 1))
