@@ -45,10 +45,14 @@ struct IGemmParams {
     // split-K (dpc_gemm_nt_splitk): workgroup group ks reduces K chunks [ks*kcps, (ks+1)*kcps) into slab ks of `out`
     int nks, kcps;
     long long slab;  // elements of TO between slabs
+
 };
 
 #ifndef DPC_IGEMM_DMA
 #define DPC_IGEMM_DMA 1
+#endif
+#ifndef DPC_IGEMM_PIPE2
+#define DPC_IGEMM_PIPE2 1   // main loop with two chunks in flight (0: the round-1 loop, one chunk in flight)
 #endif
 
 // EPI: the fused backward pieces of dpc_conv_igemm_ex in the epilogue (their registers cost the plain instantiation occupancy /
@@ -321,7 +325,36 @@ __global__ __launch_bounds__(256, (BN == 64 ? 3 : 2)) void igemm_kernel(IGemmPar
             }
         };
 
-        if (nkc_t > 0) {  // a parity class may see no tap at all (strided 1x1x1): its rows are just 0 (+ addend)
+        if constexpr (DMA && DPC_IGEMM_PIPE2) {
+            // Two chunks in flight: chunk k+2 is requested as soon as every wave is done with the buffer of chunk k, and the wait in
+            // front of chunk k+1's MFMAs counts (vmcnt(NLD): only the pieces of chunk k+2 may be outstanding) -- a chunk has two
+            // iterations to land.  With "request k+1, MFMAs of k, wait for everything" an iteration lasts one memory round trip
+            // whatever the MFMA time is: the short reductions (parity-class tiles of 2..32 chunks, split-K GEMMs) ran at 14 % MFMA
+            // utilisation with one chunk in flight per workgroup.
+            constexpr int NLD = 4 + BROWS;   // LDS-DMA instructions per thread and chunk
+            if (nkc_t > 0) load_chunk(0, 0);   // a parity class may see no tap at all (strided 1x1x1): its rows are just 0 (+ addend)
+            if (nkc_t > 1) load_chunk(1, BUF);
+            for (int kc = 0; kc < nkc_t; kc += 2) {
+                if (kc + 1 < nkc_t) wait_vmcnt<NLD>(); else wait_vmcnt<0>();
+                barrier_lds_only();
+                mma_chunk(0);
+                if (kc + 2 < nkc_t) {
+                    barrier_lds_only();
+                    load_chunk(kc + 2, 0);
+                }
+                if (kc + 1 < nkc_t) {
+                    if (kc + 2 < nkc_t) wait_vmcnt<NLD>(); else wait_vmcnt<0>();
+                    barrier_lds_only();
+                    mma_chunk(BUF);
+                    if (kc + 3 < nkc_t) {
+                        barrier_lds_only();
+                        load_chunk(kc + 3, BUF);
+                    }
+                }
+            }
+            __syncthreads();   // every wave is done with the operand buffers: the epilogue stages the tile through them
+        } else {
+        if (nkc_t > 0) {
             load_chunk(0, 0);
             store_chunk(0);
         }
@@ -337,6 +370,7 @@ __global__ __launch_bounds__(256, (BN == 64 ? 3 : 2)) void igemm_kernel(IGemmPar
                 if (kc + 2 < nkc_t) store_chunk(0);
                 __syncthreads();
             }
+        }
         }
 
         // ---- epilogue: accumulators -> LDS tile [128][BN] of TO -> 16-byte units -> global

@@ -911,10 +911,12 @@ static bool ws_plan(const dpc_conv_desc* d, WsParams* p) {
             if (p->par.cnt[0][c / (g.sw * g.sh)] * p->par.cnt[1][(c / g.sw) % g.sh] * p->par.cnt[2][c % g.sw] == 0) return false;
         p->parity = 1;
     }
-    // 64 output columns (layer2.0.conv1's input-gradient) run on the 128-column tile with the upper weight rows zero-filled by the
-    // buffer resource: half of the MFMA work is wasted and it is still 1.7x faster than the generic kernel's one-chunk-in-flight
-    // loop on tiles of 2..8 chunks (562 -> 330 us); forward / unit-stride shapes with Co < 128 have their own kernels (conv_halo)
-    if (!p->parity && d->Co < 128) return false;
+    // 64 output columns (layer2.0.conv1's input-gradient, K = 128 per tap: tiles of 2..8 chunks) would run on the 128-column tile
+    // with the upper weight rows zero-filled by the buffer resource (DPC_IGEMM_WS_PAR_MINCO=64).  Measured slower than the generic
+    // kernel (643 vs 566 us): this kernel's tile boundary -- loader decode, "tile fully read" barrier, epilogue on the compute
+    // waves -- costs ~5 us, which 13-chunk tiles (layer3.0: 395 -> 298 us) amortise and 4.5-chunk tiles do not.
+    static const int par_min_co = env_int("DPC_IGEMM_WS_PAR_MINCO", 128);
+    if (d->Co < (p->parity ? par_min_co : 128)) return false;
     if (g.M < ws_min_rows()) return false;  // too few 256-row tiles to feed 256 CUs: the 128-row kernel balances better
     p->Ncol = d->Co; p->ldw = d->ldw; p->ldo = d->ldo;
     const long long wbytes = ((long long)(d->Co - 1) * d->ldw + g.Kp) * 2;

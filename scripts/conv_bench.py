@@ -43,7 +43,7 @@ def main():
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--ops", default="fwd,dgrad,wgrad")
     args = ap.parse_args()
-    lib = L.load_hip()
+    lib = L.Lib(os.environ["DPC_BENCH_LIB"], "hip") if os.environ.get("DPC_BENCH_LIB") else L.load_hip()   # A/B against another build
     dev = torch.device("cuda", 0)
     st = lib.stream()
     for name in args.names:

@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(
 from dpc_amd import _lib as L
 import kcases as kc
 
-k = kc.K(L.load_hip(), "cuda:0")
+k = kc.K(L.Lib(os.environ["DPC_BENCH_LIB"], "hip") if os.environ.get("DPC_BENCH_LIB") else L.load_hip(), "cuda:0")   # A/B against another build
 bf = torch.bfloat16
 reps = int(os.environ.get("REPS", "10"))
 
