@@ -45,6 +45,7 @@ struct IGemmParams {
     // split-K (dpc_gemm_nt_splitk): workgroup group ks reduces K chunks [ks*kcps, (ks+1)*kcps) into slab ks of `out`
     int nks, kcps;
     long long slab;  // elements of TO between slabs
+    int xcd_cols;    // column tiles of a row tile on one XCD (launch_igemm_bn)
 
 };
 
@@ -82,9 +83,18 @@ __global__ __launch_bounds__(256, (BN == 64 ? 3 : 2)) void igemm_kernel(IGemmPar
     const int lane = tid & 63, wv = tid >> 6;
     const int wm = wv >> 1, wn = wv & 1;
     const int l31 = lane & 31, lhi = lane >> 5;
-    const int n_tile = blockIdx.x % p.ntn;
-    const int ks = (blockIdx.x / p.ntn) / p.gm;        // 0 unless the reduction is split over workgroups
-    const int m_prog = (blockIdx.x / p.ntn) - ks * p.gm;
+    // Workgroup b runs on XCD b & 7.  With more than one column tile the ntn workgroups that read the same source rows are
+    // neighbours in the linear order -- different XCDs, so the rows came from HBM ntn times (d_pred = dS @ feature: 182 MB read for a
+    // 75 MB dS, and the GEMM is bound by exactly that).  Remapped, workgroups b, b + 8, ... of one XCD are the column tiles of one
+    // row tile: the second reader hits the L2 the first one filled.
+    int bx = blockIdx.x;
+    if (p.xcd_cols) {
+        const int q = bx >> 3;
+        bx = ((q / p.ntn) * 8 + (bx & 7)) * p.ntn + q % p.ntn;
+    }
+    const int n_tile = bx % p.ntn;
+    const int ks = (bx / p.ntn) / p.gm;        // 0 unless the reduction is split over workgroups
+    const int m_prog = (bx / p.ntn) - ks * p.gm;
     const int kc0 = ks * p.kcps;
     const int nkc_all = (g.Kp + BKE - 1) / BKE;
     const int nkc = (kc0 + p.kcps < nkc_all ? kc0 + p.kcps : nkc_all) - kc0;
@@ -537,8 +547,9 @@ extern "C" int dpc_conv_stats_rows(const dpc_conv_desc* d) {
 }
 
 template <class T, class TO, int BN>
-static int launch_igemm_bn(const IGemmParams& p, int gather, hipStream_t stream) {
+static int launch_igemm_bn(IGemmParams& p, int gather, hipStream_t stream) {
     dim3 grid((unsigned)(p.gm * p.ntn * p.nks)), block(256);
+    p.xcd_cols = (p.ntn > 1 && (p.gm * p.nks) % 8 == 0) ? 1 : 0;
     dpc_plan_detail("T=%s TO=%s BN=%d", sizeof(T) == 2 ? "bf16" : "f32", sizeof(TO) == 2 ? "bf16" : "f32", BN);
     if (epi_any(p.epi)) {  // dpc_conv_igemm_ex (T == TO, vectorised output: checked by the entry)
         if constexpr (sizeof(T) == sizeof(TO)) {

@@ -43,21 +43,34 @@ __global__ void bn_relu_maxpool_fwd_kernel(const T* x, int NT, int H, int W, int
             best[e] = -1.f;
             bi[e] = 9;
         }
+        // all nine window loads are issued before the first use: with a branch around a border tap hipcc waits vmcnt(0) right
+        // behind every load (nine serialised round trips per thread: 880 us = 4.2 TB/s where the family's other kernels run 5+).
+        // Border taps re-read the window's centre (always inside) and are kept out of the comparison instead.
+        u32x4 v[9];
+        bool ok[9];
         DPC_UNROLL
         for (int kh = 0; kh < 3; ++kh) {
             const int h = 2 * oh - 1 + kh;
-            if (h < 0 || h >= H) continue;
+            const bool okh = (unsigned)h < (unsigned)H;
             DPC_UNROLL
             for (int kw = 0; kw < 3; ++kw) {
                 const int w = 2 * ow - 1 + kw;
-                if (w < 0 || w >= W) continue;
-                const u32x4 v = ((const u32x4*)x)[(long long)((unsigned)((nt * H + h) * W + w)) * upr + cu];
-                DPC_UNROLL
-                for (int e = 0; e < E; ++e) {
-                    float a = unit_get<T>(v, e) * sc[e] + sh[e];
-                    a = a > 0.f ? a : 0.f;
-                    if (a > best[e]) { best[e] = a; bi[e] = kh * 3 + kw; }
-                }
+                const bool o = okh && (unsigned)w < (unsigned)W;
+                const int hc = o ? h : 2 * oh, wc = o ? w : 2 * ow;
+                ok[kh * 3 + kw] = o;
+                v[kh * 3 + kw] = ((const u32x4*)x)[(long long)((unsigned)((nt * H + hc) * W + wc)) * upr + cu];
+            }
+        }
+        sched_fence();   // keep the nine loads together (hipcc otherwise sinks each next to its use: load, wait, use, load, ...)
+        DPC_UNROLL
+        for (int k = 0; k < 9; ++k) {
+            DPC_UNROLL
+            for (int e = 0; e < E; ++e) {
+                float a = unit_get<T>(v[k], e) * sc[e] + sh[e];
+                a = a > 0.f ? a : 0.f;
+                const bool upd = ok[k] & (a > best[e]);   // selects, not branches
+                best[e] = upd ? a : best[e];
+                bi[e] = upd ? k : bi[e];
             }
         }
         uint32_t amw[2] = {0u, 0u};
@@ -101,33 +114,37 @@ __device__ __forceinline__ void pool_routed_grad(const T* dy, const uint8_t* arg
     DPC_UNROLL
     for (int e = 0; e < E; ++e) acc[e] = 0.f;
     const int oh0 = h >> 1, ow0 = w >> 1;  // window with kh = (h odd ? 2 : 1); h odd also hits oh0+1 with kh = 0
+    // branch-free: the (<= 4) windows are all loaded (clamped to an existing one) before the first use and the ones that do not
+    // exist are kept out of the sum -- a branch around a load is a vmcnt(0) behind it
+    u32x4 g[4];
+    uint32_t am[4][2];
+    int want[4];
+    bool ok[4];
     DPC_UNROLL
     for (int a = 0; a < 2; ++a) {
-        if (a == 1 && !(h & 1)) continue;
-        const int oh = oh0 + a;
-        if (oh >= Ho) continue;
-        const int kh = h - (2 * oh - 1);
         DPC_UNROLL
         for (int b = 0; b < 2; ++b) {
-            if (b == 1 && !(w & 1)) continue;
-            const int ow = ow0 + b;
-            if (ow >= Wo) continue;
-            const int kw = w - (2 * ow - 1);
-            const int want = kh * 3 + kw;
-            const long long ui = (long long)((unsigned)((nt * Ho + oh) * Wo + ow)) * upr + cu;
-            const u32x4 g = ((const u32x4*)dy)[ui];
-            uint32_t amw[E / 4];  // the E argmax bytes of this unit as one 4/8-byte load
+            const int oh = oh0 + a, ow = ow0 + b;
+            const bool o = (a == 0 || (h & 1)) && (b == 0 || (w & 1)) && oh < Ho && ow < Wo;
+            const int ohc = o ? oh : oh0, owc = o ? ow : ow0;
+            const long long ui = (long long)((unsigned)((nt * Ho + ohc) * Wo + owc)) * upr + cu;
+            ok[a * 2 + b] = o;
+            want[a * 2 + b] = (h - (2 * oh - 1)) * 3 + (w - (2 * ow - 1));
+            g[a * 2 + b] = ((const u32x4*)dy)[ui];
             if (E == 8) {
                 const u32x2 t = *(const u32x2*)(argmax + ui * E);
-                amw[0] = t[0]; amw[E / 4 - 1] = t[1];
+                am[a * 2 + b][0] = t[0]; am[a * 2 + b][1] = t[1];
             } else {
-                amw[0] = *(const uint32_t*)(argmax + ui * E);
+                am[a * 2 + b][0] = *(const uint32_t*)(argmax + ui * E); am[a * 2 + b][1] = 0u;
             }
-            DPC_UNROLL
-            for (int e = 0; e < E; ++e)
-                if ((int)((amw[e >> 2] >> (8 * (e & 3))) & 0xffu) == want) acc[e] += unit_get<T>(g, e);
         }
     }
+    sched_fence();
+    DPC_UNROLL
+    for (int k = 0; k < 4; ++k)
+        DPC_UNROLL
+        for (int e = 0; e < E; ++e)
+            acc[e] += (ok[k] & ((int)((am[k][e >> 2] >> (8 * (e & 3))) & 0xffu) == want[k])) ? unit_get<T>(g[k], e) : 0.f;
 }
 
 template <class T>

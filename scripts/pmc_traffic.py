@@ -32,5 +32,20 @@ for f in sorted(glob.glob("dpc_amd/csrc/*")):
         h.update(open(f, "rb").read())
 res["csrc_sha16"] = h.hexdigest()[:16]
 res["git_head"] = os.environ.get("DPC_GIT_HEAD") or (open(".git_head").read().strip() if os.path.exists(".git_head") else None)
+# per kernel: bytes per launch, read side corrected as above (where the HBM traffic of the step goes, kernel by kernel)
+rows = []
+for k in sorted(set(fetch) | set(write)):
+    fv, fn = fetch.get(k, (0.0, 0))
+    wv, wn = write.get(k, (0.0, 0))
+    n = max(fn, wn, 1)
+    rows.append((2.0 * fv * 1024.0 + wv * 1024.0, n, 2.0 * fv * 1024.0 / n, wv * 1024.0 / n, k))
+rows.sort(reverse=True)
+with open(f"profiles/{tag}_pmc_traffic_per_kernel.txt", "w") as f:
+    tot = sum(r[0] for r in rows)
+    f.write(f"# HBM traffic per kernel over the profiled steps (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; reads x2: gfx950 "
+            f"wide-load correction); total {tot / 1e9:.2f} GB; csrc {res['csrc_sha16']} head {res['git_head']}\n")
+    f.write(f"{'kernel':92s} {'launches':>8s} {'read MB/launch':>15s} {'write MB/launch':>16s} {'total GB':>9s}\n")
+    for t, n, r, w, k in rows[:60]:
+        f.write(f"{k[:92]:92s} {n:8d} {r / 1e6:15.1f} {w / 1e6:16.1f} {t / 1e9:9.2f}\n")
 json.dump(res, open(f"profiles/{tag}_pmc_traffic.json", "w"), indent=1)
 print(json.dumps(res, indent=1))

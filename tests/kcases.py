@@ -494,6 +494,27 @@ def case_transpose(k: K, rows, cols, seed=12):
     assert torch.equal(o[:, :rows].cpu(), a.t().bfloat16())
 
 
+def case_pack3d_multi(k: K, dtype, shapes, seed=14):
+    """dpc_pack3d_multi: every conv weight [Co][Ci][taps] f32 -> [Co][tap][Ci] and [Ci][tap][Co] in the compute dtype, one launch
+    over a device-side table (the engine's per-step repack; tiled through LDS when the source is contiguous along the middle index)"""
+    g = torch.Generator().manual_seed(seed)
+    ents, keep, blk = [], [], 0
+    for (Co, Ci, t) in shapes:
+        w = k.t(torch.randn(Co, Ci, t, generator=g))
+        wp, wd = k.zeros(Co, t, Ci, dtype=dtype), k.zeros(Ci, t, Co, dtype=dtype)
+        for (dst, d0, d1, d2, s0, s1, s2) in ((wp, Co, t, Ci, Ci * t, 1, t), (wd, Ci, t, Co, t, 1, Ci * t)):
+            ents.append(L.PackEntry(w.data_ptr(), dst.data_ptr(), d0, d1, d2, blk, s0, s1, s2))
+            blk += max(1, min(1024, (d0 * d1 * d2 + 511) // 512))
+        keep.append((w, wp, wd))
+    tab = (L.PackEntry * len(ents))(*ents)
+    tab_dev = torch.frombuffer(bytearray(bytes(tab)), dtype=torch.uint8).clone().to(k.dev)
+    k.call("dpc_pack3d_multi", tab_dev, len(ents), blk, L.dtype_code(dtype))
+    k.sync()
+    for w, wp, wd in keep:
+        assert torch.equal(wp.cpu(), w.cpu().permute(0, 2, 1).to(dtype))
+        assert torch.equal(wd.cpu(), w.cpu().permute(1, 2, 0).to(dtype))
+
+
 # ---------------------------------------------------------------- dropout masks (Philox4x32-10) / device-side Adam step
 def philox4x32_10_np(ctr, key):
     """numpy Philox4x32-10 (Salmon et al., SC'11): ctr [n,4] uint32, key [2] uint32 -> [n,4] uint32.

@@ -164,6 +164,11 @@ def test_transpose(k):
     kc.case_transpose(k, 70, 45)
 
 
+@pytest.mark.parametrize("dtype", [F32, BF16])
+def test_pack3d_multi(k, dtype):
+    kc.case_pack3d_multi(k, dtype, [(24, 40, 9), (70, 8, 27), (16, 130, 1), (8, 8, 16), (3, 5, 70)])   # ragged tiles, 1x1, taps beyond the tile
+
+
 def test_philox_known_answers():
     """Random123 kat_vectors for philox4x32-10 pin the numpy generator the dropout-mask cases compare against"""
     import numpy as np

@@ -179,6 +179,11 @@ def test_transpose(k):
     kc.case_transpose(k, 6468, 256)
 
 
+@pytest.mark.parametrize("dtype", [F32, BF16])
+def test_pack3d_multi(k, dtype):
+    kc.case_pack3d_multi(k, dtype, [(64, 64, 9), (128, 64, 9), (256, 128, 27), (512, 256, 27), (256, 128, 1), (70, 24, 27)])
+
+
 def test_dropout_mask(k):
     kc.case_dropout_mask(k, 1027, 0.1, 233, 0)
     kc.case_dropout_mask(k, 7 * 2048 * 256, 0.1, (5 << 32) | 77, 12)  # cfg2: masks of all 7 recurrence steps
