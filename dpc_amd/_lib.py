@@ -71,6 +71,12 @@ class PackEntry(C.Structure):
                 ("s0", C.c_int64), ("s1", C.c_int64), ("s2", C.c_int64)]
 
 
+class Copy2dEntry(C.Structure):
+    """struct dpc_copy2d_entry (include/dpc_hip.h)"""
+    _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("src_ld", C.c_int64), ("dst_ld", C.c_int64), ("rows", C.c_int32), ("cols", C.c_int32),
+                ("block0", C.c_int32), ("pad", C.c_int32)]
+
+
 class DpcError(RuntimeError):
     pass
 
@@ -112,6 +118,7 @@ _SIGS = {
     "dpc_adam_dev": [_vp, _vp, _vp, _vp, _i64, _f32, _f64, _f64, _f32, _f32, _vp, _f32, _vp],
     "dpc_counter_advance": [_vp, _vp],
     "dpc_copy2d_f32": [_vp, _i64, _vp, _i64, _i32, _i32, _vp],
+    "dpc_copy2d_multi": [_vp, _i32, _i32, _vp],
     "dpc_dropout_mask": [_vp, _i64, _f32, C.c_uint64, _vp, _vp],
     "dpc_gru_pack": [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp],
     "dpc_gru_chain_fwd": [C.POINTER(GruChainDesc), _vp],

@@ -344,32 +344,52 @@ extern "C" int dpc_pack_stem_weight(const float* w, void* out, int32_t dtype_out
     return dpc_launch_status();
 }
 
+// The slabs are [Co][16 taps][16 slots] f32 (the space-to-depth layout); the gradient is [Co][3][7][7].  A thread owns four
+// consecutive SOURCE elements (16-byte loads down the slabs, the layout of reduce_unpack4_kernel) and scatters its four sums --
+// walking the slabs by destination index read every 128-byte line from several workgroups (250 MB of HBM reads for 67 MB of
+// slabs, 56 us on 294 workgroups).  Summation order is fixed by (lane, slab index): deterministic.
 __global__ __launch_bounds__(256) void unpack_stem_wgrad_kernel(const float* part, int nsplit, float* dw, int Co) {
-    __shared__ float red[8][32];
-    const int n = Co * 147;
+    __shared__ float red[8][32][4];
+    const int n = Co * 256;
     const int ol = threadIdx.x & 31, sl = threadIdx.x >> 5;
-    const int i = blockIdx.x * 32 + ol;
-    float s = 0.f;
+    const int i = (blockIdx.x * 32 + ol) * 4;
+    float a[4] = {0.f, 0.f, 0.f, 0.f}, b[4] = {0.f, 0.f, 0.f, 0.f};
     if (i < n) {
-        const int kx = i % 7, ky = (i / 7) % 7, c = (i / 49) % 3, co = i / 147;
-        const int th = (ky + 1) >> 1, sy = (ky + 1) & 1, tw = (kx + 1) >> 1, sx = (kx + 1) & 1;
-        const int src = (co * 16 + th * 4 + tw) * 16 + (sy * 2 + sx) * 3 + c;
-        for (int k = sl; k < nsplit; k += 8) s += part[(long long)k * Co * 256 + src];
+        int k = sl;
+        for (; k + 8 < nsplit; k += 16) {
+            const u32x4 v0 = *(const u32x4*)(part + (long long)k * n + i);
+            const u32x4 v1 = *(const u32x4*)(part + (long long)(k + 8) * n + i);
+            DPC_UNROLL
+            for (int e = 0; e < 4; ++e) { a[e] += unit_get<float>(v0, e); b[e] += unit_get<float>(v1, e); }
+        }
+        if (k < nsplit) {
+            const u32x4 v0 = *(const u32x4*)(part + (long long)k * n + i);
+            DPC_UNROLL
+            for (int e = 0; e < 4; ++e) a[e] += unit_get<float>(v0, e);
+        }
     }
-    red[sl][ol] = s;
+    DPC_UNROLL
+    for (int e = 0; e < 4; ++e) red[sl][ol][e] = a[e] + b[e];
     __syncthreads();
     if (sl == 0 && i < n) {
-        float t = 0.f;
         DPC_UNROLL
-        for (int k = 0; k < 8; ++k) t += red[k][ol];
-        dw[i] = t;
+        for (int e = 0; e < 4; ++e) {
+            float t = 0.f;
+            DPC_UNROLL
+            for (int k = 0; k < 8; ++k) t += red[k][ol][e];
+            const int src = i + e;                       // (co * 16 + th * 4 + tw) * 16 + (sy * 2 + sx) * 3 + c
+            const int slot = src & 15, tap = (src >> 4) & 15, co = src >> 8;
+            const int c = slot % 3, sxy = slot / 3;      // slots 12..15 are padding
+            const int ky = 2 * (tap >> 2) + (sxy >> 1) - 1, kx = 2 * (tap & 3) + (sxy & 1) - 1;
+            if (slot < 12 && ky >= 0 && ky < 7 && kx >= 0 && kx < 7) dw[((co * 3 + c) * 7 + ky) * 7 + kx] = t;
+        }
     }
 }
 
 extern "C" int dpc_unpack_stem_wgrad(const float* part, int32_t nsplit, float* dw, int32_t Co, dpc_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (!part || !dw || nsplit <= 0 || Co <= 0) return DPC_ERR_ARG;
-    DPC_LAUNCH(unpack_stem_wgrad_kernel, dim3((Co * 147 + 31) / 32), dim3(256), stream, part, nsplit, dw, Co);
+    DPC_LAUNCH(unpack_stem_wgrad_kernel, dim3((Co * 256 + 127) / 128), dim3(256), stream, part, nsplit, dw, Co);
     return dpc_launch_status();
 }
 
@@ -381,6 +401,25 @@ __global__ void copy2d_f32_kernel(const float* src, long long src_ld, float* dst
         const long long r = i / cols, c = i % cols;
         dst[r * dst_ld + c] = src[r * src_ld + c];
     }
+}
+
+__global__ void copy2d_multi_kernel(const dpc_copy2d_entry* tab, int n_entries) {
+    int e = 0;
+    while (e + 1 < n_entries && (int)blockIdx.x >= tab[e + 1].block0) ++e;
+    const dpc_copy2d_entry t = tab[e];
+    const int nblk = (e + 1 < n_entries ? tab[e + 1].block0 : (int)gridDim.x) - t.block0;
+    const long long n = (long long)t.rows * t.cols;
+    for (long long i = (long long)((int)blockIdx.x - t.block0) * blockDim.x + threadIdx.x; i < n; i += (long long)nblk * blockDim.x) {
+        const long long r = i / t.cols, c = i % t.cols;
+        t.dst[r * t.dst_ld + c] = t.src[r * t.src_ld + c];
+    }
+}
+
+extern "C" int dpc_copy2d_multi(const dpc_copy2d_entry* table_dev, int32_t n_entries, int32_t total_blocks, dpc_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!table_dev || n_entries <= 0 || total_blocks < n_entries) return DPC_ERR_ARG;
+    DPC_LAUNCH(copy2d_multi_kernel, dim3((unsigned)total_blocks), dim3(256), stream, table_dev, n_entries);
+    return dpc_launch_status();
 }
 
 extern "C" int dpc_copy2d_f32(const float* src, int64_t src_ld, float* dst, int64_t dst_ld, int32_t rows, int32_t cols,

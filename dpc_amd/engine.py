@@ -452,6 +452,7 @@ class DPCEngine:
         # an A/B knob for the first multi-GPU runs, only consulted when a two-bucket exchange is running.
         self.reserve_cus = int(os.environ.get("DPC_RESERVE_CUS", "0"))
         self._pack_table = None
+        self._gate_table = None
         self.bn_running = type(self).BN_RUNNING  # BatchNorm3d with running statistics (the LC classifier's backbone)
         self.train_mode = True       # only matters when bn_running: eval uses the running buffers
         self.BUF: Dict[str, torch.Tensor] = {}
@@ -909,11 +910,21 @@ class DPCEngine:
         self.gemm_tn(self.G_all, 3 * D, self.H_all, D, self.dWh, ns * M, 2 * D, D)
         self.gemm_tn(self.G_all[:, :, 2 * D:], 3 * D, self.HR_all, D, self.dWo, ns * M, D, D)
         self.call("dpc_colsum", self.G_all, dc, 3 * D, ns * M, 3 * D, self.db, 0, self.part, self.part.numel())
-        for i, (g, n) in enumerate((("u", "update_gate"), ("r", "reset_gate"), ("o", "out_gate"))):
-            w = Gm[f"agg.ConvGRUCell_00.{n}.weight"].view(D, 2 * D)   # [D][x half | h half]
-            self.call("dpc_copy2d_f32", self.dWx[i * D:(i + 1) * D], D, w, 2 * D, D, D)
-            self.call("dpc_copy2d_f32", self.dWh[i * D:(i + 1) * D] if g != "o" else self.dWo, D, w[:, D:], 2 * D, D, D)
-            self.call("dpc_copy2d_f32", self.db[i * D:(i + 1) * D], D, Gm[f"agg.ConvGRUCell_00.{n}.bias"], D, 1, D)
+        if self._gate_table is None:   # the nine gate slices in one launch (static table: addresses never change)
+            ents = []
+            for i, (g, n) in enumerate((("u", "update_gate"), ("r", "reset_gate"), ("o", "out_gate"))):
+                w = Gm[f"agg.ConvGRUCell_00.{n}.weight"].view(D, 2 * D)   # [D][x half | h half]
+                ents += [(self.dWx[i * D:(i + 1) * D], D, w, 2 * D, D, D),
+                         (self.dWh[i * D:(i + 1) * D] if g != "o" else self.dWo, D, w[:, D:], 2 * D, D, D),
+                         (self.db[i * D:(i + 1) * D], D, Gm[f"agg.ConvGRUCell_00.{n}.bias"], D, 1, D)]
+            tab = (L.Copy2dEntry * len(ents))()
+            blk = 0
+            for i, (src, sld, dst, dld, r, c) in enumerate(ents):
+                tab[i] = L.Copy2dEntry(src.data_ptr(), dst.data_ptr(), sld, dld, r, c, blk, 0)
+                blk += max(1, min(64, (r * c + 1023) // 1024))
+            raw = torch.frombuffer(bytearray(bytes(tab)), dtype=torch.uint8).clone()
+            self._gate_table = (raw.to(self.device), len(ents), blk)
+        self.call("dpc_copy2d_multi", *self._gate_table)
         self.gemm_tn(self.dP1, D, self.Hpred, D, Gm["network_pred.0.weight"].view(D, D), P * M, D, D)
         self.gemm_tn(self.dP2, D, self.P1_all, D, Gm["network_pred.2.weight"].view(D, D), P * M, D, D)
         self.call("dpc_colsum", self.dP1, dc, D, P * M, D, Gm["network_pred.0.bias"], 0, self.part, self.part.numel())

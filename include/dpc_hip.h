@@ -265,6 +265,15 @@ int dpc_adam_dev(float* p, const float* g, float* m, float* v, int64_t n, float 
 int dpc_counter_advance(int32_t* counter_dev, dpc_stream_t stream);
 /* f32 [rows][cols] window copy between two leading dimensions (ConvGRU gate-gradient scatter) */
 int dpc_copy2d_f32(const float* src, int64_t src_ld, float* dst, int64_t dst_ld, int32_t rows, int32_t cols, dpc_stream_t stream);
+/* the same for a device-resident table of windows in ONE launch (the nine gate slices of the ConvGRU's weight / bias gradients,
+ * backbone/convrnn.py:13-15: [D][2D] parameters filled from batched [3D][D] GEMM results); block0 = first workgroup of an entry */
+typedef struct dpc_copy2d_entry {
+    const float* src;
+    float* dst;
+    int64_t src_ld, dst_ld;
+    int32_t rows, cols, block0, pad;
+} dpc_copy2d_entry;
+int dpc_copy2d_multi(const dpc_copy2d_entry* table_dev, int32_t n_entries, int32_t total_blocks, dpc_stream_t stream);
 
 /* ---- ConvGRU dropout (nn.Dropout(p=0.1) on the carried hidden state, backbone/convrnn.py:39,59,78) ---------------
  * mask[i] = 1/(1-p) w.p. 1-p else 0: Philox4x32-10, key = seed, counter = (i/4, step_dev[0], stream id (0 here; 1 = the LC head's dropout), 0), word i%4,
