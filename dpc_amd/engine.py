@@ -383,15 +383,23 @@ class _Block:
         if self.ds is not None:
             draw_d = e.scratch(oshape, exclude=[dout, draw2])  # lives until the block's last input-gradient
             self.ds.bn_backward(dout, None, False, draw_d, ext_mask=omask)
-            self.ds.wgrad(self.x_in, draw_d)
-        self.c2.wgrad(self.act1, draw2)
         dact1 = e.scratch(oshape, exclude=[dout, draw2, draw_d, dz])
         self.c2.dgrad(draw2, dact1, None, red=self.c1 if self.fold_c1 else None)
-        draw1 = draw2  # in place over the consumed draw2
+        with e.side(reads=[draw2, draw_d]):   # beside bn1's backward on the main stream
+            if self.ds is not None:
+                self.ds.wgrad(self.x_in, draw_d)
+            self.c2.wgrad(self.act1, draw2)
+        # in place over the consumed draw2 unless the side stream may still be reading it
+        draw1 = draw2 if e._side is None or e.timer is not None else e.scratch(oshape, exclude=[dout, draw2, draw_d, dz, dact1])
         self.c1.bn_backward(dact1, self.act1, True, draw1)
-        self.c1.wgrad(self.x_in, draw1)
         if not need_dx:
+            with e.side(reads=[draw1]):
+                self.c1.wgrad(self.x_in, draw1)
             return None
+        early = e._wgrad_early   # experiment: conv1's weight gradient beside its own input-gradient instead of the next unit's BatchNorm
+        if early:
+            with e.side(reads=[draw1]):
+                self.c1.wgrad(self.x_in, draw1)
         if self.ds is not None:
             # dx = main path; the strided 1x1 downsample then accumulates IN PLACE on the positions it reads (1/4 of dx in 2D,
             # 1/8 in 3D) -- round 1 wrote a full, 75-88 % zero tensor and re-read it as the addend
@@ -405,6 +413,9 @@ class _Block:
         else:
             dx = dact1  # same shape as the input; dact1 is dead
             self.c1.dgrad(draw1, dx, dz)
+        if not early:
+            with e.side(reads=[draw1]):   # beside the previous block's bn2 backward
+                self.c1.wgrad(self.x_in, draw1)
         return dx
 
 
@@ -453,6 +464,10 @@ class DPCEngine:
         self.reserve_cus = int(os.environ.get("DPC_RESERVE_CUS", "0"))
         self._pack_table = None
         self._gate_table = None
+        # weight gradients on a second stream beside the next unit's BatchNorm backward (side() below); DPC_WGRAD_STREAM=0: in line
+        self._side = (torch.cuda.Stream(self.device) if self.device.type == "cuda" and int(os.environ.get("DPC_WGRAD_STREAM", "1")) else None)
+        self._wgrad_early = bool(int(os.environ.get("DPC_WGRAD_EARLY", "0")))
+        self._busy = []   # [(event recorded on the side stream, scratch buffers its launches read)], oldest first
         self.bn_running = type(self).BN_RUNNING  # BatchNorm3d with running statistics (the LC classifier's backbone)
         self.train_mode = True       # only matters when bn_running: eval uses the running buffers
         self.BUF: Dict[str, torch.Tensor] = {}
@@ -661,14 +676,52 @@ class DPCEngine:
             self._tag = prev
 
     def scratch(self, shape, exclude):
-        """gradient scratch of a given activation shape; at most 3 live per shape by construction"""
+        """gradient scratch of a given activation shape; a handful live per shape by construction.  Buffers a side-stream launch
+        may still be reading (side()) are passed over; when the pool has nothing else the oldest side generation is retired first
+        (the main stream waits for its event -- long complete by then)."""
         pool = self._scratch.setdefault(tuple(shape), [])
-        for t in pool:
-            if all(t is not x for x in exclude if x is not None):
-                return t
-        t = self.empty(shape, self.cdtype)
-        pool.append(t)
+
+        def free():
+            for t in pool:
+                if all(t is not x for x in exclude if x is not None) and all(t is not b for _, bufs in self._busy for b in bufs):
+                    return t
+            return None
+        t = free()
+        while t is None and self._busy:
+            ev, _ = self._busy.pop(0)
+            torch.cuda.current_stream(self.device).wait_event(ev)
+            t = free()
+        if t is None:
+            t = self.empty(shape, self.cdtype)
+            pool.append(t)
         return t
+
+    # ---- weight gradients on a second stream.  A weight gradient and the input-gradient of the same unit both read the unit's
+    # output gradient and nothing depends on the weight gradient until the optimizer; run back to back with the BatchNorm backward
+    # of the NEXT unit (HBM-bound, no LDS) the pair takes 4-19 % less than in sequence (scripts/probes/overlap_probe.py:
+    # layer2 531 -> 430 us, layer1 736 -> 705, layer3 509 -> 482).  Launches inside side() go to the side stream, ordered after
+    # everything issued on the main stream so far; `reads` are the scratch buffers they read, kept out of scratch() until the
+    # main stream has waited for the event recorded behind them.  Captured into the step's hipGraph as a fork / join.
+    @contextlib.contextmanager
+    def side(self, reads=()):
+        if self._side is None or self.timer is not None:   # instrumented pass (bench.py): one stream, clean per-kernel times
+            yield
+            return
+        main = torch.cuda.current_stream(self.device)
+        ev = torch.cuda.Event()
+        ev.record(main)
+        self._side.wait_event(ev)
+        with torch.cuda.stream(self._side):
+            yield
+            done = torch.cuda.Event()
+            done.record(self._side)
+        self._busy.append((done, [t for t in reads if t is not None]))
+
+    def side_join(self):
+        """the main stream waits for everything issued on the side stream; its buffers are free again"""
+        if self._busy:
+            torch.cuda.current_stream(self.device).wait_event(self._busy[-1][0])   # the side stream runs in order
+            self._busy.clear()
 
     def _gemm_desc(self, M, N, K, lda, ldb, ldo, out_f32=True):
         dc = L.dtype_code(self.cdtype)
@@ -752,9 +805,11 @@ class DPCEngine:
         load_frames): returns the last block's output [B*N, T, ls, ls, D] (channels-last, no final ReLU)"""
         B, N = self.B, self.N
         dc = L.dtype_code(self.cdtype)
-        self.pack_weights()
+        with self.side():   # the per-step weight repacks (0.2 ms of small launches) beside the input pack
+            self.pack_weights()
         if block is not None:
             self.call("dpc_pack_input_s2d", block.contiguous(), self.x_s2d, dc, B * N, self.SL, self.size, self.size)
+        self.side_join()
         self.stem.forward(self.x_s2d)
         st = self.stem.out_shape
         self.call("dpc_bn_relu_maxpool_fwd", self.stem.raw, dc, st[0] * st[1], st[2], st[3], self.widths[0], self.stem.scale,
@@ -770,6 +825,7 @@ class DPCEngine:
         carved = False
         for bi in reversed(range(len(self.blocks))):
             if on_tail_ready is not None and bi == self.n_head_blocks - 1:
+                self.side_join()   # the tail's weight gradients are complete before its all-reduce starts
                 on_tail_ready(self.flat_g[self.grad_split:])
                 if self.reserve_cus:  # the all-reduce of the tail is in flight from here to the end of the backward pass
                     self.lib.call("dpc_set_reserved_cus", self.reserve_cus)
@@ -786,6 +842,7 @@ class DPCEngine:
                   self.PRM[u.bnname + ".weight"], self.PRM[u.bnname + ".bias"], self.stats, C.byref(pr))
         self.call("dpc_bn_bwd_finalize", self.stats, pr.value, C0, float(u.rows), self.G[u.bnname + ".weight"],
                   self.G[u.bnname + ".bias"], self.coef)
+        self.side_join()   # the stem's weight gradient uses the same split-K slab buffer; everything is on one stream again
         if self._stem_fused:  # BN backward + pool routing inside the weight-gradient kernel: no 2.7 GB dz tensor (csrc/conv_wgrad_stem.hip)
             ns = C.c_int32(0)
             self.call("dpc_stem_wgrad_fused", C.byref(u.desc_w), self.x_s2d, u.raw, d, self.pool_arg, u.mean, u.invstd,
@@ -904,7 +961,18 @@ class DPCEngine:
         # ---- predict loop + aggregation, reversed: one launch (G_all, dP1, dP2, d_featrelu come back)
         ns = self.n_steps
         self.call("dpc_gru_chain_bwd", C.byref(self.gru_desc))
-        # ---- weight / bias grads of the ConvGRU and predictor, batched over all steps
+        # ---- temporal pool / split: the backbone's incoming gradient (the main stream's critical path goes on into the backbone)
+        fs = self.feat_shape
+        self.call("dpc_tpool_split_bwd", self.blocks[-1].out, self.d_featrelu, self.d_finf, dc, B, N, fs[1], SQ, D, P, self.d_feat)
+        # ---- weight / bias grads of the ConvGRU and predictor, batched over all steps: ~20 small launches nothing waits for until
+        # the optimizer -- on the side stream, beside layer4's backward (they share the split-K slab buffer with the backbone's
+        # weight gradients, which queue behind them on the same stream)
+        with self.side():
+            self._head_param_grads(dc)
+        self._backbone_backward(self.d_feat, on_tail_ready)
+
+    def _head_param_grads(self, dc):
+        D, M, P, ns = self.D, self.M, self.P, self.n_steps
         Gm = self.G
         self.gemm_tn(self.G_all, 3 * D, self.X_all, D, self.dWx, ns * M, 3 * D, D)
         self.gemm_tn(self.G_all, 3 * D, self.H_all, D, self.dWh, ns * M, 2 * D, D)
@@ -929,10 +997,6 @@ class DPCEngine:
         self.gemm_tn(self.dP2, D, self.P1_all, D, Gm["network_pred.2.weight"].view(D, D), P * M, D, D)
         self.call("dpc_colsum", self.dP1, dc, D, P * M, D, Gm["network_pred.0.bias"], 0, self.part, self.part.numel())
         self.call("dpc_colsum", self.dP2, dc, D, P * M, D, Gm["network_pred.2.bias"], 0, self.part, self.part.numel())
-        # ---- temporal pool / split, backbone
-        fs = self.feat_shape
-        self.call("dpc_tpool_split_bwd", self.blocks[-1].out, self.d_featrelu, self.d_finf, dc, B, N, fs[1], SQ, D, P, self.d_feat)
-        self._backbone_backward(self.d_feat, on_tail_ready)
 
     @property
     def step_count(self) -> int:

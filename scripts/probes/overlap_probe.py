@@ -51,6 +51,11 @@ def make_bn(rows, Cc):
         lib.call("dpc_bn_bwd_finalize", stats.data_ptr(), pr.value, Cc, float(rows), gw.data_ptr(), gb.data_ptr(), coef.data_ptr(), stream)
         lib.call("dpc_bn_bwd_apply", dy.data_ptr(), None, mask.data_ptr(), raw.data_ptr(), dc, rows, Cc, mean.data_ptr(), invstd.data_ptr(),
                  gamma.data_ptr(), coef.data_ptr(), 1, dx.data_ptr(), None, stream)
+    def apply_only(stream):   # the reduction was taken in the producing input-gradient's epilogue (round 3): finalize + apply
+        lib.call("dpc_bn_bwd_finalize", stats.data_ptr(), pr.value, Cc, float(rows), gw.data_ptr(), gb.data_ptr(), coef.data_ptr(), stream)
+        lib.call("dpc_bn_bwd_apply", dy.data_ptr(), None, mask.data_ptr(), raw.data_ptr(), dc, rows, Cc, mean.data_ptr(), invstd.data_ptr(),
+                 gamma.data_ptr(), coef.data_ptr(), 1, dx.data_ptr(), None, stream)
+    run.apply_only = apply_only
     return run, (dy, raw, mask, dx, stats, coef)
 
 
@@ -89,3 +94,17 @@ for name, wg_args, rows, Cc in (("layer1", (1024, 5, 32, 32, 64, 64, (1, 3, 3), 
 
     t_w = timeit(lambda: wg(ms)); t_b = timeit(lambda: bn(ms)); t_s = timeit(both_seq); t_p = timeit(both_par)
     print(f"{name}: wgrad {t_w:7.1f} us, bn backward (reduce+apply) {t_b:7.1f} us, back to back {t_s:7.1f} us, two streams {t_p:7.1f} us", flush=True)
+
+    def a_seq():
+        wg(ms); bn.apply_only(ms)
+
+    def a_par():
+        ev = torch.cuda.Event(); ev.record(main)
+        side.wait_event(ev)
+        wg(side.cuda_stream)
+        bn.apply_only(ms)
+        ev2 = torch.cuda.Event(); ev2.record(side)
+        main.wait_event(ev2)
+
+    t_a = timeit(lambda: bn.apply_only(ms)); t_s = timeit(a_seq); t_p = timeit(a_par)
+    print(f"{name}: wgrad {t_w:7.1f} us, finalize + apply {t_a:7.1f} us, back to back {t_s:7.1f} us, two streams {t_p:7.1f} us", flush=True)
