@@ -385,21 +385,17 @@ class _Block:
             self.ds.bn_backward(dout, None, False, draw_d, ext_mask=omask)
         dact1 = e.scratch(oshape, exclude=[dout, draw2, draw_d, dz])
         self.c2.dgrad(draw2, dact1, None, red=self.c1 if self.fold_c1 else None)
-        with e.side(reads=[draw2, draw_d]):   # beside bn1's backward on the main stream
+        with e.side(reads=[draw2, draw_d], kind=1):   # beside bn1's backward on the main stream
             if self.ds is not None:
                 self.ds.wgrad(self.x_in, draw_d)
             self.c2.wgrad(self.act1, draw2)
         # in place over the consumed draw2 unless the side stream may still be reading it
-        draw1 = draw2 if e._side is None or e.timer is not None else e.scratch(oshape, exclude=[dout, draw2, draw_d, dz, dact1])
+        draw1 = draw2 if e._side is None or e.timer is not None or not (e._side_mask & 1) else e.scratch(oshape, exclude=[dout, draw2, draw_d, dz, dact1])
         self.c1.bn_backward(dact1, self.act1, True, draw1)
         if not need_dx:
-            with e.side(reads=[draw1]):
+            with e.side(reads=[draw1], kind=2):
                 self.c1.wgrad(self.x_in, draw1)
             return None
-        early = e._wgrad_early   # experiment: conv1's weight gradient beside its own input-gradient instead of the next unit's BatchNorm
-        if early:
-            with e.side(reads=[draw1]):
-                self.c1.wgrad(self.x_in, draw1)
         if self.ds is not None:
             # dx = main path; the strided 1x1 downsample then accumulates IN PLACE on the positions it reads (1/4 of dx in 2D,
             # 1/8 in 3D) -- round 1 wrote a full, 75-88 % zero tensor and re-read it as the addend
@@ -413,9 +409,8 @@ class _Block:
         else:
             dx = dact1  # same shape as the input; dact1 is dead
             self.c1.dgrad(draw1, dx, dz)
-        if not early:
-            with e.side(reads=[draw1]):   # beside the previous block's bn2 backward
-                self.c1.wgrad(self.x_in, draw1)
+        with e.side(reads=[draw1], kind=2):   # beside the previous block's bn2 backward (beside conv1's own input-gradient: slower)
+            self.c1.wgrad(self.x_in, draw1)
         return dx
 
 
@@ -464,9 +459,10 @@ class DPCEngine:
         self.reserve_cus = int(os.environ.get("DPC_RESERVE_CUS", "0"))
         self._pack_table = None
         self._gate_table = None
-        # weight gradients on a second stream beside the next unit's BatchNorm backward (side() below); DPC_WGRAD_STREAM=0: in line
-        self._side = (torch.cuda.Stream(self.device) if self.device.type == "cuda" and int(os.environ.get("DPC_WGRAD_STREAM", "1")) else None)
-        self._wgrad_early = bool(int(os.environ.get("DPC_WGRAD_EARLY", "0")))
+        # DPC_WGRAD_STREAM=1 (opt-in): weight gradients on a second stream beside the next unit's BatchNorm backward (side() below);
+        # DPC_SIDE_MASK selects what goes there: 1 conv2 / downsample weight gradients, 2 conv1's, 4 head parameters, 8 weight repacks
+        self._side = (torch.cuda.Stream(self.device) if self.device.type == "cuda" and int(os.environ.get("DPC_WGRAD_STREAM", "0")) else None)
+        self._side_mask = int(os.environ.get("DPC_SIDE_MASK", "15"))
         self._busy = []   # [(event recorded on the side stream, scratch buffers its launches read)], oldest first
         self.bn_running = type(self).BN_RUNNING  # BatchNorm3d with running statistics (the LC classifier's backbone)
         self.train_mode = True       # only matters when bn_running: eval uses the running buffers
@@ -696,15 +692,21 @@ class DPCEngine:
             pool.append(t)
         return t
 
-    # ---- weight gradients on a second stream.  A weight gradient and the input-gradient of the same unit both read the unit's
+    # ---- weight gradients on a second stream (OPT-IN, DPC_WGRAD_STREAM=1).  A weight gradient and the input-gradient of the same unit both read the unit's
     # output gradient and nothing depends on the weight gradient until the optimizer; run back to back with the BatchNorm backward
     # of the NEXT unit (HBM-bound, no LDS) the pair takes 4-19 % less than in sequence (scripts/probes/overlap_probe.py:
     # layer2 531 -> 430 us, layer1 736 -> 705, layer3 509 -> 482).  Launches inside side() go to the side stream, ordered after
     # everything issued on the main stream so far; `reads` are the scratch buffers they read, kept out of scratch() until the
     # main stream has waited for the event recorded behind them.  Captured into the step's hipGraph as a fork / join.
+    # Measured +1.4 % (cfg2) / +1.9 % (cfg4) / +1.8 % (cfg5) -- and NOT the default: scripts/stream_stress.py (two engines, one per
+    # schedule, compared bit for bit after every step) finds the two schedules identical for hundreds of steps and then, about once
+    # per 300-1000 steps on some boxes (graph replay and kernel-by-kernel launches alike), a step whose gradients differ from the first
+    # BatchNorm-backward reduction behind a fork upwards.  Every buffer hand-over was checked (the divergence also shows with no
+    # main-stream wait inside the backward pass, and guard regions behind the split-K slab / statistics buffers stay intact);
+    # the cause was not found within the round, so the one-stream schedule (bit-reproducible over thousands of steps) is the default.
     @contextlib.contextmanager
-    def side(self, reads=()):
-        if self._side is None or self.timer is not None:   # instrumented pass (bench.py): one stream, clean per-kernel times
+    def side(self, reads=(), kind=1):
+        if self._side is None or self.timer is not None or not (self._side_mask & kind):   # instrumented pass (bench.py): one stream, clean per-kernel times
             yield
             return
         main = torch.cuda.current_stream(self.device)
@@ -805,7 +807,7 @@ class DPCEngine:
         load_frames): returns the last block's output [B*N, T, ls, ls, D] (channels-last, no final ReLU)"""
         B, N = self.B, self.N
         dc = L.dtype_code(self.cdtype)
-        with self.side():   # the per-step weight repacks (0.2 ms of small launches) beside the input pack
+        with self.side(kind=8):   # the per-step weight repacks (0.2 ms of small launches) beside the input pack
             self.pack_weights()
         if block is not None:
             self.call("dpc_pack_input_s2d", block.contiguous(), self.x_s2d, dc, B * N, self.SL, self.size, self.size)
@@ -967,7 +969,7 @@ class DPCEngine:
         # ---- weight / bias grads of the ConvGRU and predictor, batched over all steps: ~20 small launches nothing waits for until
         # the optimizer -- on the side stream, beside layer4's backward (they share the split-K slab buffer with the backbone's
         # weight gradients, which queue behind them on the same stream)
-        with self.side():
+        with self.side(kind=4):
             self._head_param_grads(dc)
         self._backbone_backward(self.d_feat, on_tail_ready)
 
