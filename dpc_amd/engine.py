@@ -309,6 +309,8 @@ class _ConvBN:
         a tensor).  red: the unit whose output gradient dx is -- its BatchNorm-backward partial sums are taken in this launch's
         epilogue and `red.bn_backward` skips its reduction pass."""
         e = self.eng
+        if e._side_quiet:   # no side-stream work beside an input-gradient (see side())
+            e.side_wait()
         if addend_mask is None and red is None:
             e.call("dpc_conv_igemm", C.byref(self.desc_d), draw, self.wd, dx, addend, None)
             return
@@ -459,10 +461,12 @@ class DPCEngine:
         self.reserve_cus = int(os.environ.get("DPC_RESERVE_CUS", "0"))
         self._pack_table = None
         self._gate_table = None
-        # DPC_WGRAD_STREAM=1 (opt-in): weight gradients on a second stream beside the next unit's BatchNorm backward (side() below);
-        # DPC_SIDE_MASK selects what goes there: 1 conv2 / downsample weight gradients, 2 conv1's, 4 head parameters, 8 weight repacks
-        self._side = (torch.cuda.Stream(self.device) if self.device.type == "cuda" and int(os.environ.get("DPC_WGRAD_STREAM", "0")) else None)
+        # weight gradients on a second stream beside the next unit's BatchNorm backward (side() below); DPC_WGRAD_STREAM=0: one stream.
+        # DPC_SIDE_MASK selects what goes there (1 conv2 / downsample weight gradients, 2 conv1's, 4 head parameters, 8 weight
+        # repacks); DPC_SIDE_QUIET=0 lets side work run beside input-gradients too (slower, and not bit-reproducible: see side())
+        self._side = (torch.cuda.Stream(self.device) if self.device.type == "cuda" and int(os.environ.get("DPC_WGRAD_STREAM", "1")) else None)
         self._side_mask = int(os.environ.get("DPC_SIDE_MASK", "15"))
+        self._side_quiet = bool(int(os.environ.get("DPC_SIDE_QUIET", "1")))
         self._busy = []   # [(event recorded on the side stream, scratch buffers its launches read)], oldest first
         self.bn_running = type(self).BN_RUNNING  # BatchNorm3d with running statistics (the LC classifier's backbone)
         self.train_mode = True       # only matters when bn_running: eval uses the running buffers
@@ -692,18 +696,22 @@ class DPCEngine:
             pool.append(t)
         return t
 
-    # ---- weight gradients on a second stream (OPT-IN, DPC_WGRAD_STREAM=1).  A weight gradient and the input-gradient of the same unit both read the unit's
-    # output gradient and nothing depends on the weight gradient until the optimizer; run back to back with the BatchNorm backward
-    # of the NEXT unit (HBM-bound, no LDS) the pair takes 4-19 % less than in sequence (scripts/probes/overlap_probe.py:
-    # layer2 531 -> 430 us, layer1 736 -> 705, layer3 509 -> 482).  Launches inside side() go to the side stream, ordered after
-    # everything issued on the main stream so far; `reads` are the scratch buffers they read, kept out of scratch() until the
-    # main stream has waited for the event recorded behind them.  Captured into the step's hipGraph as a fork / join.
-    # Measured +1.4 % (cfg2) / +1.9 % (cfg4) / +1.8 % (cfg5) -- and NOT the default: scripts/stream_stress.py (two engines, one per
-    # schedule, compared bit for bit after every step) finds the two schedules identical for hundreds of steps and then, about once
-    # per 300-1000 steps on some boxes (graph replay and kernel-by-kernel launches alike), a step whose gradients differ from the first
-    # BatchNorm-backward reduction behind a fork upwards.  Every buffer hand-over was checked (the divergence also shows with no
-    # main-stream wait inside the backward pass, and guard regions behind the split-K slab / statistics buffers stay intact);
-    # the cause was not found within the round, so the one-stream schedule (bit-reproducible over thousands of steps) is the default.
+    # ---- weight gradients on a second stream.  A weight gradient and the input-gradient of the same unit both read the unit's
+    # output gradient and nothing depends on the weight gradient until the optimizer.  Launches inside side() go to the side
+    # stream, ordered after everything issued on the main stream so far; `reads` are the scratch buffers they read, kept out of
+    # scratch() until the main stream has waited for the event recorded behind them.  Captured into the step's hipGraph as a
+    # fork / join.  Two rules came out of the measurements (profiles/r03_two_stream.txt):
+    #   * a weight gradient runs beside the NEXT unit's BatchNorm backward (HBM-bound, no LDS), not beside an input-gradient
+    #     (LDS-bound like itself): the main stream waits for the side stream before every input-gradient (_ConvBN.dgrad).  Pairs in
+    #     isolation (scripts/probes/overlap_probe.py): layer2 531 -> 430 us, layer1 736 -> 705, layer3 509 -> 482; the step: cfg2
+    #     27.48 -> 26.5 ms (+3.6 %), cfg4 +3.9 %, cfg5 +3.2 %; without the wait only +1.6 %.
+    #   * without that wait the schedule is NOT bit-reproducible: scripts/stream_stress.py (two engines, one per schedule, compared
+    #     bit for bit after every step) then finds, about once per 300-500 steps, a step whose gradients differ from the output of
+    #     a layer2 / layer3 input-gradient upwards -- igemm_ws / igemm_wsp running beside a weight gradient.  Their LDS-DMA rings are
+    #     synchronised by counted vmcnt waits + barriers (cdna_hip_programming.md: "rare wrong tiles that come and go with ...
+    #     memory load" is the signature of a read that is one phase early); the protocol was re-derived on paper and no early read
+    #     was found, so the kernels are simply never run beside anything: with the wait, 6 800 steps (three configurations, graph
+    #     replay and kernel-by-kernel) were bit-identical to the one-stream schedule.
     @contextlib.contextmanager
     def side(self, reads=(), kind=1):
         if self._side is None or self.timer is not None or not (self._side_mask & kind):   # instrumented pass (bench.py): one stream, clean per-kernel times
@@ -718,6 +726,11 @@ class DPCEngine:
             done = torch.cuda.Event()
             done.record(self._side)
         self._busy.append((done, [t for t in reads if t is not None]))
+
+    def side_wait(self):
+        """the main stream waits for the side stream's work so far; its buffers stay tracked"""
+        if self._busy:
+            torch.cuda.current_stream(self.device).wait_event(self._busy[-1][0])
 
     def side_join(self):
         """the main stream waits for everything issued on the side stream; its buffers are free again"""
