@@ -7,7 +7,7 @@ grep -E "passed|failed|error|bf16 anchor:|cfg5 fused|LC gradients|fold_c1|Error|
 (timeout 900 python bench.py 2>&1 | tail -2) > gpurun_out/z_bench_cfg2.log
 (DPC_FOLD=0 DPC_STEM_FUSED=0 timeout 300 python bench.py --steps 100 --no-cpu-baseline --no-also 2>&1 | tail -2) > gpurun_out/z_bench_cfg2_r2paths.log
 (timeout 300 python bench.py --score-path fused --steps 100 --no-cpu-baseline --no-also 2>&1 | tail -2) > gpurun_out/z_bench_cfg2_fused.log
-(DPC_WGRAD_STREAM=1 timeout 300 python bench.py --steps 100 --no-cpu-baseline 2>&1 | tail -2) > gpurun_out/z_bench_cfg2_two_streams.log
+(DPC_WGRAD_STREAM=0 timeout 300 python bench.py --steps 100 --no-cpu-baseline 2>&1 | tail -2) > gpurun_out/z_bench_cfg2_one_stream.log
 (DPC_IGEMM_WS_PAR=0 DPC_PARITY_ILV=0 timeout 300 python bench.py --steps 100 --no-cpu-baseline --no-also 2>&1 | tail -2) > gpurun_out/z_bench_cfg2_old_dgrad.log
 (timeout 400 python bench.py --dtype f32 --steps 20 --warmup 2 --no-cpu-baseline 2>&1 | tail -2) > gpurun_out/z_bench_cfg2_f32.log
 (timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 1 --steps 100 --warmup 3 --no-cpu-baseline --no-roofline 2>&1 | tail -2) > gpurun_out/z_bench_torchrun.log
