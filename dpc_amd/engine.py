@@ -710,7 +710,7 @@ class DPCEngine:
     #     a layer2 / layer3 input-gradient upwards -- igemm_ws / igemm_wsp running beside a weight gradient.  Their LDS-DMA rings are
     #     synchronised by counted vmcnt waits + barriers (cdna_hip_programming.md: "rare wrong tiles that come and go with ...
     #     memory load" is the signature of a read that is one phase early); the protocol was re-derived on paper and no early read
-    #     was found, so the kernels are simply never run beside anything: with the wait, 6 800 steps (three configurations, graph
+    #     was found, so the kernels are simply never run beside anything: with the wait, 9 600 steps (three configurations, graph
     #     replay and kernel-by-kernel) were bit-identical to the one-stream schedule.
     @contextlib.contextmanager
     def side(self, reads=(), kind=1):
