@@ -254,7 +254,8 @@ def main():
             "config": {"workload": f"{args.config}: {net} 2d3d, img_dim {img}, seq_len 5, num_seq 8, pred_step {P}, "
                                    f"batch {batch}/GPU, full train step (fwd+CE/top-k+bwd+all-reduce+Adam)",
                        "global_batch": batch * world, "parallelism": f"dp{world}", "init": "reference init, random",
-                       "launch": "hipGraph replay" if use_graph else "kernel by kernel" + graph_note},
+                       "launch": "hipGraph replay" if use_graph else "kernel by kernel" + graph_note,
+                       "streams": 2 if getattr(eng, "_side", None) is not None else 1},   # weight gradients beside the next BatchNorm backward
             "final_loss": round(loss[0], 4),
         }
         if dist is not None:
@@ -291,7 +292,7 @@ def main():
                     "flops_unit": "GFLOP (algorithmic)",
                     "ms_per_step": round(ig["ms"] / rs, 3),
                     "algorithmic_GBps": round(ig["bytes"] / (ig["ms"] * 1e-3) / 1e9, 1),
-                    "timed": f"separate instrumented pass of {rs} steps (HIP events on the launch stream; per launch position the median over the steps)",
+                    "timed": f"separate instrumented pass of {rs} steps (one stream, HIP events on the launch stream; per launch position the median over the steps)",
                 }
             wg = s.get("dpc_conv_wgrad")
             if wg and wg["ms"] > 0:
