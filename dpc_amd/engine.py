@@ -707,10 +707,11 @@ class DPCEngine:
     #     27.48 -> 26.5 ms (+3.6 %), cfg4 +3.9 %, cfg5 +3.2 %; without the wait only +1.6 %.
     #   * without that wait the schedule is NOT bit-reproducible: scripts/stream_stress.py (two engines, one per schedule, compared
     #     bit for bit after every step) then finds, about once per 300-500 steps, a step whose gradients differ from the output of
-    #     a layer2 / layer3 input-gradient upwards -- igemm_ws / igemm_wsp running beside a weight gradient.  Their LDS-DMA rings are
-    #     synchronised by counted vmcnt waits + barriers (cdna_hip_programming.md: "rare wrong tiles that come and go with ...
-    #     memory load" is the signature of a read that is one phase early); the protocol was re-derived on paper and no early read
-    #     was found, so the kernels are simply never run beside anything: with the wait, 9 600 steps (three configurations, graph
+    #     a layer2 / layer3 input-gradient upwards.  Not the hand-over of buffers (reproduces without any main-stream wait), not
+    #     out-of-bounds writes (guards intact), not the events' fence scope, and not the kernel pair by itself
+    #     (scripts/probes/corun_probe.py: 25 000 launches of the input-gradient beside a looping weight gradient, all identical);
+    #     the cause is open.  The condition is not: side work in flight when an input-gradient is launched -- which the wait in
+    #     _ConvBN.dgrad excludes.  With it, 9 600 steps (three configurations, graph
     #     replay and kernel-by-kernel) were bit-identical to the one-stream schedule.
     @contextlib.contextmanager
     def side(self, reads=(), kind=1):
