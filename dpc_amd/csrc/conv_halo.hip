@@ -337,7 +337,9 @@ __global__ __launch_bounds__(512, 2) void conv_halo_ws_kernel(HaloParams p) {
     constexpr int STG = BM * BN * 2;
     constexpr int NPB = 3;                        // patch ring: two tiles of lookahead (a fourth buffer = all 160 KB of LDS was measured: no change)
     static_assert(NPB * PATCH + 2 * STG <= 160 * 1024, "one workgroup per CU");
-    __shared__ __attribute__((aligned(1024))) unsigned char lds[NPB * PATCH + 2 * STG];
+    // all of the CU's LDS is claimed: a foreign LDS-using workgroup on the same CU broke igemm_ws_kernel's ring (conv_igemm_ws.hip,
+    // scripts/probes/corun_probe.py); this kernel was never seen to fail, but it runs beside RCCL's kernels in multi-GPU steps
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[160 * 1024];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;

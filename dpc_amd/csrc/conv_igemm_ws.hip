@@ -197,7 +197,15 @@ __global__ __launch_bounds__(512, 2) void igemm_ws_kernel(WsParams p) {
     constexpr int STAGE = (BM + BN) * 128;  // 48 KB
     constexpr int NST = 3;
     constexpr int EPO = 8, UPR = BN / EPO;  // 16 output units per row
-    __shared__ __attribute__((aligned(1024))) unsigned char lds[NST * STAGE];
+    // The whole CU's LDS is claimed (160 KB, 16 KB more than the ring needs) so that no workgroup that uses LDS can ever sit beside
+    // this one.  scripts/probes/corun_probe.py: with a small-LDS kernel of another stream on the same CU (reduce_unpack_t, 8 KB --
+    // the only kernel of the step that fits beside 144 KB) 38 of 15 000 launches of the layer3 input-gradient came back with one
+    // wave's 64 x 128 block of one tile wrong; beside a weight gradient whose workgroups do not fit on the CU, 0 of 25 000.  The
+    // ring's ordering (counted vmcnt + barrier before a stage is read) does not survive a foreign workgroup's LDS traffic on
+    // the same CU; what exactly gives way was not established, the co-residency is simply made impossible.
+    constexpr int LDS_ALL = 160 * 1024;
+    static_assert(NST * STAGE <= LDS_ALL, "ring fits the CU's LDS");
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[LDS_ALL];
 
     const GatherGeom& g = p.g;
     const int tid = threadIdx.x;
@@ -621,7 +629,9 @@ __global__ __launch_bounds__(512, 2) void igemm_wsp_kernel(WsParams p) {
     constexpr int EPO = 8;
     constexpr int MAXP = (NPIECE + 3) / 4;  // patch pieces per loader wave
     static_assert(4 * WS_STG_WAVE <= PATCH, "epilogue staging fits a patch buffer");
-    __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * PATCH + NSB * BST];
+    constexpr int LDS_ALL = 160 * 1024;   // all of the CU's LDS: no LDS-using workgroup of another stream beside this one (see igemm_ws_kernel)
+    static_assert(2 * PATCH + NSB * BST <= LDS_ALL, "patches + ring fit the CU's LDS");
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[LDS_ALL];
     unsigned char* const bring = lds + 2 * PATCH;
 
     const GatherGeom& g = p.g;

@@ -42,8 +42,14 @@ def dgrad():
     assert rc == 0
 
 
-def wgrad():
+gw = torch.zeros(Cc, Cc, taps, device=dev)
+
+
+def wgrad():   # weight gradient + the reduction of its split-K slabs, as the engine launches them (the reduction's small workgroups
+    # are the only ones that fit on a CU beside a 144 KB input-gradient workgroup)
     rc = lib.call("dpc_conv_wgrad", C.byref(dw), x, dy, Cc, part, C.byref(ns), C.c_void_p(side.cuda_stream))
+    assert rc == 0
+    rc = lib.call("dpc_reduce_unpack", part, ns.value, gw, Cc, taps, Cc, Cc * taps, 1, taps, 0, C.c_void_p(side.cuda_stream))
     assert rc == 0
 
 
