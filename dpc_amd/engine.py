@@ -23,6 +23,7 @@ per optimizer step.
 """
 from __future__ import annotations
 
+import atexit
 import contextlib
 import ctypes as C
 import os
@@ -189,6 +190,18 @@ def algorithmic_cost(name, args):
     else:
         by = rows_src * d.Ci * esz + rows_out * d.Co * esz + d.Co * d.Ci * taps * 4
     return 2.0 * macs, float(by)
+
+
+def _idle_at_exit():
+    # nothing of this process is still queued on the GPU when the interpreter starts tearing streams, graphs and buffers down
+    try:
+        if torch.cuda.is_available() and torch.cuda.is_initialized():
+            torch.cuda.synchronize()
+    except Exception:
+        pass
+
+
+atexit.register(_idle_at_exit)
 
 
 class _ConvBN:
