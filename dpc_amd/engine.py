@@ -720,11 +720,10 @@ class DPCEngine:
     #     27.48 -> 26.5 ms (+3.6 %), cfg4 +3.9 %, cfg5 +3.2 %; without the wait only +1.6 %.
     #   * without that wait the schedule is NOT bit-reproducible: scripts/stream_stress.py (two engines, one per schedule, compared
     #     bit for bit after every step) then finds, about once per 300-500 steps, a step whose gradients differ from the output of
-    #     a layer2 / layer3 input-gradient upwards.  Not the hand-over of buffers (reproduces without any main-stream wait), not
-    #     out-of-bounds writes (guards intact), not the events' fence scope, and not the kernel pair by itself
-    #     (scripts/probes/corun_probe.py: 25 000 launches of the input-gradient beside a looping weight gradient, all identical);
-    #     the cause is open.  The condition is not: side work in flight when an input-gradient is launched -- which the wait in
-    #     _ConvBN.dgrad excludes.  With it, 9 600 steps (three configurations, graph
+    #     a layer2 / layer3 input-gradient upwards.  scripts/probes/corun_probe.py found the pair that does it: igemm_ws_kernel with
+    #     reduce_unpack_t (8 KB of LDS: the one kernel whose workgroups fit on a CU beside igemm_ws's 144 KB) on the same CU --
+    #     one compute wave's block of a tile wrong in 38 of 15 000 launches; the persistent kernels now claim all 160 KB of LDS
+    #     and the probe is clean (conv_igemm_ws.hip).  The wait in _ConvBN.dgrad stays for the throughput.  With it, 9 600 steps (three configurations, graph
     #     replay and kernel-by-kernel) were bit-identical to the one-stream schedule.
     @contextlib.contextmanager
     def side(self, reads=(), kind=1):
