@@ -515,6 +515,36 @@ def case_pack3d_multi(k: K, dtype, shapes, seed=14):
         assert torch.equal(wd.cpu(), w.cpu().permute(1, 2, 0).to(dtype))
 
 
+def case_copy2d_multi(k: K, seed=15):
+    """dpc_copy2d_multi: a table of f32 [rows][cols] windows between different leading dimensions in one launch (the nine gate
+    slices of the ConvGRU's parameter gradients); everything outside the windows stays untouched"""
+    g = torch.Generator().manual_seed(seed)
+    D = 24
+    srcs = [k.t(torch.randn(3 * D, D, generator=g)), k.t(torch.randn(2 * D, D, generator=g)), k.t(torch.randn(3 * D, generator=g))]
+    dsts = [k.t(torch.full((D, 2 * D), -7.0)) for _ in range(3)] + [k.t(torch.full((D,), -7.0)) for _ in range(3)]
+    ents = []
+    for i in range(3):
+        ents.append((srcs[0][i * D:(i + 1) * D], D, dsts[i], 2 * D, D, D))                       # x half of gate i
+        if i < 2:
+            ents.append((srcs[1][i * D:(i + 1) * D], D, dsts[i][:, D:], 2 * D, D, D))            # h half
+        ents.append((srcs[2][i * D:(i + 1) * D], D, dsts[3 + i], D, 1, D))                       # bias
+    tab = (L.Copy2dEntry * len(ents))()
+    blk = 0
+    for i, (src, sld, dst, dld, r, c) in enumerate(ents):
+        tab[i] = L.Copy2dEntry(src.data_ptr(), dst.data_ptr(), sld, dld, r, c, blk, 0)
+        blk += 1 + (i % 2)
+    tab_dev = torch.frombuffer(bytearray(bytes(tab)), dtype=torch.uint8).clone().to(k.dev)
+    k.call("dpc_copy2d_multi", tab_dev, len(ents), blk)
+    k.sync()
+    for i in range(3):
+        assert torch.equal(dsts[i][:, :D].cpu(), srcs[0][i * D:(i + 1) * D].cpu())
+        if i < 2:
+            assert torch.equal(dsts[i][:, D:].cpu(), srcs[1][i * D:(i + 1) * D].cpu())
+        else:
+            assert bool((dsts[i][:, D:] == -7.0).all())
+        assert torch.equal(dsts[3 + i].cpu(), srcs[2][i * D:(i + 1) * D].cpu())
+
+
 # ---------------------------------------------------------------- dropout masks (Philox4x32-10) / device-side Adam step
 def philox4x32_10_np(ctr, key):
     """numpy Philox4x32-10 (Salmon et al., SC'11): ctr [n,4] uint32, key [2] uint32 -> [n,4] uint32.

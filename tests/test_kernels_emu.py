@@ -164,6 +164,10 @@ def test_transpose(k):
     kc.case_transpose(k, 70, 45)
 
 
+def test_copy2d_multi(k):
+    kc.case_copy2d_multi(k)
+
+
 @pytest.mark.parametrize("dtype", [F32, BF16])
 def test_pack3d_multi(k, dtype):
     kc.case_pack3d_multi(k, dtype, [(24, 40, 9), (70, 8, 27), (16, 130, 1), (8, 8, 16), (3, 5, 70)])   # ragged tiles, 1x1, taps beyond the tile

@@ -179,6 +179,10 @@ def test_transpose(k):
     kc.case_transpose(k, 6468, 256)
 
 
+def test_copy2d_multi(k):
+    kc.case_copy2d_multi(k)
+
+
 @pytest.mark.parametrize("dtype", [F32, BF16])
 def test_pack3d_multi(k, dtype):
     kc.case_pack3d_multi(k, dtype, [(64, 64, 9), (128, 64, 9), (256, 128, 27), (512, 256, 27), (256, 128, 1), (70, 24, 27)])
