@@ -336,10 +336,10 @@ __global__ __launch_bounds__(512, 2) void conv_halo_ws_kernel(HaloParams p) {
     constexpr int PATCH = LIT * 256 * 16;
     constexpr int STG = BM * BN * 2;
     constexpr int NPB = 3;                        // patch ring: two tiles of lookahead (a fourth buffer = all 160 KB of LDS was measured: no change)
-    static_assert(NPB * PATCH + 2 * STG <= 160 * 1024, "one workgroup per CU");
-    // all of the CU's LDS is claimed: a foreign LDS-using workgroup on the same CU broke igemm_ws_kernel's ring (conv_igemm_ws.hip,
-    // scripts/probes/corun_probe.py); this kernel was never seen to fail, but it runs beside RCCL's kernels in multi-GPU steps
-    __shared__ __attribute__((aligned(1024))) unsigned char lds[160 * 1024];
+    static_assert(NPB * PATCH + 2 * STG <= 160 * 1024 && 2 * (NPB * PATCH + 2 * STG) > 160 * 1024, "one workgroup per CU");
+    // (round 3 claimed all 160 KB here as a precaution; the failure it guarded against was a register hazard of igemm_ws_kernel,
+    // conv_igemm_ws.hip WS_RETIRE_TAIL_READS -- this kernel's asm reads are all consumed, scripts/asm_hazard_lint.py)
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[NPB * PATCH + 2 * STG];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;

@@ -95,6 +95,24 @@ template <int N> __device__ __forceinline__ void frag_wait(FragSet& f) {
                  : "memory");
 }
 #endif
+// THE HAZARD THAT LOOKED LIKE AN LDS RACE (round 3: "one wave's 64 x 128 block wrong in 38 of 15 000 launches beside a foreign
+// LDS-using workgroup").  The last step_il of a tile issues the six fragment reads of a chunk that does not exist (unconditional,
+// so that the MFMAs stay out of a branch).  Nothing consumes them, so for hipcc the six destination registers are DEAD at
+// ;;#ASMEND -- and it gave two of them (v160/v161 in <true,false>) to the epilogue's LDS staging address.  The asm reads are
+// invisible to its wait counts: if a0' (issued seven MFMAs, ~250 cycles, before the loop exit) has not landed when the
+// `v_add_u32 v161` executes, the LDS data lands ON TOP of the address, stage_block's 32 ds_write_b64 go to whatever LDS offsets
+// the bf16 pattern spells (dropped when out of range, otherwise into a stage the loaders are filling: "two rows of another tile"),
+// and both epilogue passes store a stale staging tile: one wave's whole 64 x 128 block.  An LDS round trip is ~64-128 cycles on a
+// quiet CU, so it never showed alone; a co-resident workgroup (LDS traffic, issue slots) stretches it past the seven MFMAs once in
+// a few hundred launches.  Claiming the whole LDS removed one way of stretching it, not the hazard.  The rule (cdna_hip_programming.md
+// "What hipcc does not do", 1): an asm load's destination must stay live, by a "+v" tie, until a wait has retired the load.
+// scripts/asm_hazard_lint.py checks the compiled code for exactly this (tests/test_asm_hazards.py); DPC_WS_NOFIX re-creates the
+// hazard in the probe library for the squatter repro (scripts/probes/squat_probe.py, profiles/r04_cotenant.txt).
+#ifdef DPC_WS_NOFIX
+#define WS_RETIRE_TAIL_READS(f) ((void)0)
+#else
+#define WS_RETIRE_TAIL_READS(f) frag_wait<0>(f)
+#endif
 __device__ __forceinline__ void mma_step(f32x16 (&acc)[2][4], const FragSet& f) {
     DPC_UNROLL
     for (int i = 0; i < 2; ++i)
@@ -197,15 +215,12 @@ __global__ __launch_bounds__(512, 2) void igemm_ws_kernel(WsParams p) {
     constexpr int STAGE = (BM + BN) * 128;  // 48 KB
     constexpr int NST = 3;
     constexpr int EPO = 8, UPR = BN / EPO;  // 16 output units per row
-    // The whole CU's LDS is claimed (160 KB, 16 KB more than the ring needs) so that no workgroup that uses LDS can ever sit beside
-    // this one.  scripts/probes/corun_probe.py: with a small-LDS kernel of another stream on the same CU (reduce_unpack_t, 8 KB --
-    // the only kernel of the step that fits beside 144 KB) 38 of 15 000 launches of the layer3 input-gradient came back with one
-    // wave's 64 x 128 block of one tile wrong; beside a weight gradient whose workgroups do not fit on the CU, 0 of 25 000.  The
-    // ring's ordering (counted vmcnt + barrier before a stage is read) does not survive a foreign workgroup's LDS traffic on
-    // the same CU; what exactly gives way was not established, the co-residency is simply made impossible.
-    constexpr int LDS_ALL = 160 * 1024;
-    static_assert(NST * STAGE <= LDS_ALL, "ring fits the CU's LDS");
-    __shared__ __attribute__((aligned(1024))) unsigned char lds[LDS_ALL];
+    // Round 3 claimed all 160 KB here "so that no LDS-using workgroup can sit beside this one": beside an 8 KB-LDS kernel of another
+    // stream 38 of 15 000 launches came back with one wave's 64 x 128 block wrong.  Round 4 found the mechanism (WS_RETIRE_TAIL_READS
+    // below, scripts/asm_hazard_lint.py): it was a register hazard of the end-of-tile fragment reads, not the ring's ordering, and a
+    // co-tenant only stretched the LDS latency far enough to expose it.  With the reads retired the kernel takes what it needs
+    // (144 KB) and shares the CU with whatever fits beside it (profiles/r04_cotenant.txt).
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[NST * STAGE];
 
     const GatherGeom& g = p.g;
     const int tid = threadIdx.x;
@@ -514,6 +529,7 @@ __global__ __launch_bounds__(512, 2) void igemm_ws_kernel(WsParams p) {
                 // unconditional, so that the MFMAs stay out of a branch (accumulators joined after a branch are copied and spill)
                 step_il<true, 4096>(acc, f1, f0, pa, pb);
             }
+            WS_RETIRE_TAIL_READS(f0);   // the reads past the tile's last chunk land before their registers are handed on
         }
 
         if (WS_DBG(2)) {  // probe: no epilogue at all (the accumulators stay live through one store)
@@ -629,9 +645,8 @@ __global__ __launch_bounds__(512, 2) void igemm_wsp_kernel(WsParams p) {
     constexpr int EPO = 8;
     constexpr int MAXP = (NPIECE + 3) / 4;  // patch pieces per loader wave
     static_assert(4 * WS_STG_WAVE <= PATCH, "epilogue staging fits a patch buffer");
-    constexpr int LDS_ALL = 160 * 1024;   // all of the CU's LDS: no LDS-using workgroup of another stream beside this one (see igemm_ws_kernel)
-    static_assert(2 * PATCH + NSB * BST <= LDS_ALL, "patches + ring fit the CU's LDS");
-    __shared__ __attribute__((aligned(1024))) unsigned char lds[LDS_ALL];
+    static_assert(2 * PATCH + NSB * BST <= 160 * 1024, "patches + ring fit the CU's LDS");
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * PATCH + NSB * BST];
     unsigned char* const bring = lds + 2 * PATCH;
 
     const GatherGeom& g = p.g;
@@ -813,6 +828,7 @@ __global__ __launch_bounds__(512, 2) void igemm_wsp_kernel(WsParams p) {
                     step_il<true, 4608>(acc, f1, f0, pa, pb);
                 });
             }
+            WS_RETIRE_TAIL_READS(f0);   // see the macro: reads past the tile's last chunk land before their registers are handed on
         }
 
         // ---- epilogue: two passes of 32 rows through this wave's 8 KB of the last group's patch buffer

@@ -259,7 +259,7 @@ constexpr int SF_A = 0, SF_X = 8192, SF_P = SF_X + 9 * 1024, SF_M = SF_P + 10 * 
 
 __global__ __launch_bounds__(768) void wgrad_stem_fused_kernel(WgradStemParams p) {
     static_assert(SF_NS * SF_STAGE <= 160 * 1024, "ring fits the CU's LDS");
-    __shared__ __attribute__((aligned(1024))) unsigned char lds[160 * 1024];   // all of it: no foreign LDS-using workgroup beside this one (see igemm_ws_kernel)
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[SF_NS * SF_STAGE];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
 #ifdef DPC_SIMT_EMU

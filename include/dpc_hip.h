@@ -125,6 +125,15 @@ int dpc_last_kernel(char* name, int32_t cap);
  * follows the setting: query it under the same value the launch sees. */
 int dpc_set_reserved_cus(int32_t n);
 
+/* Diagnostic co-tenant ("squatter"): n_wg workgroups of `waves` (1..4) waves that hold lds_bytes of LDS (multiple of 16, up to
+ * 160 KB) for usec microseconds and do nothing (mode 0), LDS traffic over their own allocation (1), 16-byte loads over
+ * scratch[scratch_bytes] (2) or VALU work (3).  where[n_wg] (optional) receives 0x80000000 | XCC_ID << 16 | HW_ID[15:0] per
+ * workgroup.  Emulates, on ONE GPU, what the train step meets in a multi-GPU run -- RCCL's channel kernels during the overlapped
+ * all-reduce that replaces nn.DataParallel's gradient reduce (dpc/main.py:65,229) -- and any side-stream neighbour: used by
+ * tests/test_cotenant_gpu.py and scripts/probes/squat_probe.py, never by the training path. */
+int dpc_diag_squat(int32_t n_wg, int32_t waves, int32_t lds_bytes, int32_t mode, int32_t usec, const void* scratch,
+                   int64_t scratch_bytes, uint32_t* where, uint32_t* sink, dpc_stream_t stream);
+
 /* ---- weight / operand repacking --------------------------------------------------
  * out[i0][i1][i2] (dtype_out, dense) = in[i0*s0 + i1*s1 + i2*s2] (f32).  Turns the
  * reference's [Co][Ci][kT][kH][kW] parameters (state_dict layout, §8b) into the
