@@ -157,6 +157,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-also", action="store_true", help="skip the 224^2 side measurements (cfg4 / cfg5) of the default run")
+    ap.add_argument("--no-schedules", action="store_true", help="multi-rank runs: skip the side measurement of the other exchange schedules")
     ap.add_argument("--no-graph", action="store_true", help="launch the step kernel by kernel instead of replaying a hipGraph")
     ap.add_argument("--score-path", default="auto", choices=["auto", "fused", "materialised"],
                     help="contrastive score + loss: fused (no [R][R] tensor in HBM) or materialised; auto = fused for R >= 8192")
@@ -173,14 +174,16 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
     dist = None
     rccl_knobs = {}
-    if world > 1 or "RANK" in os.environ:  # under a launcher the RCCL path is exercised even with one rank
-        import torch.distributed as dist_
+    under_launcher = world > 1 or "RANK" in os.environ   # under a launcher the RCCL path is exercised even with one rank
+    if under_launcher:
         from dpc_amd.parallel import configure_rccl
-        rccl_knobs = configure_rccl()  # DPC_RCCL_CHANNELS / DPC_RESERVE_CUS: documented A/B knobs, nothing set by default
+        rccl_knobs = configure_rccl(world)  # before the first HIP call: channel count of the gradient all-reduce, CU carve-out (parallel.py)
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if under_launcher:
+        import torch.distributed as dist_
         dist = dist_
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
@@ -191,7 +194,9 @@ def main():
     from dpc_amd.parallel import make_allreduce
 
     cdt = torch.bfloat16 if args.dtype == "bf16" else torch.float32
-    eng = DPCEngine(net, img, 8, 5, P, batch, dev, cdt, seed=233 + rank, score_path=args.score_path)
+    from dpc_amd.parallel import default_reserve_cus
+    eng = DPCEngine(net, img, 8, 5, P, batch, dev, cdt, seed=233 + rank, score_path=args.score_path,
+                    reserve_cus=default_reserve_cus(world))
     init = DPC_RNN(img, network=net, pred_step=P, seed=0)  # reference init, same on all ranks
     eng.load_params({k: v.detach() for k, v in init.named_parameters()})
     del init
@@ -232,10 +237,36 @@ def main():
     dt = tmax.item()
     loss = res.cpu().tolist()
 
+    # ---- the other exchange schedules, a few steps each (never part of `value`): the default overlaps the tail all-reduce with
+    # layer1 + stem backward and leaves reserve_cus CUs to RCCL; "overlap_all_cus" = the same with every CU claimed by the
+    # persistent grids, "serial" = one all-reduce of the whole arena after the backward pass
+    schedules = None
+    if dist is not None and use_graph and allreduce is not None and not args.no_schedules:
+        def timed_schedule(exch, reserve, n=max(4, min(args.steps, 10))):
+            keep = eng.reserve_cus
+            eng.reserve_cus = reserve
+            try:
+                fn = eng.capture_train_step(block, allreduce=exch)
+                fn(); fn()
+                sync()
+                t1 = time.perf_counter()
+                for _ in range(n):
+                    fn()
+                sync()
+                t = torch.tensor([(time.perf_counter() - t1) / n], device=dev, dtype=torch.float64)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                return round(1e3 * t.item(), 3)
+            finally:
+                eng.reserve_cus = keep
+        schedules = {"default": {"ms_per_step": round(1e3 * dt / args.steps, 3), "reserve_cus": eng.reserve_cus, "exchange": "two buckets, overlapped"}}
+        if eng.reserve_cus:
+            schedules["overlap_all_cus"] = {"ms_per_step": timed_schedule(allreduce, 0), "reserve_cus": 0}
+        schedules["serial"] = {"ms_per_step": timed_schedule(lambda flat: allreduce(flat), 0), "reserve_cus": 0, "exchange": "one all-reduce after the backward pass"}
+
     # ---- separately instrumented pass (never part of `value`): HIP events around the selected launches
     timer = None
     if not args.no_roofline and rank == 0:
-        timer = KernelTimer(["dpc_conv_igemm", "dpc_conv_igemm_ex", "dpc_conv_wgrad", "dpc_score_fwd", "dpc_score_bwd", "dpc_gemm_nt_splitk",
+        timer = KernelTimer(["dpc_conv_igemm", "dpc_conv_igemm_ex", "dpc_conv_wgrad", "dpc_score_fwd", "dpc_score_bwd", "dpc_gemm_nt_splitk", "dpc_gemm_tn_splitk",
                              "dpc_reduce_unpack"] + list(HBM_FAMILY))
         eng.timer = timer
         for _ in range(args.roofline_steps):
@@ -261,6 +292,8 @@ def main():
         if dist is not None:
             out["per_rank_ms_per_step"] = {"min": round(min(rank_ms), 3), "max": round(max(rank_ms), 3), "all": [round(v, 3) for v in rank_ms]}
             out["config"]["rccl_knobs"] = rccl_knobs
+            if schedules:
+                out["schedules"] = schedules
         if timer is not None:
             s = timer.summary(rs)
             ig = s.get("dpc_conv_igemm")

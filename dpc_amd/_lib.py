@@ -88,6 +88,7 @@ _SIGS = {
     "dpc_conv_igemm": [C.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _vp],
     "dpc_conv_igemm_ex": [C.POINTER(ConvDesc), _vp, _vp, _vp, C.POINTER(ConvEpilogue), _vp],
     "dpc_gemm_nt_splitk": [_i32, _i32, _i32, _i32, _vp, _i32, _vp, _i32, _vp, C.POINTER(_i32), _vp],
+    "dpc_gemm_tn_splitk": [_i32, _i32, _i32, _i32, _vp, _i32, _vp, _i32, _vp, C.POINTER(_i32), _vp],
     "dpc_conv_wgrad": [C.POINTER(ConvDesc), _vp, _vp, _i32, _vp, C.POINTER(_i32), _vp],
     "dpc_conv_plan": [C.POINTER(ConvDesc), _i32, _i32, _i32, C.c_char_p, _i32],
     "dpc_last_kernel": [C.c_char_p, _i32],

@@ -332,6 +332,9 @@ int dpc_conv_ws_rows(const dpc_conv_desc* d);
 
 // score_fused.hip: plain NT GEMM with bf16 operands, f32 output and a short reduction (the materialised contrastive score).
 int dpc_score_gemm_try(const dpc_conv_desc* d, const void* src, const void* wgt, void* out, hipStream_t stream);
+// gemm_ws.hip: split-K NT (trans_a = 0) / TN (trans_a = 1: A given K-major) GEMM on the loader / compute machinery; 1 = shape not served
+int dpc_gemm_ws_try(int trans_a, int M, int N, int K, const void* A, int lda, const void* B, int ldb, float* part, int32_t* nsplit,
+                    hipStream_t stream);
 
 // conv_wgrad_patch.hip: weight gradient of 1x3x3 stride-1 convs from one staged source patch (bf16).
 int dpc_wgrad_patch_try(const dpc_conv_desc* d, const void* src, const void* dy, int dy_ld, float* part, int32_t* nsplit,

@@ -680,6 +680,10 @@ extern "C" int dpc_gemm_nt_splitk(int32_t dtype, int32_t M, int32_t N, int32_t K
     if (M <= 0 || N <= 0 || K <= 0 || (dtype != DPC_F32 && dtype != DPC_BF16)) return DPC_ERR_ARG;
     const int per16 = dtype == DPC_BF16 ? 8 : 4;
     if (K % per16 || lda % per16 || ldb % per16 || lda < K || ldb < K) return DPC_ERR_UNSUPPORTED;
+    if (dtype == DPC_BF16) {   // long reductions with a narrow output: 256 x 128 tiles on the loader / compute kernel (gemm_ws.hip)
+        const int rcw = dpc_gemm_ws_try(0, M, N, K, A, lda, B, ldb, part, nsplit, stream);
+        if (rcw != 1) return rcw;
+    }
     dpc_conv_desc d = {dtype, DPC_F32, 0, M, 1, 1, 1, 1, 1, 1, K, lda, N, ldb, N, 1, 1, 1, 1, 1, 1, 0, 0, 0};
     IGemmParams p;
     int rc = make_gather_geom(&d, &p.g);

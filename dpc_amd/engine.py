@@ -161,7 +161,7 @@ def algorithmic_cost(name, args):
         return 2.0 * args[2] * args[2] * args[3], float(2 * args[2] * args[3] * 2)
     if name == "dpc_score_bwd":            # own, oth, othT, ldT, R, D, ...: one R x R x D contraction (the recompute is not counted)
         return 2.0 * args[4] * args[4] * args[5], float(2 * args[4] * args[5] * 2 + args[4] * args[5] * 4)
-    if name == "dpc_gemm_nt_splitk":       # dtype, M, N, K, A, lda, B, ldb, part, nsplit
+    if name in ("dpc_gemm_nt_splitk", "dpc_gemm_tn_splitk"):       # dtype, M, N, K, A, lda, B, ldb, part, nsplit
         e = _esz(args[0])
         return 2.0 * args[1] * args[2] * args[3], float((args[1] + args[2]) * args[3] * e + args[1] * args[2] * 4)
     if name not in ("dpc_conv_igemm", "dpc_conv_igemm_ex", "dpc_conv_wgrad"):
@@ -437,7 +437,7 @@ class DPCEngine:
                  pred_step: int = 3, batch: int = 4, device="cuda", compute_dtype=torch.float32,
                  widths: Sequence[int] = LAYER_WIDTH, lib: Optional[L.Lib] = None,
                  lr: float = 1e-3, wd: float = 1e-5, dropout: float = 0.1, seed: int = 233, score_path: str = "auto", stem_fused: bool | None = None,
-                 fold: bool | None = None):
+                 fold: bool | None = None, reserve_cus: int | None = None):
         self.device = torch.device(device)
         self.lib = L.lib_for(self.device, lib)  # raises unless HIP device (or an explicit simulator handle in tests)
         self.cdtype = compute_dtype
@@ -469,15 +469,17 @@ class DPCEngine:
         # launch): on by default, DPC_FOLD=0 / fold=False runs the separate kernels (A/B, and the reference for the fused form)
         self.fold = bool(int(os.environ.get("DPC_FOLD", "1"))) if fold is None else bool(fold)
         # CUs left to RCCL's channel kernels while the gradient tail is being all-reduced under layer1 + stem backward: the
-        # persistent one-workgroup-per-CU kernels of that phase shrink their grids (dpc_set_reserved_cus).  0 = off (default);
-        # an A/B knob for the first multi-GPU runs, only consulted when a two-bucket exchange is running.
-        self.reserve_cus = int(os.environ.get("DPC_RESERVE_CUS", "0"))
+        # persistent one-workgroup-per-CU kernels of that phase shrink their grids (dpc_set_reserved_cus).  Only consulted when a
+        # two-bucket exchange is running; data-parallel callers pass parallel.default_reserve_cus(world) (= the RCCL channel count:
+        # measured with a co-tenant on one GPU, profiles/r04_cotenant.txt), single-GPU runs 0.
+        self.reserve_cus = int(os.environ.get("DPC_RESERVE_CUS", "0")) if reserve_cus is None else int(reserve_cus)
         self._pack_table = None
         self._gate_table = None
         # weight gradients on a second stream beside the next unit's BatchNorm backward (side() below); DPC_WGRAD_STREAM=0: one stream.
         # DPC_SIDE_MASK selects what goes there (1 conv2 / downsample weight gradients, 2 conv1's, 4 head parameters, 8 weight
         # repacks); DPC_SIDE_QUIET=0 lets side work run beside input-gradients too (slower, and not bit-reproducible: see side())
         self._side = (torch.cuda.Stream(self.device) if self.device.type == "cuda" and int(os.environ.get("DPC_WGRAD_STREAM", "1")) else None)
+        self._on_side = False
         self._side_mask = int(os.environ.get("DPC_SIDE_MASK", "15"))
         self._side_quiet = bool(int(os.environ.get("DPC_SIDE_QUIET", "1")))
         self._busy = []   # [(event recorded on the side stream, scratch buffers its launches read)], oldest first
@@ -619,6 +621,13 @@ class DPCEngine:
         nsk = C.c_int32(0)  # d_pred = dS @ feature_inf: f32 slabs of the split reduction
         self.lib.call("dpc_gemm_nt_splitk", L.dtype_code(dt), R, D, self.ld_d, None, self.ld_d, None, self.ld_d, None, C.byref(nsk), self.lib.stream())
         self.need_part(nsk.value * R * D)
+        # d_feature_inf = dS^T @ pred on the loader / compute kernel with dS read K-major (csrc/gemm_ws.hip); None: weight-gradient kernel
+        self._tn_splits = None
+        if dt == torch.bfloat16:
+            rc = self.lib._fn("dpc_gemm_tn_splitk")(L.dtype_code(dt), R, D, R, None, self.ld_d, None, self.ld_d, None, C.byref(nsk), self.lib.stream())
+            if rc == 0:
+                self._tn_splits = nsk.value
+                self.need_part(nsk.value * R * D)
         gd, Pm = self.gru_desc, self.PRM
         gd.dtype, gd.M, gd.D, gd.SQ, gd.P, gd.n_agg, gd.n_steps = L.dtype_code(dt), M, D, SQ, P, self.n_agg, ns
         gd.p_drop, gd.seed = float(self.p_drop), self.seed
@@ -658,6 +667,18 @@ class DPCEngine:
         self.packed_for_step = -1
 
     # ------------------------------------------------------------------ plumbing
+    # split-K slab workspace: one buffer per stream.  Launches issued inside side() get the side stream's own slabs, so a
+    # main-stream user (dpc_gemm_*_splitk, dpc_colsum, a weight gradient that stays on the main stream under a partial
+    # DPC_SIDE_MASK or need_dx=False) can never overwrite slabs a side-stream weight gradient is still reducing.
+    @property
+    def part(self) -> torch.Tensor:
+        return self._part_side if self._on_side else self._part_main
+
+    @part.setter
+    def part(self, t: torch.Tensor):
+        self._part_main = t
+        self._part_side = torch.empty_like(t) if self._side is not None else t
+
     def empty(self, shape, dtype):
         return torch.empty(tuple(shape), dtype=dtype, device=self.device)
 
@@ -735,7 +756,11 @@ class DPCEngine:
         ev.record(main)
         self._side.wait_event(ev)
         with torch.cuda.stream(self._side):
-            yield
+            self._on_side = True
+            try:
+                yield
+            finally:
+                self._on_side = False
             done = torch.cuda.Event()
             done.record(self._side)
         self._busy.append((done, [t for t in reads if t is not None]))
@@ -983,9 +1008,16 @@ class DPCEngine:
         else:
             if self._score_fused:
                 raise L.DpcError("backward(dscore_external=...) needs a materialised score: call forward(materialise=True)")
+            if self._tn_splits:
+                self.call("dpc_transpose2d", self.pred, dc, D, self.predT, dc, self.ld_d, R, D)
             with self.tag("score"):
                 self.gemm_splitk(self.dscore, self.finfT, self.d_pred, R, D, self.ld_d, self.ld_d, self.ld_d)
-                self.gemm_tn(self.dscore, self.ld_d, self.pred, D, self.d_finf, R, R, D)
+                if self._tn_splits:
+                    ns = C.c_int32(0)
+                    self.call("dpc_gemm_tn_splitk", dc, R, D, R, self.dscore, self.ld_d, self.predT, self.ld_d, self.part, C.byref(ns))
+                    self.call("dpc_reduce_unpack", self.part, ns.value, self.d_finf, R, 1, D, D, 0, 1, 0)
+                else:
+                    self.gemm_tn(self.dscore, self.ld_d, self.pred, D, self.d_finf, R, R, D)
         # ---- predict loop + aggregation, reversed: one launch (G_all, dP1, dP2, d_featrelu come back)
         ns = self.n_steps
         self.call("dpc_gru_chain_bwd", C.byref(self.gru_desc))

@@ -77,9 +77,11 @@ def _worker(rank: int, world: int, args, port: int):
     dev = torch.device('cuda', gpus[rank] if world > 1 else gpus[0])
     torch.cuda.set_device(dev)
     dist = None
+    from .parallel import configure_rccl, default_reserve_cus
     if world > 1:
         import torch.distributed as dist_
         dist = dist_
+        configure_rccl(world)   # few long-lived channels beside the backward pass (parallel.py); before the communicator exists
         dist.init_process_group('nccl', init_method=f'tcp://127.0.0.1:{port}', rank=rank, world_size=world, device_id=dev)
     from .engine import DPCEngine
     from .model import DPC_RNN
@@ -93,7 +95,7 @@ def _worker(rank: int, world: int, args, port: int):
     per_gpu = args.batch_size // world
     cdt = torch.bfloat16 if args.dtype == 'bf16' else torch.float32
     eng = DPCEngine(args.net, args.img_dim, args.num_seq, args.seq_len, args.pred_step, per_gpu, dev, cdt, lr=args.lr, wd=args.wd,
-                    seed=233 + rank)  # dropout stream: the reference seeds 233 (dpc/model_3d.py:18); independent per replica
+                    seed=233 + rank, reserve_cus=default_reserve_cus(world))  # dropout stream: the reference seeds 233 (dpc/model_3d.py:18); independent per replica
     init = DPC_RNN(args.img_dim, args.num_seq, args.seq_len, args.pred_step, args.net, seed=0)  # same on every rank
     eng.load_params({k: v.detach() for k, v in init.named_parameters()})
     best_acc, iteration = 0.0, 0

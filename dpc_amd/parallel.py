@@ -15,27 +15,44 @@ import os
 import torch
 
 
-def configure_rccl(environ=os.environ) -> dict:
-    """Knobs for the first multi-GPU runs, applied BEFORE init_process_group (RCCL reads its environment when the communicator
-    is created).  None is set unless asked for; what is set is returned (bench.py prints it in the JSON line).
-      DPC_RCCL_CHANNELS=n   NCCL_MIN_NCHANNELS = NCCL_MAX_NCHANNELS = n: the number of channel workgroups (one CU each) an
-                            all-reduce occupies.  The 58 / 132 MB gradient over 7 xGMI links wants few, long-lived channels next to
-                            the backward kernels; RCCL's default is sized for a collective that owns the chip.
-      DPC_RESERVE_CUS=n     (read by DPCEngine) the persistent one-workgroup-per-CU kernels of layer1 + stem backward launch
-                            256 - n workgroups while the tail all-reduce is in flight, so the channel kernels are not queued
-                            behind them.  A/B both against the defaults (0 / unset) on the first 8-GPU run: DESIGN.md section 7.
-      HSA_ENABLE_IPC_MODE_LEGACY=0 is kept (dmabuf IPC is what the host driver supports); set here if the launcher dropped it."""
+DEFAULT_CHANNELS = 8   # RCCL channel workgroups (one CU each) of the gradient all-reduce, and CUs the persistent kernels leave to them
+
+
+def default_reserve_cus(world: int, environ=os.environ) -> int:
+    """CUs the one-workgroup-per-CU kernels leave free while the tail all-reduce is in flight (DPCEngine.reserve_cus):
+    DPC_RESERVE_CUS when set, else the RCCL channel count when there is more than one rank, else 0."""
+    if environ.get("DPC_RESERVE_CUS") is not None:
+        return int(environ["DPC_RESERVE_CUS"])
+    if world <= 1:
+        return 0
+    return int(environ.get("DPC_RCCL_CHANNELS") or environ.get("NCCL_MAX_NCHANNELS") or DEFAULT_CHANNELS)
+
+
+def configure_rccl(world: int = 1, environ=os.environ) -> dict:
+    """RCCL environment for the gradient exchange; call BEFORE the first HIP call of the process (RCCL reads its environment when
+    the communicator is created, the HSA runtime when it starts).  Returns what was set (bench.py prints it in the JSON line).
+
+    Why few channels.  The tail all-reduce (58 / 132 MB, dpc/main.py:65's DataParallel reduce) runs under ~9 ms of layer1 + stem
+    backward: it needs ~7 GB/s to hide completely, so bandwidth is not what to optimise -- the CUs it takes from the backward
+    pass are.  Measured with a co-tenant of k workgroups x 64 KB LDS for 1 ms on one MI355X (scripts/probes/cotenant_step.py,
+    profiles/r04_cotenant.txt): overlapped with all CUs claimed by the persistent grids +1.7..1.8 % of a step, with k CUs left
+    free +0.7 % (k = 8) / +0.8 % (16) / +1.3 % (32), not overlapped at all +4.5 %.  Hence for world > 1:
+      NCCL_MIN_NCHANNELS = NCCL_MAX_NCHANNELS = DPC_RCCL_CHANNELS (default 8) unless NCCL_*_NCHANNELS are set explicitly,
+      DPC_RESERVE_CUS defaults to the same number (default_reserve_cus; 0 switches the carve-out off).
+    HSA_ENABLE_IPC_MODE_LEGACY=0 (dmabuf IPC is what the host driver supports) is exported for child processes if the launcher
+    dropped it; in THIS process it only takes effect when the HSA runtime has not started yet, and is reported accordingly."""
     applied = {}
-    ch = environ.get("DPC_RCCL_CHANNELS")
-    if ch:
+    if world > 1 or environ.get("DPC_RCCL_CHANNELS"):
+        ch = int(environ.get("DPC_RCCL_CHANNELS") or DEFAULT_CHANNELS)
         for k in ("NCCL_MIN_NCHANNELS", "NCCL_MAX_NCHANNELS"):
-            environ[k] = str(int(ch))
-            applied[k] = int(ch)
+            if environ.get("DPC_RCCL_CHANNELS") or k not in environ:
+                environ[k] = str(ch)
+                applied[k] = ch
     if "HSA_ENABLE_IPC_MODE_LEGACY" not in environ:
         environ["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
-        applied["HSA_ENABLE_IPC_MODE_LEGACY"] = 0
-    if environ.get("DPC_RESERVE_CUS"):
-        applied["DPC_RESERVE_CUS"] = int(environ["DPC_RESERVE_CUS"])
+        started = torch.cuda.is_initialized()
+        applied["HSA_ENABLE_IPC_MODE_LEGACY"] = "0 (child processes only: the HIP runtime of this process had already started)" if started else 0
+    applied["DPC_RESERVE_CUS"] = default_reserve_cus(world, environ)
     return applied
 
 

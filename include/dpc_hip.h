@@ -94,6 +94,12 @@ int dpc_conv_igemm_ex(const dpc_conv_desc* d, const void* src, const void* wgt, 
  * part == NULL: capacity nsplit*M*N floats); sum them with dpc_reduce_unpack(part, nsplit, out, M, 1, N, N, 0, 1, 0). */
 int dpc_gemm_nt_splitk(int32_t dtype, int32_t M, int32_t N, int32_t K, const void* A, int32_t lda, const void* B, int32_t ldb,
                        float* part, int32_t* nsplit, dpc_stream_t stream);
+/* The same with A given K-major: part[ks][M][N] = sum_{k in slice ks} A[k][m] * B[n][k] (A rows are lda elements apart, bf16 only).
+ * d_feature_inf = dS^T @ pred of the contrastive loss (autograd of dpc/model_3d.py:83): A = dS [R][ld], B = pred^T [256][ld].
+ * A rows beyond K are never read; lda >= M and ldb >= K rounded up to 8 elements, the padding of B's rows holding finite values.
+ * DPC_ERR_UNSUPPORTED outside N % 128 == 0, lda % 8 == ldb % 8 == 0, M, K >= 1024 (use dpc_conv_wgrad's GEMM form there). */
+int dpc_gemm_tn_splitk(int32_t dtype, int32_t M, int32_t N, int32_t K, const void* A, int32_t lda, const void* B, int32_t ldb,
+                       float* part, int32_t* nsplit, dpc_stream_t stream);
 
 /* Weight gradient: part[ks][co][tap*Ci+ci] = sum_{m in split ks} dy[m][co]*src[gather(m,tap)][ci]
  * (autograd of the same convs / 1x1 convs / matmul; f32 partials, reduced by

@@ -55,10 +55,25 @@ for R in (6144, 6468, 15680):
     k.call("dpc_gemm_nt_splitk", 1, R, D, ld, None, ld, None, ld, None, C.byref(nsk))
     part = k.empty(max(nsk.value, 1) * R * D)
     dp = k.empty(R, D)
+    torch.cuda.synchronize()
+    dS[:, R:].zero_()   # the CE kernel zero-fills the padding columns; make sure they are finite even before its first launch here
     def dpred():
         k.call("dpc_gemm_nt_splitk", 1, R, D, ld, dS, ld, finfT, ld, part, C.byref(nsk))
         k.call("dpc_reduce_unpack", part, nsk.value, dp, R, 1, D, D, 0, 1, 0)
-    timeit(dpred, f"d_pred split-K x{nsk.value} + reduce R={R}", fl)
+    timeit(dpred, f"d_pred split-K x{nsk.value} + reduce R={R} [{L.last_kernel(k.lib) if dpred() is None else ''}]", fl)
+    timeit(lambda: k.call("dpc_gemm_nt_splitk", 1, R, D, ld, dS, ld, finfT, ld, part, C.byref(nsk)), f"  d_pred GEMM alone R={R} [{L.last_kernel(k.lib)}]", fl)
+    predT = torch.zeros(D, ld, dtype=bf, device="cuda"); predT[:, :R] = pred.t()
+    nst = C.c_int32(0)
+    if k.lib._fn("dpc_gemm_tn_splitk")(1, R, D, R, None, ld, None, ld, None, C.byref(nst), k.lib.stream()) == 0:
+        part3 = k.empty(nst.value * R * D)
+        df2 = k.empty(R, D)
+        def dfinf_ws():
+            k.call("dpc_gemm_tn_splitk", 1, R, D, R, dS, ld, predT, ld, part3, C.byref(nst))
+            k.call("dpc_reduce_unpack", part3, nst.value, df2, R, 1, D, D, 0, 1, 0)
+        timeit(dfinf_ws, f"d_finf K-major split-K x{nst.value} + reduce R={R}", fl)
+        timeit(lambda: k.call("dpc_gemm_tn_splitk", 1, R, D, R, dS, ld, predT, ld, part3, C.byref(nst)), f"  d_finf GEMM alone R={R} [{L.last_kernel(k.lib)}]", fl)
+        timeit(lambda: k.call("dpc_transpose2d", pred, 1, D, predT, 1, ld, R, D), f"  pred -> pred^T R={R}")
+        del part3
     dw = kc.conv_desc(bf, torch.float32, 0, R, (1, 1, 1), (1, 1, 1), D, D, R, D, R, (1, 1, 1), (1, 1, 1), (0, 0, 0))
     nsw = C.c_int32(0)
     k.call("dpc_conv_wgrad", C.byref(dw), None, None, ld, None, C.byref(nsw))

@@ -19,7 +19,7 @@ which = sys.argv[1] if len(sys.argv) > 1 else "l3"
 iters = int(sys.argv[2]) if len(sys.argv) > 2 else 300
 N, T, H, W, Cc, ks, pd = {"l3": (1024, 3, 8, 8, 256, (3, 3, 3), (1, 1, 1)), "l2": (1024, 5, 16, 16, 128, (1, 3, 3), (0, 1, 1)),
                           "l1": (1024, 5, 32, 32, 64, (1, 3, 3), (0, 1, 1))}[which]
-lib = L.load_hip()
+lib = L.Lib(os.environ["DPC_PROBE_LIB"], "hip") if os.environ.get("DPC_PROBE_LIB") else L.load_hip()   # e.g. scripts/probes/libdpc_nofix.so
 dev = torch.device("cuda:0")
 BF = torch.bfloat16
 taps = ks[0] * ks[1] * ks[2]

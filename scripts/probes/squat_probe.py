@@ -47,9 +47,11 @@ if os.path.exists(nofix):
     libs = {"nofix": L.Lib(nofix, "hip"), "fixed": libs["fixed"]}
 sq = libs["fixed"]
 
-# (name, workgroups, waves, LDS bytes, mode); 512 workgroups of 2 waves: two per CU, one wave on every SIMD
-SQUATS = [("none", 0, 0, 0, 0), ("lds8k-idle", 512, 2, 8192, 0), ("lds8k-ldstraffic", 512, 2, 8192, 1), ("nolds-vmem", 512, 2, 0, 2),
-          ("nolds-valu", 512, 2, 0, 3), ("nolds-idle", 512, 2, 0, 0)]
+# (name, workgroups, waves, LDS bytes, mode).  ONE workgroup of four waves per CU (a wave on every SIMD: 2 x 216 + 48 VGPRs fit; two
+# 2-wave workgroups can land on the same two SIMDs, 96 VGPRs there, and igemm_ws<false> -- 432 per SIMD -- then waits for them to
+# leave: session A of round 4 measured 1 530 us per launch = squatter life + solo time, i.e. no co-residency at all)
+SQUATS = [("none", 0, 0, 0, 0), ("lds8k-idle", 256, 4, 8192, 0), ("lds8k-ldstraffic", 256, 4, 8192, 1), ("nolds-vmem", 256, 4, 0, 2),
+          ("nolds-valu", 256, 4, 0, 3), ("nolds-idle", 256, 4, 0, 0)]
 
 
 def dgrad(lib):
@@ -72,11 +74,11 @@ usec = int(t_solo * 2.5)
 print(f"solo launch {t_solo:.0f} us; squatters live {usec} us", flush=True)
 
 # placement of the squatters on an idle chip
-squat(512, 2, 8192, 0, 50, main)
+squat(256, 4, 8192, 0, 50, main)
 torch.cuda.synchronize()
-w = where[:512].cpu().numpy().astype("uint32")
+w = where[:256].cpu().numpy().astype("uint32")
 cus = {(int(v >> 16) & 0xf, int(v >> 13) & 0x7, int(v >> 12) & 1, int(v >> 8) & 0xf) for v in w if v >> 31}
-print(f"512 squatter workgroups reported {len(cus)} distinct (xcc, se, sh, cu) placements", flush=True)
+print(f"256 squatter workgroups reported {len(cus)} distinct (xcc, se, sh, cu) placements", flush=True)
 
 for lname, lib in libs.items():
     dgrad(lib)
@@ -102,5 +104,6 @@ for lname, lib in libs.items():
                     rows = (d.abs().amax(1) > 0).nonzero().flatten()
                     cols = (d.abs().amax(0) > 0).nonzero().flatten()
                     shapes.append(f"{rows.numel()} rows x {cols.numel()} cols (rows {rows[:3].tolist()}..{rows[-2:].tolist()})")
-        print(f"{lname:6s} beside {sname:18s}: {bad:4d} of {iters} launches differ from the solo result; {ms / iters * 1e3:6.0f} us per launch"
+        co = "shared the CUs" if (not n or ms / iters * 1e3 < 0.6 * (t_solo + usec)) else "did NOT co-reside (launch waited for the squatters)"
+        print(f"{lname:6s} beside {sname:18s}: {bad:4d} of {iters} launches differ from the solo result; {ms / iters * 1e3:6.0f} us per launch, {co}"
               + (("   e.g. " + "; ".join(shapes)) if shapes else ""), flush=True)

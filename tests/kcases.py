@@ -223,7 +223,7 @@ def case_gemm_nt(k: K, dtype, M, N, Kd, seed=3, expect=None):
     assert relerr(out, A.double() @ B.double().t()) < 1e-5
 
 
-def case_gemm_nt_splitk(k: K, dtype, M, N, Kd, pad=0, seed=13):
+def case_gemm_nt_splitk(k: K, dtype, M, N, Kd, pad=0, seed=13, expect=None):
     """dpc_gemm_nt_splitk: f32 partial slabs of A @ B^T over K ranges, summed by dpc_reduce_unpack (d_pred = dS @ feature_inf);
     leading dimensions Kd + pad, the padding columns hold garbage that must not be read"""
     g = torch.Generator().manual_seed(seed)
@@ -235,10 +235,32 @@ def case_gemm_nt_splitk(k: K, dtype, M, N, Kd, pad=0, seed=13):
     k.call("dpc_gemm_nt_splitk", L.dtype_code(dtype), M, N, Kd, None, Kd + pad, None, Kd + pad, None, C.byref(ns))
     part = k.zeros(ns.value, M, N)
     k.call("dpc_gemm_nt_splitk", L.dtype_code(dtype), M, N, Kd, k.t(Ap), Kd + pad, k.t(Bp), Kd + pad, part, C.byref(ns))
+    check_kernel(k, expect)
     out = k.zeros(M, N)
     k.call("dpc_reduce_unpack", part, ns.value, out, M, 1, N, N, 0, 1, 0)
     k.sync()
     assert relerr(out, A.double() @ B.double().t()) < 1e-5
+    return ns.value
+
+
+def case_gemm_tn_splitk(k: K, M, N, Kd, pad=0, seed=17, expect="gemm_ws_kernel<true>"):
+    """dpc_gemm_tn_splitk: out[m][n] = sum_k A[k][m] * B[n][k], A K-major with leading dimension M + pad (d_feature_inf = dS^T @ pred:
+    A = dS [R][ld], B = pred^T [D][ld]); padding columns of both operands hold garbage that must not be read"""
+    g = torch.Generator().manual_seed(seed)
+    dtype = torch.bfloat16
+    A = q(torch.randn(Kd, M, generator=g), dtype)
+    B = q(torch.randn(N, Kd, generator=g), dtype)
+    Ap = torch.full((Kd, M + pad), 77.0).to(dtype); Ap[:, :M] = A.to(dtype)
+    Bp = torch.full((N, Kd + pad), -55.0).to(dtype); Bp[:, :Kd] = B.to(dtype)
+    ns = C.c_int32(0)
+    k.call("dpc_gemm_tn_splitk", L.dtype_code(dtype), M, N, Kd, None, M + pad, None, Kd + pad, None, C.byref(ns))
+    part = k.zeros(ns.value, M, N)
+    k.call("dpc_gemm_tn_splitk", L.dtype_code(dtype), M, N, Kd, k.t(Ap), M + pad, k.t(Bp), Kd + pad, part, C.byref(ns))
+    check_kernel(k, expect)
+    out = k.zeros(M, N)
+    k.call("dpc_reduce_unpack", part, ns.value, out, M, 1, N, N, 0, 1, 0)
+    k.sync()
+    assert relerr(out, A.double().t() @ B.double().t()) < 1e-5
     return ns.value
 
 

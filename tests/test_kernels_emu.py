@@ -27,6 +27,16 @@ def test_gemm_nt_splitk(k, dtype):
     assert kc.case_gemm_nt_splitk(k, dtype, 64, 32, 64) == 1             # nothing to split
 
 
+def test_gemm_ws_splitk(k, monkeypatch):
+    """the loader / compute split-K GEMMs of the score backward (csrc/gemm_ws.hip) on small shapes: ragged last row tile, K tail inside
+    a chunk, several slices, padded leading dimensions; row-major A and K-major A (transpose reads)"""
+    monkeypatch.setenv("DPC_GEMM_WS_MIN", "64")
+    assert kc.case_gemm_nt_splitk(k, BF16, 300, 128, 1096, pad=8, expect="gemm_ws_kernel<false>") > 1
+    kc.case_gemm_nt_splitk(k, BF16, 256, 256, 72, expect="gemm_ws_kernel<false>")
+    assert kc.case_gemm_tn_splitk(k, 264, 128, 1096, pad=8) > 1
+    kc.case_gemm_tn_splitk(k, 520, 256, 200, pad=16)
+
+
 @pytest.mark.parametrize("dtype", [F32, BF16])
 @pytest.mark.parametrize("shape,gate,bnred,bn_relu", [
     ((1, 32, 32, 3, 6, 6, (3, 3, 3), (1, 1, 1), (1, 1, 1)), True, True, True),     # generic kernel, 3x3x3

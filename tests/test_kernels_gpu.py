@@ -126,7 +126,16 @@ def test_gemm_nt(k, dtype, mnk):
 def test_gemm_nt_splitk(k, dtype, mnk):
     """d_pred = dS @ feature_inf at cfg2 / cfg4 (leading dimension 6 472 = R rounded up to the 16-byte unit) / cfg5 size:
     reduction split over workgroups, f32 slabs"""
-    ns = kc.case_gemm_nt_splitk(k, dtype, *mnk, pad=8)
+    ws = "gemm_ws_kernel<false>" if dtype == BF16 and mnk[2] >= 1024 else None   # long reductions: loader / compute kernel
+    ns = kc.case_gemm_nt_splitk(k, dtype, *mnk, pad=8, expect=ws)
+    assert ns >= (2 if mnk[0] > 4096 else 1)
+
+
+@pytest.mark.parametrize("mnk,pad", [((6144, 256, 6144), 8), ((6468, 256, 6468), 4), ((15680, 256, 15680), 8), ((1024, 128, 1032), 8)])
+def test_gemm_tn_splitk(k, mnk, pad):
+    """d_feature_inf = dS^T @ pred at cfg2 / cfg4 (R = 6 468: rows of 6 472 elements, the last 16-byte unit of every operand row
+    straddles the end of the operand) / cfg5 size: A read K-major through transpose reads, f32 slabs"""
+    ns = kc.case_gemm_tn_splitk(k, *mnk, pad=pad)
     assert ns >= (2 if mnk[0] > 4096 else 1)
 
 
