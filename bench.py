@@ -97,6 +97,76 @@ def side_config(name, dev, steps=8, warmup=2, roof_steps=2):
     return out
 
 
+def f32_mode(dev, steps=4):
+    """cfg2 in the f32 parity mode (the mode north_star's 1e-3 tolerance is stated in): a few hipGraph replays, same process"""
+    from dpc_amd.engine import DPCEngine
+    from dpc_amd.model import DPC_RNN
+    cfg = CONFIGS["cfg2"]
+    net, img, P, batch = cfg["net"], cfg["img_dim"], cfg["pred_step"], cfg["batch"]
+    eng = DPCEngine(net, img, 8, 5, P, batch, dev, torch.float32, seed=233)
+    init = DPC_RNN(img, network=net, pred_step=P, seed=0)
+    eng.load_params({k: v.detach() for k, v in init.named_parameters()})
+    del init
+    block = torch.randn(batch, 8, 3, 5, img, img, device=dev, generator=torch.Generator(dev).manual_seed(1234))
+    step = eng.capture_train_step(block, warmup=1)
+    step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        res = step()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    out = {"workload": "cfg2 in f32 end to end (exact f32 MFMA chains): the mode in which score / mask / top-k match the reference's CPU "
+                       "path within 1e-3 (tests/test_engine_gpu.py)", "dtype": "f32", "value": round(batch * steps / dt, 2), "unit": "clips/s",
+           "ms_per_step": round(1e3 * dt / steps, 3), "steps": steps, "final_loss": round(res.cpu().tolist()[0], 4)}
+    del eng, step, block
+    torch.cuda.empty_cache()
+    return out
+
+
+def module_loop(dev, steps=10, warmup=3):
+    """the reference's own loop lines (dpc/main.py:198-231: model(x) -> CrossEntropyLoss -> zero_grad / backward / optimizer.step)
+    over the drop-in module dpc_amd.model.DPC_RNN at cfg2, bf16 compute: what a user who only swaps the import gets"""
+    from dpc_amd.model import DPC_RNN
+    from dpc_amd.optim import Adam
+    cfg = CONFIGS["cfg2"]
+    net, img, P, batch = cfg["net"], cfg["img_dim"], cfg["pred_step"], cfg["batch"]
+    model = DPC_RNN(img, num_seq=8, seq_len=5, pred_step=P, network=net, seed=0).to(dev).bfloat16()
+    model.train()
+    optimizer = Adam(model.parameters(), lr=1e-3, weight_decay=1e-5)
+    criterion = torch.nn.CrossEntropyLoss()
+    x = torch.randn(batch, 8, 3, 5, img, img, device=dev, generator=torch.Generator(dev).manual_seed(1234))
+    target = [None]
+
+    def one():
+        score_, mask_ = model(x)
+        B, NP, SQ, B2, NS, _ = mask_.size()
+        if target[0] is None:   # the reference builds the target once (dpc/main.py:211, process_output)
+            target[0] = (mask_ == 1).view(B * NP * SQ, B2 * NS * SQ).to(int).argmax(dim=1)
+        loss = criterion(score_.view(B * NP * SQ, B2 * NS * SQ), target[0])
+        del score_
+        optimizer.zero_grad()
+        loss.backward()
+        optimizer.step()
+        return loss
+
+    for _ in range(warmup):
+        loss = one()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = one()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    out = {"workload": "cfg2 through dpc_amd.model.DPC_RNN(...).bfloat16() + torch CrossEntropyLoss + dpc_amd.optim.Adam: the reference's "
+                       "loop lines, launched kernel by kernel (no hipGraph), score materialised and returned",
+           "value": round(batch * steps / dt, 2), "unit": "clips/s", "ms_per_step": round(1e3 * dt / steps, 3), "steps": steps,
+           "final_loss": round(float(loss.item()), 4)}
+    del model, optimizer, x
+    torch.cuda.empty_cache()
+    return out
+
+
 def cpu_baseline(seconds_budget=24.0):
     """oracle (kind 'port'): forward+CE+top-k+backward+Adam of configs[0] on the host cores; the thread count is
     swept (B=4 oversubscribes a 128-thread pool) and the best rate is reported with the count that gave it."""
@@ -360,12 +430,15 @@ def main():
             del eng, step_fn, block
             torch.cuda.empty_cache()
             out["also"] = {}
-            for name in ("cfg4", "cfg5"):
+            for name, fn in (("cfg4", lambda: side_config("cfg4", dev)), ("cfg5", lambda: side_config("cfg5", dev)),
+                             ("module", lambda: module_loop(dev)), ("f32", lambda: f32_mode(dev))):
                 try:
-                    out["also"][name] = side_config(name, dev)
+                    out["also"][name] = fn()
                 except Exception as e:  # reported, never hidden
                     out["also"][name] = {"error": f"{type(e).__name__}: {str(e)[:160]}"}
                     torch.cuda.synchronize()
+            if "value" in out["also"].get("module", {}):
+                out["also"]["module"]["vs_engine_path"] = round(out["also"]["module"]["value"] / out["value"], 3)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
     if dist is not None:

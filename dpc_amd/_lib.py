@@ -97,6 +97,7 @@ _SIGS = {
     "dpc_pack3d": [_vp, _vp, _i32, _i32, _i32, _i32, _i64, _i64, _i64, _vp],
     "dpc_pack3d_multi": [_vp, _i32, _i32, _i32, _vp],
     "dpc_reduce_unpack": [_vp, _i32, _vp, _i32, _i32, _i32, _i64, _i64, _i64, _i32, _vp],
+    "dpc_transpose2d_bf16x2": [_vp, _vp, _i32, _vp, _vp, _i32, _i32, _i32, _vp],
     "dpc_transpose2d": [_vp, _i32, _i32, _vp, _i32, _i32, _i32, _i32, _vp],
     "dpc_pack_input_s2d": [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp],
     "dpc_pack_stem_weight": [_vp, _vp, _i32, _i32, _vp],

@@ -263,6 +263,66 @@ extern "C" int dpc_transpose2d(const void* in, int32_t dtype_in, int32_t ld_in, 
     return dpc_launch_status();
 }
 
+// two bf16 matrices of one shape transposed by ONE launch (blockIdx.z picks the pair): pred and feature_inf -> the K-contiguous
+// operands of the score's backward products (dpc/model_3d.py:83's autograd); 16-byte loads, a 64 x 64 tile through LDS, 16-byte stores
+__global__ __launch_bounds__(256) void transpose2d_bf16x2_kernel(const bf16_t* in0, const bf16_t* in1, int ld_in, bf16_t* out0, bf16_t* out1, int ld_out,
+                                                                int rows, int cols) {
+    __shared__ unsigned short tile[64][66];
+    const bf16_t* in = blockIdx.z ? in1 : in0;
+    bf16_t* out = blockIdx.z ? out1 : out0;
+    const int bx = blockIdx.x * 64, by = blockIdx.y * 64;   // column / row origin of the input tile
+    const int t = threadIdx.x;
+    {   // 64 rows x 8 units of 8 columns: two rows of units per thread pass
+        DPC_UNROLL
+        for (int it = 0; it < 2; ++it) {
+            const int r = (t >> 3) + 32 * it, u = t & 7;
+            const int row = by + r, col = bx + u * 8;
+            u32x4 v = {0u, 0u, 0u, 0u};
+            if (row < rows && col + 7 < cols) v = *(const u32x4*)(in + (long long)row * ld_in + col);
+            else if (row < rows) {
+                unsigned short e[8];
+                DPC_UNROLL
+                for (int k = 0; k < 8; ++k) e[k] = col + k < cols ? *(const unsigned short*)(in + (long long)row * ld_in + col + k) : (unsigned short)0;
+                v[0] = e[0] | ((unsigned)e[1] << 16); v[1] = e[2] | ((unsigned)e[3] << 16);
+                v[2] = e[4] | ((unsigned)e[5] << 16); v[3] = e[6] | ((unsigned)e[7] << 16);
+            }
+            DPC_UNROLL
+            for (int k = 0; k < 4; ++k) {
+                tile[r][u * 8 + 2 * k] = (unsigned short)(v[k] & 0xffffu);
+                tile[r][u * 8 + 2 * k + 1] = (unsigned short)(v[k] >> 16);
+            }
+        }
+    }
+    __syncthreads();
+    DPC_UNROLL
+    for (int it = 0; it < 2; ++it) {
+        const int c = (t >> 3) + 32 * it, u = t & 7;     // output row = input column bx + c, 8 input rows by + 8u ..
+        const int orow = bx + c, ocol = by + u * 8;
+        if (orow >= cols) continue;
+        unsigned short e[8];
+        DPC_UNROLL
+        for (int k = 0; k < 8; ++k) e[k] = tile[u * 8 + k][c];
+        if (ocol + 7 < rows) {
+            const u32x4 v = {e[0] | ((unsigned)e[1] << 16), e[2] | ((unsigned)e[3] << 16), e[4] | ((unsigned)e[5] << 16), e[6] | ((unsigned)e[7] << 16)};
+            *(u32x4*)(out + (long long)orow * ld_out + ocol) = v;
+        } else {
+            DPC_UNROLL
+            for (int k = 0; k < 8; ++k)
+                if (ocol + k < rows) *(unsigned short*)(out + (long long)orow * ld_out + ocol + k) = e[k];
+        }
+    }
+}
+
+extern "C" int dpc_transpose2d_bf16x2(const void* in0, const void* in1, int32_t ld_in, void* out0, void* out1, int32_t ld_out, int32_t rows,
+                                      int32_t cols, dpc_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!in0 || !out0 || rows <= 0 || cols <= 0 || ld_in < cols || ld_out < rows) return DPC_ERR_ARG;
+    if (ld_in % 8 || ld_out % 8 || (((uintptr_t)in0 | (uintptr_t)in1 | (uintptr_t)out0 | (uintptr_t)out1) % 16)) return DPC_ERR_UNSUPPORTED;
+    dim3 grid((cols + 63) / 64, (rows + 63) / 64, in1 ? 2 : 1), block(256);
+    DPC_LAUNCH(transpose2d_bf16x2_kernel, grid, block, stream, (const bf16_t*)in0, (const bf16_t*)in1, ld_in, (bf16_t*)out0, (bf16_t*)out1, ld_out, rows, cols);
+    return dpc_launch_status();
+}
+
 // ---- stem: NCDHW f32 video -> 2x2 space-to-depth channels-last, 16 channels (12 live)
 // thread = one (n,t,hb,wb) cell; reads are float2 along W (coalesced NCDHW rows),
 // the write is one contiguous 16-channel cell.

@@ -426,6 +426,92 @@ __global__ __launch_bounds__(256, 2) void score_gemm_kernel(GemmKP p) {
     }
 }
 
+// Round 4 form of the same product (default when the output rows are 16-byte addressable): the 151 MB / 983 MB of f32 score are
+// what bounds it, so everything is arranged around the stores.
+//   * a workgroup is 8 waves = 256 rows sharing the streamed tile (half the LDS-DMA traffic per output of the 4-wave form);
+//   * a wave's 32 x 64 tile (SWAP layout: a lane owns one row and quads of consecutive columns) is staged through 8.5 KB of its own
+//     LDS and leaves as eight 16-byte-per-lane NON-TEMPORAL stores of four whole 256-byte rows each -- the 4-wave form issued 32
+//     four-byte stores per tile (two 128-byte lines each), 3.6 TB/s;
+//   * no wait ever drains the stores: the loop's one wait is a COUNTED vmcnt that retires the tile's LDS-DMA pieces (older than the
+//     previous tile's eight stores, which stay in flight: "CDNA4 vmcnt counts stores too", cdna_hip_programming.md), and the
+//     barrier is the LDS-only one -- __syncthreads() is vmcnt(0) while a DMA is pending.
+constexpr int SG2_ROWB = BN * 4 + 16;          // staging row: 256 B + 16 (a ds_write_b128 lane group then covers all 64 banks)
+constexpr int SG2_WAVE = 32 * SG2_ROWB;        // 8 704 B per wave
+__device__ __forceinline__ void dma_rows8(unsigned char* tile, const bf16_t* src, long long ld, int row0, int row_limit, int ncols, int wave, int lane) {
+    // dma_rows for BN rows and 8 waves: chunks x (BN / 8) pieces, pieces wave, wave + 8, ... (the same count for every wave)
+    const char* const zero = (const char*)dpc_zero16;
+    const int chunks = (ncols * 2 + 127) / 128;
+    constexpr int groups = BN / 8;
+    for (int g = wave; g < chunks * groups; g += 8) {
+        const int c = g / groups, rg = g - c * groups;
+        const int row = rg * 8 + (lane >> 3);
+        const int u = (lane & 7) ^ lds_swz1(row);
+        const int col = (c * 8 + u) * 8;
+        const bool ok = (row0 + row < row_limit) && (col < ncols);
+        const char* a = (const char*)(src + (long long)(row0 + row) * ld + col);
+        glds16(ok ? a : zero, tile + c * (BN * 128) + rg * 8 * 128, lane);
+    }
+}
+
+template <int KS>
+__global__ __launch_bounds__(512, 2) void score_gemm2_kernel(GemmKP p) {
+    DPC_DYN_SMEM(smem);
+    const int lane = threadIdx.x & 63;
+#ifdef DPC_SIMT_EMU
+    const int wave = threadIdx.x >> 6;
+#else
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+#endif
+    constexpr int CH = (KS * 32 + 127) / 128;             // 128-byte K chunks of a streamed row
+    constexpr int TILE = CH * BN * 128;
+    constexpr int PIECES = (CH * (BN / 8) + 7) / 8;       // LDS-DMA instructions per wave and tile (4 at K = 256, 1 at K = 32)
+    static_assert(CH * (BN / 8) % 8 == 0 || CH * (BN / 8) < 8, "every wave issues the same number of pieces (or at most one)");
+    const int rb = blockIdx.x, split = blockIdx.y;
+    const int r0 = rb * 256 + wave * 32;
+    unsigned char* const stg = smem + 2 * TILE + wave * SG2_WAVE;
+    u32x4 own[KS];
+    load_own_ld<KS>(own, p.a, p.lda, p.M, r0, lane);
+    const int jt0 = split * p.tiles_per_split;
+    int jt1 = jt0 + p.tiles_per_split;
+    if (jt1 > p.ntiles) jt1 = p.ntiles;
+    if (jt0 < jt1) dma_rows8(smem, p.b, p.ldb, jt0 * BN, p.N, p.D, wave, lane);
+    const int l31 = lane & 31, lhi = lane >> 5;
+    const int su = lane & 15, sr = lane >> 4;   // store phase: 16-byte unit of the 256-byte row, row inside a group of four
+    // store instructions this wave issues per tile: a group of four rows whose first row is outside the matrix is skipped as a
+    // whole (exec = 0), so the count the wait below leaves in flight is per wave (8 except in the last row block)
+    int nst = 0;
+    DPC_UNROLL
+    for (int it = 0; it < 8; ++it) nst += (r0 + 4 * it < p.M) ? 1 : 0;
+    for (int jt = jt0; jt < jt1; ++jt) {
+        const int buf = (jt - jt0) & 1;
+        // the pieces of tile jt are older than the nst stores of tile jt - 1: let at most those stay in flight (if the compiler issues
+        // a fully masked store anyway, the wait is merely stricter)
+        if (jt == jt0) wait_vmcnt<0>(); else wait_vmcnt_upto(nst);
+        barrier_lds_only();  // tile jt has landed; every wave is done with the buffer the next DMA overwrites
+        if (jt + 1 < jt1) dma_rows8(smem + (buf ^ 1) * TILE, p.b, p.ldb, (jt + 1) * BN, p.N, p.D, wave, lane);
+        f32x16 s[2];
+        s_tile<KS, true>(s, own, smem + buf * TILE, lane);
+        DPC_UNROLL
+        for (int t = 0; t < 2; ++t)
+            DPC_UNROLL
+            for (int k = 0; k < 4; ++k) {
+                const f32x4 v = {s[t][4 * k], s[t][4 * k + 1], s[t][4 * k + 2], s[t][4 * k + 3]};
+                *(f32x4*)(stg + l31 * SG2_ROWB + (t * 32 + 8 * k + 4 * lhi) * 4) = v;
+            }
+        wave_lds_fence();
+        f32x4 ov[8];
+        DPC_UNROLL
+        for (int it = 0; it < 8; ++it) ov[it] = *(const f32x4*)(stg + (4 * it + sr) * SG2_ROWB + su * 16);
+        wave_lds_fence();  // the next tile's staging writes must not pass these reads
+        const int c = jt * BN + su * 4;
+        DPC_UNROLL
+        for (int it = 0; it < 8; ++it) {
+            const int row = r0 + 4 * it + sr;
+            if (row < p.M && c < p.N) __builtin_nontemporal_store(ov[it], (f32x4*)(p.out + (long long)row * p.ldo + c));   // N % 4 == 0 (vec)
+        }
+    }
+}
+
 template <class K> int allow_lds(K kernel, size_t bytes) {
 #ifndef DPC_SIMT_EMU
     if (bytes > 160 * 1024) return DPC_ERR_UNSUPPORTED;
@@ -466,8 +552,27 @@ int dpc_score_gemm_try(const dpc_conv_desc* d, const void* src, const void* wgt,
     p.a = (const bf16_t*)src; p.b = (const bf16_t*)wgt; p.out = (float*)out;
     p.M = d->N; p.N = d->Co; p.D = d->Ci; p.lda = d->src_ld; p.ldb = d->ldw; p.ldo = d->ldo;
     p.vec = (d->ldo % 4 == 0 && ((uintptr_t)out % 16) == 0) ? 1 : 0;
-    const int nrb = (p.M + BM - 1) / BM;
     p.ntiles = (p.N + BN - 1) / BN;
+    static const int v2 = getenv("DPC_SCORE_GEMM2") ? atoi(getenv("DPC_SCORE_GEMM2")) : 1;
+    if (v2 && p.vec && p.N % 4 == 0) {   // 8-wave form: staged full-row non-temporal stores, counted waits (see score_gemm2_kernel)
+        const int nrb2 = (p.M + 255) / 256;
+        int sp2 = (dpc_persistent_grid(256) + nrb2 - 1) / nrb2;   // one workgroup per CU
+        if (sp2 > p.ntiles / 4) sp2 = p.ntiles / 4 > 0 ? p.ntiles / 4 : 1;
+        if (sp2 < 1) sp2 = 1;
+        p.tiles_per_split = (p.ntiles + sp2 - 1) / sp2;
+        p.nsplit = (p.ntiles + p.tiles_per_split - 1) / p.tiles_per_split;
+        const dim3 grid2(nrb2, p.nsplit);
+        const size_t lds2 = 2 * (size_t)((p.D * 2 + 127) / 128) * BN * 128 + 8 * (size_t)SG2_WAVE;
+        if (p.D == 256) {
+            if (int e = allow_lds(score_gemm2_kernel<16>, lds2)) return e;
+            DPC_LAUNCH_DYN((score_gemm2_kernel<16>), grid2, dim3(512), lds2, stream, p);
+        } else {
+            if (int e = allow_lds(score_gemm2_kernel<2>, lds2)) return e;
+            DPC_LAUNCH_DYN((score_gemm2_kernel<2>), grid2, dim3(512), lds2, stream, p);
+        }
+        return dpc_launch_status();
+    }
+    const int nrb = (p.M + BM - 1) / BM;
     int sp = (512 + nrb - 1) / nrb;   // two workgroups per CU
     if (sp > p.ntiles / 4) sp = p.ntiles / 4 > 0 ? p.ntiles / 4 : 1;
     if (sp < 1) sp = 1;

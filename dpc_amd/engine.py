@@ -27,6 +27,7 @@ import atexit
 import contextlib
 import ctypes as C
 import os
+import weakref
 import math
 from typing import Dict, List, Optional, Sequence, Tuple
 
@@ -429,6 +430,19 @@ class _Block:
         return dx
 
 
+# live engines by the address of their parameter arena (weak: an engine dies with its owner)
+ENGINES: "weakref.WeakValueDictionary[int, DPCEngine]" = weakref.WeakValueDictionary()
+
+
+def engine_of(param: torch.Tensor) -> "Optional[DPCEngine]":
+    """the engine whose flat parameter arena `param` is a view of (None: an ordinary tensor)"""
+    a = param.data_ptr()
+    for base, eng in list(ENGINES.items()):
+        if base <= a < base + eng.flat_p.numel() * 4:
+            return eng
+    return None
+
+
 class DPCEngine:
     BN_RUNNING = False
     BN_MOMENTUM = 0.1  # torch.nn.BatchNorm3d default
@@ -499,6 +513,7 @@ class DPCEngine:
         self.flat_m = torch.zeros_like(self.flat_p)
         self.flat_v = torch.zeros_like(self.flat_p)
         self.PRM = {k: self.flat_p[o:o + n].view(self.shapes[k]) for k, (o, n) in self.offsets.items()}
+        ENGINES[self.flat_p.data_ptr()] = self   # dpc_amd.optim.Adam finds the engine behind a module's parameters (views of flat_p)
         self.G = {k: self.flat_g[o:o + n].view(self.shapes[k]) for k, (o, n) in self.offsets.items()}
 
         # ---- backbone plan
@@ -997,9 +1012,14 @@ class DPCEngine:
                 self.dscore.zero_()
             self.dscore[:, :R].copy_(src)  # module-boundary path only (torch hands over an arbitrary d/dscore)
         # score = pred @ finf^T  ->  d_pred = dS @ finf ; d_finf = dS^T @ pred
-        self.call("dpc_transpose2d", self.feat_inf, dc, D, self.finfT, dc, self.ld_d, R, D)
+        both = self.cdtype == torch.bfloat16 and ((self._score_fused and dscore_external is None) or bool(self._tn_splits))
+        if both:   # feature_inf^T and pred^T, one launch
+            self.call("dpc_transpose2d_bf16x2", self.feat_inf, self.pred, D, self.finfT, self.predT, self.ld_d, R, D)
+        else:
+            self.call("dpc_transpose2d", self.feat_inf, dc, D, self.finfT, dc, self.ld_d, R, D)
         if self._score_fused and dscore_external is None:
-            self.call("dpc_transpose2d", self.pred, dc, D, self.predT, dc, self.ld_d, R, D)
+            if not both:
+                self.call("dpc_transpose2d", self.pred, dc, D, self.predT, dc, self.ld_d, R, D)
             with self.tag("score"):
                 for own, oth, othT, by_owner, out in ((self.pred, self.feat_inf, self.finfT, 1, self.d_pred),
                                                       (self.feat_inf, self.pred, self.predT, 0, self.d_finf)):
@@ -1008,8 +1028,6 @@ class DPCEngine:
         else:
             if self._score_fused:
                 raise L.DpcError("backward(dscore_external=...) needs a materialised score: call forward(materialise=True)")
-            if self._tn_splits:
-                self.call("dpc_transpose2d", self.pred, dc, D, self.predT, dc, self.ld_d, R, D)
             with self.tag("score"):
                 self.gemm_splitk(self.dscore, self.finfT, self.d_pred, R, D, self.ld_d, self.ld_d, self.ld_d)
                 if self._tn_splits:

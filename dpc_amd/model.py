@@ -11,10 +11,19 @@ the kernels (and the fused Adam of ``engine.train_step``) work on one contiguous
 ``forward`` returns a score that autograd can differentiate: its backward runs the
 engine's hand-written backward kernels and hands the parameter gradients to autograd.
 There is no CPU path: calling it with CPU tensors raises (dpc_amd._lib.DpcError).
+
+Nothing is copied at the boundary (round 4): the returned score is the engine's own buffer
+(two alternate, so the previous step's score outlives one more forward), the gradients
+reach autograd as fresh views of the gradient arena, which AccumulateGrad adopts as
+``.grad``, and ``dpc_amd.optim.Adam`` is the fused arena update behind
+``torch.optim.Optimizer``'s interface.  ``model.bfloat16()`` / ``model.float()`` (or
+``DPC_COMPUTE_DTYPE=bf16``) select the kernels' operand type; parameters stay f32.
+bench.py times the reference's own loop lines over this module (``also.module``).
 """
 from __future__ import annotations
 
 import math
+import os
 from typing import Dict, List, Optional
 
 import torch
@@ -61,28 +70,48 @@ class _DPCScore(torch.autograd.Function):
     @staticmethod
     def forward(ctx, model, block, train, masks, *params):
         eng = model._engine
-        score = eng.forward(block, train=train, dropout_masks=masks)
-        ctx.model = model
         # The engine keeps ONE set of saved activations (static schedule): the graph node is only valid until the
         # next forward through the same engine, and for one backward.
         model._fwd_generation += 1
+        # The returned score IS the engine's buffer (no 151 MB / 983 MB copy per forward).  Two buffers alternate, so the score of
+        # the previous forward stays readable for one more step (the reference's loop deletes it before the next iteration,
+        # dpc/main.py:227); after that the handle shows a later step's values.
+        eng.score = model._score_buffers(eng)[model._fwd_generation & 1]
+        score = eng.forward(block, train=train, dropout_masks=masks)
+        ctx.model = model
         ctx.generation = model._fwd_generation
         ctx.used = False
-        return score.clone()  # engine buffer is reused next step
+        return score
 
     @staticmethod
     def backward(ctx, dscore):
-        eng = ctx.model._engine
-        if ctx.generation != ctx.model._fwd_generation:
+        model = ctx.model
+        eng = model._engine
+        if ctx.generation != model._fwd_generation:
             raise RuntimeError("dpc_amd.DPC_RNN: backward of a score whose saved activations were overwritten by a later "
                                "forward (the engine holds one step's activations; call backward before the next forward)")
         if ctx.used:
             raise RuntimeError("dpc_amd.DPC_RNN: trying to backward through the graph a second time (activations are "
                                "consumed in place by the backward kernels)")
         ctx.used = True
+        names = model._param_names
+        # Parameter gradients go back through autograd as FRESH views of the engine's gradient arena: AccumulateGrad adopts a
+        # gradient nobody else holds instead of copying it, so after loss.backward() a parameter's .grad IS its slice of the arena
+        # (no 58 MB of copies; dpc_amd.optim.Adam and torch's foreach Adam read it in place) while everything that hooks the
+        # autograd graph -- DistributedDataParallel's reducer, parameter hooks -- still sees every gradient arrive.
+        named = dict(model.named_parameters())
+        aliased = any(named[k].grad is not None and named[k].grad.data_ptr() == eng.G[k].data_ptr() for k in names)
+        old = eng.flat_g.clone() if aliased else None   # .grad still set (no zero_grad): torch accumulates; the kernels overwrite the arena
         eng.backward(dscore_external=dscore)
-        grads = tuple(eng.G[k].clone() for k in ctx.model._param_names)
-        return (None, None, None, None) + grads
+        src = eng.flat_g
+        if old is not None:   # hand autograd a copy of the new gradients and give the arena (= the live .grad tensors) its old values back
+            src = eng.flat_g.clone()
+            eng.flat_g.copy_(old)
+        grads = []
+        for k in names:
+            o, n = eng.offsets[k]
+            grads.append(src[o:o + n].view(eng.shapes[k]))
+        return (None, None, None, None) + tuple(grads)
 
 
 class DPC_RNN(nn.Module):
@@ -107,6 +136,10 @@ class DPC_RNN(nn.Module):
         self._forced_masks = None
         self._fwd_generation = 0
         self._simulator = _simulator  # tests only: the host-side SIMT simulator handle (CPU tier); never set by the product
+        self._score_bufs = None
+        if os.environ.get("DPC_COMPUTE_DTYPE"):   # select the throughput mode without touching the reference's constructor call
+            self.compute_dtype = {"bf16": torch.bfloat16, "bfloat16": torch.bfloat16, "f32": torch.float32, "float32": torch.float32}[
+                os.environ["DPC_COMPUTE_DTYPE"].lower()]
         shapes = param_shapes(network, widths)
         init = _init_reference_style(shapes, torch.Generator().manual_seed(seed))
         for k, shp in shapes.items():
@@ -138,7 +171,8 @@ class DPC_RNN(nn.Module):
             raise L.DpcError("dpc_amd.DPC_RNN runs on MI355X only: move the module and the input to a cuda (HIP) device")
         self._ensure_engine(block)
         self._engine.packed_for_step = -1  # parameters may have been changed by an external optimizer
-        params = [dict(self.named_parameters())[k] for k in self._param_names]
+        named = dict(self.named_parameters())
+        params = [named[k] for k in self._param_names]
         score = _DPCScore.apply(self, block.float(), self.training, self._forced_masks, *params)
         if self.mask is None:  # only compute mask once (model_3d.py:86-96); contiguous
             self.mask = self._engine.get_mask()
@@ -146,6 +180,22 @@ class DPC_RNN(nn.Module):
 
     def reset_mask(self):
         self.mask = None
+
+    # ---- compute dtype through the calls a user of the reference would make.  Parameters stay f32 (master weights of the
+    # fused Adam, the reference's state_dict dtype); only the kernels' operand type changes, and the engine is rebuilt at the
+    # next forward.  model.bfloat16() = throughput mode (BASELINE configs[1]), model.float() = the 1e-3 parity mode.
+    def bfloat16(self):
+        self.compute_dtype = torch.bfloat16
+        return self
+
+    def float(self):
+        self.compute_dtype = torch.float32
+        return self
+
+    def _score_buffers(self, eng):
+        if self._score_bufs is None or self._score_bufs[0].shape != eng.score.shape or self._score_bufs[0].device != eng.score.device:
+            self._score_bufs = (eng.score, torch.empty_like(eng.score))
+        return self._score_bufs
 
     @property
     def engine(self) -> Optional[DPCEngine]:

@@ -158,6 +158,10 @@ int dpc_pack3d_multi(const dpc_pack_entry* table_dev, int32_t n_entries, int32_t
 /* out[i0*s0+i1*s1+i2*s2] (f32) = sum_{k<nsplit} part[k][i0][i1][i2]  (+ out if accumulate) */
 int dpc_reduce_unpack(const float* part, int32_t nsplit, float* out, int32_t d0, int32_t d1, int32_t d2,
                       int64_t s0, int64_t s1, int64_t s2, int32_t accumulate, dpc_stream_t stream);
+/* two bf16 matrices of one shape in one launch: outK[j][i] = inK[i][j] (in1 / out1 may be NULL); 16-byte aligned, ld % 8 == 0.
+ * pred and feature_inf -> the K-contiguous operands of the score's backward products (autograd of dpc/model_3d.py:83). */
+int dpc_transpose2d_bf16x2(const void* in0, const void* in1, int32_t ld_in, void* out0, void* out1, int32_t ld_out, int32_t rows,
+                           int32_t cols, dpc_stream_t stream);
 /* 2-D transpose/convert between element types: out[j][i] = in[i][j] */
 int dpc_transpose2d(const void* in, int32_t dtype_in, int32_t ld_in, void* out, int32_t dtype_out, int32_t ld_out,
                     int32_t rows, int32_t cols, dpc_stream_t stream);

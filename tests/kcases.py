@@ -516,6 +516,22 @@ def case_transpose(k: K, rows, cols, seed=12):
     assert torch.equal(o[:, :rows].cpu(), a.t().bfloat16())
 
 
+def case_transpose_x2(k: K, rows, cols, seed=21):
+    """dpc_transpose2d_bf16x2: two bf16 matrices in one launch; padding columns of the outputs stay untouched (zero)"""
+    g = torch.Generator().manual_seed(seed)
+    a, b = torch.randn(rows, cols, generator=g).bfloat16(), torch.randn(rows, cols, generator=g).bfloat16()
+    ld = (rows + 7) // 8 * 8
+    oa, ob = k.zeros(cols, ld, dtype=torch.bfloat16), k.zeros(cols, ld, dtype=torch.bfloat16)
+    k.call("dpc_transpose2d_bf16x2", k.t(a), k.t(b), cols, oa, ob, ld, rows, cols)
+    k.sync()
+    assert torch.equal(oa[:, :rows].cpu(), a.t()) and torch.equal(ob[:, :rows].cpu(), b.t())
+    assert not oa[:, rows:].any() and not ob[:, rows:].any()
+    oc = k.zeros(cols, ld, dtype=torch.bfloat16)
+    k.call("dpc_transpose2d_bf16x2", k.t(b), None, cols, oc, None, ld, rows, cols)
+    k.sync()
+    assert torch.equal(oc[:, :rows].cpu(), b.t())
+
+
 def case_pack3d_multi(k: K, dtype, shapes, seed=14):
     """dpc_pack3d_multi: every conv weight [Co][Ci][taps] f32 -> [Co][tap][Ci] and [Ci][tap][Co] in the compute dtype, one launch
     over a device-side table (the engine's per-step repack; tiled through LDS when the source is contiguous along the middle index)"""

@@ -160,3 +160,69 @@ def test_fused_backward_epilogues_match_the_separate_kernels(emu):
     for k, (o, n) in eng.offsets.items():
         a, b = out[0][o:o + n], out[1][o:o + n]
         assert (a - b).abs().max().item() <= 2e-5 * max(b.abs().max().item(), 1e-6), k
+
+
+def test_module_boundary_copies_nothing_and_keeps_torch_semantics(emu):
+    """dpc/main.py:198-231 over dpc_amd.model.DPC_RNN: the returned score is the engine's buffer, after loss.backward() every .grad is
+    a view of the gradient arena (AccumulateGrad adopts the fresh views), dpc_amd.optim.Adam == torch.optim.Adam step for step,
+    a second backward without zero_grad accumulates like torch, and the optimizer state moves to torch's Adam and back."""
+    from dpc_amd.model import DPC_RNN
+    from dpc_amd.optim import Adam
+    x = O.make_input_pcg(1, 8, 5, 64)
+    crit = torch.nn.CrossEntropyLoss()
+
+    def make(opt_cls):
+        m = DPC_RNN(64, 8, 5, 3, "resnet18", widths=WIDTHS, seed=4, _simulator=emu)
+        m.eval()   # no dropout: the two replicas see the same function
+        return m, opt_cls(m.parameters(), lr=1e-3, weight_decay=1e-5)
+
+    def loss_of(m):
+        score_, mask_ = m(x)
+        B, NP, SQ, B2, NS, _ = mask_.size()
+        target = (mask_ == 1).view(B * NP * SQ, B2 * NS * SQ).to(int).argmax(dim=1)
+        return crit(score_.view(B * NP * SQ, B2 * NS * SQ), target), score_
+
+    (ma, oa), (mb, ob) = make(Adam), make(torch.optim.Adam)
+    with pytest.raises(RuntimeError):
+        oa.step()   # no engine yet: nothing to update, loud
+
+    def backward_once(m, o, zero=True):
+        loss, score_ = loss_of(m)
+        assert score_.data_ptr() in [b.data_ptr() for b in m._score_bufs]
+        if zero:
+            o.zero_grad()
+        loss.backward()
+        adopted = [p.grad.data_ptr() == m.engine.G[k].data_ptr() for k, p in m.named_parameters() if not k.startswith("agg.cell_list")]
+        assert all(adopted), f"{sum(adopted)} of {len(adopted)} gradients are arena views"
+
+    backward_once(ma, oa)
+    g1 = {k: p.grad.clone() for k, p in ma.named_parameters()}
+    backward_once(ma, oa, zero=False)   # no zero_grad: torch accumulates -- same input, same parameters: exactly twice the gradient
+    for k, p in ma.named_parameters():
+        assert torch.equal(p.grad, 2 * g1[k]), k
+        p.grad.mul_(0.5)
+    backward_once(mb, ob)
+    for k, p in mb.named_parameters():
+        assert torch.equal(p.grad, g1[k]), k
+    oa.step()
+    ob.step()
+    assert ma.engine.step_count == 1
+    for (ka, pa), (kb, pb) in zip(ma.named_parameters(), mb.named_parameters()):   # fused arena Adam == torch.optim.Adam (1 ulp)
+        assert ka == kb and (pa - pb).abs().max().item() <= 1e-7 * max(1.0, pb.abs().max().item()), ka
+    # optimizer state in torch.optim.Adam's layout: loads into torch's Adam, and into a fresh dpc_amd.optim.Adam (at once when the
+    # engine exists, at the first step when it does not)
+    sd = oa.state_dict()
+    ob.load_state_dict(sd)
+    assert float(ob.state_dict()["state"][0]["step"]) == 1.0
+    m_before = ma.engine.flat_m.clone()
+    ma.engine.flat_m.zero_()
+    oa2 = Adam(ma.parameters(), lr=5e-4, weight_decay=0.0)
+    oa2.load_state_dict(sd)
+    assert torch.equal(ma.engine.flat_m, m_before) and oa2.param_groups[0]["lr"] == 1e-3
+    mc, oc = make(Adam)
+    oc.load_state_dict(sd)
+    assert oc._pending_state is sd
+    # compute dtype through the module's own calls; parameters stay f32
+    mc.bfloat16()
+    assert mc.compute_dtype == torch.bfloat16 and next(mc.parameters()).dtype == torch.float32
+    assert mc.float().compute_dtype == torch.float32

@@ -120,11 +120,12 @@ def test_gemm_nt(k, dtype, mnk):
     kc.case_gemm_nt(k, dtype, *mnk)
 
 
-@pytest.mark.parametrize("mn", [(1100, 1028), (1027, 1027)])
-def test_score_gemm(k, mn):
-    """large bf16 -> f32 NT GEMM with a short reduction (the materialised score): register-resident rows, streamed column tiles,
-    16-byte row stores (1028: ragged last tile; 1027: odd leading dimension -> element-wise stores)"""
-    kc.case_gemm_nt(k, BF16, mn[0], mn[1], 32, expect="score_gemm_kernel<2,")
+@pytest.mark.parametrize("mn,kern", [((1100, 1028), "score_gemm2_kernel<2>"), ((1027, 1027), "score_gemm_kernel<2,"), ((1030, 1092), "score_gemm2_kernel<2>")])
+def test_score_gemm(k, mn, kern):
+    """large bf16 -> f32 NT GEMM with a short reduction (the materialised score): register-resident rows, streamed column tiles.
+    1100 x 1028 / 1030 x 1092: the 8-wave form (staged whole-row stores; ragged last row block incl. waves without any row, ragged last
+    column tile); 1027: odd leading dimension -> the 4-wave form with element-wise stores"""
+    kc.case_gemm_nt(k, BF16, mn[0], mn[1], 32, expect=kern)
 
 
 @pytest.mark.parametrize("dtype", [F32, BF16])
@@ -172,6 +173,7 @@ def test_adam(k):
 
 def test_transpose(k):
     kc.case_transpose(k, 70, 45)
+    kc.case_transpose_x2(k, 132, 72)   # ragged tiles in both directions, padded output rows
 
 
 def test_copy2d_multi(k):

@@ -118,7 +118,7 @@ def test_conv_dgrad_ex(k, dtype, shape, gate, bn_relu, kern):
 @pytest.mark.parametrize("mnk", [(6144, 6144, 256), (6468, 6468, 256), (15680, 15680, 256), (2048, 768, 256), (192, 192, 256), (130, 70, 64)])
 def test_gemm_nt(k, dtype, mnk):
     big = dtype == BF16 and mnk[2] == 256 and mnk[0] >= 1024 and mnk[1] >= 512   # the materialised score: dedicated kernel
-    kc.case_gemm_nt(k, dtype, *mnk, expect="score_gemm_kernel<16," if big else ("igemm_kernel" if dtype == BF16 else None))
+    kc.case_gemm_nt(k, dtype, *mnk, expect="score_gemm2_kernel<16>" if big else ("igemm_kernel" if dtype == BF16 else None))
 
 
 @pytest.mark.parametrize("dtype", [F32, BF16])
@@ -186,6 +186,8 @@ def test_adam(k):
 
 def test_transpose(k):
     kc.case_transpose(k, 6468, 256)
+    kc.case_transpose_x2(k, 6468, 256)
+    kc.case_transpose_x2(k, 15680, 256)
 
 
 def test_copy2d_multi(k):
