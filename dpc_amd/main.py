@@ -90,6 +90,11 @@ def _worker(rank: int, world: int, args, port: int):
 
     if args.model != 'dpc-rnn':
         raise ValueError('wrong model!')  # dpc/main.py:63
+    if args.train_what == 'last':
+        # dpc/main.py:69-72 freezes `model.module.resnet`, an attribute DPC_RNN never had (the backbone is `.backbone`,
+        # dpc/model_3d.py:29): the reference dies right there with this error, and so does the drop-in -- loudly, not by
+        # silently training everything
+        raise AttributeError("'DPC_RNN' object has no attribute 'resnet'")
     if args.batch_size % world:
         raise ValueError('batch_size must be divisible by the number of GPUs (drop_last semantics, dpc/main.py:313)')
     per_gpu = args.batch_size // world

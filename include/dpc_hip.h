@@ -49,6 +49,11 @@ int dpc_abi_version(void);
  * If `stats` != NULL it receives per-program partial sums [rows][2][Co] (sum, sum of
  * squares of the stored outputs) for the batch-norm that follows; the row count is
  * dpc_conv_stats_rows(desc).
+ * Aliasing: `addend` MAY be the same buffer as `out` (an in-place residual accumulation, dx += conv): every kernel behind
+ * this entry and dpc_conv_igemm_ex reads a 16-byte addend unit in the lane that afterwards stores exactly that unit.  For a
+ * strided input-gradient (mode 1, a stride of 2) with addend == out the positions no tap reaches are left as they are instead
+ * of being rewritten with the addend.  No other pair of arguments may overlap.  tests/kcases.py::case_conv_dgrad_alias
+ * runs every dispatch variant both ways (case_conv_dgrad_inplace: the untouched positions).
  */
 typedef struct dpc_conv_desc {
     int32_t dtype_in, dtype_out; /* DPC_F32 / DPC_BF16 */

@@ -279,6 +279,21 @@ def test_full_batch_properties(dtype):
     mk = eng.get_mask().view(R, R)
     assert torch.equal((mk == 1).sum(1), torch.ones(R, dtype=torch.long, device=DEV))
     assert torch.equal((mk == 1).to(torch.int8).argmax(1), torch.arange(R, device=DEV))
+    # every value of the reference's mask in its closed-form count (dpc/model_3d.py:86-96): same clip -> -3 (spatial negatives),
+    # same clip and position -> -1 (temporal negatives), same clip, position and step -> 1; everything else 0
+    P, SQ = 3, eng.SQ
+    counts = {int(v): int((mk == v).sum().item()) for v in (-3, -1, 0, 1)}
+    assert counts == {1: B * P * SQ, -1: B * P * P * SQ - B * P * SQ, -3: B * (P * SQ) ** 2 - B * P * P * SQ, 0: R * R - B * (P * SQ) ** 2}, counts
+    if dtype == torch.bfloat16:
+        # validate() (dpc_amd/main.py: forward(train=False, materialise=False) + loss_topk(False)): the fused eval path against the
+        # materialised score of the same eval forward
+        assert eng.forward(x, train=False, materialise=False) is None and eng.score_mode == "fused"
+        ev_f = eng.loss_topk(False).clone().cpu()
+        eng.forward(x, train=False, materialise=True)
+        ev_m = eng.loss_topk(False).clone().cpu()
+        loss_t = torch.nn.functional.cross_entropy(eng.score, torch.arange(R, device=DEV)).item()
+        assert abs(ev_m[0].item() - loss_t) < 1e-3 and abs(ev_f[0].item() - ev_m[0].item()) < 1e-3
+        assert ev_f[1:].tolist() == pytest.approx(ev_m[1:].tolist(), abs=3.0 / R)
     # loss goes down when the same batch is revisited (optimizer + backward are wired correctly)
     for _ in range(4):
         res = eng.train_step(x, dropout_masks=None)

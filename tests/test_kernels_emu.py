@@ -89,6 +89,18 @@ def test_conv_dgrad(k, dtype, shape):
 
 
 @pytest.mark.parametrize("dtype", [F32, BF16])
+@pytest.mark.parametrize("shape,gate", [
+    ((2, 64, 64, 2, 9, 33, (1, 3, 3), (1, 1, 1), (0, 1, 1)), False),     # patch kernel (bf16: role-specialised)
+    ((2, 64, 64, 2, 9, 33, (1, 3, 3), (1, 1, 1), (0, 1, 1)), True),      # ... with the addend gated by a ReLU mask (dpc_conv_igemm_ex)
+    ((1, 32, 32, 3, 6, 6, (3, 3, 3), (1, 1, 1), (1, 1, 1)), False),      # generic kernel
+    ((2, 16, 64, 5, 8, 8, (3, 3, 3), (2, 2, 2), (1, 1, 1)), False),      # strided: parity classes
+    ((2, 8, 64, 2, 8, 8, (1, 1, 1), (1, 2, 2), (0, 0, 0)), False),       # strided 1x1x1: 3 of 4 classes see no tap (left as they are)
+])
+def test_conv_dgrad_addend_may_alias_out(k, dtype, shape, gate):
+    kc.case_conv_dgrad_alias(k, dtype, *shape, gate=gate)
+
+
+@pytest.mark.parametrize("dtype", [F32, BF16])
 @pytest.mark.parametrize("shape", [
     (2, 16, 64, 2, 9, 9, (1, 3, 3), (1, 1, 1), (0, 1, 1)),
     (2, 64, 72, 3, 8, 8, (3, 3, 3), (2, 2, 2), (1, 1, 1)),

@@ -77,6 +77,21 @@ def test_conv_dgrad(k, dtype, shape):
     kc.case_conv_dgrad(k, dtype, *shape[:9], expect=shape[9] if dtype == BF16 else None)
 
 
+@pytest.mark.parametrize("shape,gate", [
+    ((66, 64, 64, 1, 32, 32, (1, 3, 3), (1, 1, 1), (0, 1, 1), "conv_halo_ws_kernel<true,8,128>"), False),
+    ((66, 64, 64, 1, 32, 32, (1, 3, 3), (1, 1, 1), (0, 1, 1), "conv_halo_ws_kernel<true,8,128,true>"), True),
+    ((66, 128, 128, 1, 16, 16, (1, 3, 3), (1, 1, 1), (0, 1, 1), "igemm_wsp_kernel<true>"), False),
+    ((87, 256, 256, 3, 8, 8, (3, 3, 3), (1, 1, 1), (1, 1, 1), "igemm_ws_kernel<true>"), False),
+    ((16, 256, 256, 3, 8, 8, (3, 3, 3), (1, 1, 1), (1, 1, 1), "igemm_kernel<T,TO,BN,1>"), False),
+    ((16, 256, 256, 3, 8, 8, (3, 3, 3), (1, 1, 1), (1, 1, 1), "igemm_kernel<T,TO,BN,1,true>"), True),   # the engine's last block: gated, generic kernel
+    ((6, 128, 256, 5, 16, 16, (3, 3, 3), (2, 2, 2), (1, 1, 1), "igemm_kernel<T,TO,BN,3>"), False),      # strided: parity classes, in-place accumulation
+    ((5, 128, 256, 5, 16, 16, (1, 1, 1), (2, 2, 2), (0, 0, 0), "igemm_kernel<T,TO,BN,3>"), False),      # the in-place 1x1 downsample gradient
+])
+def test_conv_dgrad_addend_may_alias_out(k, shape, gate):
+    """include/dpc_hip.h: addend == out is part of the contract -- every dispatch variant that takes an addend, both ways"""
+    kc.case_conv_dgrad_alias(k, BF16, *shape[:9], expect=shape[9], gate=gate)
+
+
 @pytest.mark.parametrize("dtype", [F32, BF16])
 @pytest.mark.parametrize("shape", [
     (4, 64, 64, 3, 32, 32, (1, 3, 3), (1, 1, 1), (0, 1, 1), "wgrad_patch_kernel<32>"),
