@@ -97,13 +97,14 @@ def side_config(name, dev, steps=8, warmup=2, roof_steps=2):
     return out
 
 
-def f32_mode(dev, steps=4):
-    """cfg2 in the f32 parity mode (the mode north_star's 1e-3 tolerance is stated in): a few hipGraph replays, same process"""
+def f32_mode(dev, steps=4, matmul="exact"):
+    """cfg2 in the f32 parity mode (the mode north_star's 1e-3 tolerance is stated in): a few hipGraph replays, same process.
+    matmul="bf16x6": the same f32 tensors, contractions on the bf16 matrix pipe with three-way split operands (dpc_set_f32_matmul)"""
     from dpc_amd.engine import DPCEngine
     from dpc_amd.model import DPC_RNN
     cfg = CONFIGS["cfg2"]
     net, img, P, batch = cfg["net"], cfg["img_dim"], cfg["pred_step"], cfg["batch"]
-    eng = DPCEngine(net, img, 8, 5, P, batch, dev, torch.float32, seed=233)
+    eng = DPCEngine(net, img, 8, 5, P, batch, dev, torch.float32, seed=233, f32_matmul=matmul)
     init = DPC_RNN(img, network=net, pred_step=P, seed=0)
     eng.load_params({k: v.detach() for k, v in init.named_parameters()})
     del init
@@ -116,8 +117,10 @@ def f32_mode(dev, steps=4):
         res = step()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    out = {"workload": "cfg2 in f32 end to end (exact f32 MFMA chains): the mode in which score / mask / top-k match the reference's CPU "
-                       "path within 1e-3 (tests/test_engine_gpu.py)", "dtype": "f32", "value": round(batch * steps / dt, 2), "unit": "clips/s",
+    what = ("exact f32 MFMA chains" if matmul == "exact" else
+            "f32 tensors, contractions as bf16x6: operands split three ways onto the bf16 matrix pipe, f32 accumulate")
+    out = {"workload": f"cfg2 in f32 end to end ({what}): score / mask / top-k match the reference's CPU path within 1e-3 in this mode "
+                       "(tests/test_engine_gpu.py)", "dtype": "f32" if matmul == "exact" else "f32 (bf16x6 matmul)", "value": round(batch * steps / dt, 2), "unit": "clips/s",
            "ms_per_step": round(1e3 * dt / steps, 3), "steps": steps, "final_loss": round(res.cpu().tolist()[0], 4)}
     del eng, step, block
     torch.cuda.empty_cache()
@@ -222,7 +225,8 @@ def main():
     ap.add_argument("--net", default=None)
     ap.add_argument("--img_dim", type=int, default=None)
     ap.add_argument("--pred_step", type=int, default=None)
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"], help="f32 = the parity mode (1e-3 vs the reference)")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32", "bf16x6"],
+                    help="f32 = the parity mode (1e-3 vs the reference); bf16x6 = f32 tensors with the contractions on the bf16 matrix pipe (parity-grade)")
     ap.add_argument("--roofline-steps", type=int, default=4, help="steps of the separately instrumented pass")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -266,7 +270,7 @@ def main():
     cdt = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     from dpc_amd.parallel import default_reserve_cus
     eng = DPCEngine(net, img, 8, 5, P, batch, dev, cdt, seed=233 + rank, score_path=args.score_path,
-                    reserve_cus=default_reserve_cus(world))
+                    reserve_cus=default_reserve_cus(world), f32_matmul="bf16x6" if args.dtype == "bf16x6" else "exact")
     init = DPC_RNN(img, network=net, pred_step=P, seed=0)  # reference init, same on all ranks
     eng.load_params({k: v.detach() for k, v in init.named_parameters()})
     del init
@@ -431,7 +435,8 @@ def main():
             torch.cuda.empty_cache()
             out["also"] = {}
             for name, fn in (("cfg4", lambda: side_config("cfg4", dev)), ("cfg5", lambda: side_config("cfg5", dev)),
-                             ("module", lambda: module_loop(dev)), ("f32", lambda: f32_mode(dev))):
+                             ("module", lambda: module_loop(dev)), ("f32", lambda: f32_mode(dev)),
+                             ("f32_bf16x6", lambda: f32_mode(dev, matmul="bf16x6"))):
                 try:
                     out["also"][name] = fn()
                 except Exception as e:  # reported, never hidden

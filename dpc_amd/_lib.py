@@ -93,6 +93,7 @@ _SIGS = {
     "dpc_conv_plan": [C.POINTER(ConvDesc), _i32, _i32, _i32, C.c_char_p, _i32],
     "dpc_last_kernel": [C.c_char_p, _i32],
     "dpc_set_reserved_cus": [_i32],
+    "dpc_set_f32_matmul": [_i32],
     "dpc_diag_squat": [_i32, _i32, _i32, _i32, _i32, _vp, _i64, _vp, _vp, _vp],
     "dpc_pack3d": [_vp, _vp, _i32, _i32, _i32, _i32, _i64, _i64, _i64, _vp],
     "dpc_pack3d_multi": [_vp, _i32, _i32, _i32, _vp],

@@ -46,7 +46,7 @@ struct IGemmParams {
     int nks, kcps;
     long long slab;  // elements of TO between slabs
     int xcd_cols;    // column tiles of a row tile on one XCD (launch_igemm_bn)
-
+    int x6;          // f32 operands: contractions as bf16x6 (dpc_rt.h) instead of f32 MFMA chains
 };
 
 #ifndef DPC_IGEMM_DMA
@@ -321,6 +321,27 @@ __global__ __launch_bounds__(256, (BN == 64 ? 3 : 2)) void igemm_kernel(IGemmPar
                 return;
             }
 #endif
+            if constexpr (sizeof(T) == 4) {
+                if (p.x6) {   // bf16x6: K steps in pairs (two units = 8 f32 per lane), every fragment split once, six MFMAs per block pair
+                    DPC_UNROLL
+                    for (int kp = 0; kp < 2; ++kp) {
+                        Split3 sa[2], sb[NT];
+                        DPC_UNROLL
+                        for (int i = 0; i < 2; ++i)
+                            sa[i] = split3_f32x8(*(const u32x4*)(lds + bufoff + frag_a[2 * kp] + 4096 * i),
+                                                 *(const u32x4*)(lds + bufoff + frag_a[2 * kp + 1] + 4096 * i));
+                        DPC_UNROLL
+                        for (int j = 0; j < NT; ++j)
+                            sb[j] = split3_f32x8(*(const u32x4*)(lds + bufoff + frag_b[2 * kp] + 4096 * j),
+                                                 *(const u32x4*)(lds + bufoff + frag_b[2 * kp + 1] + 4096 * j));
+                        DPC_UNROLL
+                        for (int i = 0; i < 2; ++i)
+                            DPC_UNROLL
+                            for (int j = 0; j < NT; ++j) acc[i][j] = mfma_f32x6(sa[i], sb[j], acc[i][j]);
+                    }
+                    return;
+                }
+            }
             DPC_UNROLL
             for (int kk = 0; kk < 4; ++kk) {
                 u32x4 fa[2], fb[NT];
@@ -631,6 +652,7 @@ extern "C" int dpc_conv_igemm_ex(const dpc_conv_desc* d, const void* src, const 
 static int conv_igemm_impl(const dpc_conv_desc* d, const void* src, const void* wgt, void* out, const void* addend, float* stats,
                            const EpiExtra& epi, hipStream_t stream) {
     IGemmParams p;
+    p.x6 = dpc_f32_matmul_mode();
     int rc = make_gather_geom(d, &p.g);
     if (rc) return rc;
     if (!src || !wgt || !out) return DPC_ERR_ARG;
@@ -686,6 +708,7 @@ extern "C" int dpc_gemm_nt_splitk(int32_t dtype, int32_t M, int32_t N, int32_t K
     }
     dpc_conv_desc d = {dtype, DPC_F32, 0, M, 1, 1, 1, 1, 1, 1, K, lda, N, ldb, N, 1, 1, 1, 1, 1, 1, 0, 0, 0};
     IGemmParams p;
+    p.x6 = dpc_f32_matmul_mode();
     int rc = make_gather_geom(&d, &p.g);
     if (rc) return rc;
     int bn;

@@ -22,6 +22,7 @@ struct WgradParams {
     int Co, dy_ld;
     int nks, kcps;  // K-splits, position-chunks per split
     int ntm, ntn;
+    int x6;         // f32 operands: contractions as bf16x6 (dpc_rt.h)
 };
 
 template <class T> struct Transposer;
@@ -200,6 +201,30 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
         if (ch + 1 < c_end) load_chunk(ch + 1);
         const unsigned char* As = lds + buf * (TM + TN) * 128;
         const unsigned char* Bs = As + TM * 128;
+        bool done = false;
+        if constexpr (sizeof(T) == 4) {
+            if (p.x6) {   // bf16x6: unit pairs (2 kp, 2 kp + 1) per lane half = 8 f32 of K, split once per fragment
+                DPC_UNROLL
+                for (int kp = 0; kp < 2; ++kp) {
+                    const int u0 = 4 * kp + lhi, u1 = u0 + 2;
+                    Split3 sa[MI], sb[NT];
+                    DPC_UNROLL
+                    for (int i = 0; i < MI; ++i)
+                        sa[i] = split3_f32x8(*(const u32x4*)(As + lds_unit_off3(wm * (TM / 2) + i * 32 + l31, u0)),
+                                             *(const u32x4*)(As + lds_unit_off3(wm * (TM / 2) + i * 32 + l31, u1)));
+                    DPC_UNROLL
+                    for (int j = 0; j < NT; ++j)
+                        sb[j] = split3_f32x8(*(const u32x4*)(Bs + lds_unit_off3(wn * (TN / 2) + j * 32 + l31, u0)),
+                                             *(const u32x4*)(Bs + lds_unit_off3(wn * (TN / 2) + j * 32 + l31, u1)));
+                    DPC_UNROLL
+                    for (int i = 0; i < MI; ++i)
+                        DPC_UNROLL
+                        for (int j = 0; j < NT; ++j) acc[i][j] = mfma_f32x6(sa[i], sb[j], acc[i][j]);
+                }
+                done = true;
+            }
+        }
+        if (!done) {
         DPC_UNROLL
         for (int kk = 0; kk < 4; ++kk) {
             const int unit = 2 * kk + lhi;
@@ -212,6 +237,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
             for (int i = 0; i < MI; ++i)
                 DPC_UNROLL
                 for (int j = 0; j < NT; ++j) acc[i][j] = mfma_unit<T>(fa[i], fb[j], acc[i][j]);
+        }
         }
         if (ch + 1 < c_end) store_chunk(buf ^ 1);
         __syncthreads();
@@ -258,6 +284,7 @@ struct Wgrad2Params {
     int RWm, RHm;  // padded width / height - 1
     int Mv;        // rows of the padded position grid (== g.M when RW, RH are powers of two)
     int xcd_remap;
+    int x6;        // f32 operands: contractions as bf16x6 (dpc_rt.h)
 };
 
 template <class T, int NWM, int NWN, bool PU>
@@ -484,6 +511,28 @@ __global__ __launch_bounds__(64 * NWM * NWN, 2) void wgrad2_kernel(Wgrad2Params 
                     DPC_UNROLL
                     for (int j = 0; j < 2; ++j) acc[i][j] = mfma_32x32x16_bf16(fa[i], fb[j], acc[i][j]);
             }
+        } else if (p.x6) {
+            // bf16x6 (dpc_rt.h): 16 positions per step, a lane half takes the eight positions 16 s + 2 e + lhi (the rows the f32 chain
+            // reads in eight steps), split once per fragment, six bf16 MFMAs per block pair
+            DPC_UNROLL
+            for (int s16 = 0; s16 < BKP / 16; ++s16) {
+                Split3 sa[2], sb[2];
+                DPC_UNROLL
+                for (int i = 0; i < 2; ++i) {
+                    float xa[8], xb[8];
+                    DPC_UNROLL
+                    for (int e = 0; e < 8; ++e) {
+                        xa[e] = *(const float*)(As + fo[i] + 2 * (8 * s16 + e) * RB);
+                        xb[e] = *(const float*)(Bs + fo[i] + 2 * (8 * s16 + e) * RB);
+                    }
+                    sa[i] = split3_f32(xa);
+                    sb[i] = split3_f32(xb);
+                }
+                DPC_UNROLL
+                for (int i = 0; i < 2; ++i)
+                    DPC_UNROLL
+                    for (int j = 0; j < 2; ++j) acc[i][j] = mfma_f32x6(sa[i], sb[j], acc[i][j]);
+            }
         } else {
             DPC_UNROLL
             for (int s2 = 0; s2 < BKP / 2; ++s2) {
@@ -579,6 +628,7 @@ extern "C" int dpc_conv_wgrad(const dpc_conv_desc* d, const void* src, const voi
                               float* part, int32_t* nsplit, dpc_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     WgradParams p;
+    p.x6 = dpc_f32_matmul_mode();
     if (!d || d->mode != 0) return DPC_ERR_ARG;
     int rc = make_gather_geom(d, &p.g);
     if (rc) return rc;
@@ -636,7 +686,7 @@ extern "C" int dpc_conv_wgrad(const dpc_conv_desc* d, const void* src, const voi
         Wgrad2Params q;
         q.g = p.g; q.src = src; q.dy = dy; q.part = part; q.Co = d->Co; q.dy_ld = dy_ld;
         q.nks = p.nks; q.kcps = p.kcps; q.ntm = p.ntm; q.ntn = p.ntn; q.lRW = lrw; q.lRH = lrh;
-        q.RWm = rwp - 1; q.RHm = rhp - 1; q.Mv = (int)mv;
+        q.RWm = rwp - 1; q.RHm = rhp - 1; q.Mv = (int)mv; q.x6 = p.x6;
         static const int xcd_remap = (getenv("DPC_WGRAD_XCD") && getenv("DPC_WGRAD_XCD")[0] == '0') ? 0 : 1;  // read once
         q.xcd_remap = xcd_remap;
         const bool pu = (rwp * rhp) % bkp == 0;  // a chunk never leaves its (n, t) plane

@@ -228,6 +228,47 @@ template <> __device__ __forceinline__ f32x16 mfma_unit<bf16_t>(const u32x4& a, 
     return mfma_32x32x16_bf16(a, b, c);
 }
 
+// ---- "bf16x6": f32 operands on the bf16 matrix pipe at f32-grade accuracy (round 4; profiles/r04_bf16x3_feasibility.txt).
+// x = x1 + x2 + x3 with x1 = bf16(x), x2 = bf16(x - x1), x3 = bf16(x - x1 - x2) (24 mantissa bits in three pieces); a product
+// keeps the six terms a_i b_j with i + j <= 4 -- everything down to 2^-24 |a||b| -- accumulated in f32, smallest first.
+// Six v_mfma_f32_32x32x16_bf16 (32 cycles each) replace eight v_mfma_f32_32x32x2_f32 (64 cycles each) per K = 16: 2.7x the f32
+// matrix rate.  Measured against the reference's fp32 scores on the CPU model of this arithmetic: 1.1e-4 .. 1.7e-4 (the two-piece
+// "bf16x3" misses north_star's 1e-3: 1.0e-3 .. 2.5e-3).  Two 16-byte units (8 f32, K index = the element order) per operand.
+struct Split3 {
+    u32x4 p[3];
+};
+__device__ __forceinline__ Split3 split3_f32x8(const u32x4& u0, const u32x4& u1) {
+    Split3 s;
+    DPC_UNROLL
+    for (int q = 0; q < 4; ++q) {
+        const float x0 = __builtin_bit_cast(float, q < 2 ? u0[2 * q] : u1[2 * q - 4]);
+        const float x1 = __builtin_bit_cast(float, q < 2 ? u0[2 * q + 1] : u1[2 * q - 3]);
+        const uint32_t h = bf16x2_pack(x0, x1);
+        const float r0 = x0 - __builtin_bit_cast(float, h << 16), r1 = x1 - __builtin_bit_cast(float, h & 0xffff0000u);
+        const uint32_t m = bf16x2_pack(r0, r1);
+        const float t0 = r0 - __builtin_bit_cast(float, m << 16), t1 = r1 - __builtin_bit_cast(float, m & 0xffff0000u);
+        s.p[0][q] = h;
+        s.p[1][q] = m;
+        s.p[2][q] = bf16x2_pack(t0, t1);
+    }
+    return s;
+}
+__device__ __forceinline__ Split3 split3_f32(const float (&x)[8]) {   // the same from eight loose values (K index = array index)
+    const u32x4 u0 = {__builtin_bit_cast(uint32_t, x[0]), __builtin_bit_cast(uint32_t, x[1]), __builtin_bit_cast(uint32_t, x[2]), __builtin_bit_cast(uint32_t, x[3])};
+    const u32x4 u1 = {__builtin_bit_cast(uint32_t, x[4]), __builtin_bit_cast(uint32_t, x[5]), __builtin_bit_cast(uint32_t, x[6]), __builtin_bit_cast(uint32_t, x[7])};
+    return split3_f32x8(u0, u1);
+}
+__device__ __forceinline__ f32x16 mfma_f32x6(const Split3& a, const Split3& b, f32x16 c) {
+    c = mfma_32x32x16_bf16(a.p[2], b.p[0], c);
+    c = mfma_32x32x16_bf16(a.p[0], b.p[2], c);
+    c = mfma_32x32x16_bf16(a.p[1], b.p[1], c);
+    c = mfma_32x32x16_bf16(a.p[1], b.p[0], c);
+    c = mfma_32x32x16_bf16(a.p[0], b.p[1], c);
+    return mfma_32x32x16_bf16(a.p[0], b.p[0], c);
+}
+// process-wide switch (dpc_set_f32_matmul, csrc/plan.hip): 0 = exact f32 MFMA chains, 1 = bf16x6
+int dpc_f32_matmul_mode();
+
 // LDS tile rows are 128 bytes = 8 units of 16 B; unit u of row r lives at slot u ^ swz(r).
 // swz1(r) = (r>>1)&7: a ds_read_b128 lane group (16 distinct rows, same logical unit) touches all 64
 //   banks once, and swz1(r+32) == swz1(r) so +32-row fragments are immediate offsets (conv_igemm.hip).

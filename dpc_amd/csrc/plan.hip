@@ -24,6 +24,15 @@ extern "C" int dpc_set_reserved_cus(int32_t n) {
     g_reserved_cus = n;
     return prev;
 }
+// how the f32 kernels multiply (dpc_rt.h "bf16x6"): read at launch time on the host, travels as a kernel argument
+static int g_f32_matmul = 0;
+int dpc_f32_matmul_mode() { return g_f32_matmul; }
+extern "C" int dpc_set_f32_matmul(int32_t mode) {
+    if (mode != 0 && mode != 1) return DPC_ERR_ARG;
+    const int prev = g_f32_matmul;
+    g_f32_matmul = mode;
+    return prev;
+}
 static thread_local char tls_name[192] = "";
 static thread_local char tls_detail[96] = "";
 

@@ -553,8 +553,12 @@ int dpc_score_gemm_try(const dpc_conv_desc* d, const void* src, const void* wgt,
     p.M = d->N; p.N = d->Co; p.D = d->Ci; p.lda = d->src_ld; p.ldb = d->ldw; p.ldo = d->ldo;
     p.vec = (d->ldo % 4 == 0 && ((uintptr_t)out % 16) == 0) ? 1 : 0;
     p.ntiles = (p.N + BN - 1) / BN;
-    static const int v2 = getenv("DPC_SCORE_GEMM2") ? atoi(getenv("DPC_SCORE_GEMM2")) : 1;
-    if (v2 && p.vec && p.N % 4 == 0) {   // 8-wave form: staged full-row non-temporal stores, counted waits (see score_gemm2_kernel)
+    const int v2 = getenv("DPC_SCORE_GEMM2") ? atoi(getenv("DPC_SCORE_GEMM2")) : 1;   // 0: never, 1: by size (default), 2: whenever the shape allows (tests)
+    // the 8-wave form (staged whole-row non-temporal stores, counted waits) wins where the stores dominate -- R = 15 680: 319 -> 169 us
+    // = 5.8 TB/s of score writes -- and loses its fixed cost on ten tiles per workgroup (R = 6 144: 44.8 against 42.1 us); rows that
+    // are not cache-line multiples (R = 6 468) make a non-temporal store a partial-line write: 85 against 45 us.  Hence: large
+    // outputs with 128-byte-aligned rows only (profiles/r04_head_kernels.txt).
+    if (v2 && p.vec && p.N % 4 == 0 && (v2 > 1 || ((long long)p.M * p.N >= (1ll << 26) && p.ldo % 32 == 0))) {
         const int nrb2 = (p.M + 255) / 256;
         int sp2 = dpc_persistent_grid(256) / nrb2;   // one workgroup per CU (132 KB of LDS) and ONE wave of workgroups: rounding up put
                                                       // 264 of them on 256 CUs at R = 6 144 -- 50.8 us against 42 for the 4-wave form

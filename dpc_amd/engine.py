@@ -242,6 +242,7 @@ class _ConvBN:
         self.stat_rows_d = 0 if stem else eng.lib.call("dpc_conv_stats_rows", C.byref(self.desc_d))
         eng.need_stats(self.stat_rows_d * 2 * Ci)
         self.reduced_rows = 0  # > 0: the partial sums of THIS unit's backward reduction are already in eng.stats (that many rows)
+        self._coef_ready = False  # bn_prepare ran: eng.coef holds this unit's backward coefficients
 
     # ---- per-optimizer-step repack of the f32 parameter into MFMA operand layouts
     def pack_entries(self):
@@ -294,6 +295,23 @@ class _ConvBN:
         dc = L.dtype_code(e.cdtype)
         mask = ext_mask if ext_mask is not None else (self.mask if relu else None)
         gated = int(relu or ext_mask is not None)
+        if not self._coef_ready:
+            self.bn_prepare(dy, y, relu, ext_mask)
+        self._coef_ready = False
+        e.call("dpc_bn_bwd_apply", dy, None if mask is not None else y, mask, self.raw, dc, self.rows, self.Co, self.mean,
+               self.invstd, e.PRM[self.bnname + ".weight"], e.coef, gated, dx, dz)
+
+    def bn_prepare(self, dy: torch.Tensor, y: Optional[torch.Tensor], relu: bool, ext_mask: Optional[torch.Tensor] = None):
+        """first half of bn_backward: partial sums (unless the launch that produced dy took them) -> coefficients in eng.coef.
+        Callable on its own so that the 2..8-workgroup finalize kernel is enqueued BEFORE a weight gradient is forked onto the side
+        stream: behind it, it waits for a CU -- its 1 024-thread workgroups fit on no CU beside two wgrad_patch workgroups -- until
+        the first weight-gradient workgroup retires, 120..230 us on the critical path (profiles/r03_r18_128_step_timeline.txt:
+        bn_bwd_finalize 212 us at 23.07 ms against 5 us elsewhere; 0.75 ms per step in profiles/r04_*_sessionC against 0.15 ms
+        of work).  Nothing else may write eng.coef between this call and the matching bn_backward."""
+        e = self.eng
+        dc = L.dtype_code(e.cdtype)
+        mask = ext_mask if ext_mask is not None else (self.mask if relu else None)
+        gated = int(relu or ext_mask is not None)
         if self.reduced_rows:
             prow, self.reduced_rows = self.reduced_rows, 0
         else:
@@ -303,8 +321,7 @@ class _ConvBN:
             prow = pr.value
         e.call("dpc_bn_bwd_finalize", e.stats, prow, self.Co, float(self.rows), e.G[self.bnname + ".weight"],
                e.G[self.bnname + ".bias"], e.coef)
-        e.call("dpc_bn_bwd_apply", dy, None if mask is not None else y, mask, self.raw, dc, self.rows, self.Co, self.mean,
-               self.invstd, e.PRM[self.bnname + ".weight"], e.coef, gated, dx, dz)
+        self._coef_ready = True
 
     def wgrad(self, x: torch.Tensor, draw: torch.Tensor):
         e = self.eng
@@ -401,6 +418,8 @@ class _Block:
             self.ds.bn_backward(dout, None, False, draw_d, ext_mask=omask)
         dact1 = e.scratch(oshape, exclude=[dout, draw2, draw_d, dz])
         self.c2.dgrad(draw2, dact1, None, red=self.c1 if self.fold_c1 else None)
+        if self.fold_c1 and e._early_finalize:   # coefficients of bn1 before the side stream fills the chip (bn_prepare)
+            self.c1.bn_prepare(dact1, self.act1, True)
         with e.side(reads=[draw2, draw_d], kind=1):   # beside bn1's backward on the main stream
             if self.ds is not None:
                 self.ds.wgrad(self.x_in, draw_d)
@@ -422,6 +441,9 @@ class _Block:
             # in place over dout: every lane reads its addend unit before it stores the same unit (all kernels behind the entry)
             dx = dout
             self.c1.dgrad(draw1, dx, dout, addend_mask=omask, red=self.prev.c2 if self.fold_prev else None)
+            if self.fold_prev and e._early_finalize:   # the previous block's bn2 (its backward is the next thing on the main stream)
+                pv = self.prev
+                pv.c2.bn_prepare(dx, pv.out if pv.final_relu else None, pv.final_relu)
         else:
             dx = dact1  # same shape as the input; dact1 is dead
             self.c1.dgrad(draw1, dx, dz)
@@ -451,7 +473,7 @@ class DPCEngine:
                  pred_step: int = 3, batch: int = 4, device="cuda", compute_dtype=torch.float32,
                  widths: Sequence[int] = LAYER_WIDTH, lib: Optional[L.Lib] = None,
                  lr: float = 1e-3, wd: float = 1e-5, dropout: float = 0.1, seed: int = 233, score_path: str = "auto", stem_fused: bool | None = None,
-                 fold: bool | None = None, reserve_cus: int | None = None):
+                 fold: bool | None = None, reserve_cus: int | None = None, f32_matmul: str | None = None):
         self.device = torch.device(device)
         self.lib = L.lib_for(self.device, lib)  # raises unless HIP device (or an explicit simulator handle in tests)
         self.cdtype = compute_dtype
@@ -487,6 +509,14 @@ class DPCEngine:
         # two-bucket exchange is running; data-parallel callers pass parallel.default_reserve_cus(world) (= the RCCL channel count:
         # measured with a co-tenant on one GPU, profiles/r04_cotenant.txt), single-GPU runs 0.
         self.reserve_cus = int(os.environ.get("DPC_RESERVE_CUS", "0")) if reserve_cus is None else int(reserve_cus)
+        # arithmetic of the f32 kernels' contractions (include/dpc_hip.h: dpc_set_f32_matmul): "exact" = f32 MFMA chains (default),
+        # "bf16x6" = operands split three ways onto the bf16 matrix pipe -- f32-grade results (the reference goldens hold at 1e-3:
+        # tests/test_engine_gpu.py), up to 2.7x the f32 matrix rate.  Only meaningful with compute_dtype=float32.
+        mm = (f32_matmul or os.environ.get("DPC_F32_MATMUL", "exact")).lower()
+        if mm not in ("exact", "bf16x6"):
+            raise ValueError("f32_matmul must be 'exact' or 'bf16x6'")
+        self.f32_matmul = mm
+        self._x6 = 1 if (mm == "bf16x6" and compute_dtype == torch.float32) else 0
         self._pack_table = None
         self._gate_table = None
         # weight gradients on a second stream beside the next unit's BatchNorm backward (side() below); DPC_WGRAD_STREAM=0: one stream.
@@ -494,6 +524,7 @@ class DPCEngine:
         # repacks); DPC_SIDE_QUIET=0 lets side work run beside input-gradients too (slower, and not bit-reproducible: see side())
         self._side = (torch.cuda.Stream(self.device) if self.device.type == "cuda" and int(os.environ.get("DPC_WGRAD_STREAM", "1")) else None)
         self._on_side = False
+        self._early_finalize = bool(int(os.environ.get("DPC_EARLY_FINALIZE", "1")))   # A/B switch for _ConvBN.bn_prepare's ordering
         self._side_mask = int(os.environ.get("DPC_SIDE_MASK", "15"))
         self._side_quiet = bool(int(os.environ.get("DPC_SIDE_QUIET", "1")))
         self._busy = []   # [(event recorded on the side stream, scratch buffers its launches read)], oldest first
@@ -710,6 +741,9 @@ class DPCEngine:
         self.need_part(ns.value * Co * K)
 
     def call(self, name, *args):
+        if getattr(self.lib, "_f32_mode", 0) != self._x6:   # process-wide library state, read when a launch is planned: keep it ours
+            self.lib.call("dpc_set_f32_matmul", self._x6)
+            self.lib._f32_mode = self._x6
         tm = self.timer
         if tm is not None and name in tm.names:
             return tm.timed(self, name, args)

@@ -136,6 +136,14 @@ int dpc_last_kernel(char* name, int32_t cap);
  * follows the setting: query it under the same value the launch sees. */
 int dpc_set_reserved_cus(int32_t n);
 
+/* Arithmetic of the f32 kernels' contractions (dtype_in == DPC_F32 in dpc_conv_igemm / dpc_conv_wgrad / dpc_gemm_nt_splitk):
+ *   0  exact f32 MFMA chains (v_mfma_f32_32x32x2_f32, 157 TFLOP/s peak) -- the default, bitwise an fmaf chain;
+ *   1  "bf16x6": each f32 operand split into three bf16 pieces in registers, the six products down to 2^-24 on the bf16 matrix
+ *      pipe, f32 accumulation -- f32-grade results (score within 2e-4 of the reference's fp32 CPU path, north_star asks 1e-3) at up
+ *      to 2.7x the f32 matrix rate.  Operands, activations and outputs stay f32 in HBM.
+ * Process-wide host state read when a launch is planned; returns the previous mode. */
+int dpc_set_f32_matmul(int32_t mode);
+
 /* Diagnostic co-tenant ("squatter"): n_wg workgroups of `waves` (1..4) waves that hold lds_bytes of LDS (multiple of 16, up to
  * 160 KB) for usec microseconds and do nothing (mode 0), LDS traffic over their own allocation (1), 16-byte loads over
  * scratch[scratch_bytes] (2) or VALU work (3).  where[n_wg] (optional) receives 0x80000000 | XCC_ID << 16 | HW_ID[15:0] per

@@ -108,7 +108,7 @@ def case_conv_fwd(k: K, dtype, N, Ci, Co, T, H, W, ks, st, pd, seed=0, expect=No
     assert relerr(out, cl(y)) < tol(dtype)
     if taps > 1:
         wm = w.clone()
-        wm[:, :, ks[0] - 1, ks[1] - 1, 0] = 0   # one tap gone
+        wm[:, :, ks[0] // 2, ks[1] // 2, ks[2] // 2] = 0   # the centre tap gone (the one tap every output position sees)
         rejects_dropped_tap(out, cl(y), cl(F.conv3d(x, wm, None, st, pd)), tol(dtype))
     o = out.float().cpu().reshape(-1, Co).double()
     s = stats.cpu().double()
@@ -136,7 +136,7 @@ def case_conv_dgrad(k: K, dtype, N, Ci, Co, T, H, W, ks, st, pd, seed=1, expect=
     assert relerr(out, want) < tol(dtype)
     if taps > 1:
         wm = w.clone()
-        wm[:, :, 0, ks[1] - 1, ks[2] - 1] = 0
+        wm[:, :, ks[0] // 2, ks[1] // 2, ks[2] // 2] = 0   # centre tap: a corner tap of a strided, padded conv may never touch the input
         gxm = cl(torch.autograd.grad(F.conv3d(x, wm, None, st, pd), x, gy)[0])
         rejects_dropped_tap(out, want, gxm + add if with_add else gxm, tol(dtype))
 
@@ -266,7 +266,7 @@ def case_conv_wgrad(k: K, dtype, N, Ci, Co, T, H, W, ks, st, pd, seed=2, expect=
     assert relerr(dw, gw) < 1e-4  # f32 accumulation in both modes
     if taps > 1:
         gm = gw.clone()
-        gm[:, :, ks[0] - 1, 0, ks[2] - 1] = 0
+        gm[:, :, ks[0] // 2, ks[1] // 2, ks[2] // 2] = 0
         rejects_dropped_tap(dw, gw, gm, 1e-4)
 
 

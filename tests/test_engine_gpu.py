@@ -21,23 +21,25 @@ def gold(golden_dir, name):
     return np.load(os.path.join(golden_dir, name), allow_pickle=False)
 
 
-def engine(net, size, B, dtype=torch.float32, P=3):
-    eng = DPCEngine(net, size, 8, 5, P, B, DEV, dtype)
+def engine(net, size, B, dtype=torch.float32, P=3, matmul="exact"):
+    eng = DPCEngine(net, size, 8, 5, P, B, DEV, dtype, f32_matmul=matmul)
     assert eng.lib.kind == "hip" and eng.lib.path.endswith("libdpc_hip.so")
     eng.load_params(O.make_params_pcg(net))
     return eng
 
 
+@pytest.mark.parametrize("matmul", ["exact", "bf16x6"])   # both arithmetics of the f32 mode hold north_star's 1e-3
 @pytest.mark.parametrize("tag,net,size,B,P", [("r18_64_b2", "resnet18", 64, 2, 3), ("r34_64_b2", "resnet34", 64, 2, 3),
                                               ("r18_128_b4", "resnet18", 128, 4, 3),
                                               ("r34_64_b2_p5", "resnet34", 64, 2, 5)])  # cfg5's net + pred_step together
-def test_eval_score_vs_reference(golden_dir, tag, net, size, B, P):
+def test_eval_score_vs_reference(golden_dir, tag, net, size, B, P, matmul):
     g = gold(golden_dir, "eval_scores_p5.npz" if P == 5 else "eval_scores.npz")
-    eng = engine(net, size, B, P=P)
+    eng = engine(net, size, B, P=P, matmul=matmul)
     x = O.make_input_pcg(B, 8, 5, size).to(DEV)
     score = eng.forward(x, train=False).cpu()
     ref = torch.from_numpy(g["score_" + tag])
     assert score.shape == ref.shape
+    print(f"{tag} [{matmul}]: max |score - reference| = {(score - ref).abs().max().item():.3e}")
     assert (score - ref).abs().max().item() < TOL
     res = eng.loss_topk(False).cpu()
     loss, accs = O.loss_and_topk(ref)
@@ -49,9 +51,10 @@ def test_eval_score_vs_reference(golden_dir, tag, net, size, B, P):
     assert torch.equal(eng.get_mask().cpu(), O.mask_closed_form(B, P, eng.SQ))
 
 
-def test_train_step_vs_reference(golden_dir):
+@pytest.mark.parametrize("matmul", ["exact", "bf16x6"])
+def test_train_step_vs_reference(golden_dir, matmul):
     g = gold(golden_dir, "train.npz")
-    eng = engine("resnet18", 64, 2)
+    eng = engine("resnet18", 64, 2, matmul=matmul)
     x = O.make_input_pcg(2, 8, 5, 64).to(DEV)
     score = eng.forward(x, train=False).cpu()  # golden run had dropout p=0
     assert (score - torch.from_numpy(g["score_p0"])).abs().max().item() < TOL

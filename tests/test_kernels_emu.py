@@ -133,10 +133,11 @@ def test_gemm_nt(k, dtype, mnk):
 
 
 @pytest.mark.parametrize("mn,kern", [((1100, 1028), "score_gemm2_kernel<2>"), ((1027, 1027), "score_gemm_kernel<2,"), ((1030, 1092), "score_gemm2_kernel<2>")])
-def test_score_gemm(k, mn, kern):
+def test_score_gemm(k, mn, kern, monkeypatch):
     """large bf16 -> f32 NT GEMM with a short reduction (the materialised score): register-resident rows, streamed column tiles.
     1100 x 1028 / 1030 x 1092: the 8-wave form (staged whole-row stores; ragged last row block incl. waves without any row, ragged last
     column tile); 1027: odd leading dimension -> the 4-wave form with element-wise stores"""
+    monkeypatch.setenv("DPC_SCORE_GEMM2", "2")   # the 8-wave form regardless of the output size (by default it serves >= 2^26 elements)
     kc.case_gemm_nt(k, BF16, mn[0], mn[1], 32, expect=kern)
 
 
@@ -248,3 +249,27 @@ def test_conv_dgrad_inplace(k, dtype, shape):
 def test_stem_wgrad_fused(k):
     kc.case_stem_wgrad_fused(k, 2, 2, 128, 128)   # one 64-position segment per row
     kc.case_stem_wgrad_fused(k, 1, 1, 20, 200)    # ragged last segment, odd pooled width
+
+
+@pytest.fixture
+def x6(k):
+    """f32 kernels in "bf16x6" arithmetic (include/dpc_hip.h: dpc_set_f32_matmul) for the duration of a test"""
+    prev = k.lib.call("dpc_set_f32_matmul", 1)
+    yield
+    k.lib.call("dpc_set_f32_matmul", prev)
+
+
+def test_f32_kernels_in_bf16x6_arithmetic(k, x6):
+    """every f32 contraction kernel with its operands split three ways onto the bf16 matrix pipe: same cases, same f32 tolerances
+    (1e-4 of max-abs for the convolutions, 1e-5 for the GEMMs against f64) -- the split keeps the products down to 2^-24"""
+    kc.case_conv_fwd(k, F32, 2, 16, 64, 2, 9, 9, (1, 3, 3), (1, 2, 2), (0, 1, 1))
+    kc.case_conv_fwd(k, F32, 1, 32, 32, 3, 6, 6, (3, 3, 3), (1, 1, 1), (1, 1, 1))
+    kc.case_conv_dgrad(k, F32, 2, 16, 64, 5, 8, 8, (3, 3, 3), (2, 2, 2), (1, 1, 1))
+    kc.case_conv_dgrad(k, F32, 1, 128, 128, 1, 10, 16, (1, 3, 3), (1, 1, 1), (0, 1, 1))
+    kc.case_conv_wgrad(k, F32, 2, 64, 72, 3, 8, 8, (3, 3, 3), (2, 2, 2), (1, 1, 1))      # transposing generic kernel
+    kc.case_conv_wgrad(k, F32, 2, 64, 64, 1, 8, 8, (1, 3, 3), (1, 1, 1), (0, 1, 1))      # transpose-read kernel (position-major tiles)
+    kc.case_conv_wgrad(k, F32, 5, 8, 24, 2, 6, 6, (1, 3, 3), (1, 2, 2), (0, 1, 1))
+    kc.case_gemm_nt(k, F32, 200, 100, 264)
+    assert kc.case_gemm_nt_splitk(k, F32, 130, 64, 1024, pad=8) > 1
+    with pytest.raises(L.DpcError):
+        k.lib.call("dpc_set_f32_matmul", 2)

@@ -133,7 +133,16 @@ def test_conv_dgrad_ex(k, dtype, shape, gate, bn_relu, kern):
 @pytest.mark.parametrize("mnk", [(6144, 6144, 256), (6468, 6468, 256), (15680, 15680, 256), (2048, 768, 256), (192, 192, 256), (130, 70, 64)])
 def test_gemm_nt(k, dtype, mnk):
     big = dtype == BF16 and mnk[2] == 256 and mnk[0] >= 1024 and mnk[1] >= 512   # the materialised score: dedicated kernel
-    kc.case_gemm_nt(k, dtype, *mnk, expect="score_gemm2_kernel<16>" if big else ("igemm_kernel" if dtype == BF16 else None))
+    v2 = mnk[0] * mnk[1] >= (1 << 26) and mnk[1] % 32 == 0   # large outputs with cache-line-aligned rows: the 8-wave form
+    kc.case_gemm_nt(k, dtype, *mnk, expect=("score_gemm2_kernel<16>" if v2 else "score_gemm_kernel<16,") if big else ("igemm_kernel" if dtype == BF16 else None))
+
+
+def test_score_gemm_8wave_form_on_ragged_shapes(k, monkeypatch):
+    """score_gemm2_kernel forced onto shapes it does not serve by default: ragged last row block (waves without any row), rows that
+    are not cache-line multiples, R = 6 144"""
+    monkeypatch.setenv("DPC_SCORE_GEMM2", "2")
+    for mnk in ((6468, 6468, 256), (6144, 6144, 256), (1100, 1028, 256)):
+        kc.case_gemm_nt(k, BF16, *mnk, expect="score_gemm2_kernel<16>")
 
 
 @pytest.mark.parametrize("dtype", [F32, BF16])
