@@ -127,6 +127,41 @@ def f32_mode(dev, steps=4, matmul="exact"):
     return out
 
 
+def one_stream(dev, steps=20):
+    """cfg2 with the weight gradients on the main stream (DPC_WGRAD_STREAM=0): what the two-stream schedule of the headline line buys"""
+    from dpc_amd.engine import DPCEngine
+    from dpc_amd.model import DPC_RNN
+    cfg = CONFIGS["cfg2"]
+    net, img, P, batch = cfg["net"], cfg["img_dim"], cfg["pred_step"], cfg["batch"]
+    prev = os.environ.get("DPC_WGRAD_STREAM")
+    os.environ["DPC_WGRAD_STREAM"] = "0"
+    try:
+        eng = DPCEngine(net, img, 8, 5, P, batch, dev, torch.bfloat16, seed=233)
+    finally:
+        if prev is None:
+            os.environ.pop("DPC_WGRAD_STREAM", None)
+        else:
+            os.environ["DPC_WGRAD_STREAM"] = prev
+    init = DPC_RNN(img, network=net, pred_step=P, seed=0)
+    eng.load_params({k: v.detach() for k, v in init.named_parameters()})
+    del init
+    block = torch.randn(batch, 8, 3, 5, img, img, device=dev, generator=torch.Generator(dev).manual_seed(1234))
+    step = eng.capture_train_step(block)
+    for _ in range(3):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    out = {"workload": "cfg2, bf16, hipGraph replay, ONE stream (no weight gradients beside the next unit's BatchNorm backward)",
+           "value": round(batch * steps / dt, 2), "unit": "clips/s", "ms_per_step": round(1e3 * dt / steps, 3), "steps": steps}
+    del eng, step, block
+    torch.cuda.empty_cache()
+    return out
+
+
 def module_loop(dev, steps=10, warmup=3):
     """the reference's own loop lines (dpc/main.py:198-231: model(x) -> CrossEntropyLoss -> zero_grad / backward / optimizer.step)
     over the drop-in module dpc_amd.model.DPC_RNN at cfg2, bf16 compute: what a user who only swaps the import gets"""
@@ -435,13 +470,15 @@ def main():
             torch.cuda.empty_cache()
             out["also"] = {}
             for name, fn in (("cfg4", lambda: side_config("cfg4", dev)), ("cfg5", lambda: side_config("cfg5", dev)),
-                             ("module", lambda: module_loop(dev)), ("f32", lambda: f32_mode(dev)),
+                             ("one_stream", lambda: one_stream(dev)), ("module", lambda: module_loop(dev)), ("f32", lambda: f32_mode(dev)),
                              ("f32_bf16x6", lambda: f32_mode(dev, matmul="bf16x6"))):
                 try:
                     out["also"][name] = fn()
                 except Exception as e:  # reported, never hidden
                     out["also"][name] = {"error": f"{type(e).__name__}: {str(e)[:160]}"}
                     torch.cuda.synchronize()
+            if "ms_per_step" in out["also"].get("one_stream", {}):   # overlapped efficiency: the same kernels on one stream / this schedule's step
+                out["also"]["one_stream"]["two_stream_speedup"] = round(out["also"]["one_stream"]["ms_per_step"] / out["ms_per_step"], 4)
             if "value" in out["also"].get("module", {}):
                 out["also"]["module"]["vs_engine_path"] = round(out["also"]["module"]["value"] / out["value"], 3)
         if world == 1 and not args.no_cpu_baseline:

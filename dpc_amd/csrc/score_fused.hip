@@ -367,6 +367,7 @@ struct GemmKP {
     int M, N, D, lda, ldb, ldo;
     int ntiles, tiles_per_split, nsplit;
     int vec;  // 16-byte stores: ldo % 4 == 0 and out 16-byte aligned
+    int counted;  // score_gemm_kernel: counted vmcnt + LDS-only barrier in the tile loop (DPC_SCORE_GEMM_COUNTED, default 1)
 };
 
 // SWAP: MFMA operands swapped -> a lane owns one output row and quads of consecutive columns -> 16-byte stores.  Fewer store
@@ -388,10 +389,15 @@ __global__ __launch_bounds__(256, 2) void score_gemm_kernel(GemmKP p) {
     if (jt0 < jt1) dma_rows(smem, p.b, p.ldb, jt0 * BN, BN, p.N, 0, p.D, p.D, wave, lane);
     const int row = r0 + (lane & 31), lhi = lane >> 5;
     float* const orow = p.out + (long long)row * p.ldo;
+    // counted wait (round 4): a wave whose 32 rows and whose column tile lie inside the matrix issues exactly 32 (8 in the SWAP form)
+    // stores per tile, all younger than the tile's DMA pieces -- let those stay in flight instead of draining them every tile
+    // (vmcnt counts stores too); edge waves / edge tiles keep the full drain.  p.counted = 0: round 3's loop.
+    const bool rows_inside = r0 + 32 <= p.M;
     for (int jt = jt0; jt < jt1; ++jt) {
         const int buf = (jt - jt0) & 1;
-        wait_vmcnt<0>();
-        __syncthreads();  // tile jt has landed; every wave is done with the buffer the next DMA overwrites
+        const bool prev_full = p.counted && rows_inside && jt > jt0 && jt * BN <= p.N && (!SWAP || p.vec);   // the previous tile (jt - 1) ended at or before column N
+        if (prev_full) { if (SWAP) wait_vmcnt<8>(); else wait_vmcnt<32>(); } else wait_vmcnt<0>();
+        if (p.counted) barrier_lds_only(); else __syncthreads();  // tile jt has landed; every wave is done with the buffer the next DMA overwrites
         if (jt + 1 < jt1) dma_rows(smem + (buf ^ 1) * tile_bytes, p.b, p.ldb, (jt + 1) * BN, BN, p.N, 0, p.D, p.D, wave, lane);
         f32x16 s[2];
         s_tile<KS, SWAP>(s, own, smem + buf * tile_bytes, lane);
@@ -552,6 +558,7 @@ int dpc_score_gemm_try(const dpc_conv_desc* d, const void* src, const void* wgt,
     p.a = (const bf16_t*)src; p.b = (const bf16_t*)wgt; p.out = (float*)out;
     p.M = d->N; p.N = d->Co; p.D = d->Ci; p.lda = d->src_ld; p.ldb = d->ldw; p.ldo = d->ldo;
     p.vec = (d->ldo % 4 == 0 && ((uintptr_t)out % 16) == 0) ? 1 : 0;
+    p.counted = getenv("DPC_SCORE_GEMM_COUNTED") ? atoi(getenv("DPC_SCORE_GEMM_COUNTED")) : 1;
     p.ntiles = (p.N + BN - 1) / BN;
     const int v2 = getenv("DPC_SCORE_GEMM2") ? atoi(getenv("DPC_SCORE_GEMM2")) : 1;   // 0: never, 1: by size (default), 2: whenever the shape allows (tests)
     // the 8-wave form (staged whole-row non-temporal stores, counted waits) wins where the stores dominate -- R = 15 680: 319 -> 169 us

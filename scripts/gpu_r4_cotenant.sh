@@ -1,12 +1,14 @@
 #!/bin/bash
-# round 4, session A: the squatter repro of round 3's "LDS race" (nofix vs fixed library), the co-tenancy cost table, the GPU tier
-# on the build without the LDS claim, one bench line.  Outputs: gpurun_out/a_*.log
+# round 4: the co-tenant experiments behind profiles/r04_cotenant.txt (sessions A and B of the round).
+#   1. squatter on every CU while the layer3 / layer2 input-gradient runs: round 3's code (make nofix) against the fixed library
+#   2. round 3's own repro (weight gradient + slab reduction on a side stream, 15 000 launches), both libraries
+#   3. what a co-tenant that owns k CUs costs the train step under the three exchange schedules
+#   4. the GPU tier beside a co-tenant
 R=$GRAFT_REPO_ROOT; cd $R; mkdir -p gpurun_out
-(timeout 300 python scripts/probes/squat_probe.py 400 l3 2>&1 | grep -v amdgpu.ids) > gpurun_out/a_squat_l3.log
-(timeout 300 python scripts/probes/squat_probe.py 300 l2 2>&1 | grep -v amdgpu.ids) > gpurun_out/a_squat_l2.log
-(timeout 600 python -m pytest tests/test_cotenant_gpu.py -m gpu -q -x -p no:cacheprovider 2>&1 | tail -15) > gpurun_out/a_test_cotenant.log
-(timeout 400 python scripts/probes/cotenant_step.py cfg2 1000 20 8,16,32 2>&1 | grep -v amdgpu.ids) > gpurun_out/a_cotenant_step.log
-(timeout 300 python bench.py --no-cpu-baseline --no-also 2>&1 | tail -1) > gpurun_out/a_bench_cfg2.log
-(timeout 1500 python -m pytest tests -m gpu -q -p no:cacheprovider --deselect tests/test_cotenant_gpu.py 2>&1 | tail -15) > gpurun_out/a_test_full.log
-cat gpurun_out/a_squat_l3.log gpurun_out/a_squat_l2.log gpurun_out/a_test_cotenant.log gpurun_out/a_cotenant_step.log gpurun_out/a_test_full.log
-python -c "import json; d=json.loads(open('gpurun_out/a_bench_cfg2.log').read().strip().splitlines()[-1]); print('cfg2', d['value'], d['ms_per_step'], d['roofline']['frac'], d.get('score_gemm',{}).get('frac'))"
+(timeout 300 python scripts/probes/squat_probe.py 1000 l3 2>&1 | grep -v amdgpu.ids) > gpurun_out/co_squat_l3.log
+(timeout 200 python scripts/probes/squat_probe.py 400 l2 2>&1 | grep -v amdgpu.ids) > gpurun_out/co_squat_l2.log
+(DPC_PROBE_LIB=scripts/probes/libdpc_nofix.so timeout 300 python scripts/probes/corun_probe.py l3 15000 2>&1 | grep -v amdgpu.ids | tail -12) > gpurun_out/co_corun_nofix.log
+(timeout 300 python scripts/probes/corun_probe.py l3 15000 2>&1 | grep -v amdgpu.ids | tail -4) > gpurun_out/co_corun_fixed.log
+(timeout 400 python scripts/probes/cotenant_step.py cfg2 1000 20 8,16,32 2>&1 | grep -v amdgpu.ids) > gpurun_out/co_cotenant_step.log
+(timeout 600 python -m pytest tests/test_cotenant_gpu.py -m gpu -q -x -p no:cacheprovider 2>&1 | tail -5) > gpurun_out/co_test_cotenant.log
+cat gpurun_out/co_*.log

@@ -89,11 +89,16 @@ def test_fused_reduction_of_the_previous_block_is_what_the_standalone_pass_compu
     g = torch.Generator().manual_seed(5)
     dout = (torch.randn(tuple(blk.out.shape), generator=g) * 0.05).to(torch.bfloat16).to(DEV)
     dx = blk.backward(dout.clone(), need_dx=True)
-    rows = prev.c2.reduced_rows
-    assert rows > 0
     u = prev.c2
-    dgam, dbet, coef = (torch.empty(n, device=DEV) for n in (u.Co, u.Co, 2 * u.Co))
-    eng.call("dpc_bn_bwd_finalize", eng.stats, rows, u.Co, float(u.rows), dgam, dbet, coef)
+    if u._coef_ready:   # round 4: the block finalises the carried sums itself, before it forks its weight gradient (bn_prepare)
+        assert u.reduced_rows == 0
+        dgam, dbet = eng.G[u.bnname + ".weight"].clone(), eng.G[u.bnname + ".bias"].clone()
+        u._coef_ready = False
+    else:               # DPC_EARLY_FINALIZE=0: the partial rows wait in eng.stats for the previous block's backward
+        rows = u.reduced_rows
+        assert rows > 0
+        dgam, dbet, coef = (torch.empty(n, device=DEV) for n in (u.Co, u.Co, 2 * u.Co))
+        eng.call("dpc_bn_bwd_finalize", eng.stats, rows, u.Co, float(u.rows), dgam, dbet, coef)
     pr = C.c_int32(0)
     part = torch.empty_like(eng.stats)
     eng.call("dpc_bn_bwd_reduce", dx, None, u.mask, u.raw, L.BF16, u.rows, u.Co, u.mean, u.invstd, 1, part, C.byref(pr))
