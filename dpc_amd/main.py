@@ -75,13 +75,14 @@ def _worker(rank: int, world: int, args, port: int):
     gpus = [int(g) for g in str(args.gpu).split(',') if g != '']
     torch.manual_seed(0)  # dpc/main.py:50
     dev = torch.device('cuda', gpus[rank] if world > 1 else gpus[0])
+    from .parallel import configure_rccl, default_reserve_cus
+    if world > 1:
+        configure_rccl(world)   # before this process's first HIP call: few long-lived RCCL channels beside the backward pass (parallel.py)
     torch.cuda.set_device(dev)
     dist = None
-    from .parallel import configure_rccl, default_reserve_cus
     if world > 1:
         import torch.distributed as dist_
         dist = dist_
-        configure_rccl(world)   # few long-lived channels beside the backward pass (parallel.py); before the communicator exists
         dist.init_process_group('nccl', init_method=f'tcp://127.0.0.1:{port}', rank=rank, world_size=world, device_id=dev)
     from .engine import DPCEngine
     from .model import DPC_RNN

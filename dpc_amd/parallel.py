@@ -37,17 +37,19 @@ def configure_rccl(world: int = 1, environ=os.environ) -> dict:
     pass are.  Measured with a co-tenant of k workgroups x 64 KB LDS for 1 ms on one MI355X (scripts/probes/cotenant_step.py,
     profiles/r04_cotenant.txt): overlapped with all CUs claimed by the persistent grids +1.7..1.8 % of a step, with k CUs left
     free +0.7 % (k = 8) / +0.8 % (16) / +1.3 % (32), not overlapped at all +4.5 %.  Hence for world > 1:
-      NCCL_MIN_NCHANNELS = NCCL_MAX_NCHANNELS = DPC_RCCL_CHANNELS (default 8) unless NCCL_*_NCHANNELS are set explicitly,
+      NCCL_MAX_NCHANNELS = 8 unless it is set explicitly (DPC_RCCL_CHANNELS=n pins NCCL_MIN_NCHANNELS = NCCL_MAX_NCHANNELS = n),
       DPC_RESERVE_CUS defaults to the same number (default_reserve_cus; 0 switches the carve-out off).
     HSA_ENABLE_IPC_MODE_LEGACY=0 (dmabuf IPC is what the host driver supports) is exported for child processes if the launcher
     dropped it; in THIS process it only takes effect when the HSA runtime has not started yet, and is reported accordingly."""
     applied = {}
-    if world > 1 or environ.get("DPC_RCCL_CHANNELS"):
-        ch = int(environ.get("DPC_RCCL_CHANNELS") or DEFAULT_CHANNELS)
+    if environ.get("DPC_RCCL_CHANNELS"):       # asked for: pin the channel count
+        ch = int(environ["DPC_RCCL_CHANNELS"])
         for k in ("NCCL_MIN_NCHANNELS", "NCCL_MAX_NCHANNELS"):
-            if environ.get("DPC_RCCL_CHANNELS") or k not in environ:
-                environ[k] = str(ch)
-                applied[k] = ch
+            environ[k] = str(ch)
+            applied[k] = ch
+    elif world > 1 and "NCCL_MAX_NCHANNELS" not in environ:   # default: only a cap (a forced minimum could exceed what a topology offers)
+        environ["NCCL_MAX_NCHANNELS"] = str(DEFAULT_CHANNELS)
+        applied["NCCL_MAX_NCHANNELS"] = DEFAULT_CHANNELS
     if "HSA_ENABLE_IPC_MODE_LEGACY" not in environ:
         environ["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
         started = torch.cuda.is_initialized()

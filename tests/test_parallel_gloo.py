@@ -135,12 +135,13 @@ def test_rccl_defaults_for_data_parallel_runs():
     assert configure_rccl(1, env) == {"DPC_RESERVE_CUS": 0} and "NCCL_MAX_NCHANNELS" not in env
     env = {"HSA_ENABLE_IPC_MODE_LEGACY": "0"}
     got = configure_rccl(8, env)
-    assert got["NCCL_MAX_NCHANNELS"] == DEFAULT_CHANNELS == int(env["NCCL_MIN_NCHANNELS"]) and got["DPC_RESERVE_CUS"] == DEFAULT_CHANNELS
+    assert got["NCCL_MAX_NCHANNELS"] == DEFAULT_CHANNELS == int(env["NCCL_MAX_NCHANNELS"]) and "NCCL_MIN_NCHANNELS" not in env
+    assert got["DPC_RESERVE_CUS"] == DEFAULT_CHANNELS
     env = {"NCCL_MAX_NCHANNELS": "24", "NCCL_MIN_NCHANNELS": "4"}
     got = configure_rccl(8, env)
     assert env["NCCL_MAX_NCHANNELS"] == "24" and env["NCCL_MIN_NCHANNELS"] == "4" and got["DPC_RESERVE_CUS"] == 24
     assert "HSA_ENABLE_IPC_MODE_LEGACY" in got and env["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
     env = {"DPC_RCCL_CHANNELS": "16", "DPC_RESERVE_CUS": "0", "NCCL_MAX_NCHANNELS": "2"}
     got = configure_rccl(2, env)
-    assert env["NCCL_MAX_NCHANNELS"] == "16" and got["DPC_RESERVE_CUS"] == 0
+    assert env["NCCL_MAX_NCHANNELS"] == "16" == env["NCCL_MIN_NCHANNELS"] and got["DPC_RESERVE_CUS"] == 0
     assert default_reserve_cus(1, {}) == 0 and default_reserve_cus(4, {}) == DEFAULT_CHANNELS
