@@ -854,9 +854,11 @@ class DPCEngine:
             k = k[7:] if k.startswith("module.") else k
             if k.startswith("agg.cell_list.0."):
                 continue  # alias of agg.ConvGRUCell_00 (backbone/convrnn.py:55-58)
-            if k not in self.PRM:
-                raise KeyError(k)
-            self.PRM[k].copy_(v.to(torch.float32).reshape(self.shapes[k]))
+            dst, shp = self.PRM.get(k), self.shapes.get(k)
+            if dst is None or shp is None:   # (a bare KeyError(k) here was seen once in a full GPU-tier run and never again: say more)
+                raise KeyError(f"{k}: not a parameter of this {self.network} engine ({len(self.PRM)} parameters, {len(self.shapes)} shapes, "
+                               f"in PRM: {k in self.PRM}, in shapes: {k in self.shapes})")
+            dst.copy_(v.to(torch.float32).reshape(shp))
         self.packed_for_step = -1
 
     def state_dict(self) -> Dict[str, torch.Tensor]:
