@@ -153,9 +153,13 @@ template <bool NT> __device__ __forceinline__ void st16(void* p, long long i, co
 }
 #endif
 static inline bool bn_streaming(long long units) {
-    static const long long thr = getenv("DPC_BN_NT_MB") ? atoll(getenv("DPC_BN_NT_MB")) : 192;  // tensor size in MB; 0 = never
+    const long long thr = getenv("DPC_BN_NT_MB") ? atoll(getenv("DPC_BN_NT_MB")) : 192;  // tensor size in MB; 0 = never (read per call: the test tiers lower it)
     return thr > 0 && units * 16 >= thr * (1ll << 20);
 }
+// units per thread in flight in the streaming bf16 instantiations of bn_apply / bn_bwd_apply (1: round 3's rolled loops) and the
+// workgroup cap of the forward apply (per-call reads: A/B knobs, DPC_BN_UNROLL / DPC_BN_APPLY_GRID)
+static inline int bn_unroll() { const char* e = getenv("DPC_BN_UNROLL"); const int v = e ? atoi(e) : 4; return v == 2 || v == 4 ? v : 1; }
+static inline int bn_unroll_grid() { const char* e = getenv("DPC_BN_APPLY_GRID"); return e ? atoi(e) : 8192; }
 // bit e = element e of the unit is > 0 (the ReLU pass-through mask)
 template <class T> __device__ __forceinline__ unsigned sign_bits(const u32x4& v) {
     unsigned b = 0;
@@ -164,7 +168,7 @@ template <class T> __device__ __forceinline__ unsigned sign_bits(const u32x4& v)
     return b;
 }
 
-template <class T, bool FIXED, bool NT>
+template <class T, bool FIXED, bool NT, int U = 1>
 __global__ void bn_apply_kernel(const T* x, T* y, long long units, int C, const float* scale, const float* shift,
                                 const T* res, const float* rscale, const float* rshift, int relu, uint8_t* mask) {
     constexpr int E = Elt<T>::PER16;
@@ -182,7 +186,42 @@ __global__ void bn_apply_kernel(const T* x, T* y, long long units, int C, const 
     const long long span = (units + (long long)gridDim.x * 256 - 1) / ((long long)gridDim.x * 256) * 256;
     const long long sb = (long long)blockIdx.x * span;
     const long long se = sb + span < units ? sb + span : units;
-    for (long long i = sb + threadIdx.x; i < se; i += 256) {
+    long long i = sb + threadIdx.x;
+    // Round 4: U units per thread in flight.  The rolled loop has ONE 16-byte load (two with a residual) outstanding per thread --
+    // 32 KB per CU at full occupancy, 8 MB on the chip: by Little's law about 4 TB/s of reads at the ~2 us a loaded HBM round trip
+    // takes -- which is where the family sat (5.1-5.3 TB/s with its writes).  The channel group of a thread does not change over
+    // i += 256, so the coefficients stay in registers (FIXED only).
+    if constexpr (FIXED && U > 1) {
+        for (; i + (U - 1) * 256 < se; i += 256 * U) {
+            u32x4 xv[U], rv[U];
+            DPC_UNROLL
+            for (int u = 0; u < U; ++u) xv[u] = ld16<NT>(x, i + u * 256);
+            if (res) {
+                DPC_UNROLL
+                for (int u = 0; u < U; ++u) rv[u] = ld16<NT>(res, i + u * 256);
+            }
+            DPC_UNROLL
+            for (int u = 0; u < U; ++u) {
+                float ov[E];
+                unsigned bits = 0;
+                DPC_UNROLL
+                for (int e = 0; e < E; ++e) {
+                    float v = unit_get<T>(xv[u], e) * sc[e] + sh[e];
+                    if (res) v += unit_get<T>(rv[u], e) * rs[e] + rb[e];
+                    if (relu) v = v > 0.f ? v : 0.f;
+                    ov[e] = v;
+                }
+                const u32x4 o = unit_pack<T>(ov);
+                st16<NT>(y, i + u * 256, o);
+                if (mask) {
+                    DPC_UNROLL
+                    for (int e = 0; e < E; ++e) bits |= (unit_get<T>(o, e) > 0.f ? 1u : 0u) << e;
+                    mask[i + u * 256] = (uint8_t)bits;
+                }
+            }
+        }
+    }
+    for (; i < se; i += 256) {
         if (!FIXED) {
             const int c0 = (int)((i * E) % C);
             DPC_UNROLL
@@ -230,7 +269,10 @@ extern "C" int dpc_bn_apply(const void* x, void* y, int32_t dtype, int64_t rows,
         }
     } else if (dtype == DPC_BF16) {
         if (fixed) {
-            if (bn_streaming(units)) { DPC_LAUNCH((bn_apply_kernel<bf16_t, true, true>), dim3(grid_for(units)), dim3(256), stream, (const bf16_t*)x, (bf16_t*)y, units, C, scale, shift, (const bf16_t*)res, rscale, rshift, relu, mask); } else { DPC_LAUNCH((bn_apply_kernel<bf16_t, true, false>), dim3(grid_for(units)), dim3(256), stream, (const bf16_t*)x, (bf16_t*)y, units, C, scale, shift, (const bf16_t*)res, rscale, rshift, relu, mask); }
+            const int un = bn_unroll();
+            if (bn_streaming(units) && un == 4) { DPC_LAUNCH((bn_apply_kernel<bf16_t, true, true, 4>), dim3(grid_for(units, 256, bn_unroll_grid())), dim3(256), stream, (const bf16_t*)x, (bf16_t*)y, units, C, scale, shift, (const bf16_t*)res, rscale, rshift, relu, mask); }
+            else if (bn_streaming(units) && un == 2) { DPC_LAUNCH((bn_apply_kernel<bf16_t, true, true, 2>), dim3(grid_for(units, 256, bn_unroll_grid())), dim3(256), stream, (const bf16_t*)x, (bf16_t*)y, units, C, scale, shift, (const bf16_t*)res, rscale, rshift, relu, mask); }
+            else if (bn_streaming(units)) { DPC_LAUNCH((bn_apply_kernel<bf16_t, true, true>), dim3(grid_for(units)), dim3(256), stream, (const bf16_t*)x, (bf16_t*)y, units, C, scale, shift, (const bf16_t*)res, rscale, rshift, relu, mask); } else { DPC_LAUNCH((bn_apply_kernel<bf16_t, true, false>), dim3(grid_for(units)), dim3(256), stream, (const bf16_t*)x, (bf16_t*)y, units, C, scale, shift, (const bf16_t*)res, rscale, rshift, relu, mask); }
         } else {
             if (bn_streaming(units)) { DPC_LAUNCH((bn_apply_kernel<bf16_t, false, true>), dim3(grid_for(units)), dim3(256), stream, (const bf16_t*)x, (bf16_t*)y, units, C, scale, shift, (const bf16_t*)res, rscale, rshift, relu, mask); } else { DPC_LAUNCH((bn_apply_kernel<bf16_t, false, false>), dim3(grid_for(units)), dim3(256), stream, (const bf16_t*)x, (bf16_t*)y, units, C, scale, shift, (const bf16_t*)res, rscale, rshift, relu, mask); }
         }
@@ -242,7 +284,7 @@ extern "C" int dpc_bn_apply(const void* x, void* y, int32_t dtype, int64_t rows,
 
 // ------------------------------------------------------------------ backward reduce
 // dz = dy * (y > 0 if relu);  partial[b][0][c] = sum dz, partial[b][1][c] = sum dz * xhat
-template <class T, bool NT>
+template <class T, bool NT, int U = 1>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* dy, const T* y, const uint8_t* mask, const T* x, long long rows, int C,
                                                             const float* mean, const float* invstd, int relu,
                                                             float* partials, long long rows_per_block) {
@@ -262,7 +304,32 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* dy, const T
         const long long r_begin = (long long)blockIdx.x * rows_per_block;
         long long r_end = r_begin + rows_per_block;
         if (r_end > rows) r_end = rows;
-        for (long long r = r_begin + rr; r < r_end; r += rpi) {
+        long long r = r_begin + rr;
+        if constexpr (U > 1) {   // U rows per thread in flight (see bn_apply_kernel); byte-mask form of the gate only
+            if (!relu || mask) {
+                for (; r + (long long)(U - 1) * rpi < r_end; r += (long long)U * rpi) {
+                    u32x4 dv[U], xv[U];
+                    unsigned bits[U];
+                    DPC_UNROLL
+                    for (int u = 0; u < U; ++u) dv[u] = ld16<NT>(dy, (r + (long long)u * rpi) * upr + cu);
+                    DPC_UNROLL
+                    for (int u = 0; u < U; ++u) xv[u] = ld16<NT>(x, (r + (long long)u * rpi) * upr + cu);
+                    DPC_UNROLL
+                    for (int u = 0; u < U; ++u) bits[u] = relu ? (unsigned)mask[(r + (long long)u * rpi) * upr + cu] : ~0u;
+                    DPC_UNROLL
+                    for (int u = 0; u < U; ++u)
+                        DPC_UNROLL
+                        for (int e = 0; e < E; ++e) {
+                            float dz = unit_get<T>(dv[u], e);
+                            if (!((bits[u] >> e) & 1u)) dz = 0.f;
+                            const float xh = (unit_get<T>(xv[u], e) - mu[e]) * is[e];
+                            a1[e] += dz;
+                            a2[e] += dz * xh;
+                        }
+                }
+            }
+        }
+        for (; r < r_end; r += rpi) {
             const long long ui = r * upr + cu;
             const u32x4 dv = ld16<NT>(dy, ui);
             const u32x4 xv = ld16<NT>(x, ui);
@@ -327,7 +394,8 @@ extern "C" int dpc_bn_bwd_reduce(const void* dy, const void* y, const uint8_t* m
     if (dtype == DPC_F32) {
         if (bn_streaming((long long)rows * C / E)) { DPC_LAUNCH((bn_bwd_reduce_kernel<float, true>), dim3(blocks), dim3(256), stream, (const float*)dy, (const float*)y, mask, (const float*)x, (long long)rows, C, mean, invstd, relu, partials, rpb); } else { DPC_LAUNCH((bn_bwd_reduce_kernel<float, false>), dim3(blocks), dim3(256), stream, (const float*)dy, (const float*)y, mask, (const float*)x, (long long)rows, C, mean, invstd, relu, partials, rpb); }
     } else if (dtype == DPC_BF16) {
-        if (bn_streaming((long long)rows * C / E)) { DPC_LAUNCH((bn_bwd_reduce_kernel<bf16_t, true>), dim3(blocks), dim3(256), stream, (const bf16_t*)dy, (const bf16_t*)y, mask, (const bf16_t*)x, (long long)rows, C, mean, invstd, relu, partials, rpb); } else { DPC_LAUNCH((bn_bwd_reduce_kernel<bf16_t, false>), dim3(blocks), dim3(256), stream, (const bf16_t*)dy, (const bf16_t*)y, mask, (const bf16_t*)x, (long long)rows, C, mean, invstd, relu, partials, rpb); }
+        if (bn_streaming((long long)rows * C / E) && bn_unroll() > 1) { DPC_LAUNCH((bn_bwd_reduce_kernel<bf16_t, true, 4>), dim3(blocks), dim3(256), stream, (const bf16_t*)dy, (const bf16_t*)y, mask, (const bf16_t*)x, (long long)rows, C, mean, invstd, relu, partials, rpb); }
+        else if (bn_streaming((long long)rows * C / E)) { DPC_LAUNCH((bn_bwd_reduce_kernel<bf16_t, true>), dim3(blocks), dim3(256), stream, (const bf16_t*)dy, (const bf16_t*)y, mask, (const bf16_t*)x, (long long)rows, C, mean, invstd, relu, partials, rpb); } else { DPC_LAUNCH((bn_bwd_reduce_kernel<bf16_t, false>), dim3(blocks), dim3(256), stream, (const bf16_t*)dy, (const bf16_t*)y, mask, (const bf16_t*)x, (long long)rows, C, mean, invstd, relu, partials, rpb); }
     } else {
         return DPC_ERR_ARG;
     }
@@ -355,7 +423,7 @@ extern "C" int dpc_bn_bwd_finalize(const float* partials, int32_t prow, int32_t 
 }
 
 // dx = gamma*invstd*(dz - c1 - xhat*c2)
-template <class T, bool FIXED, bool NT>
+template <class T, bool FIXED, bool NT, int U = 1>
 __global__ void bn_bwd_apply_kernel(const T* dy, const T* y, const uint8_t* mask, const T* x, long long units, int C, const float* mean,
                                     const float* invstd, const float* gamma, const float* coef, int relu, T* dx, T* dzout) {
     constexpr int E = Elt<T>::PER16;
@@ -374,7 +442,40 @@ __global__ void bn_bwd_apply_kernel(const T* dy, const T* y, const uint8_t* mask
     const long long span = (units + (long long)gridDim.x * 256 - 1) / ((long long)gridDim.x * 256) * 256;
     const long long sb = (long long)(gridDim.x - 1 - blockIdx.x) * span;
     const long long se = sb + span < units ? sb + span : units;
-    for (long long i = sb + threadIdx.x; i < se; i += 256) {
+    long long i = sb + threadIdx.x;
+    if constexpr (FIXED && U > 1) {   // U units per thread in flight (see bn_apply_kernel); only the byte-mask form of the ReLU gate
+        if (!relu || mask) {
+            for (; i + (U - 1) * 256 < se; i += 256 * U) {
+                u32x4 dv[U], xv[U];
+                unsigned bits[U];
+                DPC_UNROLL
+                for (int u = 0; u < U; ++u) dv[u] = ld16<NT>(dy, i + u * 256);
+                DPC_UNROLL
+                for (int u = 0; u < U; ++u) xv[u] = ld16<NT>(x, i + u * 256);
+                DPC_UNROLL
+                for (int u = 0; u < U; ++u) bits[u] = ~0u;
+                if (relu) {
+                    DPC_UNROLL
+                    for (int u = 0; u < U; ++u) bits[u] = (unsigned)mask[i + u * 256];
+                }
+                DPC_UNROLL
+                for (int u = 0; u < U; ++u) {
+                    float ov[E], oz[E];
+                    DPC_UNROLL
+                    for (int e = 0; e < E; ++e) {
+                        float dz = unit_get<T>(dv[u], e);
+                        if (!((bits[u] >> e) & 1u)) dz = 0.f;
+                        const float xh = (unit_get<T>(xv[u], e) - mu[e]) * is[e];
+                        ov[e] = ga[e] * (dz - c1[e] - xh * c2[e]);
+                        oz[e] = dz;
+                    }
+                    st16<NT>(dx, i + u * 256, unit_pack<T>(ov));
+                    if (dzout) st16<NT>(dzout, i + u * 256, unit_pack<T>(oz));
+                }
+            }
+        }
+    }
+    for (; i < se; i += 256) {
         if (!FIXED) {
             const int c0 = (int)((i * E) % C);
             DPC_UNROLL
@@ -419,7 +520,10 @@ extern "C" int dpc_bn_bwd_apply(const void* dy, const void* y, const uint8_t* ma
         }
     } else if (dtype == DPC_BF16) {
         if (fixed) {
-            if (bn_streaming(units)) { DPC_LAUNCH((bn_bwd_apply_kernel<bf16_t, true, true>), dim3(grid_for(units, 256, 2048)), dim3(256), stream, (const bf16_t*)dy, (const bf16_t*)y, mask, (const bf16_t*)x, units, C, mean, invstd, gamma, coef, relu, (bf16_t*)dx, (bf16_t*)dz); } else { DPC_LAUNCH((bn_bwd_apply_kernel<bf16_t, true, false>), dim3(grid_for(units, 256, 2048)), dim3(256), stream, (const bf16_t*)dy, (const bf16_t*)y, mask, (const bf16_t*)x, units, C, mean, invstd, gamma, coef, relu, (bf16_t*)dx, (bf16_t*)dz); }
+            const int un = bn_unroll();
+            if (bn_streaming(units) && un == 4) { DPC_LAUNCH((bn_bwd_apply_kernel<bf16_t, true, true, 4>), dim3(grid_for(units, 256, 2048)), dim3(256), stream, (const bf16_t*)dy, (const bf16_t*)y, mask, (const bf16_t*)x, units, C, mean, invstd, gamma, coef, relu, (bf16_t*)dx, (bf16_t*)dz); }
+            else if (bn_streaming(units) && un == 2) { DPC_LAUNCH((bn_bwd_apply_kernel<bf16_t, true, true, 2>), dim3(grid_for(units, 256, 2048)), dim3(256), stream, (const bf16_t*)dy, (const bf16_t*)y, mask, (const bf16_t*)x, units, C, mean, invstd, gamma, coef, relu, (bf16_t*)dx, (bf16_t*)dz); }
+            else if (bn_streaming(units)) { DPC_LAUNCH((bn_bwd_apply_kernel<bf16_t, true, true>), dim3(grid_for(units, 256, 2048)), dim3(256), stream, (const bf16_t*)dy, (const bf16_t*)y, mask, (const bf16_t*)x, units, C, mean, invstd, gamma, coef, relu, (bf16_t*)dx, (bf16_t*)dz); } else { DPC_LAUNCH((bn_bwd_apply_kernel<bf16_t, true, false>), dim3(grid_for(units, 256, 2048)), dim3(256), stream, (const bf16_t*)dy, (const bf16_t*)y, mask, (const bf16_t*)x, units, C, mean, invstd, gamma, coef, relu, (bf16_t*)dx, (bf16_t*)dz); }
         } else {
             if (bn_streaming(units)) { DPC_LAUNCH((bn_bwd_apply_kernel<bf16_t, false, true>), dim3(grid_for(units, 256, 2048)), dim3(256), stream, (const bf16_t*)dy, (const bf16_t*)y, mask, (const bf16_t*)x, units, C, mean, invstd, gamma, coef, relu, (bf16_t*)dx, (bf16_t*)dz); } else { DPC_LAUNCH((bn_bwd_apply_kernel<bf16_t, false, false>), dim3(grid_for(units, 256, 2048)), dim3(256), stream, (const bf16_t*)dy, (const bf16_t*)y, mask, (const bf16_t*)x, units, C, mean, invstd, gamma, coef, relu, (bf16_t*)dx, (bf16_t*)dz); }
         }

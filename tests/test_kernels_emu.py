@@ -155,6 +155,17 @@ def test_bn(k, dtype, relu, res_mode, C):
     kc.case_bn_fwd_bwd(k, dtype, 333, C, relu, res_mode)
 
 
+@pytest.mark.parametrize("unroll", ["4", "2", "1"])
+@pytest.mark.parametrize("relu,res_mode,C", [(True, 0, 64), (True, 1, 128), (False, 2, 256)])
+def test_bn_streaming_forms(k, monkeypatch, unroll, relu, res_mode, C):
+    """the large-tensor instantiations (non-temporal accesses, U units per thread in flight: DPC_BN_UNROLL) on a tensor just above
+    a lowered threshold: spans that are not multiples of the unrolled stride, a ragged tail"""
+    monkeypatch.setenv("DPC_BN_NT_MB", "1")
+    monkeypatch.setenv("DPC_BN_UNROLL", unroll)
+    monkeypatch.setenv("DPC_BN_APPLY_GRID", "7")
+    kc.case_bn_fwd_bwd(k, BF16, (1 << 20) // (2 * C) + 37, C, relu, res_mode)
+
+
 @pytest.mark.parametrize("dtype", [F32, BF16])
 @pytest.mark.parametrize("hw", [(8, 8), (7, 10)])
 def test_stem_pool(k, dtype, hw):

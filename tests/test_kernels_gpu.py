@@ -178,6 +178,14 @@ def test_bn(k, dtype, relu, res_mode, C):
     kc.case_bn_fwd_bwd(k, dtype, 20011, C, relu, res_mode)
 
 
+@pytest.mark.parametrize("unroll", ["4", "1"])
+@pytest.mark.parametrize("relu,res_mode,C", [(True, 0, 64), (True, 1, 128), (False, 2, 256)])
+def test_bn_streaming_forms(k, monkeypatch, unroll, relu, res_mode, C):
+    """the >= 192 MB instantiations of bn_apply / bn_bwd_apply (non-temporal, U units per thread in flight) on a 200 MB tensor"""
+    monkeypatch.setenv("DPC_BN_UNROLL", unroll)
+    kc.case_bn_fwd_bwd(k, BF16, (200 << 20) // (2 * C) + 37, C, relu, res_mode)
+
+
 @pytest.mark.parametrize("dtype", [F32, BF16])
 @pytest.mark.parametrize("hw", [(64, 64), (7, 10)])
 def test_stem_pool(k, dtype, hw):
