@@ -367,10 +367,16 @@ def main():
                 return round(1e3 * t.item(), 3)
             finally:
                 eng.reserve_cus = keep
+        def side(exch, reserve):   # a side measurement must never cost the line: a failure is reported in its place
+            try:
+                return timed_schedule(exch, reserve)
+            except Exception as e:
+                torch.cuda.synchronize()
+                return f"failed: {type(e).__name__}: {str(e)[:120]}"
         schedules = {"default": {"ms_per_step": round(1e3 * dt / args.steps, 3), "reserve_cus": eng.reserve_cus, "exchange": "two buckets, overlapped"}}
         if eng.reserve_cus:
-            schedules["overlap_all_cus"] = {"ms_per_step": timed_schedule(allreduce, 0), "reserve_cus": 0}
-        schedules["serial"] = {"ms_per_step": timed_schedule(lambda flat: allreduce(flat), 0), "reserve_cus": 0, "exchange": "one all-reduce after the backward pass"}
+            schedules["overlap_all_cus"] = {"ms_per_step": side(allreduce, 0), "reserve_cus": 0}
+        schedules["serial"] = {"ms_per_step": side(lambda flat: allreduce(flat), 0), "reserve_cus": 0, "exchange": "one all-reduce after the backward pass"}
 
     # ---- separately instrumented pass (never part of `value`): HIP events around the selected launches
     timer = None
