@@ -160,6 +160,7 @@ static inline bool bn_streaming(long long units) {
 // workgroup cap of the forward apply (per-call reads: A/B knobs, DPC_BN_UNROLL / DPC_BN_APPLY_GRID)
 static inline int bn_unroll() { const char* e = getenv("DPC_BN_UNROLL"); const int v = e ? atoi(e) : 4; return v == 2 || v == 4 ? v : 1; }
 static inline int bn_unroll_grid() { const char* e = getenv("DPC_BN_APPLY_GRID"); return e ? atoi(e) : 8192; }
+static inline int bn_bwd_grid() { const char* e = getenv("DPC_BN_BWD_GRID"); return e ? atoi(e) : 8192; }
 // bit e = element e of the unit is > 0 (the ReLU pass-through mask)
 template <class T> __device__ __forceinline__ unsigned sign_bits(const u32x4& v) {
     unsigned b = 0;
@@ -521,8 +522,8 @@ extern "C" int dpc_bn_bwd_apply(const void* dy, const void* y, const uint8_t* ma
     } else if (dtype == DPC_BF16) {
         if (fixed) {
             const int un = bn_unroll();
-            if (bn_streaming(units) && un == 4) { DPC_LAUNCH((bn_bwd_apply_kernel<bf16_t, true, true, 4>), dim3(grid_for(units, 256, 2048)), dim3(256), stream, (const bf16_t*)dy, (const bf16_t*)y, mask, (const bf16_t*)x, units, C, mean, invstd, gamma, coef, relu, (bf16_t*)dx, (bf16_t*)dz); }
-            else if (bn_streaming(units) && un == 2) { DPC_LAUNCH((bn_bwd_apply_kernel<bf16_t, true, true, 2>), dim3(grid_for(units, 256, 2048)), dim3(256), stream, (const bf16_t*)dy, (const bf16_t*)y, mask, (const bf16_t*)x, units, C, mean, invstd, gamma, coef, relu, (bf16_t*)dx, (bf16_t*)dz); }
+            if (bn_streaming(units) && un == 4) { DPC_LAUNCH((bn_bwd_apply_kernel<bf16_t, true, true, 4>), dim3(grid_for(units, 256, bn_bwd_grid())), dim3(256), stream, (const bf16_t*)dy, (const bf16_t*)y, mask, (const bf16_t*)x, units, C, mean, invstd, gamma, coef, relu, (bf16_t*)dx, (bf16_t*)dz); }
+            else if (bn_streaming(units) && un == 2) { DPC_LAUNCH((bn_bwd_apply_kernel<bf16_t, true, true, 2>), dim3(grid_for(units, 256, bn_bwd_grid())), dim3(256), stream, (const bf16_t*)dy, (const bf16_t*)y, mask, (const bf16_t*)x, units, C, mean, invstd, gamma, coef, relu, (bf16_t*)dx, (bf16_t*)dz); }
             else if (bn_streaming(units)) { DPC_LAUNCH((bn_bwd_apply_kernel<bf16_t, true, true>), dim3(grid_for(units, 256, 2048)), dim3(256), stream, (const bf16_t*)dy, (const bf16_t*)y, mask, (const bf16_t*)x, units, C, mean, invstd, gamma, coef, relu, (bf16_t*)dx, (bf16_t*)dz); } else { DPC_LAUNCH((bn_bwd_apply_kernel<bf16_t, true, false>), dim3(grid_for(units, 256, 2048)), dim3(256), stream, (const bf16_t*)dy, (const bf16_t*)y, mask, (const bf16_t*)x, units, C, mean, invstd, gamma, coef, relu, (bf16_t*)dx, (bf16_t*)dz); }
         } else {
             if (bn_streaming(units)) { DPC_LAUNCH((bn_bwd_apply_kernel<bf16_t, false, true>), dim3(grid_for(units, 256, 2048)), dim3(256), stream, (const bf16_t*)dy, (const bf16_t*)y, mask, (const bf16_t*)x, units, C, mean, invstd, gamma, coef, relu, (bf16_t*)dx, (bf16_t*)dz); } else { DPC_LAUNCH((bn_bwd_apply_kernel<bf16_t, false, false>), dim3(grid_for(units, 256, 2048)), dim3(256), stream, (const bf16_t*)dy, (const bf16_t*)y, mask, (const bf16_t*)x, units, C, mean, invstd, gamma, coef, relu, (bf16_t*)dx, (bf16_t*)dz); }
