@@ -161,6 +161,9 @@ static inline bool bn_streaming(long long units) {
 static inline int bn_unroll() { const char* e = getenv("DPC_BN_UNROLL"); const int v = e ? atoi(e) : 4; return v == 2 || v == 4 ? v : 1; }
 static inline int bn_unroll_grid() { const char* e = getenv("DPC_BN_APPLY_GRID"); return e ? atoi(e) : 8192; }
 static inline int bn_bwd_grid() { const char* e = getenv("DPC_BN_BWD_GRID"); return e ? atoi(e) : 8192; }
+// tensors below the streaming threshold (layer3 / layer4 of cfg2: 100 / 17 MB): the same unrolled forms with the default cache policy
+static inline int bn_small_unroll() { const char* e = getenv("DPC_BN_SMALL_UNROLL"); const int v = e ? atoi(e) : 4; return v == 2 || v == 4 ? v : 1; }
+static inline int bn_small_grid(int dflt) { const char* e = getenv("DPC_BN_SMALL_GRID"); return e ? atoi(e) : dflt; }
 // bit e = element e of the unit is > 0 (the ReLU pass-through mask)
 template <class T> __device__ __forceinline__ unsigned sign_bits(const u32x4& v) {
     unsigned b = 0;
@@ -270,10 +273,14 @@ extern "C" int dpc_bn_apply(const void* x, void* y, int32_t dtype, int64_t rows,
         }
     } else if (dtype == DPC_BF16) {
         if (fixed) {
-            const int un = bn_unroll();
-            if (bn_streaming(units) && un == 4) { DPC_LAUNCH((bn_apply_kernel<bf16_t, true, true, 4>), dim3(grid_for(units, 256, bn_unroll_grid())), dim3(256), stream, (const bf16_t*)x, (bf16_t*)y, units, C, scale, shift, (const bf16_t*)res, rscale, rshift, relu, mask); }
-            else if (bn_streaming(units) && un == 2) { DPC_LAUNCH((bn_apply_kernel<bf16_t, true, true, 2>), dim3(grid_for(units, 256, bn_unroll_grid())), dim3(256), stream, (const bf16_t*)x, (bf16_t*)y, units, C, scale, shift, (const bf16_t*)res, rscale, rshift, relu, mask); }
-            else if (bn_streaming(units)) { DPC_LAUNCH((bn_apply_kernel<bf16_t, true, true>), dim3(grid_for(units)), dim3(256), stream, (const bf16_t*)x, (bf16_t*)y, units, C, scale, shift, (const bf16_t*)res, rscale, rshift, relu, mask); } else { DPC_LAUNCH((bn_apply_kernel<bf16_t, true, false>), dim3(grid_for(units)), dim3(256), stream, (const bf16_t*)x, (bf16_t*)y, units, C, scale, shift, (const bf16_t*)res, rscale, rshift, relu, mask); }
+            // (NT, U) instantiation and grid: U units per thread per iteration, so at most units / (256 U) workgroups
+            const bool nt = bn_streaming(units);
+            const int un = nt ? bn_unroll() : bn_small_unroll();
+            const unsigned grid = grid_for((units + un - 1) / un, 256, nt ? (un > 1 ? bn_unroll_grid() : 8192) : bn_small_grid(512));   // small tensors: workgroup dispatch (~5 ns each) is what 8 192 short workgroups cost
+#define DPC_BN_GO(NTV, UV) DPC_LAUNCH((bn_apply_kernel<bf16_t, true, NTV, UV>), dim3(grid), dim3(256), stream, (const bf16_t*)x, (bf16_t*)y, units, C, scale, shift, (const bf16_t*)res, rscale, rshift, relu, mask)
+            if (nt) { if (un == 4) DPC_BN_GO(true, 4); else if (un == 2) DPC_BN_GO(true, 2); else DPC_BN_GO(true, 1); }
+            else { if (un == 4) DPC_BN_GO(false, 4); else if (un == 2) DPC_BN_GO(false, 2); else DPC_BN_GO(false, 1); }
+#undef DPC_BN_GO
         } else {
             if (bn_streaming(units)) { DPC_LAUNCH((bn_apply_kernel<bf16_t, false, true>), dim3(grid_for(units)), dim3(256), stream, (const bf16_t*)x, (bf16_t*)y, units, C, scale, shift, (const bf16_t*)res, rscale, rshift, relu, mask); } else { DPC_LAUNCH((bn_apply_kernel<bf16_t, false, false>), dim3(grid_for(units)), dim3(256), stream, (const bf16_t*)x, (bf16_t*)y, units, C, scale, shift, (const bf16_t*)res, rscale, rshift, relu, mask); }
         }
@@ -395,8 +402,12 @@ extern "C" int dpc_bn_bwd_reduce(const void* dy, const void* y, const uint8_t* m
     if (dtype == DPC_F32) {
         if (bn_streaming((long long)rows * C / E)) { DPC_LAUNCH((bn_bwd_reduce_kernel<float, true>), dim3(blocks), dim3(256), stream, (const float*)dy, (const float*)y, mask, (const float*)x, (long long)rows, C, mean, invstd, relu, partials, rpb); } else { DPC_LAUNCH((bn_bwd_reduce_kernel<float, false>), dim3(blocks), dim3(256), stream, (const float*)dy, (const float*)y, mask, (const float*)x, (long long)rows, C, mean, invstd, relu, partials, rpb); }
     } else if (dtype == DPC_BF16) {
-        if (bn_streaming((long long)rows * C / E) && bn_unroll() > 1) { DPC_LAUNCH((bn_bwd_reduce_kernel<bf16_t, true, 4>), dim3(blocks), dim3(256), stream, (const bf16_t*)dy, (const bf16_t*)y, mask, (const bf16_t*)x, (long long)rows, C, mean, invstd, relu, partials, rpb); }
-        else if (bn_streaming((long long)rows * C / E)) { DPC_LAUNCH((bn_bwd_reduce_kernel<bf16_t, true>), dim3(blocks), dim3(256), stream, (const bf16_t*)dy, (const bf16_t*)y, mask, (const bf16_t*)x, (long long)rows, C, mean, invstd, relu, partials, rpb); } else { DPC_LAUNCH((bn_bwd_reduce_kernel<bf16_t, false>), dim3(blocks), dim3(256), stream, (const bf16_t*)dy, (const bf16_t*)y, mask, (const bf16_t*)x, (long long)rows, C, mean, invstd, relu, partials, rpb); }
+        const bool nt = bn_streaming((long long)rows * C / E);
+        const int un = nt ? bn_unroll() : bn_small_unroll();
+#define DPC_BN_GO(NTV, UV) DPC_LAUNCH((bn_bwd_reduce_kernel<bf16_t, NTV, UV>), dim3(blocks), dim3(256), stream, (const bf16_t*)dy, (const bf16_t*)y, mask, (const bf16_t*)x, (long long)rows, C, mean, invstd, relu, partials, rpb)
+        if (nt) { if (un > 1) DPC_BN_GO(true, 4); else DPC_BN_GO(true, 1); }
+        else { if (un > 1) DPC_BN_GO(false, 4); else DPC_BN_GO(false, 1); }
+#undef DPC_BN_GO
     } else {
         return DPC_ERR_ARG;
     }
@@ -521,10 +532,13 @@ extern "C" int dpc_bn_bwd_apply(const void* dy, const void* y, const uint8_t* ma
         }
     } else if (dtype == DPC_BF16) {
         if (fixed) {
-            const int un = bn_unroll();
-            if (bn_streaming(units) && un == 4) { DPC_LAUNCH((bn_bwd_apply_kernel<bf16_t, true, true, 4>), dim3(grid_for(units, 256, bn_bwd_grid())), dim3(256), stream, (const bf16_t*)dy, (const bf16_t*)y, mask, (const bf16_t*)x, units, C, mean, invstd, gamma, coef, relu, (bf16_t*)dx, (bf16_t*)dz); }
-            else if (bn_streaming(units) && un == 2) { DPC_LAUNCH((bn_bwd_apply_kernel<bf16_t, true, true, 2>), dim3(grid_for(units, 256, bn_bwd_grid())), dim3(256), stream, (const bf16_t*)dy, (const bf16_t*)y, mask, (const bf16_t*)x, units, C, mean, invstd, gamma, coef, relu, (bf16_t*)dx, (bf16_t*)dz); }
-            else if (bn_streaming(units)) { DPC_LAUNCH((bn_bwd_apply_kernel<bf16_t, true, true>), dim3(grid_for(units, 256, 2048)), dim3(256), stream, (const bf16_t*)dy, (const bf16_t*)y, mask, (const bf16_t*)x, units, C, mean, invstd, gamma, coef, relu, (bf16_t*)dx, (bf16_t*)dz); } else { DPC_LAUNCH((bn_bwd_apply_kernel<bf16_t, true, false>), dim3(grid_for(units, 256, 2048)), dim3(256), stream, (const bf16_t*)dy, (const bf16_t*)y, mask, (const bf16_t*)x, units, C, mean, invstd, gamma, coef, relu, (bf16_t*)dx, (bf16_t*)dz); }
+            const bool nt = bn_streaming(units);
+            const int un = nt ? bn_unroll() : bn_small_unroll();
+            const unsigned grid = grid_for((units + un - 1) / un, 256, nt ? (un > 1 ? bn_bwd_grid() : 2048) : bn_small_grid(2048));
+#define DPC_BN_GO(NTV, UV) DPC_LAUNCH((bn_bwd_apply_kernel<bf16_t, true, NTV, UV>), dim3(grid), dim3(256), stream, (const bf16_t*)dy, (const bf16_t*)y, mask, (const bf16_t*)x, units, C, mean, invstd, gamma, coef, relu, (bf16_t*)dx, (bf16_t*)dz)
+            if (nt) { if (un == 4) DPC_BN_GO(true, 4); else if (un == 2) DPC_BN_GO(true, 2); else DPC_BN_GO(true, 1); }
+            else { if (un == 4) DPC_BN_GO(false, 4); else if (un == 2) DPC_BN_GO(false, 2); else DPC_BN_GO(false, 1); }
+#undef DPC_BN_GO
         } else {
             if (bn_streaming(units)) { DPC_LAUNCH((bn_bwd_apply_kernel<bf16_t, false, true>), dim3(grid_for(units, 256, 2048)), dim3(256), stream, (const bf16_t*)dy, (const bf16_t*)y, mask, (const bf16_t*)x, units, C, mean, invstd, gamma, coef, relu, (bf16_t*)dx, (bf16_t*)dz); } else { DPC_LAUNCH((bn_bwd_apply_kernel<bf16_t, false, false>), dim3(grid_for(units, 256, 2048)), dim3(256), stream, (const bf16_t*)dy, (const bf16_t*)y, mask, (const bf16_t*)x, units, C, mean, invstd, gamma, coef, relu, (bf16_t*)dx, (bf16_t*)dz); }
         }

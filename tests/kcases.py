@@ -282,6 +282,27 @@ def case_gemm_nt(k: K, dtype, M, N, Kd, seed=3, expect=None):
     assert relerr(out, A.double() @ B.double().t()) < 1e-5
 
 
+def case_reduce_unpack(k: K, ns, d0, d1, d2, permute, accumulate, expect=None, seed=5):
+    """dpc_reduce_unpack: out[i0, i1, i2] (+)= sum over ns slabs of part[s][i0][i1][i2], written through arbitrary strides
+    (permute = the conv-parameter layout [d0][d2][d1]); the few-slab / many-slab / transposing kernels"""
+    g = torch.Generator().manual_seed(seed)
+    part = torch.randn(ns, d0, d1, d2, generator=g)
+    base = torch.randn(d0, d1, d2, generator=g)
+    want = part.double().sum(0) + (base.double() if accumulate else 0)
+    if permute:
+        out = k.t(base.permute(0, 2, 1).contiguous())
+        s0, s1, s2 = d1 * d2, 1, d1
+    else:
+        out = k.t(base.clone())
+        s0, s1, s2 = d1 * d2, d2, 1
+    k.call("dpc_reduce_unpack", k.t(part), ns, out, d0, d1, d2, s0, s1, s2, int(accumulate))
+    check_kernel(k, expect)
+    k.sync()
+    got = out.cpu()
+    got = got.permute(0, 2, 1) if permute else got
+    assert relerr(got, want) < 1e-6
+
+
 def case_gemm_nt_splitk(k: K, dtype, M, N, Kd, pad=0, seed=13, expect=None):
     """dpc_gemm_nt_splitk: f32 partial slabs of A @ B^T over K ranges, summed by dpc_reduce_unpack (d_pred = dS @ feature_inf);
     leading dimensions Kd + pad, the padding columns hold garbage that must not be read"""

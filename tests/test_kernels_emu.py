@@ -166,6 +166,16 @@ def test_bn_streaming_forms(k, monkeypatch, unroll, relu, res_mode, C):
     kc.case_bn_fwd_bwd(k, BF16, (1 << 20) // (2 * C) + 37, C, relu, res_mode)
 
 
+@pytest.mark.parametrize("unroll", ["4", "2", "1"])
+@pytest.mark.parametrize("relu,res_mode,C", [(True, 0, 64), (True, 1, 256), (False, 2, 128)])
+def test_bn_small_tensor_forms(k, monkeypatch, unroll, relu, res_mode, C):
+    """the instantiations for tensors below the streaming threshold (default cache policy, DPC_BN_SMALL_UNROLL units per thread in
+    flight) with few workgroups: several unrolled iterations per thread, spans that end inside an unrolled stride, a ragged tail"""
+    monkeypatch.setenv("DPC_BN_SMALL_UNROLL", unroll)
+    monkeypatch.setenv("DPC_BN_SMALL_GRID", "3")
+    kc.case_bn_fwd_bwd(k, BF16, (1 << 19) // (2 * C) + 21, C, relu, res_mode)
+
+
 @pytest.mark.parametrize("dtype", [F32, BF16])
 @pytest.mark.parametrize("hw", [(8, 8), (7, 10)])
 def test_stem_pool(k, dtype, hw):
@@ -176,6 +186,16 @@ def test_stem_pool(k, dtype, hw):
 def test_tpool_split(k, dtype):
     kc.case_tpool_split(k, dtype, 2, 8, 2, 4, 32, 3)
     kc.case_tpool_split(k, dtype, 3, 5, 1, 9, 16, 2)
+
+
+def test_reduce_unpack_forms(k):
+    """every kernel behind dpc_reduce_unpack"""
+    kc.case_reduce_unpack(k, 5, 1100, 1, 256, False, False, expect="reduce_unpack4s_kernel")   # few slabs, many sums (score backward)
+    kc.case_reduce_unpack(k, 3, 300, 4, 256, False, True, expect="reduce_unpack4s_kernel")     # + accumulate, a grid-stride tail
+    kc.case_reduce_unpack(k, 8, 2049, 1, 128, True, False, expect="reduce_unpack4s_kernel")    # permuted strides
+    kc.case_reduce_unpack(k, 19, 64, 9, 64, True, True, expect="reduce_unpack4_kernel")        # many slabs: the split-lane form
+    kc.case_reduce_unpack(k, 4, 64, 9, 64, True, False, expect="reduce_unpack_t_kernel")       # conv layout, few slabs
+    kc.case_reduce_unpack(k, 3, 33, 5, 7, False, True, expect="reduce_unpack_kernel")          # unaligned: element form
 
 
 @pytest.mark.parametrize("bps", [(4, 3, 16), (2, 1, 4), (3, 5, 9)])

@@ -186,6 +186,14 @@ def test_bn_streaming_forms(k, monkeypatch, unroll, relu, res_mode, C):
     kc.case_bn_fwd_bwd(k, BF16, (200 << 20) // (2 * C) + 37, C, relu, res_mode)
 
 
+@pytest.mark.parametrize("unroll", ["4", "1"])
+@pytest.mark.parametrize("rows,C,relu,res_mode", [(196608 + 5, 256, True, 1), (32768 + 3, 256, True, 0), (40000, 128, False, 2)])
+def test_bn_small_tensor_forms(k, monkeypatch, unroll, rows, C, relu, res_mode):
+    """the instantiations for tensors below the streaming threshold at layer3 / layer4 size of cfg2 (U units per thread in flight)"""
+    monkeypatch.setenv("DPC_BN_SMALL_UNROLL", unroll)
+    kc.case_bn_fwd_bwd(k, BF16, rows, C, relu, res_mode)
+
+
 @pytest.mark.parametrize("dtype", [F32, BF16])
 @pytest.mark.parametrize("hw", [(64, 64), (7, 10)])
 def test_stem_pool(k, dtype, hw):
@@ -196,6 +204,16 @@ def test_stem_pool(k, dtype, hw):
 def test_tpool_split(k, dtype):
     kc.case_tpool_split(k, dtype, 4, 8, 2, 16, 256, 3)
     kc.case_tpool_split(k, dtype, 3, 8, 2, 49, 256, 5)
+
+
+def test_reduce_unpack_forms(k):
+    """every kernel behind dpc_reduce_unpack"""
+    kc.case_reduce_unpack(k, 5, 6144, 1, 256, False, False, expect="reduce_unpack4s_kernel")   # the score backward's reductions at cfg2
+    kc.case_reduce_unpack(k, 2, 15680, 1, 256, False, True, expect="reduce_unpack4s_kernel")   # cfg5: grid-stride, accumulate
+    kc.case_reduce_unpack(k, 8, 2049, 1, 128, True, False, expect="reduce_unpack4s_kernel")    # permuted strides
+    kc.case_reduce_unpack(k, 300, 64, 9, 64, True, True, expect="reduce_unpack4_kernel")       # many slabs: the split-lane form
+    kc.case_reduce_unpack(k, 4, 256, 27, 256, True, False, expect="reduce_unpack_t_kernel")    # conv layout, few slabs
+    kc.case_reduce_unpack(k, 3, 33, 5, 7, False, True, expect="reduce_unpack_kernel")          # unaligned: element form
 
 
 @pytest.mark.parametrize("bps", [(4, 3, 16), (2, 1, 4), (3, 5, 49), (16, 3, 16)])
