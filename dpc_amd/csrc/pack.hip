@@ -170,32 +170,6 @@ __global__ __launch_bounds__(256) void reduce_unpack4_kernel(const float* part, 
     }
 }
 
-// Few slabs (split-K GEMMs of the score backward: 5 slabs of 1.5 M sums): the form above would be 12 288 workgroups with three of
-// the eight split lanes idle and one load per thread -- 10 us, all of it workgroup dispatch (~5 ns per workgroup on this chip).
-// Here a thread owns four consecutive outputs and has all NS slab loads in flight; summation order = slab index (deterministic).
-template <int NS>
-__global__ __launch_bounds__(256) void reduce_unpack4s_kernel(const float* part, int nsplit, float* out, int d0, int d1, int d2, long long s0,
-                                                               long long s1, long long s2, int accumulate) {
-    const long long n = (long long)d0 * d1 * d2;
-    for (long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += (long long)gridDim.x * 1024) {
-        u32x4 v[NS];
-        DPC_UNROLL
-        for (int k = 0; k < NS; ++k) v[k] = k < nsplit ? *(const u32x4*)(part + (long long)k * n + i) : u32x4{0u, 0u, 0u, 0u};
-        float t[4] = {0.f, 0.f, 0.f, 0.f};
-        DPC_UNROLL
-        for (int k = 0; k < NS; ++k)
-            DPC_UNROLL
-            for (int e = 0; e < 4; ++e) t[e] += unit_get<float>(v[k], e);
-        const int i2 = (int)(i % d2);
-        const long long q = i / d2;
-        const int i1 = (int)(q % d1);
-        const int i0 = (int)(q / d1);
-        float* o = out + i0 * s0 + i1 * s1 + i2 * s2;
-        DPC_UNROLL
-        for (int e = 0; e < 4; ++e) o[e * s2] = accumulate ? (o[e * s2] + t[e]) : t[e];
-    }
-}
-
 // The conv weight-gradient case: slabs [co][tap][ci] -> parameter layout [co][ci][tap] (s0 = d1*d2, s1 = 1, s2 = d1).  The
 // generic kernel above writes it with 4-byte stores `taps` floats apart and reads 128 bytes per wave and slab (34 us for a
 // 256 x 256 x 27 gradient, 25 launches per step); here a workgroup owns (co, 64 input channels): the slab sums are read as
@@ -245,12 +219,6 @@ extern "C" int dpc_reduce_unpack(const float* part, int32_t nsplit, float* out, 
         return dpc_launch_status();
     }
     const long long n = (long long)d0 * d1 * d2;
-    if (d2 % 4 == 0 && ((uintptr_t)part % 16) == 0 && nsplit <= 8 && n >= (1 << 18)) {   // few slabs, many sums
-        const long long wgs = (n / 4 + 255) / 256;
-        DPC_LAUNCH(reduce_unpack4s_kernel<8>, dim3((unsigned)(wgs < 2048 ? wgs : 2048)), dim3(256), stream, part, nsplit, out, d0, d1, d2, (long long)s0,
-                   (long long)s1, (long long)s2, accumulate);
-        return dpc_launch_status();
-    }
     if (d2 % 4 == 0 && ((uintptr_t)part % 16) == 0) {   // n % 4 == 0 follows: every slab starts 16-byte aligned
         DPC_LAUNCH(reduce_unpack4_kernel, dim3((unsigned)((n / 4 + 31) / 32)), dim3(256), stream, part, nsplit, out, d0, d1, d2, (long long)s0, (long long)s1,
                    (long long)s2, accumulate);

@@ -208,9 +208,9 @@ def test_tpool_split(k, dtype):
 
 def test_reduce_unpack_forms(k):
     """every kernel behind dpc_reduce_unpack"""
-    kc.case_reduce_unpack(k, 5, 6144, 1, 256, False, False, expect="reduce_unpack4s_kernel")   # the score backward's reductions at cfg2
-    kc.case_reduce_unpack(k, 2, 15680, 1, 256, False, True, expect="reduce_unpack4s_kernel")   # cfg5: grid-stride, accumulate
-    kc.case_reduce_unpack(k, 8, 2049, 1, 128, True, False, expect="reduce_unpack4s_kernel")    # permuted strides
+    kc.case_reduce_unpack(k, 5, 6144, 1, 256, False, False, expect="reduce_unpack4_kernel")    # the score backward's reductions at cfg2
+    kc.case_reduce_unpack(k, 2, 15680, 1, 256, False, True, expect="reduce_unpack4_kernel")    # cfg5, accumulate
+    kc.case_reduce_unpack(k, 8, 2049, 1, 128, True, False, expect="reduce_unpack4_kernel")     # permuted strides
     kc.case_reduce_unpack(k, 300, 64, 9, 64, True, True, expect="reduce_unpack4_kernel")       # many slabs: the split-lane form
     kc.case_reduce_unpack(k, 4, 256, 27, 256, True, False, expect="reduce_unpack_t_kernel")    # conv layout, few slabs
     kc.case_reduce_unpack(k, 3, 33, 5, 7, False, True, expect="reduce_unpack_kernel")          # unaligned: element form
