@@ -411,8 +411,10 @@ __global__ __launch_bounds__(512, 2) void conv_halo_ws_kernel(HaloParams p) {
             auto fetch = [&](auto sc) {
                 constexpr int s = decltype(sc)::value;
                 constexpr int kh = s / (NCH * 4), ch = (s / 4) % NCH, kk = s % 4;
+                // probe bit 64: only the first of the MI fragments is read (timing of the loop with half its LDS reads; wrong results)
                 DPC_UNROLL
-                for (int i = 0; i < MI; ++i) lds_read_b128_async_off<ch * CBP + kk * KKSTEP>(ring[s % R][i], rowp[kh][i]);
+                for (int i = 0; i < MI; ++i)
+                    if (i == 0 || !HP_DBG(64)) lds_read_b128_async_off<ch * CBP + kk * KKSTEP>(ring[s % R][i], rowp[kh][i]);
             };
             if (!HP_DBG(2)) static_for<D>(fetch);
             if (!HP_DBG(2)) static_for<S>([&](auto sc) {

@@ -53,4 +53,6 @@ run("no epilogue, no staging", 12)
 run("no DMA, no epilogue, no staging (MFMA + reads + barriers)", 13)
 run("no MFMA, no staging (DMA + epilogue + barriers)", 6)
 run("same, round-robin tile slots", 22)
+run("half of the fragment reads left out (wrong results: what the loop costs with half its LDS reads)", 64)
+run("  + no DMA, no epilogue, no staging", 64 + 13)
 run("full kernel", 0)
