@@ -104,6 +104,7 @@ struct ChainP {
 };
 
 constexpr int TM = 32;          // rows per workgroup
+#define NWV ((int)(blockDim.x >> 6))   // waves of the workgroup = stride between the column tiles a wave owns (4, or 8 for D = 256: one tile per wave)
 constexpr int CHUNK = TM * 128; // bytes of one 128-byte-column chunk of an LDS operand tile
 
 template <class T> struct TileIO {
@@ -218,7 +219,7 @@ __device__ __forceinline__ void stage_put(float* stage, int D, const f32x16 (&ac
     const int ld = D + SPAD;
     DPC_UNROLL
     for (int t = 0; t < NT; ++t) {
-        float* base = stage + (4 * (lane >> 5)) * ld + (wave + 4 * t) * 32 + (lane & 31);
+        float* base = stage + (4 * (lane >> 5)) * ld + (wave + NWV * t) * 32 + (lane & 31);
         DPC_UNROLL
         for (int r = 0; r < 16; ++r) base[((r & 3) + 8 * (r >> 2)) * ld] = acc[t][r];
     }
@@ -227,7 +228,7 @@ __device__ __forceinline__ void stage_put(float* stage, int D, const f32x16 (&ac
 // u, dh, dx -- lives in memory the same thread wrote, never in per-iteration registers next to the accumulators)
 #define RM_FOR(D_)                                                                      \
     DPC_NOUNROLL                                                                        \
-    for (int q_ = (int)threadIdx.x; q_ < TM * ((D_) / 4); q_ += 256)                    \
+    for (int q_ = (int)threadIdx.x; q_ < TM * ((D_) / 4); q_ += (int)blockDim.x)                    \
         if (const int row = q_ / ((D_) / 4), col = (q_ % ((D_) / 4)) * 4; true)
 
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *(const f32x4*)p; }
@@ -299,17 +300,17 @@ __device__ __forceinline__ void gru_chain_fwd_body(const ChainP& p, unsigned cha
         f32x16 a3[3][2];
         zero_acc<3>(a3);
         {
-            const u32x4* const Bx[3][2] = {{frag<T>(p, M_WU, wave, 2 * KSD, 0), frag<T>(p, M_WU, wave + 4, 2 * KSD, 0)},
-                                           {frag<T>(p, M_WR, wave, 2 * KSD, 0), frag<T>(p, M_WR, wave + 4, 2 * KSD, 0)},
-                                           {frag<T>(p, M_WOX, wave, KSD, 0), frag<T>(p, M_WOX, wave + 4, KSD, 0)}};
+            const u32x4* const Bx[3][2] = {{frag<T>(p, M_WU, wave, 2 * KSD, 0), frag<T>(p, M_WU, wave + NWV, 2 * KSD, 0)},
+                                           {frag<T>(p, M_WR, wave, 2 * KSD, 0), frag<T>(p, M_WR, wave + NWV, 2 * KSD, 0)},
+                                           {frag<T>(p, M_WOX, wave, KSD, 0), frag<T>(p, M_WOX, wave + NWV, KSD, 0)}};
             gemm_acc<T, 3, NT>(a3, tx, KSD, Bx, lane);
         }
         f32x16 aur[2][2];
         DPC_UNROLL
         for (int t = 0; t < 2; ++t) { aur[0][t] = a3[0][t]; aur[1][t] = a3[1][t]; }
         {
-            const u32x4* const Bh[2][2] = {{frag<T>(p, M_WU, wave, 2 * KSD, KSD), frag<T>(p, M_WU, wave + 4, 2 * KSD, KSD)},
-                                           {frag<T>(p, M_WR, wave, 2 * KSD, KSD), frag<T>(p, M_WR, wave + 4, 2 * KSD, KSD)}};
+            const u32x4* const Bh[2][2] = {{frag<T>(p, M_WU, wave, 2 * KSD, KSD), frag<T>(p, M_WU, wave + NWV, 2 * KSD, KSD)},
+                                           {frag<T>(p, M_WR, wave, 2 * KSD, KSD), frag<T>(p, M_WR, wave + NWV, 2 * KSD, KSD)}};
             gemm_acc<T, 2, NT>(aur, th, KSD, Bh, lane);
         }
         // ---- r = sigmoid(.), h*r (the operand of the next product)
@@ -345,7 +346,7 @@ __device__ __forceinline__ void gru_chain_fwd_body(const ChainP& p, unsigned cha
         DPC_UNROLL
         for (int t = 0; t < 2; ++t) ao[0][t] = a3[2][t];
         {
-            const u32x4* const Bo[1][2] = {{frag<T>(p, M_WOH, wave, KSD, 0), frag<T>(p, M_WOH, wave + 4, KSD, 0)}};
+            const u32x4* const Bo[1][2] = {{frag<T>(p, M_WOH, wave, KSD, 0), frag<T>(p, M_WOH, wave + NWV, KSD, 0)}};
             gemm_acc<T, 1, NT>(ao, thr, KSD, Bo, lane);
         }
         __syncthreads();  // every thread has read its u pre-activations
@@ -377,7 +378,7 @@ __device__ __forceinline__ void gru_chain_fwd_body(const ChainP& p, unsigned cha
             f32x16 a1[1][2];
             zero_acc<1>(a1);
             {
-                const u32x4* const B1[1][2] = {{frag<T>(p, M_W1, wave, KSD, 0), frag<T>(p, M_W1, wave + 4, KSD, 0)}};
+                const u32x4* const B1[1][2] = {{frag<T>(p, M_W1, wave, KSD, 0), frag<T>(p, M_W1, wave + NWV, KSD, 0)}};
                 gemm_acc<T, 1, NT>(a1, th, KSD, B1, lane);
             }
             stage_put<NT>(stage, D, a1[0], wave, lane);
@@ -393,7 +394,7 @@ __device__ __forceinline__ void gru_chain_fwd_body(const ChainP& p, unsigned cha
             __syncthreads();
             zero_acc<1>(a1);
             {
-                const u32x4* const B2[1][2] = {{frag<T>(p, M_W2, wave, KSD, 0), frag<T>(p, M_W2, wave + 4, KSD, 0)}};
+                const u32x4* const B2[1][2] = {{frag<T>(p, M_W2, wave, KSD, 0), frag<T>(p, M_W2, wave + NWV, KSD, 0)}};
                 gemm_acc<T, 1, NT>(a1, thr, KSD, B2, lane);
             }
             stage_put<NT>(stage, D, a1[0], wave, lane);
@@ -461,7 +462,7 @@ __device__ __forceinline__ void gru_step_bwd(const ChainP& p, int s, int m0, int
     f32x16 acc[1][2];
     zero_acc<1>(acc);
     {
-        const u32x4* const B[1][2] = {{frag<T>(p, M_WOHT, wave, KSD, 0), frag<T>(p, M_WOHT, wave + 4, KSD, 0)}};
+        const u32x4* const B[1][2] = {{frag<T>(p, M_WOHT, wave, KSD, 0), frag<T>(p, M_WOHT, wave + NWV, KSD, 0)}};
         gemm_acc<T, 1, NT>(acc, to, KSD, B, lane);
     }
     stage_put<NT>(stage, D, acc[0], wave, lane);
@@ -487,9 +488,9 @@ __device__ __forceinline__ void gru_step_bwd(const ChainP& p, int s, int m0, int
     // dx
     zero_acc<1>(acc);
     {
-        const u32x4* const B0[1][2] = {{frag<T>(p, M_WUXT, wave, KSD, 0), frag<T>(p, M_WUXT, wave + 4, KSD, 0)}};
-        const u32x4* const B1[1][2] = {{frag<T>(p, M_WRXT, wave, KSD, 0), frag<T>(p, M_WRXT, wave + 4, KSD, 0)}};
-        const u32x4* const B2[1][2] = {{frag<T>(p, M_WOXT, wave, KSD, 0), frag<T>(p, M_WOXT, wave + 4, KSD, 0)}};
+        const u32x4* const B0[1][2] = {{frag<T>(p, M_WUXT, wave, KSD, 0), frag<T>(p, M_WUXT, wave + NWV, KSD, 0)}};
+        const u32x4* const B1[1][2] = {{frag<T>(p, M_WRXT, wave, KSD, 0), frag<T>(p, M_WRXT, wave + NWV, KSD, 0)}};
+        const u32x4* const B2[1][2] = {{frag<T>(p, M_WOXT, wave, KSD, 0), frag<T>(p, M_WOXT, wave + NWV, KSD, 0)}};
         gemm_acc<T, 1, NT>(acc, tu, KSD, B0, lane);
         gemm_acc<T, 1, NT>(acc, tr, KSD, B1, lane);
         gemm_acc<T, 1, NT>(acc, to, KSD, B2, lane);
@@ -503,8 +504,8 @@ __device__ __forceinline__ void gru_step_bwd(const ChainP& p, int s, int m0, int
     // dh
     zero_acc<1>(acc);
     {
-        const u32x4* const B0[1][2] = {{frag<T>(p, M_WUHT, wave, KSD, 0), frag<T>(p, M_WUHT, wave + 4, KSD, 0)}};
-        const u32x4* const B1[1][2] = {{frag<T>(p, M_WRHT, wave, KSD, 0), frag<T>(p, M_WRHT, wave + 4, KSD, 0)}};
+        const u32x4* const B0[1][2] = {{frag<T>(p, M_WUHT, wave, KSD, 0), frag<T>(p, M_WUHT, wave + NWV, KSD, 0)}};
+        const u32x4* const B1[1][2] = {{frag<T>(p, M_WRHT, wave, KSD, 0), frag<T>(p, M_WRHT, wave + NWV, KSD, 0)}};
         gemm_acc<T, 1, NT>(acc, tu, KSD, B0, lane);
         gemm_acc<T, 1, NT>(acc, tr, KSD, B1, lane);
     }
@@ -577,7 +578,7 @@ __device__ __forceinline__ void gru_chain_bwd_body(const ChainP& p, unsigned cha
         f32x16 acc[1][2];
         zero_acc<1>(acc);
         {
-            const u32x4* const B[1][2] = {{frag<T>(p, M_W2T, wave, KSD, 0), frag<T>(p, M_W2T, wave + 4, KSD, 0)}};
+            const u32x4* const B[1][2] = {{frag<T>(p, M_W2T, wave, KSD, 0), frag<T>(p, M_W2T, wave + NWV, KSD, 0)}};
             gemm_acc<T, 1, NT>(acc, tu, KSD, B, lane);
         }
         stage_put<NT>(stage, D, acc[0], wave, lane);
@@ -597,7 +598,7 @@ __device__ __forceinline__ void gru_chain_bwd_body(const ChainP& p, unsigned cha
         __syncthreads();
         zero_acc<1>(acc);
         {
-            const u32x4* const B[1][2] = {{frag<T>(p, M_W1T, wave, KSD, 0), frag<T>(p, M_W1T, wave + 4, KSD, 0)}};
+            const u32x4* const B[1][2] = {{frag<T>(p, M_W1T, wave, KSD, 0), frag<T>(p, M_W1T, wave + NWV, KSD, 0)}};
             gemm_acc<T, 1, NT>(acc, tr, KSD, B, lane);  // dP1 @ W1
         }
         stage_put<NT>(stage, D, acc[0], wave, lane);
@@ -631,7 +632,7 @@ __global__ __launch_bounds__(256) void gru_chain_fwd_kernel(ChainP p) {
         gru_chain_fwd_body<T, 2, 256>(p, smem);
     } else {
         const int wave = threadIdx.x >> 6, ntiles = p.D / 32;
-        const int ntw = wave < ntiles ? (wave + 4 < ntiles ? 2 : 1) : 0;
+        const int ntw = wave < ntiles ? (wave + NWV < ntiles ? 2 : 1) : 0;
         if (ntw == 2) gru_chain_fwd_body<T, 2, 0>(p, smem);
         else if (ntw == 1) gru_chain_fwd_body<T, 1, 0>(p, smem);
         else gru_chain_fwd_body<T, 0, 0>(p, smem);
@@ -644,11 +645,29 @@ __global__ __launch_bounds__(256) void gru_chain_bwd_kernel(ChainP p) {
         gru_chain_bwd_body<T, 2, 256>(p, smem);
     } else {
         const int wave = threadIdx.x >> 6, ntiles = p.D / 32;
-        const int ntw = wave < ntiles ? (wave + 4 < ntiles ? 2 : 1) : 0;
+        const int ntw = wave < ntiles ? (wave + NWV < ntiles ? 2 : 1) : 0;
         if (ntw == 2) gru_chain_bwd_body<T, 2, 0>(p, smem);
         else if (ntw == 1) gru_chain_bwd_body<T, 1, 0>(p, smem);
         else gru_chain_bwd_body<T, 0, 0>(p, smem);
     }
+}
+
+// D = 256 on EIGHT waves (round 4): a wave owns one column tile instead of two, so the dependent phases of a step (products, staging,
+// gate math, barrier) are half as long per wave and each SIMD has two waves to interleave; 64 workgroups stay 64 (the rows of a
+// sequence are all the parallelism there is), but each CU now runs 8 waves instead of 4.
+template <class T>
+__global__ __launch_bounds__(512) void gru_chain_fwd8_kernel(ChainP p) {
+    DPC_DYN_SMEM(smem);
+    gru_chain_fwd_body<T, 1, 0>(p, smem);
+}
+template <class T>
+__global__ __launch_bounds__(512) void gru_chain_bwd8_kernel(ChainP p) {
+    DPC_DYN_SMEM(smem);
+    gru_chain_bwd_body<T, 1, 0>(p, smem);
+}
+static inline bool chain_eight_waves(const dpc_gru_chain_desc* c) {
+    const char* e = getenv("DPC_GRU_WAVES");   // read per call (A/B knob)
+    return c->D == 256 && (!e || atoi(e) == 8);
 }
 
 int chain_params(const dpc_gru_chain_desc* c, ChainP* p, bool backward) {
@@ -726,7 +745,15 @@ extern "C" int dpc_gru_chain_fwd(const dpc_gru_chain_desc* c, dpc_stream_t strea
         if (int e = allow_lds(gru_chain_fwd_kernel<T_, DC_>, lds)) return e;                     \
         DPC_LAUNCH_DYN((gru_chain_fwd_kernel<T_, DC_>), dim3(grid), dim3(256), lds, stream, p); \
     } while (0)
-    if (c->dtype == DPC_F32) {
+    if (chain_eight_waves(c) && (c->dtype == DPC_F32 || c->dtype == DPC_BF16)) {
+        if (c->dtype == DPC_F32) {
+            if (int e = allow_lds(gru_chain_fwd8_kernel<float>, lds)) return e;
+            DPC_LAUNCH_DYN((gru_chain_fwd8_kernel<float>), dim3(grid), dim3(512), lds, stream, p);
+        } else {
+            if (int e = allow_lds(gru_chain_fwd8_kernel<bf16_t>, lds)) return e;
+            DPC_LAUNCH_DYN((gru_chain_fwd8_kernel<bf16_t>), dim3(grid), dim3(512), lds, stream, p);
+        }
+    } else if (c->dtype == DPC_F32) {
         DPC_CHAIN_GO(float, 0);
     } else if (c->dtype == DPC_BF16) {
         DPC_CHAIN_GO(bf16_t, 0);
@@ -749,7 +776,15 @@ extern "C" int dpc_gru_chain_bwd(const dpc_gru_chain_desc* c, dpc_stream_t strea
         if (int e = allow_lds(gru_chain_bwd_kernel<T_, DC_>, lds)) return e;                     \
         DPC_LAUNCH_DYN((gru_chain_bwd_kernel<T_, DC_>), dim3(grid), dim3(256), lds, stream, p); \
     } while (0)
-    if (c->dtype == DPC_F32) {
+    if (chain_eight_waves(c) && (c->dtype == DPC_F32 || c->dtype == DPC_BF16)) {
+        if (c->dtype == DPC_F32) {
+            if (int e = allow_lds(gru_chain_bwd8_kernel<float>, lds)) return e;
+            DPC_LAUNCH_DYN((gru_chain_bwd8_kernel<float>), dim3(grid), dim3(512), lds, stream, p);
+        } else {
+            if (int e = allow_lds(gru_chain_bwd8_kernel<bf16_t>, lds)) return e;
+            DPC_LAUNCH_DYN((gru_chain_bwd8_kernel<bf16_t>), dim3(grid), dim3(512), lds, stream, p);
+        }
+    } else if (c->dtype == DPC_F32) {
         DPC_CHAIN_GO(float, 0);
     } else if (c->dtype == DPC_BF16) {
         DPC_CHAIN_GO(bf16_t, 0);

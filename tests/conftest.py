@@ -10,13 +10,74 @@ if ROOT not in sys.path:
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 
+# ---- a launcher process started BEFORE this process touches the GPU.
+# The RCCL tests start their ranks as child processes (torch.distributed.run).  Forking from the pytest process once the HIP / HSA
+# runtime is up (hundreds of GB of device mappings, runtime threads) segfaulted inside subprocess.Popen about once in five runs of the GPU
+# tier on the MI355X boxes (faulthandler: subprocess.py `__init__` <- tests/test_graph_rccl_gpu.py `_run_ranks`; round 4).  So the children
+# are forked by a small helper that is itself forked at configure time, while this process is still an ordinary Python process.
+_LAUNCHER_CODE = r"""
+import json, subprocess, sys
+for line in sys.stdin:
+    req = json.loads(line)
+    try:
+        r = subprocess.run(req["argv"], env=req["env"], capture_output=True, text=True, timeout=req["timeout"])
+        out = {"returncode": r.returncode, "stdout": r.stdout[-20000:], "stderr": r.stderr[-20000:]}
+    except Exception as e:
+        out = {"returncode": -999, "stdout": "", "stderr": repr(e)}
+    sys.stdout.write(json.dumps(out) + "\n")
+    sys.stdout.flush()
+"""
+_launcher = None
+
+
+class CleanLauncher:
+    def __init__(self):
+        import subprocess
+        self.p = subprocess.Popen([sys.executable, "-u", "-c", _LAUNCHER_CODE], stdin=subprocess.PIPE, stdout=subprocess.PIPE, text=True)
+
+    def run(self, argv, env, timeout):
+        """subprocess.run(argv, env=env, capture_output=True, text=True, timeout=timeout) in the helper: (returncode, stdout, stderr)"""
+        import json
+        self.p.stdin.write(json.dumps({"argv": list(argv), "env": dict(env), "timeout": timeout}) + "\n")
+        self.p.stdin.flush()
+        line = self.p.stdout.readline()
+        if not line:
+            raise RuntimeError("the launcher process died")
+        out = json.loads(line)
+        return out["returncode"], out["stdout"], out["stderr"]
+
+    def close(self):
+        try:
+            self.p.stdin.close()
+            self.p.wait(timeout=10)
+        except Exception:
+            self.p.kill()
+
+
 def pytest_configure(config):
+    global _launcher
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
+    expr = config.getoption("-m", default="") or ""
+    if "gpu" in expr and "not gpu" not in expr and _launcher is None:   # the GPU tier: nothing has initialised HIP yet
+        _launcher = CleanLauncher()
+
+
+@pytest.fixture(scope="session")
+def clean_launcher():
+    """the pre-GPU launcher process (None outside the GPU tier: callers fall back to subprocess.run)"""
+    return _launcher
 
 
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+def pytest_unconfigure(config):
+    global _launcher
+    if _launcher is not None:
+        _launcher.close()
+        _launcher = None
 
 
 def pytest_sessionfinish(session, exitstatus):

@@ -105,14 +105,19 @@ dist.destroy_process_group()
 """
 
 
-def _run_ranks(world, tmp_path):
+def _run_ranks(world, tmp_path, launcher):
+    """the ranks as child processes -- forked by the pre-GPU launcher of conftest.py, not by this (GPU-initialised) process"""
     script = tmp_path / "rank.py"
     script.write_text(_RANK_SCRIPT.format(root=ROOT, out=str(tmp_path)))
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
-    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
-                        "--master-addr", "127.0.0.1", "--master-port", str(29700 + os.getpid() % 200), str(script)],
-                       env=env, capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0, r.stderr[-4000:]
+    argv = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
+            "--master-addr", "127.0.0.1", "--master-port", str(29700 + os.getpid() % 200), str(script)]
+    if launcher is not None:
+        rc, _, err = launcher.run(argv, env, 900)
+    else:   # a single test run by hand without "-m gpu"
+        r = subprocess.run(argv, env=env, capture_output=True, text=True, timeout=900)
+        rc, err = r.returncode, r.stderr
+    assert rc == 0, err[-4000:]
     return [torch.load(tmp_path / f"rank{i}.pt") for i in range(world)]
 
 
@@ -123,10 +128,10 @@ def _check_modes(r):
     assert torch.isfinite(m["C"]["res"]).all()
 
 
-def test_rccl_single_rank_exchange_and_graph_cut(tmp_path):
+def test_rccl_single_rank_exchange_and_graph_cut(tmp_path, clean_launcher):
     """the RCCL path with world_size 1 (all a 1-GPU box can run): eager two-bucket exchange == three-graph replay cut at
     the exchange points == one graph without exchange, bit for bit"""
-    (r,) = _run_ranks(1, tmp_path)
+    (r,) = _run_ranks(1, tmp_path, clean_launcher)
     _check_modes(r)
     m = r["modes"]
     assert m["D"]["ngraphs"] == 1 and torch.equal(m["A"]["params"], m["D"]["params"])
@@ -134,11 +139,11 @@ def test_rccl_single_rank_exchange_and_graph_cut(tmp_path):
 
 
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two MI355X on the node")
-def test_rccl_two_rank_data_parallel(tmp_path):
+def test_rccl_two_rank_data_parallel(tmp_path, clean_launcher):
     """as tests/test_parallel_gloo.py, over RCCL/xGMI: averaged gradient == mean of the local ones, identical parameters
     on both ranks after the step (eager and graph-replayed), local gradients differ (per-rank shards, negatives and BN
     statistics, dpc/main.py:180,211-213)"""
-    r = _run_ranks(2, tmp_path)
+    r = _run_ranks(2, tmp_path, clean_launcher)
     assert torch.equal(r[0]["params"], r[1]["params"]) and torch.equal(r[0]["avg"], r[1]["avg"])
     assert not torch.equal(r[0]["local"], r[1]["local"])
     assert torch.allclose(r[0]["avg"], 0.5 * (r[0]["local"] + r[1]["local"]), rtol=0, atol=1e-6)

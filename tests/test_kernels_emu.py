@@ -255,6 +255,14 @@ def test_gru_chain(k, dtype, shape):
     kc.case_gru_chain(k, dtype, *shape)  # 48 rows: one full and one ragged row tile; 64/160 channels: one / two tiles per wave
 
 
+@pytest.mark.parametrize("waves", ["8", "4"])
+def test_gru_chain_full_width(k, monkeypatch, waves):
+    """D = 256 (the reference's feature size): the eight-wave kernels (one column tile per wave; default) and the four-wave form"""
+    monkeypatch.setenv("DPC_GRU_WAVES", waves)
+    kc.case_gru_chain(k, BF16, 3, 12, 256, 2, 2)   # 36 rows: one full, one ragged row tile
+    kc.case_gru_chain_philox(k, BF16, 2, 16, 256, 2, 1)
+
+
 @pytest.mark.parametrize("dtype", [F32, BF16])
 def test_gru_chain_philox(k, dtype):
     kc.case_gru_chain_philox(k, dtype, 3, 16, 64, 2, 2)

@@ -270,6 +270,13 @@ def test_gru_chain_philox(k, dtype):
     kc.case_gru_chain_philox(k, dtype, 3, 16, 256, 3, 5)
 
 
+def test_gru_chain_four_waves(k, monkeypatch):
+    """the four-wave form of the D = 256 recurrence (two column tiles per wave; the default is eight waves)"""
+    monkeypatch.setenv("DPC_GRU_WAVES", "4")
+    kc.case_gru_chain(k, BF16, 40, 16, 256, 3, 5)
+    kc.case_gru_chain_philox(k, F32, 3, 16, 256, 3, 5)
+
+
 def test_gru_chain_reference_fixture(k, golden_dir):
     import os
     import numpy as np
