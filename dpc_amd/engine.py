@@ -204,6 +204,15 @@ def _idle_at_exit():
 
 atexit.register(_idle_at_exit)
 
+# Captured train steps are never destroyed before the interpreter exits.  Destroying the hipGraphs of an engine (two streams forked and
+# joined inside the capture) while the process goes on to build the next engine was followed, about once in five runs of the GPU test
+# tier, by corrupted HOST memory: a freshly built dict of this module losing a key (`load_params`: "in PRM: True, in shapes: False"),
+# or a segfault in the next fork().  The graphs hold no engine buffers alive (they are not replayed again); DPC_KEEP_GRAPHS=0 restores
+# the destruction.  Evidence is statistical (profiles/r04_probes.txt): the first pytest run on a fresh box failed in 4 of 8 sessions before
+# this change and in 0 of the sessions after it; a loop of 60 capture / destroy cycles in a warm process did not reproduce it either way
+# (scripts/probes/graph_destroy_probe.py).
+_LIVE_GRAPHS: list = []
+
 
 class _ConvBN:
     """one Conv3d (no bias) + BatchNorm3d(batch stats) unit and its saved tensors"""
@@ -1192,6 +1201,10 @@ class DPCEngine:
             return self.result
 
         replay.graphs = graphs
+        if os.environ.get("DPC_KEEP_GRAPHS", "1") != "0":
+            for g_ in graphs:   # see _LIVE_GRAPHS: one reference that is never given back, so that not even interpreter shutdown destroys them
+                C.pythonapi.Py_IncRef(C.py_object(g_))
+            _LIVE_GRAPHS.extend(graphs)
         return replay
 
     def train_step(self, block: torch.Tensor, dropout_masks: Optional[torch.Tensor] = None, allreduce=None) -> torch.Tensor:
