@@ -29,6 +29,8 @@ def test_graph_replay_equals_eager(dtype):
         ra = a.train_step(x).clone()
     replay = b.capture_train_step(x, warmup=2)  # 2 real warm-up steps, then every replay is one more step
     assert len(replay.graphs) == 1
+    from dpc_amd import engine as E_
+    assert any(g is replay.graphs[0] for g in E_._LIVE_GRAPHS)   # never destroyed before the process exits
     for _ in range(3):
         rb = replay().clone()
     torch.cuda.synchronize()
