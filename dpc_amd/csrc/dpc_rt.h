@@ -293,7 +293,7 @@ static __device__ const uint32_t dpc_zero16[4] __attribute__((aligned(16))) = {0
 // s_waitcnt vmcnt / __syncthreads().  wave_base must be wave-uniform.
 __device__ __forceinline__ void glds16(const void* gsrc, unsigned char* lds_wave_base, int lane) {
 #ifdef DPC_SIMT_EMU
-    std::memcpy(lds_wave_base + lane * 16, gsrc, 16);
+    simt::dma_issue(lds_wave_base + lane * 16, gsrc);   // lands at the wait that retires it (tests/simt_emu/simt_emu.h)
 #else
     (void)lane;
     __builtin_amdgcn_global_load_lds(gsrc, (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
@@ -355,8 +355,7 @@ static inline BufRsrc make_buf_rsrc(const void* p, uint32_t nbytes) {
 }
 static inline void glds16_buf(const BufRsrc& r, uint32_t voff, uint32_t soff, unsigned char* lds_wave_base, int lane) {
     const uint64_t o = (uint64_t)voff + soff;
-    if (voff < r.nbytes && o + 16 <= r.nbytes) std::memcpy(lds_wave_base + lane * 16, r.base + o, 16);
-    else std::memset(lds_wave_base + lane * 16, 0, 16);
+    simt::dma_issue(lds_wave_base + lane * 16, (voff < r.nbytes && o + 16 <= r.nbytes) ? r.base + o : nullptr);
 }
 #else
 typedef __amdgpu_buffer_rsrc_t BufRsrc;
@@ -446,6 +445,17 @@ __device__ __forceinline__ void lds_wait_tie_n(int n, u32x4& a, u32x4& b) {  // 
 template <int N> __device__ __forceinline__ void wait_vmcnt() {
 #ifndef DPC_SIMT_EMU
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+#else
+    simt::dma_wait(N);
+#endif
+}
+// n stores were just issued that a later counted wait relies on (vmcnt counts stores): nothing on the device, place-holders in the
+// simulator's completion queue (tests/simt_emu/simt_emu.h)
+__device__ __forceinline__ void vm_note_stores(int n) {
+#ifdef DPC_SIMT_EMU
+    simt::dma_note_stores(n);
+#else
+    (void)n;
 #endif
 }
 

@@ -429,6 +429,7 @@ __global__ __launch_bounds__(256, 2) void score_gemm_kernel(GemmKP p) {
                 }
             }
         }
+        vm_note_stores(SWAP ? 8 : 32);   // what the counted wait of the next tile leaves in flight (simulator bookkeeping; nothing on the device)
     }
 }
 
@@ -515,6 +516,7 @@ __global__ __launch_bounds__(512, 2) void score_gemm2_kernel(GemmKP p) {
             const int row = r0 + 4 * it + sr;
             if (row < p.M && c < p.N) __builtin_nontemporal_store(ov[it], (f32x4*)(p.out + (long long)row * p.ldo + c));   // N % 4 == 0 (vec)
         }
+        vm_note_stores(nst);   // simulator bookkeeping for wait_vmcnt_upto(nst) above; nothing on the device
     }
 }
 

@@ -60,9 +60,53 @@ static void yield_to_sched(State st) {
 
 static void fiber_main() {
     (*body_fn)();
+    dma_wait(0);   // pieces still in flight at the end of the work-item land (zero fills of a free stage, typically)
     yield_to_sched(DONE);
     std::fprintf(stderr, "simt: resumed a finished fiber\n");
     std::abort();
+}
+
+// ---- LDS-DMA completion model (simt_emu.h)
+struct DmaRec {
+    unsigned char* dst;   // nullptr: a store place-holder
+    unsigned char data[16];
+};
+static std::vector<DmaRec> dmaq[MAX_THREADS];
+static int dma_mode = -1, dma_weak = 0;   // mode 0 eager, 1 late
+
+static int fiber_index() { return (int)(running - fibers.data()); }
+static void dma_land(std::vector<DmaRec>& q, size_t n) {
+    for (size_t i = 0; i < n; ++i)
+        if (q[i].dst) std::memcpy(q[i].dst, q[i].data, 16);
+    q.erase(q.begin(), q.begin() + (long)n);
+}
+void dma_issue(unsigned char* lds_dst, const void* src16) {
+    if (dma_mode < 0) {
+        const char* e = std::getenv("DPC_EMU_DMA");
+        dma_mode = (e && e[0] == 'e') ? 0 : 1;
+        const char* w = std::getenv("DPC_EMU_DMA_WEAK");
+        dma_weak = w ? std::atoi(w) : 0;
+    }
+    if (dma_mode == 0) {
+        if (src16) std::memcpy(lds_dst, src16, 16); else std::memset(lds_dst, 0, 16);
+        return;
+    }
+    DmaRec r;
+    r.dst = lds_dst;
+    if (src16) std::memcpy(r.data, src16, 16); else std::memset(r.data, 0, 16);
+    dmaq[fiber_index()].push_back(r);
+}
+void dma_note_stores(int n) {
+    if (dma_mode == 0) return;
+    DmaRec r;
+    r.dst = nullptr;
+    for (int i = 0; i < n; ++i) dmaq[fiber_index()].push_back(r);
+}
+void dma_wait(int leave) {
+    if (!running) return;
+    std::vector<DmaRec>& q = dmaq[fiber_index()];
+    const size_t keep = (size_t)(leave > 0 ? leave + dma_weak : 0);   // DPC_EMU_DMA_WEAK: a counted wait that is too weak by that many pieces
+    if (q.size() > keep) dma_land(q, q.size() - keep);
 }
 
 void sync_block() { yield_to_sched(WAIT_BLOCK); }
@@ -87,6 +131,7 @@ static void prepare(Fiber& f, int idx) {
     for (int i = 0; i < 6; ++i) *--sp = nullptr;  // rbp rbx r12..r15
     f.sp = (void*)sp;
     f.st = READY;
+    dmaq[idx].clear();
 }
 
 unsigned char* dyn_smem = nullptr;

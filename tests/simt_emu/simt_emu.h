@@ -53,6 +53,19 @@ extern Cur cur;
 void sync_block();
 void sync_wave();
 void launch(dim3 grid, dim3 block, const std::function<void()>& body);
+// ---- LDS-DMA completion model (round 4).  On gfx950 a global_load_lds / buffer_load ... lds piece is asynchronous: its 16 bytes per
+// lane land in LDS some time between the instruction and the s_waitcnt vmcnt(N) that retires it (pieces of a wave complete in issue
+// order; vmcnt counts the wave's stores too).  The kernels hand-count those waits, and with an eager copy the simulator could not tell a
+// correct count from one that is too weak.  Model: dma_issue() reads the source now and queues the piece; dma_wait(leave) lands every
+// queued piece except the newest `leave`; __syncthreads() lands everything (it is s_waitcnt vmcnt(0) on the device); whatever is
+// still queued when the work-item ends lands then.  A wait that leaves the wrong pieces in flight makes its consumer read stale LDS
+// -- deterministically.  dma_note_stores(n) queues n place-holders for stores the kernel's count relies on (score_fused.hip).
+// DPC_EMU_DMA=eager restores the immediate copy (the other extreme of what the hardware may do: a piece that lands at once overwrites
+// a stage somebody is still reading); the kernel tier runs the LDS-DMA kernels under both.  DPC_EMU_DMA_WEAK=k makes every wait
+// leave k more pieces in flight than asked: the positive control of tests/test_ws_emu.py.
+void dma_issue(unsigned char* lds_dst, const void* src16);   // src16 == nullptr: 16 zero bytes (out-of-range buffer lane)
+void dma_wait(int leave);
+void dma_note_stores(int n);
 // dynamic LDS: one zero-initialised buffer of `lds_bytes` for the launch (workgroups run one at a time)
 extern unsigned char* dyn_smem;
 void launch_dyn(dim3 grid, dim3 block, size_t lds_bytes, const std::function<void()>& body);
@@ -70,7 +83,7 @@ void launch_dyn(dim3 grid, dim3 block, size_t lds_bytes, const std::function<voi
 #define __shared__ static
 #define __launch_bounds__(...)
 #define __restrict__
-#define __syncthreads() simt::sync_block()
+#define __syncthreads() (simt::dma_wait(0), simt::sync_block())
 
 template <class T>
 static inline T simt_shfl_from(T v, int src) {
