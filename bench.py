@@ -26,6 +26,8 @@ Prints ONE JSON line on rank 0, including
                   conv family's roofline fraction.  They never enter `value`.
 """
 import hashlib
+import os as _os
+_os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")   # before HIP initialises; see dpc_amd/__init__.py (this file touches the GPU before it imports the package)
 import argparse
 import json
 import os
