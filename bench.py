@@ -60,13 +60,28 @@ def csrc_sha16():
     return h.hexdigest()[:16]
 
 
-def side_config(name, dev, steps=8, warmup=2, roof_steps=2):
+def score_block(eng, sc, steps, peak):
+    """the `score_gemm` object of a bench line from KernelTimer's tag:score totals of `steps` instrumented steps"""
+    R = eng.R
+    ach = sc["flops"] / (sc["ms"] * 1e-3) / 1e12
+    return {
+        "what": f"contrastive score {R}x{R}x{eng.D}: forward + d_pred + d_feature_inf contractions ({eng.score_mode} path)",
+        "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
+        "us_per_step": round(1e3 * sc["ms"] / steps, 1), "launches_per_step": sc["launches"] // steps,
+        "flops_per_step": round(sc["flops"] / steps / 1e9, 2), "flops_unit": "GFLOP (algorithmic: 3 x 2 R^2 D)",
+        "score_bytes_f32": R * R * 4,
+        "includes": ("the softmax statistics / loss and the recomputation of dS inside the backward (no [R][R] tensor is "
+                     "written)" if eng.score_mode == "fused" else "the three GEMMs with the reductions of their split-K slabs (CE/top-k and dS are a separate kernel)"),
+    }
+
+
+def side_config(name, dev, steps=8, warmup=2, roof_steps=2, score_path="auto"):
     """one of the 224^2 configurations, measured after the headline run in the same process (single GPU, no exchange)"""
     from dpc_amd.engine import DPCEngine, KernelTimer
     from dpc_amd.model import DPC_RNN
     cfg = CONFIGS[name]
     net, img, P, batch = cfg["net"], cfg["img_dim"], cfg["pred_step"], cfg["batch"]
-    eng = DPCEngine(net, img, 8, 5, P, batch, dev, torch.bfloat16, seed=233)
+    eng = DPCEngine(net, img, 8, 5, P, batch, dev, torch.bfloat16, seed=233, score_path=score_path)
     init = DPC_RNN(img, network=net, pred_step=P, seed=0)
     eng.load_params({k: v.detach() for k, v in init.named_parameters()})
     del init
@@ -83,17 +98,22 @@ def side_config(name, dev, steps=8, warmup=2, roof_steps=2):
     out = {"workload": f"{net} 2d3d, img_dim {img}, pred_step {P}, batch {batch}/GPU, bf16, full train step, hipGraph replay",
            "value": round(batch * steps / dt, 2), "unit": "clips/s", "ms_per_step": round(1e3 * dt / steps, 3), "steps": steps,
            "final_loss": round(res.cpu().tolist()[0], 4), "score_path": eng.score_mode}
-    timer = KernelTimer(["dpc_conv_igemm", "dpc_conv_igemm_ex"])
+    timer = KernelTimer(["dpc_conv_igemm", "dpc_conv_igemm_ex", "dpc_score_fwd", "dpc_score_bwd", "dpc_gemm_nt_splitk", "dpc_gemm_tn_splitk",
+                         "dpc_reduce_unpack"])
     eng.timer = timer
     for _ in range(roof_steps):
         eng.train_step(block)
     torch.cuda.synchronize()
     eng.timer = None
-    ig = timer.summary(roof_steps).get("dpc_conv_igemm")
+    summ = timer.summary(roof_steps)
+    ig = summ.get("dpc_conv_igemm")
     if ig and ig["ms"] > 0:
         ach = ig["flops"] / (ig["ms"] * 1e-3) / 1e12
         out["roofline"] = {"kernel": "dpc_conv_igemm", "bound": "mfma", "achieved": round(ach, 2), "peak": MFMA_PEAK_BF16,
                            "unit": "TFLOP/s", "frac": round(ach / MFMA_PEAK_BF16, 4), "ms_per_step": round(ig["ms"] / roof_steps, 3)}
+    sc = summ.get("tag:score")
+    if sc and sc["ms"] > 0:
+        out["score_gemm"] = score_block(eng, sc, roof_steps, MFMA_PEAK_BF16)
     del eng, step, block
     torch.cuda.empty_cache()
     return out
@@ -129,37 +149,58 @@ def f32_mode(dev, steps=4, matmul="exact"):
     return out
 
 
-def one_stream(dev, steps=20):
-    """cfg2 with the weight gradients on the main stream (DPC_WGRAD_STREAM=0): what the two-stream schedule of the headline line buys"""
+def one_stream(dev, steps=20, rounds=3):
+    """cfg2 with the weight gradients on the main stream (DPC_WGRAD_STREAM=0) against the two-stream schedule of the headline line,
+    PAIRED: both engines live in this process, both steps are captured, and blocks of `steps` replays alternate (two, one, two, one,
+    ...), so the two schedules see the same clocks and the same allocator state.  Round 4 compared this leg -- run minutes into the
+    process -- with the headline measured in the process's first second and read 1.0035; an alternating fresh-process A/B of the same
+    two schedules on one box says 1.033 / 1.030 / 1.029 at cfg2 / cfg4 / cfg5 (profiles/r05_two_stream_ab.txt)."""
     from dpc_amd.engine import DPCEngine
     from dpc_amd.model import DPC_RNN
     cfg = CONFIGS["cfg2"]
     net, img, P, batch = cfg["net"], cfg["img_dim"], cfg["pred_step"], cfg["batch"]
-    prev = os.environ.get("DPC_WGRAD_STREAM")
-    os.environ["DPC_WGRAD_STREAM"] = "0"
-    try:
-        eng = DPCEngine(net, img, 8, 5, P, batch, dev, torch.bfloat16, seed=233)
-    finally:
-        if prev is None:
-            os.environ.pop("DPC_WGRAD_STREAM", None)
-        else:
-            os.environ["DPC_WGRAD_STREAM"] = prev
     init = DPC_RNN(img, network=net, pred_step=P, seed=0)
-    eng.load_params({k: v.detach() for k, v in init.named_parameters()})
-    del init
+    params = {k: v.detach() for k, v in init.named_parameters()}
     block = torch.randn(batch, 8, 3, 5, img, img, device=dev, generator=torch.Generator(dev).manual_seed(1234))
-    step = eng.capture_train_step(block)
+
+    def build(streams):
+        prev = os.environ.get("DPC_WGRAD_STREAM")
+        os.environ["DPC_WGRAD_STREAM"] = str(streams)
+        try:
+            eng = DPCEngine(net, img, 8, 5, P, batch, dev, torch.bfloat16, seed=233)
+        finally:
+            if prev is None:
+                os.environ.pop("DPC_WGRAD_STREAM", None)
+            else:
+                os.environ["DPC_WGRAD_STREAM"] = prev
+        eng.load_params(params)
+        return eng, eng.capture_train_step(block)
+
+    def timed(step):
+        step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        torch.cuda.synchronize()
+        return 1e3 * (time.perf_counter() - t0) / steps
+
+    e2, s2 = build(1)
+    e1, s1 = build(0)
+    assert e2._side is not None and e1._side is None
     for _ in range(3):
-        step()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        step()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    out = {"workload": "cfg2, bf16, hipGraph replay, ONE stream (no weight gradients beside the next unit's BatchNorm backward)",
-           "value": round(batch * steps / dt, 2), "unit": "clips/s", "ms_per_step": round(1e3 * dt / steps, 3), "steps": steps}
-    del eng, step, block
+        s2(); s1()
+    two, one = [], []
+    for _ in range(rounds):
+        two.append(timed(s2))
+        one.append(timed(s1))
+    med = lambda v: sorted(v)[len(v) // 2]   # noqa: E731
+    out = {"workload": "cfg2, bf16, hipGraph replay, ONE stream (no weight gradients beside the next unit's BatchNorm backward) against the "
+                       f"two-stream schedule, paired in this process: {rounds} alternating blocks of {steps} steps each",
+           "value": round(batch / (med(one) * 1e-3), 2), "unit": "clips/s", "ms_per_step": round(med(one), 3), "steps": steps * rounds,
+           "two_stream_ms_per_step": round(med(two), 3), "all_ms_per_step": {"two": [round(v, 3) for v in two], "one": [round(v, 3) for v in one]},
+           "two_stream_speedup": round(med(one) / med(two), 4)}
+    del e1, e2, s1, s2, block
     torch.cuda.empty_cache()
     return out
 
@@ -271,7 +312,7 @@ def main():
     ap.add_argument("--no-schedules", action="store_true", help="multi-rank runs: skip the side measurement of the other exchange schedules")
     ap.add_argument("--no-graph", action="store_true", help="launch the step kernel by kernel instead of replaying a hipGraph")
     ap.add_argument("--score-path", default="auto", choices=["auto", "fused", "materialised"],
-                    help="contrastive score + loss: fused (no [R][R] tensor in HBM) or materialised; auto = fused for R >= 8192")
+                    help="contrastive score + loss: fused (no [R][R] tensor in HBM) or materialised; auto = materialised (the faster one at cfg2 and at cfg5)")
     args = ap.parse_args()
     cfg = dict(CONFIGS[args.config])
     for k in ("batch", "net", "img_dim", "pred_step"):
@@ -353,28 +394,51 @@ def main():
     # persistent grids, "serial" = one all-reduce of the whole arena after the backward pass
     schedules = None
     if dist is not None and use_graph and allreduce is not None and not args.no_schedules:
-        def timed_schedule(exch, reserve, n=max(4, min(args.steps, 10))):
-            keep = eng.reserve_cus
+        def agree(ok: bool) -> bool:
+            """every rank learns whether ALL ranks got here without an exception (one tiny all-reduce, same place on every rank)"""
+            f = torch.tensor([1.0 if ok else 0.0], device=dev)
+            dist.all_reduce(f, op=dist.ReduceOp.MIN)
+            return bool(f.item() > 0.5)
+
+        failed = []   # once any rank failed a side schedule, every rank skips the rest: their collectives would no longer pair up
+
+        def side(exch, reserve, n=max(4, min(args.steps, 10))):
+            """a side measurement must never cost the line.  A failure on ONE rank (capture refused, out of memory) must not leave the
+            other ranks inside collectives nobody answers: the ranks agree after the capture and again after the timed loop, and
+            whatever one rank could not do, no rank goes on with.  What this cannot cure is a rank dying INSIDE a
+            gradient exchange; RCCL's own watchdog ends that run."""
+            if failed:
+                return f"skipped: {failed[0]}"
+            keep, note, fn, t = eng.reserve_cus, None, None, None
             eng.reserve_cus = reserve
             try:
-                fn = eng.capture_train_step(block, allreduce=exch)
-                fn(); fn()
-                sync()
-                t1 = time.perf_counter()
-                for _ in range(n):
-                    fn()
-                sync()
-                t = torch.tensor([(time.perf_counter() - t1) / n], device=dev, dtype=torch.float64)
-                dist.all_reduce(t, op=dist.ReduceOp.MAX)
-                return round(1e3 * t.item(), 3)
+                try:
+                    fn = eng.capture_train_step(block, allreduce=exch)
+                except Exception as e:
+                    note = f"failed: {type(e).__name__}: {str(e)[:120]}"
+                    torch.cuda.synchronize()
+                if not agree(fn is not None):
+                    failed.append(note or "capture failed on another rank")
+                    return failed[0]
+                try:
+                    fn(); fn()
+                    sync()
+                    t1 = time.perf_counter()
+                    for _ in range(n):
+                        fn()
+                    sync()
+                    t = (time.perf_counter() - t1) / n
+                except Exception as e:
+                    note = f"failed: {type(e).__name__}: {str(e)[:120]}"
+                    torch.cuda.synchronize()
+                if not agree(t is not None):
+                    failed.append(note or "timed loop failed on another rank")
+                    return failed[0]
+                tt = torch.tensor([t], device=dev, dtype=torch.float64)
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                return round(1e3 * tt.item(), 3)
             finally:
                 eng.reserve_cus = keep
-        def side(exch, reserve):   # a side measurement must never cost the line: a failure is reported in its place
-            try:
-                return timed_schedule(exch, reserve)
-            except Exception as e:
-                torch.cuda.synchronize()
-                return f"failed: {type(e).__name__}: {str(e)[:120]}"
         schedules = {"default": {"ms_per_step": round(1e3 * dt / args.steps, 3), "reserve_cus": eng.reserve_cus, "exchange": "two buckets, overlapped"}}
         if eng.reserve_cus:
             schedules["overlap_all_cus"] = {"ms_per_step": side(allreduce, 0), "reserve_cus": 0}
@@ -451,18 +515,7 @@ def main():
                                        "launches_per_step": wg["launches"] // rs}
             sc = s.get("tag:score")
             if sc and sc["ms"] > 0:
-                R = eng.R
-                ach = sc["flops"] / (sc["ms"] * 1e-3) / 1e12
-                out["score_gemm"] = {
-                    "what": f"contrastive score {R}x{R}x{eng.D}: forward + d_pred + d_feature_inf contractions "
-                            f"({eng.score_mode} path)",
-                    "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
-                    "us_per_step": round(1e3 * sc["ms"] / rs, 1), "launches_per_step": sc["launches"] // rs,
-                    "flops_per_step": round(sc["flops"] / rs / 1e9, 2), "flops_unit": "GFLOP (algorithmic: 3 x 2 R^2 D)",
-                    "score_bytes_f32": R * R * 4,
-                    "includes": ("the softmax statistics / loss and the recomputation of dS inside the backward (no [R][R] tensor is "
-                                 "written)" if eng.score_mode == "fused" else "the three GEMMs with the reductions of their split-K slabs (CE/top-k and dS are a separate kernel)"),
-                }
+                out["score_gemm"] = score_block(eng, sc, rs, peak)
             hb = [s[n] for n in HBM_FAMILY if n in s]
             if hb:
                 ms = sum(d["ms"] for d in hb)
@@ -478,6 +531,7 @@ def main():
             torch.cuda.empty_cache()
             out["also"] = {}
             for name, fn in (("cfg4", lambda: side_config("cfg4", dev)), ("cfg5", lambda: side_config("cfg5", dev)),
+                             ("cfg5_fused_score", lambda: side_config("cfg5", dev, steps=6, score_path="fused")),
                              ("one_stream", lambda: one_stream(dev)), ("module", lambda: module_loop(dev)), ("f32", lambda: f32_mode(dev)),
                              ("f32_bf16x6", lambda: f32_mode(dev, matmul="bf16x6"))):
                 try:
@@ -485,8 +539,6 @@ def main():
                 except Exception as e:  # reported, never hidden
                     out["also"][name] = {"error": f"{type(e).__name__}: {str(e)[:160]}"}
                     torch.cuda.synchronize()
-            if "ms_per_step" in out["also"].get("one_stream", {}):   # overlapped efficiency: the same kernels on one stream / this schedule's step
-                out["also"]["one_stream"]["two_stream_speedup"] = round(out["also"]["one_stream"]["ms_per_step"] / out["ms_per_step"], 4)
             if "value" in out["also"].get("module", {}):
                 out["also"]["module"]["vs_engine_path"] = round(out["also"]["module"]["value"] / out["value"], 3)
         if world == 1 and not args.no_cpu_baseline:

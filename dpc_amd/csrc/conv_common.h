@@ -231,10 +231,6 @@ static inline bool dpc_plan_parity(const GatherGeom& g, ParityInfo& par, int bke
     for (int c = par.ncls; c < 9; ++c) par.tile_start[c] = tiles;
     par.tstart_t[0] = 0;
     par.tstart_t[1] = par.tile_start[par.nsp];
-    {
-        static const int ilv_on = getenv("DPC_PARITY_ILV") ? atoi(getenv("DPC_PARITY_ILV")) : 1;
-        if (!ilv_on) par.ilv = 0;
-    }
     *ntm = tiles;
     return true;
 }

@@ -615,15 +615,6 @@ static int launch_wgrad(const WgradParams& p, int tm, int tn, hipStream_t stream
     return launch_wgrad_rf<T, false>(p, tm, tn, stream);
 }
 
-static bool wgrad_use_v1() {
-    static int v = -1;
-    if (v < 0) {
-        const char* e = getenv("DPC_WGRAD_V1");
-        v = (e && e[0] == '1') ? 1 : 0;
-    }
-    return v == 1;
-}
-
 extern "C" int dpc_conv_wgrad(const dpc_conv_desc* d, const void* src, const void* dy, int32_t dy_ld,
                               float* part, int32_t* nsplit, dpc_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
@@ -648,7 +639,7 @@ extern "C" int dpc_conv_wgrad(const dpc_conv_desc* d, const void* src, const voi
     const bool padded = rwp != d->RW || rhp != d->RH;
     const long long mv = (long long)d->N * d->RT * rhp * rwp;
     static const int pad_on = getenv("DPC_WGRAD2_PAD") ? atoi(getenv("DPC_WGRAD2_PAD")) : 1;
-    const bool v2 = bkp % rwp == 0 && !wgrad_use_v1() && mv < (1ll << 31) &&
+    const bool v2 = bkp % rwp == 0 && mv < (1ll << 31) &&
                     (!padded || (pad_on && (rwp * rhp) % bkp == 0 && (long long)d->RW * d->RH * 10 >= (long long)rwp * rhp * 6));
     const int lrw = ilog2_exact(rwp), lrh = ilog2_exact(rhp);
     const int nchunks = (int)(((v2 ? mv : (long long)p.g.M) + bkp - 1) / bkp);
@@ -687,8 +678,7 @@ extern "C" int dpc_conv_wgrad(const dpc_conv_desc* d, const void* src, const voi
         q.g = p.g; q.src = src; q.dy = dy; q.part = part; q.Co = d->Co; q.dy_ld = dy_ld;
         q.nks = p.nks; q.kcps = p.kcps; q.ntm = p.ntm; q.ntn = p.ntn; q.lRW = lrw; q.lRH = lrh;
         q.RWm = rwp - 1; q.RHm = rhp - 1; q.Mv = (int)mv; q.x6 = p.x6;
-        static const int xcd_remap = (getenv("DPC_WGRAD_XCD") && getenv("DPC_WGRAD_XCD")[0] == '0') ? 0 : 1;  // read once
-        q.xcd_remap = xcd_remap;
+        q.xcd_remap = 1;   // the tiles of one K-split share an L2 (round-robin placement measured slower in round 2; the switch is gone)
         const bool pu = (rwp * rhp) % bkp == 0;  // a chunk never leaves its (n, t) plane
         if (d->dtype_in == DPC_F32) return launch_wgrad2<float>(q, nwm, nwn, pu, stream);
         return launch_wgrad2<bf16_t>(q, nwm, nwn, pu, stream);

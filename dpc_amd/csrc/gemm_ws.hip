@@ -324,7 +324,10 @@ static int gemm_ws_plan(int trans_a, int M, int N, int K, int lda, int ldb, Gemm
     p->a_bytes = (unsigned)a_bytes; p->b_bytes = (unsigned)b_bytes;
     p->ntm = (M + 255) / 256; p->ntn = N / 128;
     const int tiles = p->ntm * p->ntn, nch = (K + 63) / 64;
-    const int cus = dpc_persistent_grid(256);
+    // The slice count is a function of the SHAPE alone: the caller sizes `part` from a planning call and launches later, possibly
+    // with another CU carve-out in force (dpc_set_reserved_cus) -- a count that followed the carve-out could outgrow the buffer
+    // (ADVICE r4).  These products run at the head of the backward pass, before any exchange is in flight: all 256 CUs.
+    const int cus = 256;
     int want = cus / tiles;                        // slices so that tiles x slices fills the chip once ...
     if (want > nch / 8) want = nch / 8;            // ... and every slice amortises its 128 KB slab over >= 8 chunks
     if (want < 1) want = 1;

@@ -367,14 +367,12 @@ struct GemmKP {
     int M, N, D, lda, ldb, ldo;
     int ntiles, tiles_per_split, nsplit;
     int vec;  // 16-byte stores: ldo % 4 == 0 and out 16-byte aligned
-    int counted;  // score_gemm_kernel: counted vmcnt + LDS-only barrier in the tile loop (DPC_SCORE_GEMM_COUNTED, default 1)
 };
 
-// SWAP: MFMA operands swapped -> a lane owns one output row and quads of consecutive columns -> 16-byte stores.  Fewer store
-// instructions (8 against 32 per tile and wave), but each touches 64 different cache lines with 32 bytes (the texture addresser
-// walks an instruction line by line); the plain form writes two whole 128-byte lines per instruction.  Both are kept for the A/B
-// (DPC_SCORE_GEMM_SWAP); the default is what measured faster.
-template <int KS, bool SWAP>
+// (The transposed-accumulator store form of this kernel -- 8 sixteen-byte stores per tile and wave instead of 32 four-byte ones, each
+// touching 64 cache lines with 32 bytes -- and round 3's loop without the counted wait measured slower in rounds 3 / 4 and are gone;
+// score_gemm2_kernel below is where the transposed accumulators pay: staged through LDS they leave as whole rows.)
+template <int KS>
 __global__ __launch_bounds__(256, 2) void score_gemm_kernel(GemmKP p) {
     DPC_DYN_SMEM(smem);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -387,49 +385,29 @@ __global__ __launch_bounds__(256, 2) void score_gemm_kernel(GemmKP p) {
     int jt1 = jt0 + p.tiles_per_split;
     if (jt1 > p.ntiles) jt1 = p.ntiles;
     if (jt0 < jt1) dma_rows(smem, p.b, p.ldb, jt0 * BN, BN, p.N, 0, p.D, p.D, wave, lane);
-    const int row = r0 + (lane & 31), lhi = lane >> 5;
-    float* const orow = p.out + (long long)row * p.ldo;
-    // counted wait (round 4): a wave whose 32 rows and whose column tile lie inside the matrix issues exactly 32 (8 in the SWAP form)
-    // stores per tile, all younger than the tile's DMA pieces -- let those stay in flight instead of draining them every tile
-    // (vmcnt counts stores too); edge waves / edge tiles keep the full drain.  p.counted = 0: round 3's loop.
+    // counted wait: a wave whose 32 rows and whose column tile lie inside the matrix issues exactly 32 stores per tile, all younger
+    // than the tile's DMA pieces -- let those stay in flight instead of draining them every tile (vmcnt counts stores too); edge
+    // waves / edge tiles keep the full drain
     const bool rows_inside = r0 + 32 <= p.M;
     for (int jt = jt0; jt < jt1; ++jt) {
         const int buf = (jt - jt0) & 1;
-        const bool prev_full = p.counted && rows_inside && jt > jt0 && jt * BN <= p.N && (!SWAP || p.vec);   // the previous tile (jt - 1) ended at or before column N
-        if (prev_full) { if (SWAP) wait_vmcnt<8>(); else wait_vmcnt<32>(); } else wait_vmcnt<0>();
-        if (p.counted) barrier_lds_only(); else __syncthreads();  // tile jt has landed; every wave is done with the buffer the next DMA overwrites
+        const bool prev_full = rows_inside && jt > jt0 && jt * BN <= p.N;   // the previous tile (jt - 1) ended at or before column N
+        if (prev_full) wait_vmcnt<32>(); else wait_vmcnt<0>();
+        barrier_lds_only();  // tile jt has landed; every wave is done with the buffer the next DMA overwrites
         if (jt + 1 < jt1) dma_rows(smem + (buf ^ 1) * tile_bytes, p.b, p.ldb, (jt + 1) * BN, BN, p.N, 0, p.D, p.D, wave, lane);
         f32x16 s[2];
-        s_tile<KS, SWAP>(s, own, smem + buf * tile_bytes, lane);
-        if (SWAP) {
-            if (row < p.M) {
-                DPC_UNROLL
-                for (int t = 0; t < 2; ++t)
-                    DPC_UNROLL
-                    for (int k = 0; k < 4; ++k) {
-                        const int c = jt * BN + t * 32 + 8 * k + 4 * lhi;
-                        if (p.vec && c + 3 < p.N) {
-                            const f32x4 v = {s[t][4 * k], s[t][4 * k + 1], s[t][4 * k + 2], s[t][4 * k + 3]};
-                            *(f32x4*)(orow + c) = v;
-                        } else {
-                            DPC_UNROLL
-                            for (int e = 0; e < 4; ++e)
-                                if (c + e < p.N) orow[c + e] = s[t][4 * k + e];
-                        }
-                    }
-            }
-        } else {   // lanes = 32 consecutive columns of one row (x 2 rows): every store instruction writes two full 128-byte lines
+        s_tile<KS, false>(s, own, smem + buf * tile_bytes, lane);
+        // lanes = 32 consecutive columns of one row (x 2 rows): every store instruction writes two full 128-byte lines
+        DPC_UNROLL
+        for (int t = 0; t < 2; ++t) {
+            const int c = jt * BN + t * 32 + (lane & 31);
             DPC_UNROLL
-            for (int t = 0; t < 2; ++t) {
-                const int c = jt * BN + t * 32 + (lane & 31);
-                DPC_UNROLL
-                for (int r = 0; r < 16; ++r) {
-                    const int grow = r0 + crow(r, lane);
-                    if (c < p.N && grow < p.M) p.out[(long long)grow * p.ldo + c] = s[t][r];
-                }
+            for (int r = 0; r < 16; ++r) {
+                const int grow = r0 + crow(r, lane);
+                if (c < p.N && grow < p.M) p.out[(long long)grow * p.ldo + c] = s[t][r];
             }
         }
-        vm_note_stores(SWAP ? 8 : 32);   // what the counted wait of the next tile leaves in flight (simulator bookkeeping; nothing on the device)
+        vm_note_stores(32);   // what the counted wait of the next tile leaves in flight (simulator bookkeeping; nothing on the device)
     }
 }
 
@@ -560,7 +538,6 @@ int dpc_score_gemm_try(const dpc_conv_desc* d, const void* src, const void* wgt,
     p.a = (const bf16_t*)src; p.b = (const bf16_t*)wgt; p.out = (float*)out;
     p.M = d->N; p.N = d->Co; p.D = d->Ci; p.lda = d->src_ld; p.ldb = d->ldw; p.ldo = d->ldo;
     p.vec = (d->ldo % 4 == 0 && ((uintptr_t)out % 16) == 0) ? 1 : 0;
-    p.counted = getenv("DPC_SCORE_GEMM_COUNTED") ? atoi(getenv("DPC_SCORE_GEMM_COUNTED")) : 1;
     p.ntiles = (p.N + BN - 1) / BN;
     const int v2 = getenv("DPC_SCORE_GEMM2") ? atoi(getenv("DPC_SCORE_GEMM2")) : 1;   // 0: never, 1: by size (default), 2: whenever the shape allows (tests)
     // the 8-wave form (staged whole-row non-temporal stores, counted waits) wins where the stores dominate -- R = 15 680: 319 -> 169 us
@@ -594,23 +571,12 @@ int dpc_score_gemm_try(const dpc_conv_desc* d, const void* src, const void* wgt,
     p.nsplit = (p.ntiles + p.tiles_per_split - 1) / p.tiles_per_split;
     const dim3 grid(nrb, p.nsplit);
     const size_t lds = 2 * (size_t)((p.D * 2 + 127) / 128) * BN * 128;
-    static const int swap = getenv("DPC_SCORE_GEMM_SWAP") ? atoi(getenv("DPC_SCORE_GEMM_SWAP")) : 0;
     if (p.D == 256) {
-        if (swap) {
-            if (int e = allow_lds(score_gemm_kernel<16, true>, lds)) return e;
-            DPC_LAUNCH_DYN((score_gemm_kernel<16, true>), grid, dim3(256), lds, stream, p);
-        } else {
-            if (int e = allow_lds(score_gemm_kernel<16, false>, lds)) return e;
-            DPC_LAUNCH_DYN((score_gemm_kernel<16, false>), grid, dim3(256), lds, stream, p);
-        }
+        if (int e = allow_lds(score_gemm_kernel<16>, lds)) return e;
+        DPC_LAUNCH_DYN((score_gemm_kernel<16>), grid, dim3(256), lds, stream, p);
     } else {
-        if (swap) {
-            if (int e = allow_lds(score_gemm_kernel<2, true>, lds)) return e;
-            DPC_LAUNCH_DYN((score_gemm_kernel<2, true>), grid, dim3(256), lds, stream, p);
-        } else {
-            if (int e = allow_lds(score_gemm_kernel<2, false>, lds)) return e;
-            DPC_LAUNCH_DYN((score_gemm_kernel<2, false>), grid, dim3(256), lds, stream, p);
-        }
+        if (int e = allow_lds(score_gemm_kernel<2>, lds)) return e;
+        DPC_LAUNCH_DYN((score_gemm_kernel<2>), grid, dim3(256), lds, stream, p);
     }
     return dpc_launch_status();
 }

@@ -204,14 +204,29 @@ def _idle_at_exit():
 
 atexit.register(_idle_at_exit)
 
-# Captured train steps are never destroyed before the interpreter exits.  Destroying the hipGraphs of an engine (two streams forked and
-# joined inside the capture) while the process goes on to build the next engine was followed, about once in five runs of the GPU test
-# tier, by corrupted HOST memory: a freshly built dict of this module losing a key (`load_params`: "in PRM: True, in shapes: False"),
-# or a segfault in the next fork().  The graphs hold no engine buffers alive (they are not replayed again); DPC_KEEP_GRAPHS=0 restores
-# the destruction.  Evidence is statistical (profiles/r04_probes.txt): the first pytest run on a fresh box failed in 4 of 8 sessions before
-# this change and in 0 of the sessions after it; a loop of 60 capture / destroy cycles in a warm process did not reproduce it either way
-# (scripts/probes/graph_destroy_probe.py).
+# Captured train steps: ONE capture per (engine, input buffer, exchange) and no destruction while the process is running.
+#   * capture_train_step() caches its result on the engine: asking again with the same static input buffer and the same exchange
+#     returns the replay that exists (a trainer that "re-captures" every epoch holds one set of graphs, not one per epoch).
+#   * hipGraphs are not destroyed while the process goes on.  Destroying the graphs of an engine (two streams forked and joined
+#     inside the capture) and then building the next engine was followed, about once in five first runs of the GPU test tier on a
+#     fresh box, by corrupted HOST memory -- a freshly built dict of this module losing a key (`load_params`: "in PRM: True, in
+#     shapes: False"), a segfault in the next fork() -- and in 0 of 10 + 10 runs once the graphs were kept (profiles/r04_probes.txt).
+#     A warm-process loop of 60 capture / destroy cycles reproduces nothing either way (scripts/probes/graph_destroy_probe.py), so
+#     the mechanism inside the runtime is NOT established; what is established is the cost of the workaround, which this module
+#     bounds: a graph set is parked in _LIVE_GRAPHS when its engine drops it (the engine dies, or release_captures() is called) and
+#     stays there, with the private memory pool it captured into (= whatever the capture itself allocated: nothing after the two
+#     eager warm-up steps, which size every lazy buffer), until the interpreter exits.  The list therefore grows with the number of
+#     ENGINES that captured, not with the number of capture calls; DPC_KEEP_GRAPHS=0 destroys instead of parking.
 _LIVE_GRAPHS: list = []
+
+
+def _park_graphs(graphs):
+    """keep `graphs` (torch.cuda.CUDAGraph objects) alive until the interpreter exits -- not even module teardown destroys them"""
+    if os.environ.get("DPC_KEEP_GRAPHS", "1") == "0":
+        return
+    for g_ in graphs:
+        C.pythonapi.Py_IncRef(C.py_object(g_))
+    _LIVE_GRAPHS.extend(graphs)
 
 
 class _ConvBN:
@@ -427,7 +442,7 @@ class _Block:
             self.ds.bn_backward(dout, None, False, draw_d, ext_mask=omask)
         dact1 = e.scratch(oshape, exclude=[dout, draw2, draw_d, dz])
         self.c2.dgrad(draw2, dact1, None, red=self.c1 if self.fold_c1 else None)
-        if self.fold_c1 and e._early_finalize:   # coefficients of bn1 before the side stream fills the chip (bn_prepare)
+        if self.fold_c1:   # coefficients of bn1 before the side stream fills the chip (bn_prepare)
             self.c1.bn_prepare(dact1, self.act1, True)
         with e.side(reads=[draw2, draw_d], kind=1):   # beside bn1's backward on the main stream
             if self.ds is not None:
@@ -450,7 +465,7 @@ class _Block:
             # in place over dout: every lane reads its addend unit before it stores the same unit (all kernels behind the entry)
             dx = dout
             self.c1.dgrad(draw1, dx, dout, addend_mask=omask, red=self.prev.c2 if self.fold_prev else None)
-            if self.fold_prev and e._early_finalize:   # the previous block's bn2 (its backward is the next thing on the main stream)
+            if self.fold_prev:   # the previous block's bn2 (its backward is the next thing on the main stream)
                 pv = self.prev
                 pv.c2.bn_prepare(dx, pv.out if pv.final_relu else None, pv.final_relu)
         else:
@@ -503,6 +518,9 @@ class DPCEngine:
         self.score_mode = "materialised"  # what the last train step ran ("fused": no [R][R] tensor in HBM)
         self.timer: Optional["KernelTimer"] = None
         self._tag: Optional[str] = None
+        self._captures: Dict[tuple, object] = {}   # capture_train_step results by (input buffer, exchange, carve-out)
+        self._capture_graphs: list = []            # their hipGraphs; parked in _LIVE_GRAPHS when the engine goes (see there)
+        weakref.finalize(self, _park_graphs, self._capture_graphs)
 
         # ---- flat f32 arenas: parameters, gradients, Adam moments
         self._score_path = score_path
@@ -533,7 +551,6 @@ class DPCEngine:
         # repacks); DPC_SIDE_QUIET=0 lets side work run beside input-gradients too (slower, and not bit-reproducible: see side())
         self._side = (torch.cuda.Stream(self.device) if self.device.type == "cuda" and int(os.environ.get("DPC_WGRAD_STREAM", "1")) else None)
         self._on_side = False
-        self._early_finalize = bool(int(os.environ.get("DPC_EARLY_FINALIZE", "1")))   # A/B switch for _ConvBN.bn_prepare's ordering
         self._side_mask = int(os.environ.get("DPC_SIDE_MASK", "15"))
         self._side_quiet = bool(int(os.environ.get("DPC_SIDE_QUIET", "1")))
         self._busy = []   # [(event recorded on the side stream, scratch buffers its launches read)], oldest first
@@ -638,15 +655,18 @@ class DPCEngine:
         self.result = self.empty((4,), f32)
         self.predT = torch.zeros((D, self.ld_d), dtype=dt, device=self.device)   # transposed operands of the score backward
         self.finfT = torch.zeros((D, self.ld_d), dtype=dt, device=self.device)   # (columns >= R stay zero)
-        # fused score + loss (throughput mode): the [R][R] matrix and its gradient are never materialised in a train step
-        # score_path: "fused" | "materialised" | "auto".  Measured on MI355X (profiles/r02_head_kernels.txt): the fused forward
-        # (72 us at R = 6 144) beats GEMM + three-sweep CE (173 us), the fused backward (2 x 140 us + slab sums) loses to the
-        # two plain GEMMs over a materialised bf16 dS (176 us) -- exp() is quarter rate and K = 256 gives the matrix cores
-        # too little to hide it behind; at R = 15 680 both total the same and fusion saves 1.5 GB of traffic-heavy buffers.
+        # The score + loss of a bf16 train step, two ways (csrc/score_fused.hip):
+        #   "materialised": score GEMM -> [R][R] f32 in HBM -> CE / top-k / dS (bf16) -> two split-K GEMMs;
+        #   "fused": LSE, target logit and rank inside the forward contraction, dS recomputed inside the two backward contractions -- no
+        #            [R][R] tensor in HBM (151 MB + 75 MB at cfg2, 983 MB + 492 MB at cfg5).
+        # Measured on MI355X: at R = 6 144 the materialised step wins clearly (fused backward 2 x 140 us against 2 x 37 us: exp() is
+        # quarter rate and K = 256 gives the matrix cores too little to hide it behind); at R = 15 680 it wins by 1.5 % of the step
+        # (813 against 801 clips/s at cfg5, round 4).  288 GB of HBM make the 1.5 GB a non-issue, so "auto" = materialised at every
+        # size since round 5 (round 2-4: fused from R = 8 192); "fused" keeps the other path selectable (bench.py --score-path fused).
         if score_path not in ("auto", "fused", "materialised"):
             raise ValueError("score_path must be auto, fused or materialised")
         fusable = dt == torch.bfloat16 and D in (256, 32)
-        self.score_fusable = fusable and (score_path == "fused" or (score_path == "auto" and R >= 8192))
+        self.score_fusable = fusable and score_path == "fused"
         self._score_fused = False
         if self.score_fusable:
             nf, nb = C.c_int64(0), C.c_int64(0)
@@ -868,6 +888,22 @@ class DPCEngine:
                 raise KeyError(f"{k}: not a parameter of this {self.network} engine ({len(self.PRM)} parameters, {len(self.shapes)} shapes, "
                                f"in PRM: {k in self.PRM}, in shapes: {k in self.shapes})")
             dst.copy_(v.to(torch.float32).reshape(shp))
+        self.packed_for_step = -1
+
+    def adopt_optimizer_state(self, old: "DPCEngine"):
+        """continue `old`'s optimisation in this engine (same network, any batch / compute dtype / device): Adam moments, the
+        optimizer-step counter with its device-side bias corrections, the dropout draw counter, lr / weight decay.  The module
+        boundary rebuilds its engine when the batch size, model.bfloat16() / .float() or the device change (model._ensure_engine);
+        torch.optim.Adam over the same Parameters would keep its state through all three."""
+        if old.numel != self.numel or list(old.offsets) != list(self.offsets):
+            raise ValueError("adopt_optimizer_state: the engines hold different parameter sets")
+        self.flat_m.copy_(old.flat_m)
+        self.flat_v.copy_(old.flat_v)
+        self.dev_step.copy_(old.dev_step)
+        self.dev_bc.copy_(old.dev_bc)
+        self.dev_draw.copy_(old.dev_draw)
+        self._step_count = old._step_count
+        self.lr, self.wd = old.lr, old.wd
         self.packed_for_step = -1
 
     def state_dict(self) -> Dict[str, torch.Tensor]:
@@ -1147,6 +1183,10 @@ class DPCEngine:
         the device-side step counter, so every replay is a new optimizer step."""
         if self.device.type != "cuda":
             raise L.DpcError("hipGraph capture needs the HIP device")
+        key = (block.data_ptr(), tuple(block.shape), id(allreduce) if allreduce is not None else None, self.reserve_cus)
+        hit = self._captures.get(key)
+        if hit is not None:   # the same static buffer, the same exchange: the capture that exists (see _LIVE_GRAPHS)
+            return hit
         cur = torch.cuda.current_stream(self.device)
         side = torch.cuda.Stream(self.device)
         side.wait_stream(cur)
@@ -1184,9 +1224,13 @@ class DPCEngine:
             state["g"].capture_end()
             graphs.append(state["g"])
         cur.wait_stream(side)
-        tail, head = self.flat_g[self.grad_split:], self.flat_g[:self.grad_split]
+        tail, head, whole, result = self.flat_g[self.grad_split:], self.flat_g[:self.grad_split], self.flat_g, self.result
+        me = weakref.ref(self)   # the cached closure must not keep its engine (tens of GB of buffers) alive through a cycle
 
         def replay():
+            eng = me()
+            if eng is None:
+                raise RuntimeError("replay of a captured train step whose engine is gone")
             graphs[0].replay()
             if two_bucket:
                 allreduce.start(tail)
@@ -1194,18 +1238,26 @@ class DPCEngine:
                 allreduce.finish(head)
                 graphs[2].replay()
             elif allreduce is not None:
-                allreduce(self.flat_g)
+                allreduce(whole)
                 graphs[1].replay()
-            self._step_count += 1
-            self.packed_for_step = -1
-            return self.result
+            eng._step_count += 1
+            eng.packed_for_step = -1
+            return result
 
         replay.graphs = graphs
-        if os.environ.get("DPC_KEEP_GRAPHS", "1") != "0":
-            for g_ in graphs:   # see _LIVE_GRAPHS: one reference that is never given back, so that not even interpreter shutdown destroys them
-                C.pythonapi.Py_IncRef(C.py_object(g_))
-            _LIVE_GRAPHS.extend(graphs)
+        replay.block = block   # the static input buffer stays alive (and its address un-reused) as long as the capture does
+        self._captures[key] = replay
+        self._capture_graphs.extend(graphs)
         return replay
+
+    def release_captures(self):
+        """forget this engine's captured train steps (the next capture_train_step captures again).  The hipGraphs are parked until the
+        interpreter exits, not destroyed -- see _LIVE_GRAPHS for why and for what that costs; DPC_KEEP_GRAPHS=0 destroys them here,
+        after the device has gone idle."""
+        torch.cuda.synchronize(self.device)
+        self._captures.clear()
+        _park_graphs(list(self._capture_graphs))
+        self._capture_graphs.clear()
 
     def train_step(self, block: torch.Tensor, dropout_masks: Optional[torch.Tensor] = None, allreduce=None) -> torch.Tensor:
         """forward + CE/top-k + backward (+ gradient all-reduce) + Adam.  Returns device f32[4] = loss, top1, top3, top5."""

@@ -76,8 +76,10 @@ def lr_milestones(dataset: str, img_dim: int):
 
 def _worker(rank: int, world: int, args, port: int):
     gpus = [int(g) for g in str(args.gpu).split(',') if g != '']
-    dev = torch.device('cuda', gpus[rank] if world > 1 else gpus[0])
-    torch.cuda.set_device(dev)
+    sim = getattr(args, '_simulator', None)   # tests only (CPU tier): the host-side SIMT simulator handle; the command line cannot set it
+    dev = torch.device('cpu') if sim is not None else torch.device('cuda', gpus[rank] if world > 1 else gpus[0])
+    if sim is None:
+        torch.cuda.set_device(dev)
     dist = None
     if world > 1:
         import torch.distributed as dist_
@@ -97,9 +99,11 @@ def _worker(rank: int, world: int, args, port: int):
         raise ValueError('batch_size must be divisible by the number of GPUs')
     per_gpu = args.batch_size // world
     cdt = torch.bfloat16 if args.dtype == 'bf16' else torch.float32
-    eng = LCEngine(args.net, args.img_dim, args.num_seq, args.seq_len, per_gpu, dev, cdt, lr=args.lr, wd=args.wd,
+    from .plan import LAYER_WIDTH
+    widths = getattr(args, '_widths', None) or LAYER_WIDTH
+    eng = LCEngine(args.net, args.img_dim, args.num_seq, args.seq_len, per_gpu, dev, cdt, widths, lib=sim, lr=args.lr, wd=args.wd,
                    dropout=args.dropout, num_class=args.num_class, seed=666 + rank)  # model_3d_lc.py:16 seeds 666
-    init = LC(args.img_dim, args.num_seq, args.seq_len, args.net, args.dropout, args.num_class, seed=0)
+    init = LC(args.img_dim, args.num_seq, args.seq_len, args.net, args.dropout, args.num_class, widths=widths, seed=0)
     eng.load_params({k: v.detach() for k, v in init.state_dict().items()})
     log = print if rank == 0 else (lambda *a, **k: None)
     if args.train_what == 'ft':
@@ -197,10 +201,13 @@ def _worker(rank: int, world: int, args, port: int):
         dist.destroy_process_group()
 
 
-def main(argv=None):
+def main(argv=None, _simulator=None, _widths=None):
     args = build_parser().parse_args(argv)
+    args._simulator, args._widths = _simulator, _widths   # tests/test_entries.py: the CPU tier runs the entry on the simulator
     gpus = [g for g in str(args.gpu).split(',') if g != '']
     world = max(len(gpus), 1)
+    if _simulator is not None and world != 1:
+        raise ValueError('the simulator runs one rank')
     if world == 1:
         _worker(0, 1, args, 0)
     else:

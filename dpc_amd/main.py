@@ -74,11 +74,13 @@ class AverageMeter:
 def _worker(rank: int, world: int, args, port: int):
     gpus = [int(g) for g in str(args.gpu).split(',') if g != '']
     torch.manual_seed(0)  # dpc/main.py:50
-    dev = torch.device('cuda', gpus[rank] if world > 1 else gpus[0])
+    sim = getattr(args, '_simulator', None)   # tests only (CPU tier): the host-side SIMT simulator handle; the command line cannot set it
+    dev = torch.device('cpu') if sim is not None else torch.device('cuda', gpus[rank] if world > 1 else gpus[0])
     from .parallel import configure_rccl, default_reserve_cus
     if world > 1:
         configure_rccl(world)   # before this process's first HIP call: few long-lived RCCL channels beside the backward pass (parallel.py)
-    torch.cuda.set_device(dev)
+    if sim is None:
+        torch.cuda.set_device(dev)
     dist = None
     if world > 1:
         import torch.distributed as dist_
@@ -100,9 +102,11 @@ def _worker(rank: int, world: int, args, port: int):
         raise ValueError('batch_size must be divisible by the number of GPUs (drop_last semantics, dpc/main.py:313)')
     per_gpu = args.batch_size // world
     cdt = torch.bfloat16 if args.dtype == 'bf16' else torch.float32
-    eng = DPCEngine(args.net, args.img_dim, args.num_seq, args.seq_len, args.pred_step, per_gpu, dev, cdt, lr=args.lr, wd=args.wd,
+    from .plan import LAYER_WIDTH
+    widths = getattr(args, '_widths', None) or LAYER_WIDTH
+    eng = DPCEngine(args.net, args.img_dim, args.num_seq, args.seq_len, args.pred_step, per_gpu, dev, cdt, widths, lib=sim, lr=args.lr, wd=args.wd,
                     seed=233 + rank, reserve_cus=default_reserve_cus(world))  # dropout stream: the reference seeds 233 (dpc/model_3d.py:18); independent per replica
-    init = DPC_RNN(args.img_dim, args.num_seq, args.seq_len, args.pred_step, args.net, seed=0)  # same on every rank
+    init = DPC_RNN(args.img_dim, args.num_seq, args.seq_len, args.pred_step, args.net, widths=widths, seed=0)  # same on every rank
     eng.load_params({k: v.detach() for k, v in init.named_parameters()})
     best_acc, iteration = 0.0, 0
     if args.resume:  # dpc/main.py:88-102: strict model load + optimizer state (unless --reset_lr)
@@ -175,10 +179,13 @@ def _worker(rank: int, world: int, args, port: int):
         dist.destroy_process_group()
 
 
-def main(argv=None):
+def main(argv=None, _simulator=None, _widths=None):
     args = build_parser().parse_args(argv)
+    args._simulator, args._widths = _simulator, _widths   # tests/test_entries.py: the CPU tier runs the entry on the simulator
     gpus = [g for g in str(args.gpu).split(',') if g != '']
     world = max(len(gpus), 1)
+    if _simulator is not None and world != 1:
+        raise ValueError('the simulator runs one rank')
     if world == 1:
         _worker(0, 1, args, 0)
     else:

@@ -33,6 +33,21 @@ from . import _lib as L
 from .engine import DPCEngine, LAYER_PLAN, LAYER_WIDTH, param_shapes
 
 
+_DTYPE_NAMES = {"bf16": torch.bfloat16, "bfloat16": torch.bfloat16, "f32": torch.float32, "float32": torch.float32}
+
+# nn.DataParallel over several devices (dpc/main.py:65 with more than one id in --gpu): torch replicates the module per forward --
+# shallow copies whose parameters are broadcast non-leaf tensors (torch nn/parallel/replicate.py) -- and runs them in threads.  The
+# engine behind this module is ONE device's static schedule (buffers, arenas, captured graphs): a replica would rebuild a whole engine
+# every forward, on another device, and hand its gradients to nobody.  The multi-GPU route of this build is one process per GPU with
+# an RCCL all-reduce (dpc_amd/parallel.py), so a replica's forward stops here.  One visible device is fine: DataParallel then calls
+# the module itself (torch nn/parallel/data_parallel.py:187-195) and never replicates.
+_REPLICA_ERROR = ("dpc_amd.DPC_RNN cannot run as an nn.DataParallel replica (DataParallel over more than one device replicates the "
+                  "module every forward; the MI355X engine is a single-device static schedule).  Multi-GPU training is one process "
+                  "per GPU with an RCCL gradient all-reduce: `python -m dpc_amd.main --gpu 0,1,...` (same flags as dpc/main.py), or "
+                  "wrap the module in torch.nn.parallel.DistributedDataParallel under torch.distributed.run; with a single device "
+                  "nn.DataParallel(model, device_ids=[0]) works unchanged")
+
+
 class _Holder(nn.Module):
     """namespace module so that parameters appear under the reference's dotted names"""
 
@@ -138,8 +153,10 @@ class DPC_RNN(nn.Module):
         self._simulator = _simulator  # tests only: the host-side SIMT simulator handle (CPU tier); never set by the product
         self._score_bufs = None
         if os.environ.get("DPC_COMPUTE_DTYPE"):   # select the throughput mode without touching the reference's constructor call
-            self.compute_dtype = {"bf16": torch.bfloat16, "bfloat16": torch.bfloat16, "f32": torch.float32, "float32": torch.float32}[
-                os.environ["DPC_COMPUTE_DTYPE"].lower()]
+            want = os.environ["DPC_COMPUTE_DTYPE"].lower()
+            if want not in _DTYPE_NAMES:
+                raise ValueError(f"DPC_COMPUTE_DTYPE={os.environ['DPC_COMPUTE_DTYPE']!r}: accepted values are {sorted(_DTYPE_NAMES)}")
+            self.compute_dtype = _DTYPE_NAMES[want]
         shapes = param_shapes(network, widths)
         init = _init_reference_style(shapes, torch.Generator().manual_seed(seed))
         for k, shp in shapes.items():
@@ -156,10 +173,20 @@ class DPC_RNN(nn.Module):
         first = self.backbone.conv1.weight
         if self._engine is not None and self._engine_key == key and first.data_ptr() == self._engine.PRM[self._param_names[0]].data_ptr():
             return
+        named = {k: v for k, v in self.named_parameters()}
+        bad = [k for k in self._param_names if named[k].dtype != torch.float32]
+        if bad:   # .half() / .double() / .to(torch.bfloat16) cast the Parameters themselves; the arena holds f32 master weights
+            raise TypeError(f"dpc_amd.DPC_RNN keeps float32 master parameters (the reference's state_dict dtype); {bad[0]} is "
+                            f"{named[bad[0]].dtype}.  Select the kernels' operand type with model.bfloat16() / model.float() (or "
+                            "DPC_COMPUTE_DTYPE=bf16|f32); .half() and .double() are not supported")
         eng = DPCEngine(self.network, self.sample_size, self.num_seq, self.seq_len, self.pred_step, B, dev,
                         self.compute_dtype, self.widths, lib=self._simulator)
-        named = {k: v for k, v in self.named_parameters()}
         eng.load_params({k: named[k].detach() for k in self._param_names})
+        if self._engine is not None:
+            # a rebuild (another batch size, model.bfloat16() after training started, a device move) continues the SAME optimisation:
+            # Adam moments, step counter / bias corrections and the dropout draw counter move over, as they would stay put under
+            # torch.optim.Adam, whose state is keyed on the Parameter objects and survives all three
+            eng.adopt_optimizer_state(self._engine)
         for k in self._param_names:
             named[k].data = eng.PRM[k]  # re-point the Parameter at its slice of the flat arena
         self._engine, self._engine_key = eng, key
@@ -167,6 +194,8 @@ class DPC_RNN(nn.Module):
 
     def forward(self, block):
         # block: [B, N, C, SL, H, W] (dpc/model_3d.py:47-49)
+        if getattr(self, "_is_replica", False):
+            raise RuntimeError(_REPLICA_ERROR)
         if block.device.type != "cuda" and self._simulator is None:
             raise L.DpcError("dpc_amd.DPC_RNN runs on MI355X only: move the module and the input to a cuda (HIP) device")
         self._ensure_engine(block)
@@ -190,6 +219,25 @@ class DPC_RNN(nn.Module):
 
     def float(self):
         self.compute_dtype = torch.float32
+        return self
+
+    def half(self):
+        raise TypeError("dpc_amd.DPC_RNN: fp16 is not a mode of this build (bf16 operands with f32 accumulation and f32 master "
+                        "weights are: model.bfloat16())")
+
+    def double(self):
+        raise TypeError("dpc_amd.DPC_RNN: parameters are float32 master weights; there is no f64 mode")
+
+    def to(self, *args, **kwargs):
+        """device moves as nn.Module.to; a floating dtype selects the compute dtype like .bfloat16() / .float() instead of casting
+        the f32 master parameters (model.to(torch.bfloat16) == model.bfloat16())"""
+        device, dtype, non_blocking, fmt = torch._C._nn._parse_to(*args, **kwargs)
+        if dtype is not None:
+            if dtype not in (torch.float32, torch.bfloat16):
+                raise TypeError(f"dpc_amd.DPC_RNN.to({dtype}): compute dtypes are torch.float32 and torch.bfloat16")
+            self.compute_dtype = dtype
+        if device is not None:
+            return super().to(device, non_blocking=non_blocking)
         return self
 
     def _score_buffers(self, eng):

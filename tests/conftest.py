@@ -54,10 +54,45 @@ class CleanLauncher:
             self.p.kill()
 
 
+def _cpu_tier_workers(config, expr):
+    """The CPU tier (`-m "not gpu"`) spends its time in the host-side SIMT simulator, one core per test: spread it over
+    pytest-xdist workers unless the caller chose a worker count (-n ...) or DPC_TEST_WORKERS=0 asks for one process.  The GPU tier
+    always runs in ONE process (one device, timing-sensitive tests, the pre-GPU launcher below)."""
+    if hasattr(config, "workerinput") or "not gpu" not in expr:
+        return 0
+    if not config.pluginmanager.hasplugin("xdist") or getattr(config.option, "numprocesses", None) is not None:
+        return 0
+    if getattr(config.option, "collectonly", False) or getattr(config.option, "usepdb", False):
+        return 0
+    want = os.environ.get("DPC_TEST_WORKERS")
+    n = int(want) if want is not None else min(6, max(1, (os.cpu_count() or 2) - 2))
+    return n if n > 1 else 0
+
+
+def _build_once():
+    """`make all emu` under an exclusive file lock: the test modules call `make emu` themselves, several xdist workers at a time --
+    after this that is a no-op everywhere, and only one process ever writes the objects"""
+    import fcntl
+    import subprocess
+    with open(os.path.join(ROOT, ".build.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            subprocess.run(["make", "-s", "-j8", "all", "emu"], cwd=ROOT, check=True)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
+
+
 def pytest_configure(config):
     global _launcher
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
     expr = config.getoption("-m", default="") or ""
+    if "not gpu" in expr and not getattr(config.option, "collectonly", False):
+        _build_once()   # controller first, then every worker finds nothing to do
+    n = _cpu_tier_workers(config, expr)
+    if n:   # what `-n N` does in xdist's pytest_cmdline_main; its own pytest_configure (trylast) then starts the workers
+        config.option.numprocesses = n
+        config.option.dist = "load"
+        config.option.tx = ["popen"] * n
     if "gpu" in expr and "not gpu" not in expr and _launcher is None:   # the GPU tier: nothing has initialised HIP yet
         _launcher = CleanLauncher()
 

@@ -226,3 +226,89 @@ def test_module_boundary_copies_nothing_and_keeps_torch_semantics(emu):
     mc.bfloat16()
     assert mc.compute_dtype == torch.bfloat16 and next(mc.parameters()).dtype == torch.float32
     assert mc.float().compute_dtype == torch.float32
+
+
+def _ref_loop_step(model, opt, x, crit):
+    """the loop lines of dpc/main.py:198-231 (forward, target from the mask, CrossEntropyLoss, zero_grad / backward / step)"""
+    score_, mask_ = model(x)
+    B, NP, SQ, B2, NS, _ = mask_.size()
+    target = (mask_ == 1).view(B * NP * SQ, B2 * NS * SQ).to(int).argmax(dim=1)
+    loss = crit(score_.view(B * NP * SQ, B2 * NS * SQ), target)
+    opt.zero_grad()
+    loss.backward()
+    opt.step()
+    return loss.item()
+
+
+def _small(emu, seed):
+    """the drop-in at half the sequence (4 blocks, 1 prediction step): these tests are about the host side"""
+    from dpc_amd.model import DPC_RNN
+    return DPC_RNN(64, 4, 5, 1, "resnet18", widths=WIDTHS, seed=seed, _simulator=emu).eval()
+
+
+def test_data_parallel_entry(emu):
+    """dpc/main.py:65-66: `model = nn.DataParallel(model)`.  With one (or no) visible device DataParallel calls the wrapped module
+    itself (torch nn/parallel/data_parallel.py:187-195): the wrapped drop-in steps exactly like the bare one.  A REPLICA -- what
+    DataParallel builds per forward over several devices -- refuses loudly and names the supported multi-GPU entry."""
+    from dpc_amd.optim import Adam
+    x = O.make_input_pcg(1, 4, 5, 64)
+    crit = torch.nn.CrossEntropyLoss()
+    bare = _small(emu, 4)
+    wrapped = torch.nn.DataParallel(_small(emu, 4)).eval()
+    assert list(wrapped.state_dict()) == ["module." + k for k in bare.state_dict()]   # the keys dpc/main.py:170 saves
+    la = _ref_loop_step(bare, Adam(bare.parameters(), lr=1e-3, weight_decay=1e-5), x, crit)
+    lb = _ref_loop_step(wrapped, Adam(wrapped.parameters(), lr=1e-3, weight_decay=1e-5), x, crit)
+    assert la == lb
+    for (ka, pa), (kb, pb) in zip(bare.named_parameters(), wrapped.module.named_parameters()):
+        assert ka == kb and torch.equal(pa, pb), ka
+    replica = wrapped.module._replicate_for_data_parallel()
+    with pytest.raises(RuntimeError, match=r"python -m dpc_amd\.main --gpu"):
+        replica(x)
+
+
+def test_engine_rebuild_keeps_the_optimizer_state(emu):
+    """a forward with another batch size rebuilds the engine; dpc_amd.optim.Adam must go on with the moments, step
+    counter and bias corrections it had -- as torch.optim.Adam over the same module does (its state is keyed on the Parameters).
+    The second step is checked against Adam's recurrences written out: m2 = b1 m1 + (1 - b1) g2 etc. with step-2 bias corrections."""
+    from dpc_amd.optim import Adam
+    crit = torch.nn.CrossEntropyLoss()
+    m = _small(emu, 5)
+    opt = Adam(m.parameters(), lr=1e-3, weight_decay=1e-5)
+    _ref_loop_step(m, opt, O.make_input_pcg(1, 4, 5, 64), crit)
+    first = m.engine
+    m1, v1, p1 = first.flat_m.clone(), first.flat_v.clone(), first.flat_p.clone()
+    assert first.step_count == 1 and m1.abs().max().item() > 0
+    _ref_loop_step(m, opt, O.make_input_pcg(2, 4, 5, 64), crit)   # B = 2: a new engine
+    eng = m.engine
+    assert eng is not first and eng.B == 2 and eng.step_count == 2 and int(eng.dev_step.item()) == 2
+    assert float(opt.state_dict()["state"][0]["step"]) == 2.0
+    g = eng.flat_g + 1e-5 * p1                     # L2 weight decay goes into the gradient (torch.optim.Adam, dpc/main.py:80)
+    m2, v2 = 0.9 * m1 + 0.1 * g, 0.999 * v1 + 0.001 * g * g
+    assert torch.allclose(eng.flat_m, m2, rtol=1e-5, atol=1e-9) and torch.allclose(eng.flat_v, v2, rtol=1e-5, atol=1e-12)
+    p2 = p1 - 1e-3 * (m2 / (1 - 0.9 ** 2)) / ((v2 / (1 - 0.999 ** 2)).sqrt() + 1e-8)
+    # (zeroed moments / a restarted bias correction would move every weight by ~lr = 1e-3 instead)
+    assert (eng.flat_p - p2).abs().max().item() <= 2e-6
+
+
+def test_module_dtype_calls(monkeypatch):
+    """parameters are f32 master weights whatever the caller casts; what cannot be honoured raises instead of silently running f32"""
+    from dpc_amd.model import DPC_RNN
+    m = DPC_RNN(64, 8, 5, 3, "resnet18", widths=WIDTHS)
+    assert m.to(torch.bfloat16).compute_dtype == torch.bfloat16 and next(m.parameters()).dtype == torch.float32
+    assert m.to(dtype=torch.float32).compute_dtype == torch.float32
+    for call in (m.half, m.double, lambda: m.to(torch.float16)):
+        with pytest.raises(TypeError):
+            call()
+    monkeypatch.setenv("DPC_COMPUTE_DTYPE", "fp8")
+    with pytest.raises(ValueError, match="accepted values"):
+        DPC_RNN(64, 8, 5, 3, "resnet18", widths=WIDTHS)
+    monkeypatch.setenv("DPC_COMPUTE_DTYPE", "bf16")
+    assert DPC_RNN(64, 8, 5, 3, "resnet18", widths=WIDTHS).compute_dtype == torch.bfloat16
+
+
+def test_cast_parameters_are_refused(emu):
+    from dpc_amd.model import DPC_RNN
+    m = DPC_RNN(64, 4, 5, 1, "resnet18", widths=WIDTHS, _simulator=emu)
+    torch.nn.Module.double(m)   # what .double() would have done
+    with pytest.raises(TypeError, match="float32 master parameters"):
+        m(O.make_input_pcg(1, 4, 5, 64))

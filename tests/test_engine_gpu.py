@@ -136,6 +136,54 @@ def test_module_drop_in(golden_dir):
     assert (s2.detach() - score_.detach()).abs().max().item() > 1e-4
 
 
+def test_data_parallel_entry_vs_reference(golden_dir):
+    """The reference's literal entry, dpc/main.py:65-66: `model = nn.DataParallel(model); model = model.to(cuda)`, then its loop lines
+    (:198-231) -- score, loss, gradient norms and the Adam step against the reference's own outputs (train.npz).  With one visible
+    device DataParallel calls the module itself (torch nn/parallel/data_parallel.py:187-195); over several devices it replicates,
+    and a replica refuses loudly (tests/test_engine_emu.py::test_data_parallel_entry holds the message on the CPU tier)."""
+    g = gold(golden_dir, "train.npz")
+    model = DPC_RNN(sample_size=64, num_seq=8, seq_len=5, pred_step=3, network="resnet18")
+    model.load_state_dict(O.make_params_pcg("resnet18"), strict=True)
+    if torch.cuda.device_count() > 1:
+        many = torch.nn.DataParallel(model).to(DEV)
+        with pytest.raises(RuntimeError, match=r"python -m dpc_amd\.main --gpu"):
+            many(O.make_input_pcg(2, 8, 5, 64).to(DEV))
+        model = torch.nn.DataParallel(model, device_ids=[0])
+    else:
+        model = torch.nn.DataParallel(model)                     # dpc/main.py:65
+    model = model.to(DEV)                                         # :66
+    criterion = torch.nn.CrossEntropyLoss()                       # :67
+    params = model.parameters()                                   # :74
+    optimizer = torch.optim.Adam(params, lr=1e-3, weight_decay=1e-5)   # :80
+    model.eval()   # the golden step ran with dropout p = 0; BatchNorm is batch-statistics either way (model_3d.py:28)
+    input_seq = O.make_input_pcg(2, 8, 5, 64).to(DEV)            # :196
+    B = input_seq.size(0)
+    [score_, mask_] = model(input_seq)                            # :198
+    assert (score_.detach().cpu() - torch.from_numpy(g["score_p0"])).abs().max().item() < TOL
+    (B2, NP, SQ, _, NS, _) = mask_.size()                         # utils process_output + main.py:209-215
+    target_ = (mask_ == 1).to(int)
+    target_.requires_grad = False
+    score_flattened = score_.view(B * NP * SQ, B2 * NS * SQ)
+    target_flattened = target_.view(B * NP * SQ, B2 * NS * SQ).argmax(dim=1)
+    loss = criterion(score_flattened, target_flattened)           # :217
+    assert abs(loss.item() - g["loss_topk_p0"][0]) < TOL
+    _, accs = O.loss_and_topk(score_.detach().cpu(), target_flattened.cpu())   # calc_topk_accuracy, utils/utils.py:38-55 restated
+    assert [a.item() for a in accs] == pytest.approx(list(g["loss_topk_p0"][1:]), abs=1e-6)
+    optimizer.zero_grad()                                         # :229
+    loss.backward()                                               # :230
+    names = [str(n) for n in g["param_names"]]
+    named = dict(model.module.named_parameters())
+    for i, n in enumerate(names):
+        assert named[n].grad.norm().item() == pytest.approx(float(g["grad_norm_p0"][i]), rel=1e-2, abs=1e-6), n
+    optimizer.step()                                              # :231
+    sd = model.state_dict()                                       # what :170 saves: `module.`-prefixed, alias keys included
+    assert "module.agg.cell_list.0.reset_gate.weight" in sd and all(k.startswith("module.") for k in sd)
+    for i, n in enumerate(names):
+        w = sd["module." + n].cpu()
+        slack = 2e-3 * (2 + 2e-3 * w.numel())
+        assert w.double().sum().item() == pytest.approx(float(g["adam_sum_p0"][i]), rel=1e-5, abs=slack), n
+
+
 def test_bf16_mode_tracks_fp32(golden_dir):
     g = gold(golden_dir, "eval_scores.npz")
     eng = engine("resnet18", 64, 2, torch.bfloat16)
@@ -201,7 +249,7 @@ def test_cfg5_full_shape_properties():
     """BASELINE.json configs[4] on one GPU shard: resnet34, 224^2, pred_step 5, B=64 -> R = 15 680 rows, a 983 MB f32
     score and its gradient.  Too big for the CPU oracle: size-independent invariants (bf16 throughput mode)."""
     B, P = 64, 5
-    eng = DPCEngine("resnet34", 224, 8, 5, P, B, DEV, torch.bfloat16)
+    eng = DPCEngine("resnet34", 224, 8, 5, P, B, DEV, torch.bfloat16, score_path="fused")  # both paths are exercised below
     eng.load_params(O.init_params_reference_style("resnet34", seed=0))
     x = torch.randn(B, 8, 3, 5, 224, 224, device=DEV, generator=torch.Generator(DEV).manual_seed(2))
     # (1) the materialised path of the same step: 983 MB of f32 logits + their bf16 gradient

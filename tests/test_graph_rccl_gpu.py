@@ -30,7 +30,9 @@ def test_graph_replay_equals_eager(dtype):
     replay = b.capture_train_step(x, warmup=2)  # 2 real warm-up steps, then every replay is one more step
     assert len(replay.graphs) == 1
     from dpc_amd import engine as E_
-    assert any(g is replay.graphs[0] for g in E_._LIVE_GRAPHS)   # never destroyed before the process exits
+    # one capture per (engine, input buffer, exchange): asking again returns the replay that exists, the graph list does not grow
+    live = len(E_._LIVE_GRAPHS)
+    assert b.capture_train_step(x, warmup=2) is replay and len(b._capture_graphs) == 1 and len(E_._LIVE_GRAPHS) == live
     for _ in range(3):
         rb = replay().clone()
     torch.cuda.synchronize()
@@ -46,6 +48,10 @@ def test_graph_replay_equals_eager(dtype):
     x.copy_(torch.randn(x.shape, device=DEV, generator=torch.Generator(DEV).manual_seed(2)))
     r7 = replay().clone()
     assert not torch.equal(r7, rb)
+    # dropped captures are parked until the process exits, never destroyed while it runs (engine._LIVE_GRAPHS says why)
+    g0 = replay.graphs[0]
+    b.release_captures()
+    assert not b._captures and any(g is g0 for g in E_._LIVE_GRAPHS) and len(E_._LIVE_GRAPHS) == live + 1
 
 
 _RANK_SCRIPT = r"""

@@ -132,7 +132,7 @@ def test_gemm_nt(k, dtype, mnk):
     kc.case_gemm_nt(k, dtype, *mnk)
 
 
-@pytest.mark.parametrize("mn,kern", [((1100, 1028), "score_gemm2_kernel<2>"), ((1027, 1027), "score_gemm_kernel<2,"), ((1030, 1092), "score_gemm2_kernel<2>")])
+@pytest.mark.parametrize("mn,kern", [((1100, 1028), "score_gemm2_kernel<2>"), ((1027, 1027), "score_gemm_kernel<2>"), ((1030, 1092), "score_gemm2_kernel<2>")])
 def test_score_gemm(k, mn, kern, monkeypatch):
     """large bf16 -> f32 NT GEMM with a short reduction (the materialised score): register-resident rows, streamed column tiles.
     1100 x 1028 / 1030 x 1092: the 8-wave form (staged whole-row stores; ragged last row block incl. waves without any row, ragged last
