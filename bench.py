@@ -60,6 +60,47 @@ def csrc_sha16():
     return h.hexdigest()[:16]
 
 
+def live_pmc_traffic(config="cfg2", timeout_s=240):
+    """HBM bytes per launch of the conv family, measured IN THIS RUN: two rocprofv3 passes (FETCH_SIZE, then WRITE_SIZE -- separate
+    --pmc runs with --kernel-trace only, as /opt/skills/guides/MI355X_MICROARCH.md prescribes) of a child `bench.py` that launches two
+    eager steps of the same workload, summarised with the guide's gfx950 correction (scripts/pmc_traffic.py).  Returns
+    (summary dict, None) or (None, reason).  Costs ~40 s; `--pmc file` reads the tracked profile instead, `--pmc off` skips it."""
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    if shutil.which("rocprofv3") is None:
+        return None, "rocprofv3 is not on PATH"
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    try:
+        import pmc_traffic as PT
+    finally:
+        sys.path.pop(0)
+    tmp = tempfile.mkdtemp(prefix="dpc_pmc_", dir="/tmp")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["TMPDIR"] = "/tmp"
+    child = [sys.executable, os.path.join(ROOT, "bench.py"), "--config", config, "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--no-roofline",
+             "--no-also", "--no-graph", "--pmc", "off"]
+    got = {}
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            out = os.path.join(tmp, counter)
+            try:
+                r = subprocess.run(["rocprofv3", "--kernel-trace", "--pmc", counter, "-d", out, "-o", "pmc", "--"] + child, cwd="/tmp", env=env,
+                                   capture_output=True, text=True, timeout=timeout_s)
+            except subprocess.TimeoutExpired:
+                return None, f"the {counter} pass did not finish in {timeout_s} s"
+            dbs = glob.glob(os.path.join(out, "**", "*.db"), recursive=True)
+            if r.returncode != 0 or not dbs:
+                return None, f"the {counter} pass failed (rc {r.returncode}): {(r.stderr or r.stdout)[-160:]}"
+            got[counter] = PT.per_kernel(dbs[0], counter)
+        return PT.summarise(got["FETCH_SIZE"], got["WRITE_SIZE"]), None
+    except Exception as e:   # reported in the line, never fatal to it
+        return None, f"{type(e).__name__}: {str(e)[:160]}"
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 def score_block(eng, sc, steps, peak):
     """the `score_gemm` object of a bench line from KernelTimer's tag:score totals of `steps` instrumented steps"""
     R = eng.R
@@ -110,7 +151,8 @@ def side_config(name, dev, steps=8, warmup=2, roof_steps=2, score_path="auto"):
     if ig and ig["ms"] > 0:
         ach = ig["flops"] / (ig["ms"] * 1e-3) / 1e12
         out["roofline"] = {"kernel": "dpc_conv_igemm", "bound": "mfma", "achieved": round(ach, 2), "peak": MFMA_PEAK_BF16,
-                           "unit": "TFLOP/s", "frac": round(ach / MFMA_PEAK_BF16, 4), "ms_per_step": round(ig["ms"] / roof_steps, 3)}
+                           "unit": "TFLOP/s", "frac": round(ach / MFMA_PEAK_BF16, 4), "ms_per_step": round(ig["ms"] / roof_steps, 3),
+                           "executed_frac": round(ig["executed_flops"] / (ig["ms"] * 1e-3) / 1e12 / MFMA_PEAK_BF16, 4)}
     sc = summ.get("tag:score")
     if sc and sc["ms"] > 0:
         out["score_gemm"] = score_block(eng, sc, roof_steps, MFMA_PEAK_BF16)
@@ -311,6 +353,9 @@ def main():
     ap.add_argument("--no-also", action="store_true", help="skip the 224^2 side measurements (cfg4 / cfg5) of the default run")
     ap.add_argument("--no-schedules", action="store_true", help="multi-rank runs: skip the side measurement of the other exchange schedules")
     ap.add_argument("--no-graph", action="store_true", help="launch the step kernel by kernel instead of replaying a hipGraph")
+    ap.add_argument("--pmc", default="auto", choices=["auto", "live", "file", "off"],
+                    help="roofline.traffic: live = two rocprofv3 --pmc passes of a child run (default at cfg2 / bf16 / one GPU: 'auto' tries it and "
+                         "falls back to the tracked profiles/*_pmc_traffic.json, flagged); file = the tracked profile only; off = null")
     ap.add_argument("--score-path", default="auto", choices=["auto", "fused", "materialised"],
                     help="contrastive score + loss: fused (no [R][R] tensor in HBM) or materialised; auto = materialised (the faster one at cfg2 and at cfg5)")
     args = ap.parse_args()
@@ -480,25 +525,38 @@ def main():
             ig = s.get("dpc_conv_igemm")
             peak = MFMA_PEAK_BF16 if args.dtype == "bf16" else MFMA_PEAK_F32
             traffic, traffic_src = None, None
-            try:  # HBM bytes per launch from the rocprofv3 PMC passes (scripts/gpu_pmc_traffic.sh + scripts/pmc_traffic.py)
-                import glob
-                cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))
-                if cands and args.dtype == "bf16" and args.config == "cfg2" and batch == 128:
-                    tj = json.load(open(cands[-1]))
-                    traffic = round(tj["dpc_conv_igemm"]["hbm_bytes_per_launch"] / 1e9, 4)
-                    # the counters are a separate rocprofv3 session: the file says which kernel sources it was measured on
-                    traffic_src = {"file": os.path.basename(cands[-1]), "measured_on_csrc_sha16": tj.get("csrc_sha16"),
-                                   "measured_on_git_head": tj.get("git_head"), "this_build_csrc_sha16": csrc_sha16(),
-                                   "stale": tj.get("csrc_sha16") != csrc_sha16()}
-            except Exception:
-                traffic, traffic_src = None, None
+            std = args.dtype == "bf16" and args.config == "cfg2" and batch == 128 and args.net is None and args.img_dim is None and args.pred_step is None
+            if args.pmc in ("auto", "live") and std and world == 1 and dist is None:
+                summ, why = live_pmc_traffic(args.config)
+                if summ is not None and summ["dpc_conv_igemm"]["launches"] > 0:
+                    traffic = round(summ["dpc_conv_igemm"]["hbm_bytes_per_launch"] / 1e9, 4)
+                    traffic_src = {"live": True, "how": "two rocprofv3 passes in this run (--kernel-trace --pmc FETCH_SIZE | WRITE_SIZE, separate), a child "
+                                                        "bench.py launching 2 eager steps of this workload; FETCH_SIZE x2 (gfx950 wide-load correction)",
+                                   "launches_counted": summ["dpc_conv_igemm"]["launches"], "csrc_sha16": csrc_sha16(), "stale": False}
+                else:
+                    traffic_src = {"live": False, "live_failed": why}
+            if traffic is None and args.pmc in ("auto", "file"):
+                try:  # fallback: the tracked profile of an earlier session (scripts/gpu_pmc_traffic.sh); it says which kernel sources it saw
+                    import glob
+                    cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))
+                    if cands and std:
+                        tj = json.load(open(cands[-1]))
+                        traffic = round(tj["dpc_conv_igemm"]["hbm_bytes_per_launch"] / 1e9, 4)
+                        traffic_src = dict(traffic_src or {}, live=False, file=os.path.basename(cands[-1]), measured_on_csrc_sha16=tj.get("csrc_sha16"),
+                                           measured_on_git_head=tj.get("git_head"), this_build_csrc_sha16=csrc_sha16(),
+                                           stale=tj.get("csrc_sha16") != csrc_sha16())
+                except Exception:
+                    traffic = None
             if ig and ig["ms"] > 0:
                 ach = ig["flops"] / (ig["ms"] * 1e-3) / 1e12
                 out["roofline"] = {
                     "kernel": "dpc_conv_igemm (igemm_ws_kernel + conv_halo(_ws)_kernel + igemm_kernel: conv fwd + input-grad + 1x1 GEMMs)",
                     "bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
-                    "traffic": traffic, "traffic_unit": "GB of HBM traffic per launch (rocprofv3 PMC, profiles/*_pmc_traffic.json)",
+                    "traffic": traffic, "traffic_unit": "GB of HBM traffic per launch (rocprofv3 PMC: see traffic_source)",
                     "traffic_source": traffic_src,
+                    "executed": {"achieved": round(ig["executed_flops"] / (ig["ms"] * 1e-3) / 1e12, 2), "frac": round(ig["executed_flops"] / (ig["ms"] * 1e-3) / 1e12 / peak, 4),
+                                 "what": "the same launches charged only with the MACs the matrix pipe runs: igemm_ws skips the temporal taps of a 3x3x3 conv "
+                                         "that read zero padding (7 of 9 at T = 3, 4 of 6 at T = 2); `achieved` / `frac` above are the algorithmic rate"},
                     "algorithmic_GB_per_launch": round(ig["bytes"] / ig["launches"] / 1e9, 4),
                     "launches_per_step": ig["launches"] // rs,
                     "avg_launch_us": round(1e3 * ig["ms"] / ig["launches"], 2),

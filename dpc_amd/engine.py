@@ -85,7 +85,7 @@ class KernelTimer:
 
     def __init__(self, names):
         self.names = set(names)
-        self.records = []  # (name, tag, start_event, end_event, flops, bytes)
+        self.records = []  # (name, tag, start_event, end_event, flops, bytes, executed flops)
         self.enabled = True
 
     def timed(self, eng, name, args):
@@ -96,7 +96,8 @@ class KernelTimer:
         rc = eng.lib.call(name, *args, eng.lib.stream())
         b.record()
         fl, by = algorithmic_cost(name, args)
-        self.records.append((TIMER_FAMILY.get(name, name), eng._tag, a, b, fl, by))
+        xf = fl * executed_fraction(name, args, L.last_kernel(eng.lib)) if fl else 0.0
+        self.records.append((TIMER_FAMILY.get(name, name), eng._tag, a, b, fl, by, xf))
         return rc
 
     def summary(self, steps: int = 1):
@@ -106,7 +107,7 @@ class KernelTimer:
         once doubled the family's reported time."""
         torch.cuda.synchronize()
         out = {}
-        times = [a.elapsed_time(b) for _, _, a, b, _, _ in self.records]
+        times = [r[2].elapsed_time(r[3]) for r in self.records]
         n = len(times)
         if steps > 1 and n % steps == 0:
             per = n // steps
@@ -117,13 +118,14 @@ class KernelTimer:
                     med = col[len(col) // 2] if len(col) % 2 else 0.5 * (col[len(col) // 2 - 1] + col[len(col) // 2])
                     for k in range(steps):
                         times[i + k * per] = med
-        for (name, tag, a, b, fl, by), ms in zip(self.records, times):
+        for (name, tag, a, b, fl, by, xf), ms in zip(self.records, times):
             for key in (name,) + ((f"tag:{tag}",) if tag else ()):
-                d = out.setdefault(key, {"launches": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0})
+                d = out.setdefault(key, {"launches": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0, "executed_flops": 0.0})
                 d["launches"] += 1
                 d["ms"] += ms
                 d["flops"] += fl
                 d["bytes"] += by
+                d["executed_flops"] += xf
         return out
 
 
@@ -191,6 +193,22 @@ def algorithmic_cost(name, args):
     else:
         by = rows_src * d.Ci * esz + rows_out * d.Co * esz + d.Co * d.Ci * taps * 4
     return 2.0 * macs, float(by)
+
+
+def executed_fraction(name, args, kernel: str) -> float:
+    """share of a launch's algorithmic FLOPs the matrix pipe actually executes.  The loader / compute kernel walks a 3x3x3 unit-stride
+    convolution (forward or input-gradient) frame by frame and skips the temporal taps that would read zero padding as a K sub-range
+    (csrc/conv_igemm_ws.hip `tgroup`): of the KT taps of output frame t only those with 0 <= t - pt + kt < ST run -- 7 of 9 at T = 3
+    (layer3), 4 of 6 at T = 2 (layer4).  Everything else executes what it is charged (1.0); the stem's 147/256 is already in the
+    algorithmic count."""
+    if name not in ("dpc_conv_igemm", "dpc_conv_igemm_ex") or not kernel.startswith("igemm_ws_kernel"):
+        return 1.0
+    d = args[0]._obj
+    unit = d.st == 1 and d.sh == 1 and d.sw == 1
+    if not (d.KT > 1 and unit and d.RT == d.ST and d.RT > 1):
+        return 1.0
+    live = sum(1 for t in range(d.RT) for kt in range(d.KT) if 0 <= t - d.pt + kt < d.ST)
+    return live / float(d.RT * d.KT)
 
 
 def _idle_at_exit():

@@ -66,10 +66,27 @@ def test_kernel_timer_charges_the_median_per_launch_position(monkeypatch):
     monkeypatch.setattr(torch.cuda, "synchronize", lambda *a, **k: None)
     tm = E.KernelTimer(["a", "b"])
     for x, y in ((1.0, 2.0), (1.1, 2.1), (30.0, 2.0), (0.9, 1.9)):   # four steps; one hiccup on "a"
-        tm.records.append(("a", None, Ev(0.0), Ev(x), 1.0, 8.0))
-        tm.records.append(("b", "score", Ev(0.0), Ev(y), 2.0, 4.0))
+        tm.records.append(("a", None, Ev(0.0), Ev(x), 1.0, 8.0, 1.0))
+        tm.records.append(("b", "score", Ev(0.0), Ev(y), 2.0, 4.0, 1.5))
     s = tm.summary(4)
     assert s["a"]["launches"] == 4 and abs(s["a"]["ms"] - 4 * 1.05) < 1e-9 and s["a"]["bytes"] == 32.0
     assert abs(s["b"]["ms"] - 4 * 2.0) < 1e-9 and abs(s["tag:score"]["ms"] - 8.0) < 1e-9
     assert abs(tm.summary(1)["a"]["ms"] - 33.0) < 1e-9          # plain totals when the steps are not declared
     assert abs(tm.summary(3)["a"]["ms"] - 33.0) < 1e-9          # ... or do not divide the record count
+
+
+def test_executed_fraction_of_the_temporal_taps():
+    """bench.py `roofline.executed`: igemm_ws runs 7 of the 9 temporal taps of a unit-stride 3x3x3 conv at T = 3 (layer3) and 4 of 6
+    at T = 2 (layer4); every other kernel and shape executes what it is charged"""
+    import ctypes as C
+    from dpc_amd import engine as E, _lib as L
+    from dpc_amd.plan import unit_descs
+
+    def frac(T, k=(3, 3, 3), s=(1, 1, 1), kernel="igemm_ws_kernel<false, false>", name="dpc_conv_igemm"):
+        f, d, w = unit_descs(256, 256, k, s, (1, 1, 1) if k[0] == 3 else (0, 1, 1), (4, T, 8, 8), torch.bfloat16, False)
+        return [E.executed_fraction(name, (C.byref(x),), kernel) for x in (f, d)]
+
+    assert frac(3) == [7 / 9, 7 / 9] and frac(2) == [4 / 6, 4 / 6]
+    assert frac(3, kernel="igemm_kernel<bf16, bf16, 128, 3, false>") == [1.0, 1.0]      # the generic kernel skips nothing
+    assert frac(5, k=(1, 3, 3)) == [1.0, 1.0] and frac(5, s=(2, 2, 2))[0] == 1.0        # 2D convs; strided convs
+    assert frac(3, name="dpc_conv_wgrad") == [1.0, 1.0]
