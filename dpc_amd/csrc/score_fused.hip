@@ -564,7 +564,10 @@ int dpc_score_gemm_try(const dpc_conv_desc* d, const void* src, const void* wgt,
         return dpc_launch_status();
     }
     const int nrb = (p.M + BM - 1) / BM;
-    int sp = (512 + nrb - 1) / nrb;   // two workgroups per CU
+    // two workgroups per CU = 512 slots, and ONE wave of workgroups: rounded DOWN.  Rounds 3-4 rounded up -- 528 workgroups at
+    // R = 6 144, 561 at R = 6 468 -- and the last 16 / 49 ran after everybody else (DPC_SCORE_GEMM_WGS: the slot count to fill, A/B)
+    static const int slots = getenv("DPC_SCORE_GEMM_WGS") ? atoi(getenv("DPC_SCORE_GEMM_WGS")) : 512;
+    int sp = slots / nrb;
     if (sp > p.ntiles / 4) sp = p.ntiles / 4 > 0 ? p.ntiles / 4 : 1;
     if (sp < 1) sp = 1;
     p.tiles_per_split = (p.ntiles + sp - 1) / sp;
