@@ -60,7 +60,7 @@ def csrc_sha16():
     return h.hexdigest()[:16]
 
 
-def live_pmc_traffic(config="cfg2", timeout_s=240):
+def live_pmc_traffic(config="cfg2", timeout_s=150):
     """HBM bytes per launch of the conv family, measured IN THIS RUN: two rocprofv3 passes (FETCH_SIZE, then WRITE_SIZE -- separate
     --pmc runs with --kernel-trace only, as /opt/skills/guides/MI355X_MICROARCH.md prescribes) of a child `bench.py` that launches two
     eager steps of the same workload, summarised with the guide's gfx950 correction (scripts/pmc_traffic.py).  Returns
@@ -85,14 +85,22 @@ def live_pmc_traffic(config="cfg2", timeout_s=240):
     try:
         for counter in ("FETCH_SIZE", "WRITE_SIZE"):
             out = os.path.join(tmp, counter)
+            # its own session: on a timeout the whole group goes (rocprofv3 AND the python it started), nothing keeps the GPU busy behind us
+            proc = subprocess.Popen(["rocprofv3", "--kernel-trace", "--pmc", counter, "-d", out, "-o", "pmc", "--"] + child, cwd="/tmp", env=env,
+                                    stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, start_new_session=True)
             try:
-                r = subprocess.run(["rocprofv3", "--kernel-trace", "--pmc", counter, "-d", out, "-o", "pmc", "--"] + child, cwd="/tmp", env=env,
-                                   capture_output=True, text=True, timeout=timeout_s)
+                so, se = proc.communicate(timeout=timeout_s)
             except subprocess.TimeoutExpired:
+                import signal
+                try:
+                    os.killpg(proc.pid, signal.SIGKILL)
+                except OSError:
+                    pass
+                proc.communicate()
                 return None, f"the {counter} pass did not finish in {timeout_s} s"
             dbs = glob.glob(os.path.join(out, "**", "*.db"), recursive=True)
-            if r.returncode != 0 or not dbs:
-                return None, f"the {counter} pass failed (rc {r.returncode}): {(r.stderr or r.stdout)[-160:]}"
+            if proc.returncode != 0 or not dbs:
+                return None, f"the {counter} pass failed (rc {proc.returncode}): {(se or so)[-160:]}"
             got[counter] = PT.per_kernel(dbs[0], counter)
         return PT.summarise(got["FETCH_SIZE"], got["WRITE_SIZE"]), None
     except Exception as e:   # reported in the line, never fatal to it

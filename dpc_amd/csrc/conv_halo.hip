@@ -47,6 +47,7 @@ struct HaloParams {
     unsigned src_bytes;
     int ws;  // shape served by the role-specialised kernel
     int dbg; // DPC_WS_PROBE builds only: phases to leave out, for timing (scripts/probes/halo_probe.py)
+    void* probe_buf;   // DPC_WS_PROBE builds only: where the BNIN load probe (bit 256) stores its interior units
 };
 #ifdef DPC_WS_PROBE
 #define HP_DBG(bit) (p.dbg & (bit))
@@ -339,7 +340,11 @@ __global__ __launch_bounds__(512, 2) void conv_halo_ws_kernel(HaloParams p) {
     static_assert(NPB * PATCH + 2 * STG <= 160 * 1024 && 2 * (NPB * PATCH + 2 * STG) > 160 * 1024, "one workgroup per CU");
     // (round 3 claimed all 160 KB here as a precaution; the failure it guarded against was a register hazard of igemm_ws_kernel,
     // conv_igemm_ws.hip WS_RETIRE_TAIL_READS -- this kernel's asm reads are all consumed, scripts/asm_hazard_lint.py)
+#ifdef DPC_WS_PROBE
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[NPB * PATCH + 2 * STG + 1024];   // + the probe's coefficient table
+#else
     __shared__ __attribute__((aligned(1024))) unsigned char lds[NPB * PATCH + 2 * STG];
+#endif
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -347,6 +352,9 @@ __global__ __launch_bounds__(512, 2) void conv_halo_ws_kernel(HaloParams p) {
     const int wv = tid >> 6;
 #else
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+#endif
+#ifdef DPC_WS_PROBE
+    if (tid < 128) ((float*)(lds + NPB * PATCH + 2 * STG))[tid] = tid < 64 ? 1.0f : 0.01f;
 #endif
     // Workgroup b runs on XCD b & 7 (its own L2).  The tiles of one frame are consecutive tile indices and neighbouring row bands
     // share two of their six patch rows: give every XCD a contiguous range of tile slots, so that those re-reads hit its L2
@@ -555,6 +563,46 @@ __global__ __launch_bounds__(512, 2) void conv_halo_ws_kernel(HaloParams p) {
                 if (newer >= 2) wait_vmcnt<2 * LIT>(); else if (newer == 1) wait_vmcnt<LIT>(); else wait_vmcnt<0>();
             }
             barrier_lds_only();  // B1(j)
+#ifdef DPC_WS_PROBE
+            // LOAD PROBE (bit 256; results are wrong by design): what would a BatchNorm-apply + ReLU of the SOURCE cost if it ran here,
+            // on the staged patch, instead of as its own kernel?  Every helper lane rewrites the units its own DMA
+            // pieces brought (patch j+1: read, 8 x {fma, max}, round, write back; coefficients from a 512-byte LDS table) and stores the
+            // interior ones -- the activation the backward pass wants -- to a scratch tensor (bit 512: without that store).
+            if (HP_DBG(256) && UPP == 8 && j + 1 < ntiles) {
+                wait_vmcnt<0>();
+                unsigned char* pn = lds + ((j + 1) % NPB) * PATCH;
+                const float* tab = (const float*)(lds + NPB * PATCH + 2 * STG);
+                int frame, h0, w0;
+                tile_origin(m_prog + (j + 1) * p.gm, frame, h0, w0);
+                const unsigned base = (unsigned)(((frame * p.H + h0 - p.ph) * p.W + w0 - p.pw) * p.C * 2);
+                DPC_UNROLL
+                for (int it = 0; it < LIT; ++it) {
+                    const int slot = it * 256 + htid;
+                    const int cu_ = slot % SPP;
+                    if (cu_ >= UPP) continue;
+                    u32x4 v = *(const u32x4*)(pn + slot * 16);
+                    const f32x4 sc0 = *(const f32x4*)(tab + cu_ * 8), sc1 = *(const f32x4*)(tab + cu_ * 8 + 4);
+                    const f32x4 sh0 = *(const f32x4*)(tab + 64 + cu_ * 8), sh1 = *(const f32x4*)(tab + 64 + cu_ * 8 + 4);
+                    float x[8];
+                    DPC_UNROLL
+                    for (int e = 0; e < 4; ++e) {
+                        x[2 * e] = __builtin_bit_cast(float, v[e] << 16);
+                        x[2 * e + 1] = __builtin_bit_cast(float, v[e] & 0xffff0000u);
+                    }
+                    DPC_UNROLL
+                    for (int e = 0; e < 4; ++e) {
+                        x[e] = fmaxf(fmaf(x[e], sc0[e], sh0[e]), 0.f);
+                        x[4 + e] = fmaxf(fmaf(x[4 + e], sc1[e], sh1[e]), 0.f);
+                    }
+                    DPC_UNROLL
+                    for (int e = 0; e < 4; ++e) v[e] = bf16x2_pack(x[2 * e], x[2 * e + 1]);
+                    *(u32x4*)(pn + slot * 16) = v;
+                    const int hr = hrc[it] >> 16, hc = hrc[it] & 0xffff;
+                    const bool inner = hr >= p.ph && hr < p.ph + p.TR && hc >= p.pw && hc < p.pw + p.TW;
+                    if (inner && !HP_DBG(512) && p.probe_buf) *(u32x4*)((char*)p.probe_buf + base + rel[it]) = v;
+                }
+            }
+#endif
             if (PRE) {
                 Pre nxt = cur;
                 if (j < ntiles && j >= 1) prefetch(j, nxt);
@@ -646,6 +694,11 @@ int dpc_conv_halo_rows(const dpc_conv_desc* d) {
     return p.gm;
 }
 
+#ifdef DPC_WS_PROBE
+static void* g_halo_probe_buf = nullptr;
+extern "C" int dpc_probe_set_halo_buf(void* buf) { g_halo_probe_buf = buf; return 0; }   // scripts/probes/halo_probe.py
+#endif
+
 // returns 1 when the shape is not served by this kernel (caller falls back to dpc_conv_igemm's generic path)
 int dpc_conv_halo_try(const dpc_conv_desc* d, const void* src, const void* wgt, void* out, const void* addend, float* stats,
                       const EpiExtra& epi, hipStream_t stream) {
@@ -654,8 +707,10 @@ int dpc_conv_halo_try(const dpc_conv_desc* d, const void* src, const void* wgt, 
     p.src = src; p.wgt = wgt; p.out = out; p.addend = addend; p.stats = stats; p.epi = epi;
 #ifdef DPC_WS_PROBE
     p.dbg = getenv("DPC_WS_DBG") ? atoi(getenv("DPC_WS_DBG")) : 0;
+    p.probe_buf = g_halo_probe_buf;
 #else
     p.dbg = 0;
+    p.probe_buf = nullptr;
 #endif
     const int epo = d->dtype_out == DPC_BF16 ? 8 : 4;
     p.vec_out = (d->Co % epo == 0 && d->ldo % epo == 0 && ((uintptr_t)out % 16 == 0) && ((uintptr_t)addend % 16 == 0)) ? 1 : 0;

@@ -238,13 +238,31 @@ atexit.register(_idle_at_exit)
 _LIVE_GRAPHS: list = []
 
 
-def _park_graphs(graphs):
-    """keep `graphs` (torch.cuda.CUDAGraph objects) alive until the interpreter exits -- not even module teardown destroys them"""
+class _Capture:
+    """the hipGraphs of one captured train step and the fork / join events that were recorded into them"""
+
+    def __init__(self, graphs, events):
+        self.graphs, self.events = graphs, events
+
+    def destroy(self):
+        """DPC_KEEP_GRAPHS=0 only: graphs first, then the events captured into them"""
+        self.graphs.clear()
+        if self.events is not None:
+            self.events.clear()
+
+
+def _park_graphs(captures):
+    """keep the graphs of `captures` (list of _Capture) alive until the interpreter exits -- not even module teardown destroys them;
+    DPC_KEEP_GRAPHS=0: destroy them now, in order"""
     if os.environ.get("DPC_KEEP_GRAPHS", "1") == "0":
+        for c in captures:
+            c.destroy()
         return
-    for g_ in graphs:
-        C.pythonapi.Py_IncRef(C.py_object(g_))
-    _LIVE_GRAPHS.extend(graphs)
+    for c in captures:
+        for g_ in c.graphs:
+            C.pythonapi.Py_IncRef(C.py_object(g_))
+        _LIVE_GRAPHS.extend(c.graphs)
+        _LIVE_GRAPHS.append(c.events)   # (a list of torch events, or None)
 
 
 class _ConvBN:
@@ -382,8 +400,7 @@ class _ConvBN:
         a tensor).  red: the unit whose output gradient dx is -- its BatchNorm-backward partial sums are taken in this launch's
         epilogue and `red.bn_backward` skips its reduction pass."""
         e = self.eng
-        if e._side_quiet:   # no side-stream work beside an input-gradient (see side())
-            e.side_wait()
+        e.side_wait()   # no side-stream work beside an input-gradient (see side())
         if addend_mask is None and red is None:
             e.call("dpc_conv_igemm", C.byref(self.desc_d), draw, self.wd, dx, addend, None)
             return
@@ -462,15 +479,15 @@ class _Block:
         self.c2.dgrad(draw2, dact1, None, red=self.c1 if self.fold_c1 else None)
         if self.fold_c1:   # coefficients of bn1 before the side stream fills the chip (bn_prepare)
             self.c1.bn_prepare(dact1, self.act1, True)
-        with e.side(reads=[draw2, draw_d], kind=1):   # beside bn1's backward on the main stream
+        with e.side(reads=[draw2, draw_d]):   # beside bn1's backward on the main stream
             if self.ds is not None:
                 self.ds.wgrad(self.x_in, draw_d)
             self.c2.wgrad(self.act1, draw2)
         # in place over the consumed draw2 unless the side stream may still be reading it
-        draw1 = draw2 if e._side is None or e.timer is not None or not (e._side_mask & 1) else e.scratch(oshape, exclude=[dout, draw2, draw_d, dz, dact1])
+        draw1 = draw2 if e._side is None or e.timer is not None else e.scratch(oshape, exclude=[dout, draw2, draw_d, dz, dact1])
         self.c1.bn_backward(dact1, self.act1, True, draw1)
         if not need_dx:
-            with e.side(reads=[draw1], kind=2):
+            with e.side(reads=[draw1]):
                 self.c1.wgrad(self.x_in, draw1)
             return None
         if self.ds is not None:
@@ -489,7 +506,7 @@ class _Block:
         else:
             dx = dact1  # same shape as the input; dact1 is dead
             self.c1.dgrad(draw1, dx, dz)
-        with e.side(reads=[draw1], kind=2):   # beside the previous block's bn2 backward (beside conv1's own input-gradient: slower)
+        with e.side(reads=[draw1]):   # beside the previous block's bn2 backward (beside conv1's own input-gradient: slower)
             self.c1.wgrad(self.x_in, draw1)
         return dx
 
@@ -536,8 +553,9 @@ class DPCEngine:
         self.score_mode = "materialised"  # what the last train step ran ("fused": no [R][R] tensor in HBM)
         self.timer: Optional["KernelTimer"] = None
         self._tag: Optional[str] = None
+        self._capture_events: Optional[list] = None   # fork / join events of the capture in progress (capture_train_step)
         self._captures: Dict[tuple, object] = {}   # capture_train_step results by (input buffer, exchange, carve-out)
-        self._capture_graphs: list = []            # their hipGraphs; parked in _LIVE_GRAPHS when the engine goes (see there)
+        self._capture_graphs: list = []            # their _Capture records; parked in _LIVE_GRAPHS when the engine goes (see there)
         weakref.finalize(self, _park_graphs, self._capture_graphs)
 
         # ---- flat f32 arenas: parameters, gradients, Adam moments
@@ -565,12 +583,11 @@ class DPCEngine:
         self._pack_table = None
         self._gate_table = None
         # weight gradients on a second stream beside the next unit's BatchNorm backward (side() below); DPC_WGRAD_STREAM=0: one stream.
-        # DPC_SIDE_MASK selects what goes there (1 conv2 / downsample weight gradients, 2 conv1's, 4 head parameters, 8 weight
-        # repacks); DPC_SIDE_QUIET=0 lets side work run beside input-gradients too (slower, and not bit-reproducible: see side())
+        # What goes there: conv2 / downsample weight gradients, conv1's, the head's parameter gradients, the per-step weight repacks;
+        # the main stream waits for the side stream before every input-gradient (side()).  Rounds 3-4 had switches for both choices
+        # (DPC_SIDE_MASK, DPC_SIDE_QUIET); every other setting measured slower and the switches are gone (round 5).
         self._side = (torch.cuda.Stream(self.device) if self.device.type == "cuda" and int(os.environ.get("DPC_WGRAD_STREAM", "1")) else None)
         self._on_side = False
-        self._side_mask = int(os.environ.get("DPC_SIDE_MASK", "15"))
-        self._side_quiet = bool(int(os.environ.get("DPC_SIDE_QUIET", "1")))
         self._busy = []   # [(event recorded on the side stream, scratch buffers its launches read)], oldest first
         self.bn_running = type(self).BN_RUNNING  # BatchNorm3d with running statistics (the LC classifier's backbone)
         self.train_mode = True       # only matters when bn_running: eval uses the running buffers
@@ -761,8 +778,7 @@ class DPCEngine:
 
     # ------------------------------------------------------------------ plumbing
     # split-K slab workspace: one buffer per stream.  Launches issued inside side() get the side stream's own slabs, so a
-    # main-stream user (dpc_gemm_*_splitk, dpc_colsum, a weight gradient that stays on the main stream under a partial
-    # DPC_SIDE_MASK or need_dx=False) can never overwrite slabs a side-stream weight gradient is still reducing.
+    # main-stream user (dpc_gemm_*_splitk, dpc_colsum, a weight gradient that stays on the main stream with need_dx=False) can never overwrite slabs a side-stream weight gradient is still reducing.
     @property
     def part(self) -> torch.Tensor:
         return self._part_side if self._on_side else self._part_main
@@ -843,8 +859,8 @@ class DPCEngine:
     #     and the probe is clean (conv_igemm_ws.hip).  The wait in _ConvBN.dgrad stays for the throughput.  With it, 9 600 steps (three configurations, graph
     #     replay and kernel-by-kernel) were bit-identical to the one-stream schedule.
     @contextlib.contextmanager
-    def side(self, reads=(), kind=1):
-        if self._side is None or self.timer is not None or not (self._side_mask & kind):   # instrumented pass (bench.py): one stream, clean per-kernel times
+    def side(self, reads=()):
+        if self._side is None or self.timer is not None:   # instrumented pass (bench.py): one stream, clean per-kernel times
             yield
             return
         main = torch.cuda.current_stream(self.device)
@@ -860,6 +876,8 @@ class DPCEngine:
             done = torch.cuda.Event()
             done.record(self._side)
         self._busy.append((done, [t for t in reads if t is not None]))
+        if self._capture_events is not None:   # recorded into a hipGraph being captured: see capture_train_step
+            self._capture_events += [ev, done]
 
     def side_wait(self):
         """the main stream waits for the side stream's work so far; its buffers stay tracked"""
@@ -972,7 +990,7 @@ class DPCEngine:
         load_frames): returns the last block's output [B*N, T, ls, ls, D] (channels-last, no final ReLU)"""
         B, N = self.B, self.N
         dc = L.dtype_code(self.cdtype)
-        with self.side(kind=8):   # the per-step weight repacks (0.2 ms of small launches) beside the input pack
+        with self.side():   # the per-step weight repacks (0.2 ms of small launches) beside the input pack
             self.pack_weights()
         if block is not None:
             self.call("dpc_pack_input_s2d", block.contiguous(), self.x_s2d, dc, B * N, self.SL, self.size, self.size)
@@ -1144,7 +1162,7 @@ class DPCEngine:
         # ---- weight / bias grads of the ConvGRU and predictor, batched over all steps: ~20 small launches nothing waits for until
         # the optimizer -- on the side stream, beside layer4's backward (they share the split-K slab buffer with the backbone's
         # weight gradients, which queue behind them on the same stream)
-        with self.side(kind=4):
+        with self.side():
             self._head_param_grads(dc)
         self._backbone_backward(self.d_feat, on_tail_ready)
 
@@ -1228,19 +1246,28 @@ class DPCEngine:
             begin()
 
         side.wait_stream(cur)
-        with torch.cuda.stream(side):
-            begin()
-            self.packed_for_step = -1
-            self.forward(block, train=True, materialise=False)
-            self.loss_topk(with_grad=True)
-            self.backward(on_tail_ready=cut if two_bucket else None)
-            if allreduce is not None:
-                cut()
-            host_steps = self._step_count
-            self.adam_step()
-            self._step_count = host_steps  # capture executes nothing
-            state["g"].capture_end()
-            graphs.append(state["g"])
+        # The fork / join events side() records while the step is being captured live as long as the graphs do (they hang off the
+        # replay closure): a captured event that is destroyed before its graph is the one candidate mechanism found for the host-memory
+        # corruption that used to follow graph destruction (see _LIVE_GRAPHS; DPC_KEEP_CAPTURE_EVENTS=0 lets them go when side()
+        # returns, as rounds 3-4 did -- the A/B of scripts/gpu_r5_graph_destroy.sh).
+        keep_events = os.environ.get("DPC_KEEP_CAPTURE_EVENTS", "1") != "0"
+        self._capture_events = [] if keep_events else None
+        try:
+            with torch.cuda.stream(side):
+                begin()
+                self.packed_for_step = -1
+                self.forward(block, train=True, materialise=False)
+                self.loss_topk(with_grad=True)
+                self.backward(on_tail_ready=cut if two_bucket else None)
+                if allreduce is not None:
+                    cut()
+                host_steps = self._step_count
+                self.adam_step()
+                self._step_count = host_steps  # capture executes nothing
+                state["g"].capture_end()
+                graphs.append(state["g"])
+        finally:
+            events, self._capture_events = self._capture_events, None
         cur.wait_stream(side)
         tail, head, whole, result = self.flat_g[self.grad_split:], self.flat_g[:self.grad_split], self.flat_g, self.result
         me = weakref.ref(self)   # the cached closure must not keep its engine (tens of GB of buffers) alive through a cycle
@@ -1263,9 +1290,10 @@ class DPCEngine:
             return result
 
         replay.graphs = graphs
+        replay.events = events   # destroyed after the graphs, not before
         replay.block = block   # the static input buffer stays alive (and its address un-reused) as long as the capture does
         self._captures[key] = replay
-        self._capture_graphs.extend(graphs)
+        self._capture_graphs.append(_Capture(graphs, events))
         return replay
 
     def release_captures(self):

@@ -6,6 +6,6 @@ R=$GRAFT_REPO_ROOT; cd $R; mkdir -p gpurun_out
 (timeout 600 python scripts/stream_stress.py cfg2 1500 1 2>&1 | grep -v amdgpu.ids | tail -4) > gpurun_out/s_stress_cfg2.log
 (timeout 600 python scripts/stream_stress.py cfg4 400 1 2>&1 | grep -v amdgpu.ids | tail -4) > gpurun_out/s_stress_cfg4.log
 (timeout 600 python scripts/stream_stress.py cfg5 250 1 2>&1 | grep -v amdgpu.ids | tail -4) > gpurun_out/s_stress_cfg5.log
-(DPC_SIDE_QUIET=0 timeout 900 python scripts/stream_stress.py cfg2 2500 1 2>&1 | grep -v amdgpu.ids | tail -4) > gpurun_out/s_stress_cfg2_freerun.log
-(DPC_SIDE_QUIET=0 STRESS_EAGER=1 timeout 900 python scripts/stream_stress.py cfg2 1000 1 2>&1 | grep -v amdgpu.ids | tail -4) > gpurun_out/s_stress_cfg2_freerun_eager.log
+# (switch removed in round 5) (DPC_SIDE_QUIET=0 timeout 900 python scripts/stream_stress.py cfg2 2500 1 2>&1 | grep -v amdgpu.ids | tail -4) > gpurun_out/s_stress_cfg2_freerun.log
+# (switch removed in round 5) (DPC_SIDE_QUIET=0 STRESS_EAGER=1 timeout 900 python scripts/stream_stress.py cfg2 1000 1 2>&1 | grep -v amdgpu.ids | tail -4) > gpurun_out/s_stress_cfg2_freerun_eager.log
 for f in gpurun_out/s_stress_*.log; do echo "== $f"; cat $f; done

@@ -40,8 +40,17 @@ def run(tag, dbg, reps=20):
     print(f"{tag:50s} dbg={dbg:3d}  {us:8.1f} us  {flops / us * 1e-6:7.1f} TFLOP/s-equivalent", flush=True)
 
 
+# round 5: what a BatchNorm-apply + ReLU of the source would cost inside this kernel (DPC_WS_DBG bit 256, see conv_halo.hip)
+scratch = torch.empty_like(src)
+_set = lib.c.dpc_probe_set_halo_buf
+_set.argtypes, _set.restype = [C.c_void_p], C.c_int
+_set(scratch.data_ptr())
 run("full kernel", 0)
 run("full kernel", 0)
+run("BNIN load probe: patch rewritten in LDS + activation stored", 256)
+run("BNIN load probe: patch rewritten in LDS, no activation store", 256 + 512)
+run("full kernel", 0)
+run("BNIN load probe: patch rewritten in LDS + activation stored", 256)
 run("round-robin tile slots (no XCD grouping)", 16)
 run("compute waves at default priority", 32)
 run("full kernel", 0)

@@ -51,7 +51,10 @@ def test_graph_replay_equals_eager(dtype):
     # dropped captures are parked until the process exits, never destroyed while it runs (engine._LIVE_GRAPHS says why)
     g0 = replay.graphs[0]
     b.release_captures()
-    assert not b._captures and any(g is g0 for g in E_._LIVE_GRAPHS) and len(E_._LIVE_GRAPHS) == live + 1
+    if os.environ.get("DPC_KEEP_GRAPHS", "1") != "0":
+        assert not b._captures and any(g is g0 for g in E_._LIVE_GRAPHS) and len(E_._LIVE_GRAPHS) == live + 2   # the graph + its events
+    else:   # the A/B of scripts/gpu_r5_graph_destroy.sh: destroyed here, graphs first
+        assert not b._captures and len(E_._LIVE_GRAPHS) == live and not replay.graphs
 
 
 _RANK_SCRIPT = r"""
