@@ -359,7 +359,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-also", action="store_true", help="skip the 224^2 side measurements (cfg4 / cfg5) of the default run")
-    ap.add_argument("--no-schedules", action="store_true", help="multi-rank runs: skip the side measurement of the other exchange schedules")
+    ap.add_argument("--schedules", action="store_true",
+                    help="multi-rank runs: after the timed region also time the other gradient-exchange schedules (two more captures with other "
+                         "collectives; opt-in: a side measurement must not be able to cost a scaling run its line)")
+    ap.add_argument("--no-schedules", action="store_true", help="(accepted for compatibility: the side schedules are opt-in since round 5)")
     ap.add_argument("--no-graph", action="store_true", help="launch the step kernel by kernel instead of replaying a hipGraph")
     ap.add_argument("--pmc", default="auto", choices=["auto", "live", "file", "off"],
                     help="roofline.traffic: live = two rocprofv3 --pmc passes of a child run (default at cfg2 / bf16 / one GPU: 'auto' tries it and "
@@ -446,7 +449,7 @@ def main():
     # layer1 + stem backward and leaves reserve_cus CUs to RCCL; "overlap_all_cus" = the same with every CU claimed by the
     # persistent grids, "serial" = one all-reduce of the whole arena after the backward pass
     schedules = None
-    if dist is not None and use_graph and allreduce is not None and not args.no_schedules:
+    if dist is not None and use_graph and allreduce is not None and args.schedules and not args.no_schedules:
         def agree(ok: bool) -> bool:
             """every rank learns whether ALL ranks got here without an exception (one tiny all-reduce, same place on every rank)"""
             f = torch.tensor([1.0 if ok else 0.0], device=dev)
