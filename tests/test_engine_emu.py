@@ -312,3 +312,19 @@ def test_cast_parameters_are_refused(emu):
     torch.nn.Module.double(m)   # what .double() would have done
     with pytest.raises(TypeError, match="float32 master parameters"):
         m(O.make_input_pcg(1, 4, 5, 64))
+
+
+@pytest.mark.parametrize("N,SL,P,B,size", [(6, 4, 2, 1, 64), (5, 8, 1, 1, 64), (8, 5, 3, 3, 64), (4, 6, 1, 2, 96)])
+def test_other_sequence_shapes(emu, N, SL, P, B, size):
+    """the reference's constructor takes any num_seq / seq_len / pred_step (dpc/model_3d.py:16-25: last_duration = ceil(seq_len / 4),
+    last_size = ceil(sample_size / 32)); BASELINE's configurations only use 8 / 5 / 3|5.  Eval-mode score against the oracle for
+    other block counts, block lengths (T path 4 -> 2 -> 1, 8 -> 4 -> 2, 6 -> 3 -> 2), an odd batch and a 3 x 3 feature map."""
+    eng = DPCEngine("resnet18", size, N, SL, P, B, "cpu", torch.float32, WIDTHS, lib=emu)
+    p = O.make_params_pcg("resnet18", WIDTHS)
+    eng.load_params(p)
+    x = O.make_input_pcg(B, N, SL, size)
+    score = eng.forward(x, train=False)
+    ref = O.dpc_forward(p, x, "resnet18", P)
+    assert tuple(score.shape) == tuple(ref.shape) == (B, P, eng.SQ, B, P, eng.SQ)
+    assert (score - ref).abs().max().item() < 1e-4
+    assert torch.equal(eng.get_mask(), O.mask_closed_form(B, P, eng.SQ))
