@@ -15,7 +15,9 @@ GRAD_L2 = 2e-2  # observed <= 0.9 % (ReLU-boundary flips); 
                                                ("resnet18", 96, 3, 2, 8, 5), ("resnet18", 128, 2, 3, 8, 5),
                                                # other block counts / block lengths than BASELINE's 8 x 5 (dpc/model_3d.py:16-25 takes any):
                                                # T path 4 -> 2 -> 1 (last_duration 1), 8 -> 4 -> 2, and an odd batch
-                                               ("resnet18", 128, 3, 2, 6, 4), ("resnet18", 64, 2, 1, 5, 8)])
+                                               ("resnet18", 128, 3, 2, 6, 4), ("resnet18", 64, 2, 1, 5, 8),
+                                               # image sizes that are not multiples of 32: odd planes all the way down (66 -> 33 -> 17 -> 9 -> 5 -> 3)
+                                               ("resnet18", 66, 2, 3, 8, 5), ("resnet34", 112, 2, 3, 8, 5)])
 def test_config_shapes_vs_oracle(net, size, B, P, N, SL):
     eng = DPCEngine(net, size, N, SL, P, B, DEV, torch.float32)
     p = O.make_params_pcg(net)
@@ -37,24 +39,31 @@ def test_config_shapes_vs_oracle(net, size, B, P, N, SL):
     assert errs[worst] < GRAD_L2, (worst, errs[worst])
 
 
-@pytest.mark.parametrize("N,SL,P", [(6, 4, 2), (5, 8, 1)])
-def test_bf16_other_sequence_shapes_track_f32(N, SL, P):
-    """throughput mode at other block counts / lengths (the specialised kernels see T = 4 -> 2 -> 1 and 8 -> 4 -> 2 instead of 5 -> 3 -> 2,
-    at a batch where they are all selected): the score tracks the f32 engine, a train step lowers the loss, everything stays finite"""
-    B, size = 16, 128
+@pytest.mark.parametrize("N,SL,P,size", [(6, 4, 2, 128), (5, 8, 1, 128), (8, 5, 3, 80), (8, 5, 3, 112)])
+def test_bf16_other_shapes_track_f32(N, SL, P, size):
+    """throughput mode at other block counts / lengths (the specialised kernels see T = 4 -> 2 -> 1 and 8 -> 4 -> 2 instead of 5 -> 3 -> 2)
+    and at image sizes with odd planes (80: 20 -> 10 -> 5 -> 3; 112: 28 -> 14 -> 7 -> 4), at a batch where the specialised kernels are
+    selected: score and every gradient track the f32 engine at the level of bf16's rounding noise (4-5 % on the score,
+    5-7 % on the head's gradients, 30-46 % in layer1 / stem at r18 / 128; a wrong kernel is O(1) on the score and > 100 % on gradients)"""
+    B = 16
     p = O.make_params_pcg("resnet18")
     x = O.make_input_pcg(B, N, SL, size).to(DEV)
-    scores = {}
+    score, grads = {}, {}
     for dt in (torch.float32, torch.bfloat16):
         eng = DPCEngine("resnet18", size, N, SL, P, B, DEV, dt)
         eng.load_params(p)
-        scores[dt] = eng.forward(x, train=False).clone()
-    ref, got = scores[torch.float32], scores[torch.bfloat16]
-    assert ((got - ref).norm() / ref.norm()).item() < 0.1     # bf16 rounding noise is 4-5 % at this depth (DESIGN section 5); a wrong kernel is O(1)
-    r0 = eng.train_step(x).cpu()
-    for _ in range(3):
-        r = eng.train_step(x).cpu()
-    assert torch.isfinite(r).all() and torch.isfinite(eng.flat_g).all() and r[0] < r0[0]
+        score[dt] = eng.forward(x, train=False).clone()
+        eng.loss_topk(True)
+        eng.backward()
+        torch.cuda.synchronize()
+        grads[dt] = {k: v.clone() for k, v in eng.G.items()}
+    ref, got = score[torch.float32], score[torch.bfloat16]
+    assert ((got - ref).norm() / ref.norm()).item() < 0.1
+    for k, g32 in grads[torch.float32].items():
+        g16 = grads[torch.bfloat16][k]
+        assert torch.isfinite(g16).all(), k
+        rel = ((g16 - g32).norm() / g32.norm().clamp_min(1e-12)).item()
+        assert rel < (0.2 if k.startswith(("agg.", "network_pred.")) else 0.8), (k, rel)
 
 
 def test_bf16_full_config4_shape_runs():

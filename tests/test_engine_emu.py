@@ -328,3 +328,21 @@ def test_other_sequence_shapes(emu, N, SL, P, B, size):
     assert tuple(score.shape) == tuple(ref.shape) == (B, P, eng.SQ, B, P, eng.SQ)
     assert (score - ref).abs().max().item() < 1e-4
     assert torch.equal(eng.get_mask(), O.mask_closed_form(B, P, eng.SQ))
+
+
+@pytest.mark.parametrize("size,B", [(66, 1), (80, 1)])
+def test_image_sizes_that_are_not_multiples_of_32(emu, size, B):
+    """last_size = ceil(sample_size / 32) (dpc/model_3d.py:25): 66 -> 33 -> 17 -> 9 -> 5 -> 3 and 80 -> 40 -> 20 -> 10 -> 5 -> 3 -- odd planes
+    under the stem's stride, the max-pool and every strided conv.  Score and every gradient against the oracle (f32, simulator)."""
+    N, SL, P = 4, 5, 1
+    eng = DPCEngine("resnet18", size, N, SL, P, B, "cpu", torch.float32, WIDTHS, lib=emu)
+    p = O.make_params_pcg("resnet18", WIDTHS)
+    eng.load_params(p)
+    x = O.make_input_pcg(B, N, SL, size)
+    score = eng.forward(x, train=False)
+    eng.loss_topk(True)
+    eng.backward()
+    loss, accs, grads, ref = O.train_step_reference(p, x, "resnet18", P, None)
+    assert eng.SQ == 9 and (score - ref).abs().max().item() < 1e-4
+    worst = max(((eng.G[k] - g).norm() / g.norm().clamp_min(1e-12)).item() for k, g in grads.items())
+    assert worst < 1e-3, worst
