@@ -240,6 +240,25 @@ class DPC_RNN(nn.Module):
             return super().to(device, non_blocking=non_blocking)
         return self
 
+    # ---- copies.  The engine holds device buffers, ctypes descriptors and captured graphs: none of that is copied or pickled.
+    def __deepcopy__(self, memo):
+        """a fresh module with the same constructor arguments, the same parameter VALUES (clones, not arena views) and no engine --
+        it builds its own at its first forward (copy.deepcopy(model): EMA / averaged copies, torch.optim.swa_utils.AveragedModel)"""
+        new = type(self)(self.sample_size, self.num_seq, self.seq_len, self.pred_step, self.network, compute_dtype=self.compute_dtype,
+                         widths=self.widths, _simulator=self._simulator)
+        mine = dict(self.named_parameters())
+        with torch.no_grad():
+            for k, q in new.named_parameters():
+                q.data = mine[k].detach().clone()
+                q.requires_grad_(mine[k].requires_grad)
+        new.train(self.training)
+        memo[id(self)] = new
+        return new
+
+    def __reduce_ex__(self, protocol):
+        raise TypeError("dpc_amd.DPC_RNN is not picklable as a whole (its engine owns device buffers and captured graphs): save "
+                        "model.state_dict() as dpc/main.py:166-174 does (dpc_amd.checkpoint writes the reference's dictionary)")
+
     def _score_buffers(self, eng):
         if self._score_bufs is None or self._score_bufs[0].shape != eng.score.shape or self._score_bufs[0].device != eng.score.device:
             self._score_bufs = (eng.score, torch.empty_like(eng.score))

@@ -346,3 +346,29 @@ def test_image_sizes_that_are_not_multiples_of_32(emu, size, B):
     assert eng.SQ == 9 and (score - ref).abs().max().item() < 1e-4
     worst = max(((eng.G[k] - g).norm() / g.norm().clamp_min(1e-12)).item() for k, g in grads.items())
     assert worst < 1e-3, worst
+
+
+def test_module_copies_and_no_grad(emu):
+    """what a user of the reference may do with the module besides the training loop: forward under torch.no_grad() (validate(),
+    dpc/main.py:253), copy.deepcopy (an averaged / EMA copy): same values, own engine, independent parameters; pickling the whole module
+    is refused with a pointer to state_dict()"""
+    import copy
+    import pickle
+    m = _small(emu, 6)
+    x = O.make_input_pcg(1, 4, 5, 64)
+    with torch.no_grad():
+        s0, _ = m(x)
+    assert not s0.requires_grad
+    s1, _ = m(x)
+    assert s1.requires_grad and torch.equal(s0, s1.detach())
+    c = copy.deepcopy(m)
+    assert c.engine is None and c is not m and not c.training
+    for (ka, pa), (kb, pb) in zip(m.named_parameters(), c.named_parameters()):
+        assert ka == kb and torch.equal(pa, pb) and pa.data_ptr() != pb.data_ptr()
+    sc, _ = c(x)
+    assert c.engine is not m.engine and torch.equal(sc.detach(), s0)
+    with torch.no_grad():
+        next(c.parameters()).add_(1.0)
+    assert not torch.equal(next(c.parameters()), next(m.parameters()))
+    with pytest.raises(TypeError, match="state_dict"):
+        pickle.dumps(m)
