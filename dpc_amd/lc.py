@@ -290,7 +290,7 @@ class LC(nn.Module):
     def _ensure_engine(self, block):
         """Parameters and BatchNorm buffers of the module ARE the engine's arenas (as in DPC_RNN): ``load_state_dict`` / an
         optimizer writing through them reach the kernels, and what ``engine.train_step`` / a train-mode forward update (weights,
-        running statistics, num_batches_tracked) is what ``state_dict()`` / ``torch.save(model)`` return."""
+        running statistics, num_batches_tracked) is what ``state_dict()`` returns."""
         key = (block.shape[0], block.device, self.compute_dtype)
         first = self.backbone.conv1.weight
         if self._engine is not None and self._engine_key == key and first.data_ptr() == self._engine.PRM["backbone.conv1.weight"].data_ptr():
@@ -313,7 +313,23 @@ class LC(nn.Module):
     def engine(self) -> Optional[LCEngine]:
         return self._engine
 
+    def __deepcopy__(self, memo):
+        """a fresh module with the same constructor arguments, cloned parameter / buffer values and no engine (as DPC_RNN.__deepcopy__)"""
+        new = type(self)(self.sample_size, self.num_seq, self.seq_len, self.network, self.dropout, self.num_class, self.compute_dtype,
+                         self.widths, _simulator=self._simulator)
+        new.load_state_dict({k: v.detach().clone() for k, v in self.state_dict().items()})
+        new.train(self.training)
+        memo[id(self)] = new
+        return new
+
+    def __reduce_ex__(self, protocol):
+        raise TypeError("dpc_amd.LC is not picklable as a whole (its engine owns device buffers): save model.state_dict() as "
+                        "eval/test.py:205-214 does")
+
     def forward(self, block, target: Optional[torch.Tensor] = None):
+        if getattr(self, "_is_replica", False):   # nn.DataParallel over several devices (eval/test.py:63): see dpc_amd.model._REPLICA_ERROR
+            from .model import _REPLICA_ERROR
+            raise RuntimeError(_REPLICA_ERROR.replace("dpc_amd.DPC_RNN", "dpc_amd.LC").replace("dpc_amd.main", "dpc_amd.lc_main").replace("dpc/main.py", "eval/test.py"))
         if block.device.type != "cuda" and self._simulator is None:
             raise L.DpcError("dpc_amd.LC runs on MI355X only: move the module and the input to a cuda (HIP) device")
         self._ensure_engine(block)

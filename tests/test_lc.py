@@ -179,6 +179,18 @@ def test_module_parameters_alias_the_engine(emu):
     assert not torch.equal(before["backbone.bn1.running_mean"], after["backbone.bn1.running_mean"])
     assert int(after["backbone.bn1.num_batches_tracked"]) == int(before["backbone.bn1.num_batches_tracked"]) + 1
     assert int(after["final_bn.num_batches_tracked"]) == int(before["final_bn.num_batches_tracked"]) + 1
+    # (3) copies: deepcopy = same values (running statistics included), own storage, own engine at its first forward; a DataParallel
+    # replica refuses; pickling the whole module points at state_dict()
+    import copy
+    import pickle
+    c = copy.deepcopy(m)
+    assert c.engine is None and not c.training
+    for (ka, va), (kb, vb) in zip(m.state_dict().items(), c.state_dict().items()):
+        assert ka == kb and torch.equal(va, vb) and (va.numel() == 0 or va.data_ptr() != vb.data_ptr()), ka
+    with pytest.raises(RuntimeError, match=r"python -m dpc_amd\.lc_main --gpu"):
+        m._replicate_for_data_parallel()(x)
+    with pytest.raises(TypeError, match="state_dict"):
+        pickle.dumps(m)
 
 
 def test_lr_schedule_and_train_what():
