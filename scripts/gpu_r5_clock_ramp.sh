@@ -1,9 +1,7 @@
 #!/bin/bash
-# round 5, session 2: does a fresh process measure its steady step time?  (clock ramp probe + the driver's flags against a long run)
+# round 5 -> profiles/r05_clock_ramp.txt: does a fresh process measure its steady step time?  (clock ramp probe + the driver's flags against a long run)
 R=$GRAFT_REPO_ROOT; cd $R; mkdir -p gpurun_out
 O=gpurun_out/r05_clock_ramp.txt
-(timeout 600 python -m pytest tests/test_kernels_gpu.py -m gpu -q -p no:cacheprovider -x -k "gemm or wgrad or score or dgrad" 2>&1 | tail -4) > gpurun_out/s2_tests.log
-cat gpurun_out/s2_tests.log
 (timeout 300 python scripts/probes/clock_ramp_probe.py 300 2>&1 | grep -v amdgpu.ids) > $O
 for k in 20 20 200; do
   line=$(timeout 300 python bench.py --steps $k --warmup 5 --no-also --no-roofline --no-cpu-baseline 2>/dev/null | tail -1)

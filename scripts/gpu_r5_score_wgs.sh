@@ -1,5 +1,5 @@
 #!/bin/bash
-# round 5, session 4: score GEMM workgroup count (one wave of workgroups against rounds 3-4's rounding up), isolated and in the step
+# round 5 -> profiles/r05_score_gemm_wgs.txt: score GEMM workgroup count (one wave of workgroups against rounds 3-4's rounding up), isolated and in the step
 R=$GRAFT_REPO_ROOT; cd $R; mkdir -p gpurun_out
 O=gpurun_out/r05_score_gemm_wgs.txt; : > $O
 for w in 559 512 559 512; do

@@ -1,10 +1,7 @@
 #!/bin/bash
-# round 5, session 1: the new GPU-tier tests (DataParallel entry, command-line entries, capture cache) and the alternating A/B of the
-# one-stream / two-stream schedules with HIP_FORCE_DEV_KERNARG=1 (the package default), fresh process per arm
+# round 5: alternating A/B of the one-stream / two-stream schedules with HIP_FORCE_DEV_KERNARG=1 (the package default), fresh process per arm
+#  -> profiles/r05_two_stream_ab.txt
 R=$GRAFT_REPO_ROOT; cd $R; mkdir -p gpurun_out
-(timeout 600 python -m pytest tests/test_entries.py tests/test_graph_rccl_gpu.py "tests/test_engine_gpu.py::test_data_parallel_entry_vs_reference" \
-   "tests/test_engine_gpu.py::test_module_drop_in" -m gpu -q -p no:cacheprovider -x 2>&1 | tail -15) > gpurun_out/s1_tests.log
-cat gpurun_out/s1_tests.log
 AB=gpurun_out/r05_two_stream_ab.txt
 echo "# alternating A/B, fresh process per arm, HIP_FORCE_DEV_KERNARG default (=1); bench.py --no-also --no-roofline --no-cpu-baseline" > $AB
 arm() {  # config steps stream
