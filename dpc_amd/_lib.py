@@ -57,8 +57,7 @@ class LcHeadDesc(C.Structure):
 
 class ConvEpilogue(C.Structure):
     """struct dpc_conv_epilogue (include/dpc_hip.h)"""
-    _fields_ = [(n, C.c_void_p) for n in ("addend", "addend_mask", "bn_raw", "bn_mask", "bn_mean", "bn_invstd", "stats",
-                                          "in_scale", "in_shift", "in_act", "in_mask")]
+    _fields_ = [(n, C.c_void_p) for n in ("addend", "addend_mask", "bn_raw", "bn_mask", "bn_mean", "bn_invstd", "stats")]
 
 
 class Resample(C.Structure):
@@ -188,16 +187,16 @@ class Lib:
         return rc
 
 
-PLAN_IGEMM, PLAN_WGRAD, PLAN_ADDEND, PLAN_STATS, PLAN_ADDEND_MASK, PLAN_BNRED, PLAN_BNIN = 0, 1, 1, 2, 4, 8, 16
+PLAN_IGEMM, PLAN_WGRAD, PLAN_ADDEND, PLAN_STATS, PLAN_ADDEND_MASK, PLAN_BNRED = 0, 1, 1, 2, 4, 8
 
 
 def conv_plan(lib: "Lib", desc: ConvDesc, op: int = PLAN_IGEMM, addend: bool = False, stats: bool = False, dy_ld: int = 0,
-              addend_mask: bool = False, bnred: bool = False, bnin: bool = False) -> str:
+              addend_mask: bool = False, bnred: bool = False) -> str:
     """name of the kernel dpc_conv_igemm(_ex) / dpc_conv_wgrad would launch for `desc` (include/dpc_hip.h: dpc_conv_plan);
     "" when the combination is not supported (dpc_conv_igemm_ex returns DPC_ERR_UNSUPPORTED)"""
     buf = C.create_string_buffer(192)
     flags = ((PLAN_ADDEND if addend else 0) | (PLAN_STATS if stats else 0) | (PLAN_ADDEND_MASK if addend_mask else 0) |
-             (PLAN_BNRED if bnred else 0) | (PLAN_BNIN if bnin else 0))
+             (PLAN_BNRED if bnred else 0))
     rc = lib._fn("dpc_conv_plan")(C.byref(desc), op, flags, dy_ld or desc.Co, buf, 192)
     if rc == -3:
         return ""

@@ -273,21 +273,15 @@ __device__ __forceinline__ void parity_tile(const ParityInfo& par, int mt, int& 
 // bn_raw / bn_mask / bn_mean / bn_invstd: the BatchNorm-backward reduction of the unit whose output gradient this launch produces,
 //   taken from the stored (rounded) outputs: dz = out (bit-gated when bn_mask), stats rows = (sum dz, sum dz * xhat).
 // Masks are dpc_bn_apply's: one byte per 16-byte unit of a DENSE [rows][Co] tensor (ldo == Co is required).
-// in_scale / in_shift / in_act / in_mask (round 5, forward only): the source is a RAW conv output whose BatchNorm-apply + ReLU run on the
-//   staged patch inside this launch; the activation and its ReLU byte mask are written as a by-product (conv_halo.hip BNIN).
 struct EpiExtra {
     const uint8_t* addend_mask;
     const void* bn_raw;
     const uint8_t* bn_mask;
     const float* bn_mean;
     const float* bn_invstd;
-    const float* in_scale;
-    const float* in_shift;
-    void* in_act;
-    uint8_t* in_mask;
 };
 static inline EpiExtra epi_none() {
-    EpiExtra e = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    EpiExtra e = {nullptr, nullptr, nullptr, nullptr, nullptr};
     return e;
 }
 static inline bool epi_any(const EpiExtra& e) { return e.addend_mask || e.bn_raw; }

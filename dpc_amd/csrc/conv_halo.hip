@@ -47,6 +47,7 @@ struct HaloParams {
     unsigned src_bytes;
     int ws;  // shape served by the role-specialised kernel
     int dbg; // DPC_WS_PROBE builds only: phases to leave out, for timing (scripts/probes/halo_probe.py)
+    void* probe_buf;   // DPC_WS_PROBE builds only: where the BNIN load probe (bit 256) stores its interior units
 };
 #ifdef DPC_WS_PROBE
 #define HP_DBG(bit) (p.dbg & (bit))
@@ -323,15 +324,8 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(HaloParams p) {
 // tile -- two workgroup barriers, staging, address arithmetic: ~0.5 us -- was 40 % of its 1.35 us tile period).
 // EPI: the fused backward pieces of dpc_conv_igemm_ex (gated residual addend, BatchNorm-backward partial sums); like the addend
 // they belong to the helper waves: the mask bytes and the raw unit of tile j are requested one interval before its epilogue.
-// BNIN (round 5; forward, 3x3 only): the SOURCE is the raw output of the unit upstream and its BatchNorm-apply + ReLU happen HERE, on the
-// staged patch: every helper lane rewrites the 16-byte units its own DMA pieces brought -- y = relu(x * scale[c] + shift[c]), the
-// arithmetic of bn_apply_kernel bit for bit; units outside the image stay the zeros the buffer resource filled in -- one tile ahead of
-// the compute waves, and stores the interior units (each belongs to exactly one tile) as the activation tensor + ReLU byte mask the
-// backward pass reads.  The separate dpc_bn_apply launch (read raw, write activation: 247 us at layer1 of cfg2) disappears; this
-// kernel pays one more tensor of stores and the LDS rewrite (load probe: +135 us in the probe build, profiles/r05_halo_bnin_probe.txt).
-template <bool HAS_ADD, int UPP, int BM, bool EPI = false, bool BNIN = false>
+template <bool HAS_ADD, int UPP, int BM, bool EPI = false>
 __global__ __launch_bounds__(512, 2) void conv_halo_ws_kernel(HaloParams p) {
-    static_assert(!BNIN || (UPP == 8 && !HAS_ADD && !EPI), "the source transform is built for the forward 3x3 instantiation");
     typedef bf16_t T;
     typedef bf16_t TO;
     constexpr int KH = UPP == 8 ? 3 : 4, NCH = UPP == 8 ? 3 : 1, NTAPS = KH * NCH;
@@ -346,7 +340,11 @@ __global__ __launch_bounds__(512, 2) void conv_halo_ws_kernel(HaloParams p) {
     static_assert(NPB * PATCH + 2 * STG <= 160 * 1024 && 2 * (NPB * PATCH + 2 * STG) > 160 * 1024, "one workgroup per CU");
     // (round 3 claimed all 160 KB here as a precaution; the failure it guarded against was a register hazard of igemm_ws_kernel,
     // conv_igemm_ws.hip WS_RETIRE_TAIL_READS -- this kernel's asm reads are all consumed, scripts/asm_hazard_lint.py)
-    __shared__ __attribute__((aligned(1024))) unsigned char lds[NPB * PATCH + 2 * STG + (BNIN ? 512 : 0)];   // BNIN: + scale[64] | shift[64]
+#ifdef DPC_WS_PROBE
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[NPB * PATCH + 2 * STG + 1024];   // + the probe's coefficient table
+#else
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[NPB * PATCH + 2 * STG];
+#endif
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -355,10 +353,9 @@ __global__ __launch_bounds__(512, 2) void conv_halo_ws_kernel(HaloParams p) {
 #else
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
 #endif
-    if (BNIN) {   // the source unit's BatchNorm coefficients, read by the helper lanes per 8-channel group
-        if (tid < 128) ((float*)(lds + NPB * PATCH + 2 * STG))[tid] = tid < 64 ? p.epi.in_scale[tid] : p.epi.in_shift[tid - 64];
-        __syncthreads();
-    }
+#ifdef DPC_WS_PROBE
+    if (tid < 128) ((float*)(lds + NPB * PATCH + 2 * STG))[tid] = tid < 64 ? 1.0f : 0.01f;
+#endif
     // Workgroup b runs on XCD b & 7 (its own L2).  The tiles of one frame are consecutive tile indices and neighbouring row bands
     // share two of their six patch rows: give every XCD a contiguous range of tile slots, so that those re-reads hit its L2
     // instead of going to HBM a second time (round-robin slots put neighbouring bands on different XCDs: 1.5x input traffic).
@@ -374,66 +371,6 @@ __global__ __launch_bounds__(512, 2) void conv_halo_ws_kernel(HaloParams p) {
         frame = (int)f;
         h0 = (int)th * p.TR;
         w0 = (tin - (int)th * p.tiles_w) * p.TW;
-    };
-
-    // ---- BNIN: the rewrite of a staged patch (shared code; round 5 runs it on the COMPUTE waves, which idle at the tile barriers for a
-    // third of a tile period, instead of on the helper waves, whose store / DMA chain sets the tile period: there it cost +160 us per
-    // launch, profiles/r05_halo_bnin_probe.txt).  Lane x of 256 owns the units slot = it * 256 + x of a patch: position hpos = slot / 9,
-    // channel group slot % 9 (8 = the pad slot).  bn_consts fills (patch row << 16 | patch column) and the byte offset of the unit
-    // relative to the patch origin in the source tensor; bn_rewrite rewrites patch j in place -- y = relu(x * scale[c] + shift[c]),
-    // dpc_bn_apply's arithmetic bit for bit; units outside the image keep the zeros of the buffer resource -- and stores the interior
-    // units (each belongs to exactly one tile) to the activation tensor + ReLU byte mask.
-    auto bn_consts = [&](int x, int (&hrc_)[8], unsigned (&rel_)[8]) {
-        const int npos_ = p.HR * p.HWd;
-        DPC_UNROLL
-        for (int it = 0; it < 8; ++it) {
-            const int slot = it * 256 + x;
-            const int hpos = slot / SPP, cu = slot - hpos * SPP;
-            const unsigned hr = fdiv((unsigned)hpos, p.d_hwd);
-            const int hc = hpos - (int)hr * p.HWd;
-            hrc_[it] = (cu < UPP && hpos < npos_) ? (((int)hr << 16) | hc) : (0x4000 << 16);
-            rel_[it] = (unsigned)((((int)hr * p.W + hc) * p.C + cu * 8) * 2);
-        }
-    };
-    auto bn_rewrite = [&](int j, int x, const int (&hrc_)[8], const unsigned (&rel_)[8]) {
-        unsigned char* pn = lds + (j % NPB) * PATCH;
-        const float* tab = (const float*)(lds + NPB * PATCH + 2 * STG);
-        int frame, h0, w0;
-        tile_origin(m_prog + j * p.gm, frame, h0, w0);
-        const int hb = h0 - p.ph, wb = w0 - p.pw;
-        const unsigned base = (unsigned)(((frame * p.H + hb) * p.W + wb) * p.C * 2);
-        u32x4 xv[8];
-        DPC_UNROLL
-        for (int it = 0; it < 8; ++it) xv[it] = *(const u32x4*)(pn + (it * 256 + x) * 16);
-        DPC_UNROLL
-        for (int it = 0; it < 8; ++it) {
-            const int slot = it * 256 + x;
-            const int cg = (slot - (slot / SPP) * SPP) & 7;   // (the pad slot reads group 0's coefficients and is never used)
-            const f32x4 sc0 = *(const f32x4*)(tab + cg * 8), sc1 = *(const f32x4*)(tab + cg * 8 + 4);
-            const f32x4 sh0 = *(const f32x4*)(tab + 64 + cg * 8), sh1 = *(const f32x4*)(tab + 64 + cg * 8 + 4);
-            const int hr = hrc_[it] >> 16, hc = hrc_[it] & 0xffff;
-            const int h = hb + hr, w = wb + hc;
-            const bool ok = ((unsigned)h < (unsigned)p.H) & ((unsigned)w < (unsigned)p.W);   // false for padding and for slots without data
-            float ov[8];
-            DPC_UNROLL
-            for (int e = 0; e < 8; ++e) {
-                const float v = unit_get<T>(xv[it], e) * (e < 4 ? sc0[e & 3] : sc1[e & 3]) + (e < 4 ? sh0[e & 3] : sh1[e & 3]);
-                ov[e] = v > 0.f ? v : 0.f;
-            }
-            u32x4 o = unit_pack<T>(ov);
-            DPC_UNROLL
-            for (int q4 = 0; q4 < 4; ++q4) o[q4] = ok ? o[q4] : xv[it][q4];
-            if (!HP_DBG(1024)) *(u32x4*)(pn + slot * 16) = o;
-            const bool inner = ok && hr >= p.ph && hr < p.ph + p.TR && hc >= p.pw && hc < p.pw + p.TW;
-            if (inner) {
-                const unsigned off = base + rel_[it];                     // byte offset of the unit in the source tensor = in the activation
-                if (!HP_DBG(512)) *(u32x4*)((char*)p.epi.in_act + off) = o;
-                unsigned bits = 0;
-                DPC_UNROLL
-                for (int e = 0; e < 8; ++e) bits |= (unit_get<T>(o, e) > 0.f ? 1u : 0u) << e;
-                if (!HP_DBG(256)) p.epi.in_mask[off >> 4] = (uint8_t)bits;
-            }
-        }
     };
 
     if (wv < 4) {
@@ -462,13 +399,6 @@ __global__ __launch_bounds__(512, 2) void conv_halo_ws_kernel(HaloParams p) {
             frag_a[i] = (r * p.HWd + c) * CBP + lhi * 16;
         }
         const int rowpitch = p.HWd * CBP;
-        int bhrc[8];
-        unsigned brel[8];
-        if (BNIN) {
-            bn_consts(tid, bhrc, brel);
-            barrier_lds_only();            // B0: patch 0 has landed (helper waves)
-            bn_rewrite(0, tid, bhrc, brel);
-        }
         for (int j = 0; j < ntiles; ++j) {
             f32x16 acc[MI];
             DPC_UNROLL
@@ -514,7 +444,6 @@ __global__ __launch_bounds__(512, 2) void conv_halo_ws_kernel(HaloParams p) {
                     const int row_l = wm * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
                     tile[row_l * BN + wn * 32 + l31] = f32_to_bf16(acc[i][r]);
                 }
-            if (BNIN && j + 1 < ntiles && !HP_DBG(2048)) bn_rewrite(j + 1, tid, bhrc, brel);   // patch j+1 landed before B1(j) (helper waves)
             barrier_lds_only();  // B2(j)
         }
         barrier_lds_only();
@@ -623,31 +552,57 @@ __global__ __launch_bounds__(512, 2) void conv_halo_ws_kernel(HaloParams p) {
         for (int a = 1; a < NPB - 1; ++a)
             if (ntiles > a) issue(a);
         if (PRE) prefetch(0, cur);
-        if (BNIN) {   // patch 0 for the compute waves' first rewrite
-            if (ntiles > 1) wait_vmcnt<LIT>(); else wait_vmcnt<0>();
-            barrier_lds_only();  // B0
-        }
         for (int j = 0; j <= ntiles; ++j) {
             // patch j must have landed.  Newer than its pieces are: this wave's stores of older tiles and the LIT pieces of each
             // of the patches j+1 .. j+NPB-2.  Loads (LDS-DMA included) complete in order among themselves, so "at most that many
             // outstanding" implies every piece of patch j is done whatever the stores do.  (The addend / raw / mask loads of the
             // residual and fused-reduction variants are requested between two patches: counting them as absent only makes the
             // wait stricter.)
-            if (BNIN) {
-                // the compute waves rewrite patch j+1 behind their MFMAs of tile j: everything this wave has in flight is at least
-                // half a tile period old here (the DMA of patch j+1 was the first thing of the last interval, its stores followed)
-                wait_vmcnt<0>();
-            } else if (j < ntiles) {
+            if (j < ntiles) {
                 const int newer = ntiles - 1 - j < NPB - 2 ? ntiles - 1 - j : NPB - 2;
                 if (newer >= 2) wait_vmcnt<2 * LIT>(); else if (newer == 1) wait_vmcnt<LIT>(); else wait_vmcnt<0>();
             }
             barrier_lds_only();  // B1(j)
-            if (BNIN) {   // the DMA of patch j+2 first (a whole interval to land), the epilogue of tile j-1 behind it
-                if (j + NPB - 1 < ntiles) issue(j + NPB - 1);
-                if (j >= 1 && !HP_DBG(8)) epilogue(j - 1, cur);
-                barrier_lds_only();  // B2(j)
-                continue;
+#ifdef DPC_WS_PROBE
+            // LOAD PROBE (bit 256; results are wrong by design): what would a BatchNorm-apply + ReLU of the SOURCE cost if it ran here,
+            // on the staged patch, instead of as its own kernel?  Every helper lane rewrites the units its own DMA
+            // pieces brought (patch j+1: read, 8 x {fma, max}, round, write back; coefficients from a 512-byte LDS table) and stores the
+            // interior ones -- the activation the backward pass wants -- to a scratch tensor (bit 512: without that store).
+            if (HP_DBG(256) && UPP == 8 && j + 1 < ntiles) {
+                wait_vmcnt<0>();
+                unsigned char* pn = lds + ((j + 1) % NPB) * PATCH;
+                const float* tab = (const float*)(lds + NPB * PATCH + 2 * STG);
+                int frame, h0, w0;
+                tile_origin(m_prog + (j + 1) * p.gm, frame, h0, w0);
+                const unsigned base = (unsigned)(((frame * p.H + h0 - p.ph) * p.W + w0 - p.pw) * p.C * 2);
+                DPC_UNROLL
+                for (int it = 0; it < LIT; ++it) {
+                    const int slot = it * 256 + htid;
+                    const int cu_ = slot % SPP;
+                    if (cu_ >= UPP) continue;
+                    u32x4 v = *(const u32x4*)(pn + slot * 16);
+                    const f32x4 sc0 = *(const f32x4*)(tab + cu_ * 8), sc1 = *(const f32x4*)(tab + cu_ * 8 + 4);
+                    const f32x4 sh0 = *(const f32x4*)(tab + 64 + cu_ * 8), sh1 = *(const f32x4*)(tab + 64 + cu_ * 8 + 4);
+                    float x[8];
+                    DPC_UNROLL
+                    for (int e = 0; e < 4; ++e) {
+                        x[2 * e] = __builtin_bit_cast(float, v[e] << 16);
+                        x[2 * e + 1] = __builtin_bit_cast(float, v[e] & 0xffff0000u);
+                    }
+                    DPC_UNROLL
+                    for (int e = 0; e < 4; ++e) {
+                        x[e] = fmaxf(fmaf(x[e], sc0[e], sh0[e]), 0.f);
+                        x[4 + e] = fmaxf(fmaf(x[4 + e], sc1[e], sh1[e]), 0.f);
+                    }
+                    DPC_UNROLL
+                    for (int e = 0; e < 4; ++e) v[e] = bf16x2_pack(x[2 * e], x[2 * e + 1]);
+                    *(u32x4*)(pn + slot * 16) = v;
+                    const int hr = hrc[it] >> 16, hc = hrc[it] & 0xffff;
+                    const bool inner = hr >= p.ph && hr < p.ph + p.TR && hc >= p.pw && hc < p.pw + p.TW;
+                    if (inner && !HP_DBG(512) && p.probe_buf) *(u32x4*)((char*)p.probe_buf + base + rel[it]) = v;
+                }
             }
+#endif
             if (PRE) {
                 Pre nxt = cur;
                 if (j < ntiles && j >= 1) prefetch(j, nxt);
@@ -739,6 +694,11 @@ int dpc_conv_halo_rows(const dpc_conv_desc* d) {
     return p.gm;
 }
 
+#ifdef DPC_WS_PROBE
+static void* g_halo_probe_buf = nullptr;
+extern "C" int dpc_probe_set_halo_buf(void* buf) { g_halo_probe_buf = buf; return 0; }   // scripts/probes/halo_probe.py
+#endif
+
 // returns 1 when the shape is not served by this kernel (caller falls back to dpc_conv_igemm's generic path)
 int dpc_conv_halo_try(const dpc_conv_desc* d, const void* src, const void* wgt, void* out, const void* addend, float* stats,
                       const EpiExtra& epi, hipStream_t stream) {
@@ -747,13 +707,14 @@ int dpc_conv_halo_try(const dpc_conv_desc* d, const void* src, const void* wgt, 
     p.src = src; p.wgt = wgt; p.out = out; p.addend = addend; p.stats = stats; p.epi = epi;
 #ifdef DPC_WS_PROBE
     p.dbg = getenv("DPC_WS_DBG") ? atoi(getenv("DPC_WS_DBG")) : 0;
+    p.probe_buf = g_halo_probe_buf;
 #else
     p.dbg = 0;
+    p.probe_buf = nullptr;
 #endif
     const int epo = d->dtype_out == DPC_BF16 ? 8 : 4;
     p.vec_out = (d->Co % epo == 0 && d->ldo % epo == 0 && ((uintptr_t)out % 16 == 0) && ((uintptr_t)addend % 16 == 0)) ? 1 : 0;
     const bool ws_go = p.ws && p.vec_out && ((uintptr_t)src % 16 == 0) && !(d->KH == 4 && addend);
-    if (epi.in_scale && !(ws_go && d->KH == 3 && d->mode == 0 && !addend && !epi_any(epi) && d->Ci == 64)) return DPC_ERR_UNSUPPORTED;
     if (p.ws && !ws_go) {  // the specialised kernel declined at launch: generic patch kernel, same number of stats rows as promised
         const int promised = p.gm, vo = p.vec_out;
         if (!halo_plan(d, &p, false)) return 1;
@@ -766,8 +727,6 @@ int dpc_conv_halo_try(const dpc_conv_desc* d, const void* src, const void* wgt, 
         if (d->KH == 4) {
             if (epi_any(epi)) return DPC_ERR_UNSUPPORTED;  // the stem has no input-gradient
             DPC_LAUNCH((conv_halo_ws_kernel<false, 2, 256>), grid, dim3(512), stream, p);
-        } else if (epi.in_scale) {   // BatchNorm-apply + ReLU of the source on the staged patch (dpc_conv_igemm_ex: in_scale / in_shift / in_act / in_mask)
-            DPC_LAUNCH((conv_halo_ws_kernel<false, 8, 128, false, true>), grid, dim3(512), stream, p);
         } else if (epi_any(epi)) {
             if (addend) {
                 DPC_LAUNCH((conv_halo_ws_kernel<true, 8, 128, true>), grid, dim3(512), stream, p);

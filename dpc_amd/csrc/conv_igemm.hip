@@ -636,15 +636,7 @@ extern "C" int dpc_conv_igemm(const dpc_conv_desc* d, const void* src, const voi
 extern "C" int dpc_conv_igemm_ex(const dpc_conv_desc* d, const void* src, const void* wgt, void* out, const dpc_conv_epilogue* e,
                                  dpc_stream_t stream_) {
     if (!d || !e) return DPC_ERR_ARG;
-    EpiExtra x = {e->addend_mask, e->bn_raw, e->bn_mask, e->bn_mean, e->bn_invstd, e->in_scale, e->in_shift, e->in_act, e->in_mask};
-    if ((x.in_scale || x.in_shift || x.in_act || x.in_mask) && !(x.in_scale && x.in_shift && x.in_act && x.in_mask)) return DPC_ERR_ARG;
-    if (x.in_scale) {   // forward with the source's BatchNorm-apply inside: only the layer1 patch kernel builds it (conv_halo.hip BNIN)
-        if (d->mode != 0 || e->addend || epi_any(x)) return DPC_ERR_UNSUPPORTED;
-        if (d->dtype_in != DPC_BF16 || d->dtype_out != DPC_BF16 || d->src_ld != d->Ci || ((uintptr_t)x.in_act % 16)) return DPC_ERR_UNSUPPORTED;
-        if (!src || !wgt || !out) return DPC_ERR_ARG;
-        const int rc = dpc_conv_halo_try(d, src, wgt, out, nullptr, e->stats, x, (hipStream_t)stream_);
-        return rc == 1 ? DPC_ERR_UNSUPPORTED : rc;
-    }
+    EpiExtra x = {e->addend_mask, e->bn_raw, e->bn_mask, e->bn_mean, e->bn_invstd};
     if (x.addend_mask && !e->addend) return DPC_ERR_ARG;
     if (x.bn_raw && (!x.bn_mean || !x.bn_invstd || !e->stats)) return DPC_ERR_ARG;
     if (x.bn_mask && !x.bn_raw) return DPC_ERR_ARG;

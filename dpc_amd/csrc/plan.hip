@@ -77,14 +77,9 @@ extern "C" int dpc_conv_plan(const dpc_conv_desc* d, int32_t op, int32_t flags, 
     tls_detail[0] = 0;
     dpc_tls_plan_only = 1;
     int rc;
-    if (op == DPC_PLAN_IGEMM && (flags & (DPC_PLAN_ADDEND_MASK | DPC_PLAN_BNRED | DPC_PLAN_BNIN))) {
+    if (op == DPC_PLAN_IGEMM && (flags & (DPC_PLAN_ADDEND_MASK | DPC_PLAN_BNRED))) {
         dpc_conv_epilogue e = {};
         const bool red = flags & DPC_PLAN_BNRED;
-        if (flags & DPC_PLAN_BNIN) {
-            e.in_scale = e.in_shift = (const float*)dummy;
-            e.in_act = dummy;
-            e.in_mask = (uint8_t*)dummy;
-        }
         e.addend = (flags & (DPC_PLAN_ADDEND | DPC_PLAN_ADDEND_MASK)) ? dummy : nullptr;
         e.addend_mask = (flags & DPC_PLAN_ADDEND_MASK) ? (const uint8_t*)dummy : nullptr;
         e.bn_raw = red ? dummy : nullptr;

@@ -189,7 +189,6 @@ def algorithmic_cost(name, args):
         n = rows_out * d.Co * osz
         by = rows_src * d.Ci * esz + d.Co * d.Ci * taps * esz + n
         by += (n if ep.addend else 0) + (n // 16 if ep.addend_mask else 0) + (n if ep.bn_raw else 0) + (n // 16 if ep.bn_mask else 0)
-        by += (rows_src * d.Ci * esz + rows_src * d.Ci * esz // 16) if ep.in_act else 0   # the activation + mask written as a by-product
         name = "dpc_conv_igemm"
     else:
         by = rows_src * d.Ci * esz + rows_out * d.Co * esz + d.Co * d.Ci * taps * 4
@@ -313,32 +312,15 @@ class _ConvBN:
         # wp[co][tap][ci] = w[co][ci][tap] ; wd[ci][tap][co] = w[co][ci][tap]
         return [(w, self.wp, Co, t, Ci, Ci * t, 1, t), (w, self.wd, Ci, t, Co, t, 1, Ci * t)]
 
-    def forward(self, x: torch.Tensor, bn_in: "Optional[Tuple[_ConvBN, torch.Tensor]]" = None):
-        """conv + BatchNorm statistics of this unit.  bn_in = (upstream unit, activation buffer): `x` is that unit's RAW output and its
-        BatchNorm-apply + ReLU run inside this conv launch, which writes the activation and its ReLU mask as a by-product
-        (dpc_conv_igemm_ex in_scale / in_shift / in_act / in_mask; _Block.bnin decides)"""
+    def forward(self, x: torch.Tensor):
         e = self.eng
         g, b = e.PRM[self.bnname + ".weight"], e.PRM[self.bnname + ".bias"]
-
-        def conv(stats):
-            if bn_in is None:
-                e.call("dpc_conv_igemm", C.byref(self.desc_f), x, self.wp, self.raw, None, stats)
-                return
-            up, act = bn_in
-            if up.mask is None:
-                up.mask = e.empty((up.rows * up.Co * up.raw.element_size() // 16,), torch.uint8)
-            ep = L.ConvEpilogue()
-            ep.stats = stats.data_ptr() if stats is not None else None
-            ep.in_scale, ep.in_shift = up.scale.data_ptr(), up.shift.data_ptr()
-            ep.in_act, ep.in_mask = act.data_ptr(), up.mask.data_ptr()
-            e.call("dpc_conv_igemm_ex", C.byref(self.desc_f), x, self.wp, self.raw, C.byref(ep))
-
         if e.bn_running and not e.train_mode:  # eval: coefficients from the running buffers, no batch statistics
-            conv(None)
+            e.call("dpc_conv_igemm", C.byref(self.desc_f), x, self.wp, self.raw, None, None)
             e.call("dpc_bn_eval_coeffs", g, b, e.BUF[self.bnname + ".running_mean"], e.BUF[self.bnname + ".running_var"], BN_EPS,
                    self.Co, self.mean, self.invstd, self.scale, self.shift)
             return
-        conv(e.stats)
+        e.call("dpc_conv_igemm", C.byref(self.desc_f), x, self.wp, self.raw, None, e.stats)
         if e.bn_running:
             e.call("dpc_bn_finalize_running", e.stats, self.stat_rows, self.Co, float(self.rows), g, b, BN_EPS, self.mean, self.invstd,
                    self.scale, self.shift, e.BUF[self.bnname + ".running_mean"], e.BUF[self.bnname + ".running_var"],
@@ -452,8 +434,6 @@ class _Block:
         self.act1 = eng.empty(self.c1.out_shape + (Co,), eng.cdtype)
         self.out = eng.empty(self.out_shape + (Co,), eng.cdtype)
         self.x_in: Optional[torch.Tensor] = None
-        # bn1's apply + ReLU inside conv2 (the layer1 patch kernel serves it: plan query, no launch): one tensor read and one launch less
-        self.bnin = bool(eng.bnin and L.conv_plan(eng.lib, self.c2.desc_f, L.PLAN_IGEMM, stats=True, bnin=True))
 
     def units(self):
         return [u for u in (self.c1, self.c2, self.ds) if u is not None]
@@ -461,11 +441,8 @@ class _Block:
     def forward(self, x):
         self.x_in = x
         self.c1.forward(x)
-        if self.bnin:   # bn1 + ReLU inside conv2's launch: act1 and its mask are written by conv2's helper waves, no dpc_bn_apply pass
-            self.c2.forward(self.c1.raw, bn_in=(self.c1, self.act1))
-        else:
-            self.c1.apply(self.act1, relu=True)
-            self.c2.forward(self.act1)
+        self.c1.apply(self.act1, relu=True)
+        self.c2.forward(self.act1)
         if self.ds is not None:
             self.ds.forward(x)
             self.c2.apply(self.out, relu=self.final_relu, res=self.ds.raw, res_unit=self.ds)
@@ -555,7 +532,7 @@ class DPCEngine:
                  pred_step: int = 3, batch: int = 4, device="cuda", compute_dtype=torch.float32,
                  widths: Sequence[int] = LAYER_WIDTH, lib: Optional[L.Lib] = None,
                  lr: float = 1e-3, wd: float = 1e-5, dropout: float = 0.1, seed: int = 233, score_path: str = "auto", stem_fused: bool | None = None,
-                 fold: bool | None = None, reserve_cus: int | None = None, f32_matmul: str | None = None, bnin: bool | None = None):
+                 fold: bool | None = None, reserve_cus: int | None = None, f32_matmul: str | None = None):
         self.device = torch.device(device)
         self.lib = L.lib_for(self.device, lib)  # raises unless HIP device (or an explicit simulator handle in tests)
         self.cdtype = compute_dtype
@@ -590,9 +567,6 @@ class DPCEngine:
         # backward pieces fused into input-gradient epilogues (dz never written, BatchNorm-backward reductions in the producing
         # launch): on by default, DPC_FOLD=0 / fold=False runs the separate kernels (A/B, and the reference for the fused form)
         self.fold = bool(int(os.environ.get("DPC_FOLD", "1"))) if fold is None else bool(fold)
-        # BatchNorm-apply + ReLU of a block's first unit inside the consuming conv2 launch where the kernel serves it (layer1, bf16):
-        # DPC_BNIN=0 / bnin=False run dpc_bn_apply + the plain conv (bit-identical; the A/B and the reference for the fused form)
-        self.bnin = bool(int(os.environ.get("DPC_BNIN", "1"))) if bnin is None else bool(bnin)
         # CUs left to RCCL's channel kernels while the gradient tail is being all-reduced under layer1 + stem backward: the
         # persistent one-workgroup-per-CU kernels of that phase shrink their grids (dpc_set_reserved_cus).  Only consulted when a
         # two-bucket exchange is running; data-parallel callers pass parallel.default_reserve_cus(world) (= the RCCL channel count:

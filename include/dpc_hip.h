@@ -89,16 +89,6 @@ typedef struct dpc_conv_epilogue {
     const float* bn_mean;
     const float* bn_invstd;
     float* stats;
-    /* round 5, forward (mode 0) only: `src` is the RAW output of the unit upstream ([rows][Ci], dtype_in) and its BatchNorm-apply +
-     * ReLU, y = relu(src * in_scale[c] + in_shift[c]) -- dpc_bn_apply's arithmetic bit for bit --, happen on the staged patch inside
-     * this launch; y and its ReLU byte mask (dpc_bn_apply's: one byte per 16-byte unit) are written to in_act / in_mask as a
-     * by-product (what backbone/resnet_2d3d.py:90-93's bn1 + relu produce for conv2).  All four or none; `stats` then has
-     * dpc_conv_igemm's meaning.  Served for the 1x3x3 stride-1 convs with 64 input channels in bf16 (layer1 of the 2d3d-ResNet):
-     * DPC_ERR_UNSUPPORTED otherwise -- run dpc_bn_apply and dpc_conv_igemm.  dpc_conv_plan: DPC_PLAN_BNIN. */
-    const float* in_scale;
-    const float* in_shift;
-    void* in_act;
-    uint8_t* in_mask;
 } dpc_conv_epilogue;
 int dpc_conv_igemm_ex(const dpc_conv_desc* d, const void* src, const void* wgt, void* out, const dpc_conv_epilogue* epi,
                       dpc_stream_t stream);
@@ -136,7 +126,6 @@ int dpc_conv_wgrad(const dpc_conv_desc* d, const void* src, const void* dy, int3
 #define DPC_PLAN_STATS 2
 #define DPC_PLAN_ADDEND_MASK 4 /* dpc_conv_igemm_ex: gated addend */
 #define DPC_PLAN_BNRED 8       /* dpc_conv_igemm_ex: fused BatchNorm-backward reduction */
-#define DPC_PLAN_BNIN 16       /* dpc_conv_igemm_ex: BatchNorm-apply + ReLU of the source inside the launch (forward) */
 int dpc_conv_plan(const dpc_conv_desc* d, int32_t op, int32_t flags, int32_t dy_ld, char* name, int32_t cap);
 int dpc_last_kernel(char* name, int32_t cap);
 

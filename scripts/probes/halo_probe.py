@@ -40,42 +40,17 @@ def run(tag, dbg, reps=20):
     print(f"{tag:50s} dbg={dbg:3d}  {us:8.1f} us  {flops / us * 1e-6:7.1f} TFLOP/s-equivalent", flush=True)
 
 
-# round 5: the BatchNorm-apply + ReLU of the source inside this kernel (conv_halo.hip BNIN, dpc_conv_igemm_ex in_scale / in_shift / in_act /
-# in_mask), with parts of it left out (DPC_WS_DBG bits 256: no mask bytes, 512: no activation store, 1024: no LDS write-back, 2048: no
-# rewrite at all -- only the reordered helper schedule; results wrong by design)
-act = torch.empty_like(src)
-amask = torch.zeros(src.numel() // 8, dtype=torch.uint8, device=dev)
-scale = (torch.rand(Ci, device=dev) + 0.5)
-shift = torch.randn(Ci, device=dev) * 0.3
-
-
-def run_bnin(tag, dbg, reps=20):
-    os.environ["DPC_WS_DBG"] = str(dbg)
-    ep = L.ConvEpilogue()
-    ep.stats, ep.in_scale, ep.in_shift, ep.in_act, ep.in_mask = stats.data_ptr(), scale.data_ptr(), shift.data_ptr(), act.data_ptr(), amask.data_ptr()
-    go = lambda: lib.call("dpc_conv_igemm_ex", C.byref(d), src.data_ptr(), wgt.data_ptr(), out.data_ptr(), C.byref(ep), lib.stream())  # noqa: E731
-    for _ in range(3):
-        go()
-    torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(reps):
-        go()
-    e1.record()
-    torch.cuda.synchronize()
-    us = e0.elapsed_time(e1) * 1e3 / reps
-    print(f"{tag:50s} dbg={dbg:4d}  {us:8.1f} us", flush=True)
-
-
+# round 5: what a BatchNorm-apply + ReLU of the source would cost inside this kernel (DPC_WS_DBG bit 256, see conv_halo.hip)
+scratch = torch.empty_like(src)
+_set = lib.c.dpc_probe_set_halo_buf
+_set.argtypes, _set.restype = [C.c_void_p], C.c_int
+_set(scratch.data_ptr())
 run("full kernel", 0)
 run("full kernel", 0)
-run_bnin("BNIN: full", 0)
-run_bnin("BNIN: no mask bytes", 256)
-run_bnin("BNIN: no mask bytes, no activation store", 256 + 512)
-run_bnin("BNIN: no stores, no LDS write-back", 256 + 512 + 1024)
-run_bnin("BNIN: reordered helper schedule only (no rewrite)", 2048)
-run_bnin("BNIN: full", 0)
+run("BNIN load probe: patch rewritten in LDS + activation stored", 256)
+run("BNIN load probe: patch rewritten in LDS, no activation store", 256 + 512)
 run("full kernel", 0)
+run("BNIN load probe: patch rewritten in LDS + activation stored", 256)
 run("round-robin tile slots (no XCD grouping)", 16)
 run("compute waves at default priority", 32)
 run("full kernel", 0)

@@ -88,49 +88,6 @@ def conv_desc(dtype_in, dtype_out, mode, N, R, S, Ci, src_ld, Co, ldw, ldo, k, s
                       Ci, src_ld, Co, ldw, ldo, k[0], k[1], k[2], s[0], s[1], s[2], p[0], p[1], p[2])
 
 
-# ------------------------------------------------------------------ conv forward with the source's BatchNorm-apply + ReLU inside (round 5)
-def case_conv_fwd_bnin(k: K, N, T, H, W, Co=64, seed=41, expect="conv_halo_ws_kernel<false,8,128,false,true>"):
-    """dpc_conv_igemm_ex with in_scale / in_shift / in_act / in_mask == dpc_bn_apply (+ mask) followed by dpc_conv_igemm, BIT FOR BIT:
-    conv output, BatchNorm partial sums, the activation written as a by-product and its ReLU byte mask (bf16, 64 input channels, 1x3x3
-    stride 1: layer1's second conv; backbone/resnet_2d3d.py:90-94)"""
-    dtype, Ci, ks, st, pd = torch.bfloat16, 64, (1, 3, 3), (1, 1, 1), (0, 1, 1)
-    g = torch.Generator().manual_seed(seed)
-    raw = q(torch.randn(N, T, H, W, Ci, generator=g), dtype)
-    w = q(torch.randn(Co, Ci, *ks, generator=g) * 0.1, dtype)
-    scale = (torch.rand(Ci, generator=g) + 0.5) * torch.where(torch.rand(Ci, generator=g) < 0.2, -1.0, 1.0)   # some negative gammas
-    shift = torch.randn(Ci, generator=g) * 0.3
-    d = conv_desc(dtype, dtype, 0, N, (T, H, W), (T, H, W), Ci, Ci, Co, 9 * Ci, Co, ks, st, pd)
-    src, wp = k.t(raw, dtype), k.t(w.permute(0, 2, 3, 4, 1).reshape(Co, 9 * Ci), dtype)
-    sc, sh = k.t(scale), k.t(shift)
-    rows = N * T * H * W
-    srows = k.lib.call("dpc_conv_stats_rows", C.byref(d))
-    # the two launches it replaces
-    act0 = k.empty(N, T, H, W, Ci, dtype=dtype)
-    mask0 = torch.zeros(rows * Ci // 8, dtype=torch.uint8, device=k.dev)
-    out0 = k.empty(N, T, H, W, Co, dtype=dtype)
-    stats0 = k.zeros(srows, 2, Co)
-    k.call("dpc_bn_apply", src, act0, L.dtype_code(dtype), rows, Ci, sc, sh, None, None, None, 1, mask0)
-    k.call("dpc_conv_igemm", C.byref(d), act0, wp, out0, None, stats0)
-    # the fused launch
-    act1 = torch.full_like(act0, 7.0)
-    mask1 = torch.full_like(mask0, 0xAA)
-    out1 = k.empty(N, T, H, W, Co, dtype=dtype)
-    stats1 = k.zeros(srows, 2, Co)
-    ep = L.ConvEpilogue()
-    ep.stats, ep.in_scale, ep.in_shift, ep.in_act, ep.in_mask = stats1.data_ptr(), sc.data_ptr(), sh.data_ptr(), act1.data_ptr(), mask1.data_ptr()
-    k.call("dpc_conv_igemm_ex", C.byref(d), src, wp, out1, C.byref(ep))
-    check_kernel(k, expect)
-    k.sync()
-    assert torch.equal(act1.view(torch.int16), act0.view(torch.int16)), "activation by-product"
-    assert torch.equal(mask1, mask0), "ReLU byte mask"
-    assert torch.equal(out1.view(torch.int16), out0.view(torch.int16)), "conv output"
-    assert torch.equal(stats1, stats0), "BatchNorm partial sums"
-    # ... and the pair is right: torch on the CPU
-    ref_act = F.relu(raw.float() * scale + shift).to(dtype)
-    y = F.conv3d(ref_act.float().permute(0, 4, 1, 2, 3), w.float(), None, st, pd)
-    assert relerr(out1, cl(y)) < tol(dtype)
-
-
 # ------------------------------------------------------------------ conv forward (+ BN partial sums)
 def case_conv_fwd(k: K, dtype, N, Ci, Co, T, H, W, ks, st, pd, seed=0, expect=None):
     g = torch.Generator().manual_seed(seed)

@@ -372,23 +372,3 @@ def test_module_copies_and_no_grad(emu):
     assert not torch.equal(next(c.parameters()), next(m.parameters()))
     with pytest.raises(TypeError, match="state_dict"):
         pickle.dumps(m)
-
-
-def test_bn_apply_inside_the_consuming_conv_is_bit_identical(emu):
-    """round 5 (VERDICT r4 #2a): in layer1 (64 channels, bf16) bn1's apply + ReLU run inside conv2's launch, which writes act1 and its
-    mask as a by-product; the step -- score, loss, every gradient -- is bit-identical to the one with dpc_bn_apply launches (bnin=False)"""
-    widths = (64, 16, 32, 32)   # layer1 at its real width: that is where the kernel serves the fused form
-    B, size = 1, 64
-    p = O.make_params_pcg("resnet18", widths)
-    x = O.make_input_pcg(B, 4, 5, size)
-    out = []
-    for bnin in (True, False):
-        eng = DPCEngine("resnet18", size, 4, 5, 1, B, "cpu", torch.bfloat16, widths, lib=emu, bnin=bnin)
-        eng.load_params(p)
-        assert [b.bnin for b in eng.blocks] == [bnin, bnin] + [False] * 6
-        score = eng.forward(x, train=False).clone()
-        res = eng.loss_topk(True).clone()
-        eng.backward()
-        out.append((score, res, eng.flat_g.clone(), eng.blocks[0].act1.clone(), eng.blocks[0].c1.mask.clone()))
-    for a, b in zip(*out):
-        assert torch.equal(a, b)

@@ -67,11 +67,6 @@ def test_conv_fwd(k, dtype, shape):
     kc.case_conv_fwd(k, dtype, *shape)
 
 
-@pytest.mark.parametrize("shape", [(2, 2, 9, 33), (1, 1, 20, 12), (3, 1, 4, 70)])   # ragged tiles, a narrow image (8 x 16 tiles), several tile columns
-def test_conv_fwd_bnin(k, shape):
-    kc.case_conv_fwd_bnin(k, *shape)
-
-
 @pytest.mark.parametrize("dtype", [F32, BF16])
 @pytest.mark.parametrize("shape", [
     (2, 16, 64, 2, 9, 9, (1, 3, 3), (1, 2, 2), (0, 1, 1)),

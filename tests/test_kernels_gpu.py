@@ -42,12 +42,6 @@ def test_conv_fwd(k, dtype, shape):
     kc.case_conv_fwd(k, dtype, *shape[:9], expect=shape[9] if dtype == BF16 else None)
 
 
-@pytest.mark.parametrize("shape", [(70, 1, 32, 32), (4, 3, 32, 32), (3, 2, 56, 56), (5, 1, 20, 44)])   # 560 tiles > 256 workgroups; layer1; 224-pixel family (ragged); odd sizes
-def test_conv_fwd_bnin(k, shape):
-    """BatchNorm-apply + ReLU of the source inside the layer1 conv == dpc_bn_apply + dpc_conv_igemm, bit for bit"""
-    kc.case_conv_fwd_bnin(k, *shape)
-
-
 @pytest.mark.parametrize("dtype", [F32, BF16])
 @pytest.mark.parametrize("shape", [
     (24, 128, 256, 3, 16, 16, (3, 3, 3), (2, 2, 2), (1, 1, 1), "igemm_ws_kernel<false,true>"),   # layer3.0.conv1 at 128^2: 12 tiles per class (8 interleaved + 4)

@@ -56,9 +56,6 @@ def main():
     kc.case_conv_fwd(k, BF16, 2, 64, 64, 2, 9, 33, (1, 3, 3), (1, 1, 1), (0, 1, 1))
     kc.case_conv_fwd(k, BF16, 1, 64, 40, 1, 20, 12, (1, 3, 3), (1, 1, 1), (0, 1, 1))
     kc.case_conv_dgrad(k, BF16, 2, 64, 64, 2, 9, 33, (1, 3, 3), (1, 1, 1), (0, 1, 1))
-    # ... with the source's BatchNorm-apply + ReLU inside (BNIN): the rewrite runs one tile ahead across many tiles per workgroup
-    kc.case_conv_fwd_bnin(k, 2, 2, 9, 33)
-    kc.case_conv_fwd_bnin(k, 1, 1, 20, 12, Co=40)
     kc.case_stem(k, BF16, 2, 2, 16, 72)   # stem geometry (4x4 taps, 32-byte positions) on the role-specialised patch kernel
     # plain NT GEMMs
     kc.case_gemm_nt(k, BF16, 600, 136, 256)
