@@ -314,7 +314,7 @@ def test_cast_parameters_are_refused(emu):
         m(O.make_input_pcg(1, 4, 5, 64))
 
 
-@pytest.mark.parametrize("N,SL,P,B,size", [(6, 4, 2, 1, 64), (5, 8, 1, 1, 64), (8, 5, 3, 3, 64), (4, 6, 1, 2, 96)])
+@pytest.mark.parametrize("N,SL,P,B,size", [(6, 4, 2, 1, 64), (5, 8, 1, 1, 64), (4, 5, 2, 3, 64), (4, 6, 1, 1, 96)])
 def test_other_sequence_shapes(emu, N, SL, P, B, size):
     """the reference's constructor takes any num_seq / seq_len / pred_step (dpc/model_3d.py:16-25: last_duration = ceil(seq_len / 4),
     last_size = ceil(sample_size / 32)); BASELINE's configurations only use 8 / 5 / 3|5.  Eval-mode score against the oracle for
