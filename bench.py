@@ -435,14 +435,8 @@ def main():
         res = step_fn()
     sync()
     dt = time.perf_counter() - t0
-    tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
-    rank_ms = [1e3 * dt / args.steps]
-    if dist is not None:
-        every = [torch.zeros_like(tmax) for _ in range(world)]
-        dist.all_gather(every, tmax)          # per-rank wall time of the same K steps: stragglers show as a spread
-        rank_ms = [1e3 * t.item() / args.steps for t in every]
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    dt = tmax.item()
+    from dpc_amd.parallel import gather_step_times, ranks_agree
+    dt, rank_ms = gather_step_times(dist, dt, args.steps, dev, world)   # max over ranks; per-rank spread (tests/test_parallel_gloo.py)
     loss = res.cpu().tolist()
 
     # ---- the other exchange schedules, a few steps each (never part of `value`): the default overlaps the tail all-reduce with
@@ -451,10 +445,7 @@ def main():
     schedules = None
     if dist is not None and use_graph and allreduce is not None and args.schedules and not args.no_schedules:
         def agree(ok: bool) -> bool:
-            """every rank learns whether ALL ranks got here without an exception (one tiny all-reduce, same place on every rank)"""
-            f = torch.tensor([1.0 if ok else 0.0], device=dev)
-            dist.all_reduce(f, op=dist.ReduceOp.MIN)
-            return bool(f.item() > 0.5)
+            return ranks_agree(dist, ok, dev)
 
         failed = []   # once any rank failed a side schedule, every rank skips the rest: their collectives would no longer pair up
 

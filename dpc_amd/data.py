@@ -254,3 +254,53 @@ def recipe_to_input(lib: L.Lib, frames: torch.Tensor, starts, clips: "List[dict]
     lib.call("dpc_frames_to_input_ex", frames.contiguous(), B, F, H0, W0, t["aug"], t["gray"], num_seq, seq_len, ds, size, size, C.byref(rs),
              jt, u8, ls, mean, std, block, s2d, L.dtype_code(s2d.dtype) if s2d is not None else L.F32, lib.stream())
     return block, s2d
+
+
+class FrameSource:
+    """Decoded clips as ONE uint8 array [clips, F, H0, W0, 3] (``np.load(path, mmap_mode='r')`` or an array) -- the data source of
+    ``python -m dpc_amd.main --frames``.  It stands where the reference has ``dataset[index]`` under
+    ``DataLoader(RandomSampler(dataset), batch_size, drop_last=True)`` (dpc/dataset_3d.py:88-111, dpc/main.py:304-313): per
+    epoch a random permutation of the clips cut into batches (the last partial one dropped); per clip the start frame of
+    ``idx_sampler`` (``np.random.choice(range(vlen - num_seq * seq_len * ds), 1)``, dataset_3d.py:88-92) and then the draws of the
+    training transform (``draw_k400`` / ``draw_ucf101``: the ``Compose`` of dpc/main.py:114-132, same ``random`` / ``np.random``
+    calls in the same order).  What it hands out is NOT a float tensor: the uint8 frames the clip needs (its span of
+    (num_seq * seq_len - 1) * ds + 1 frames) and the draws; ``DPCEngine.load_recipe`` runs crop / resize / flip / grey / jitter /
+    ToTensor / Normalize / layout on the GPU and fills the stem's operand.  Readers of video files are out of scope (SURVEY section 2
+    row 8); anything that can produce this array (a decoder, a frame cache) plugs in here."""
+
+    def __init__(self, frames, dataset: str, num_seq: int, seq_len: int, ds: int, size: int, batch: int, rank: int = 0, world: int = 1,
+                 crop: int = 224):
+        self.frames = np.load(frames, mmap_mode="r") if isinstance(frames, (str, bytes)) or hasattr(frames, "__fspath__") else frames
+        fr = self.frames
+        if fr.ndim != 5 or fr.shape[4] != 3 or fr.dtype != np.uint8:
+            raise ValueError("--frames wants a uint8 array [clips, F, H0, W0, 3]")
+        if dataset not in ("k400", "ucf101"):
+            raise ValueError("dataset not supported")   # dpc/main.py:301
+        self.dataset, self.N, self.SL, self.size, self.batch, self.rank, self.world, self.crop = dataset, num_seq, seq_len, size, batch, rank, world, crop
+        self.ds = 5 if dataset == "k400" else ds           # dpc/main.py:294 (k400: downsample=5), :299 (ucf101: args.ds)
+        self.n_fr = num_seq * seq_len
+        self.span = (self.n_fr - 1) * self.ds + 1
+        if fr.shape[1] - self.n_fr * self.ds <= 0:
+            raise ValueError(f"clips of {fr.shape[1]} frames are too short for {num_seq} x {seq_len} frames at stride {self.ds} "
+                             "(dpc/dataset_3d.py:80-82 drops such videos)")
+        if dataset == "ucf101" and (fr.shape[2] < crop or fr.shape[3] < crop):
+            raise ValueError(f"the ucf101 recipe crops {crop} x {crop} (dpc/main.py:117): frames of {fr.shape[3]} x {fr.shape[2]} are too small")
+
+    def __len__(self):   # batches per epoch, drop_last
+        return self.frames.shape[0] // (self.batch * self.world)
+
+    def epoch(self, device):
+        """yields (frames u8 [B, span, H0, W0, 3] on `device`, starts (all 0: the span is cut out on the host), clips) per batch of THIS rank"""
+        fr = self.frames
+        F, H0, W0 = fr.shape[1:4]
+        order = torch.randperm(fr.shape[0]).tolist()     # RandomSampler: torch's generator, seeded by torch.manual_seed(0) (dpc/main.py:50)
+        gb = self.batch * self.world
+        for i in range(len(self)):
+            mine = order[i * gb + self.rank * self.batch: i * gb + (self.rank + 1) * self.batch]
+            clips, host = [], np.empty((self.batch, self.span, H0, W0, 3), np.uint8)
+            for j, ci in enumerate(mine):
+                start = int(np.random.choice(range(F - self.n_fr * self.ds), 1)[0])         # idx_sampler
+                host[j] = fr[ci, start:start + self.span]
+                clips.append(draw_k400(W0, H0, self.size, self.n_fr) if self.dataset == "k400"
+                             else draw_ucf101(W0, H0, self.crop, self.size, self.n_fr))
+            yield torch.from_numpy(host).to(device, non_blocking=False), [0] * self.batch, clips

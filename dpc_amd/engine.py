@@ -429,6 +429,7 @@ class _Block:
         self.ds = _ConvBN(eng, pre + "downsample.0.weight", pre + "downsample.1", Ci, Co, (1, 1, 1), s, (0, 0, 0),
                           in_shape) if has_ds else None
         self.final_relu = final_relu
+        self.site = pre[len("backbone."):]   # "layer2.0.": names this block's side-stream sites (DPCEngine.side_off)
         self.out_shape = self.c2.out_shape
         self.Co = Co
         self.act1 = eng.empty(self.c1.out_shape + (Co,), eng.cdtype)
@@ -479,7 +480,7 @@ class _Block:
         self.c2.dgrad(draw2, dact1, None, red=self.c1 if self.fold_c1 else None)
         if self.fold_c1:   # coefficients of bn1 before the side stream fills the chip (bn_prepare)
             self.c1.bn_prepare(dact1, self.act1, True)
-        with e.side(reads=[draw2, draw_d]):   # beside bn1's backward on the main stream
+        with e.side(reads=[draw2, draw_d], site=self.site + "c2"):   # beside bn1's backward on the main stream
             if self.ds is not None:
                 self.ds.wgrad(self.x_in, draw_d)
             self.c2.wgrad(self.act1, draw2)
@@ -487,7 +488,7 @@ class _Block:
         draw1 = draw2 if e._side is None or e.timer is not None else e.scratch(oshape, exclude=[dout, draw2, draw_d, dz, dact1])
         self.c1.bn_backward(dact1, self.act1, True, draw1)
         if not need_dx:
-            with e.side(reads=[draw1]):
+            with e.side(reads=[draw1], site=self.site + "c1"):
                 self.c1.wgrad(self.x_in, draw1)
             return None
         if self.ds is not None:
@@ -506,7 +507,7 @@ class _Block:
         else:
             dx = dact1  # same shape as the input; dact1 is dead
             self.c1.dgrad(draw1, dx, dz)
-        with e.side(reads=[draw1]):   # beside the previous block's bn2 backward (beside conv1's own input-gradient: slower)
+        with e.side(reads=[draw1], site=self.site + "c1"):   # beside the previous block's bn2 backward (beside conv1's own input-gradient: slower)
             self.c1.wgrad(self.x_in, draw1)
         return dx
 
@@ -588,6 +589,7 @@ class DPCEngine:
         # (DPC_SIDE_MASK, DPC_SIDE_QUIET); every other setting measured slower and the switches are gone (round 5).
         self._side = (torch.cuda.Stream(self.device) if self.device.type == "cuda" and int(os.environ.get("DPC_WGRAD_STREAM", "1")) else None)
         self._on_side = False
+        self.side_off = frozenset(x for x in os.environ.get("DPC_SIDE_OFF", "").split(",") if x)   # probe knob (scripts/probes/side_sites.py)
         self._busy = []   # [(event recorded on the side stream, scratch buffers its launches read)], oldest first
         self.bn_running = type(self).BN_RUNNING  # BatchNorm3d with running statistics (the LC classifier's backbone)
         self.train_mode = True       # only matters when bn_running: eval uses the running buffers
@@ -859,8 +861,9 @@ class DPCEngine:
     #     and the probe is clean (conv_igemm_ws.hip).  The wait in _ConvBN.dgrad stays for the throughput.  With it, 9 600 steps (three configurations, graph
     #     replay and kernel-by-kernel) were bit-identical to the one-stream schedule.
     @contextlib.contextmanager
-    def side(self, reads=()):
-        if self._side is None or self.timer is not None:   # instrumented pass (bench.py): one stream, clean per-kernel times
+    def side(self, reads=(), site: str = ""):
+        # instrumented pass (bench.py): one stream, clean per-kernel times.  side_off: sites whose launches stay on the main stream
+        if self._side is None or self.timer is not None or site in self.side_off:
             yield
             return
         main = torch.cuda.current_stream(self.device)
@@ -990,7 +993,7 @@ class DPCEngine:
         load_frames): returns the last block's output [B*N, T, ls, ls, D] (channels-last, no final ReLU)"""
         B, N = self.B, self.N
         dc = L.dtype_code(self.cdtype)
-        with self.side():   # the per-step weight repacks (0.2 ms of small launches) beside the input pack
+        with self.side(site="pack"):   # the per-step weight repacks (0.2 ms of small launches) beside the input pack
             self.pack_weights()
         if block is not None:
             self.call("dpc_pack_input_s2d", block.contiguous(), self.x_s2d, dc, B * N, self.SL, self.size, self.size)
@@ -1162,7 +1165,7 @@ class DPCEngine:
         # ---- weight / bias grads of the ConvGRU and predictor, batched over all steps: ~20 small launches nothing waits for until
         # the optimizer -- on the side stream, beside layer4's backward (they share the split-K slab buffer with the backbone's
         # weight gradients, which queue behind them on the same stream)
-        with self.side():
+        with self.side(site="head"):
             self._head_param_grads(dc)
         self._backbone_backward(self.d_feat, on_tail_ready)
 
@@ -1210,6 +1213,11 @@ class DPCEngine:
         self.call("dpc_adam_dev", self.flat_p, self.flat_g, self.flat_m, self.flat_v, self.numel, self.lr, 0.9, 0.999, 1e-8,
                   self.wd, self.dev_bc, grad_scale)
 
+    def _baked_scalars(self) -> tuple:
+        """host scalars a captured step carries as kernel arguments (a replay keeps the values of its capture)"""
+        gd = getattr(self, "gru_desc", None)
+        return (float(self.lr), float(self.wd), float(gd.p_drop) if gd is not None else 0.0, int(gd.seed) if gd is not None else 0)
+
     def capture_train_step(self, block: torch.Tensor, allreduce=None, warmup: int = 2):
         """Captures the whole train step on `block` (a static device buffer: refill it in place between replays) into
         hipGraphs and returns ``replay() -> device f32[4]``.  One graph without data parallelism; with the two-bucket
@@ -1219,7 +1227,10 @@ class DPCEngine:
         the device-side step counter, so every replay is a new optimizer step."""
         if self.device.type != "cuda":
             raise L.DpcError("hipGraph capture needs the HIP device")
-        key = (block.data_ptr(), tuple(block.shape), id(allreduce) if allreduce is not None else None, self.reserve_cus)
+        # every host scalar the capture bakes into kernel arguments is part of the key (dpc_adam_dev takes lr / wd by value, the
+        # recurrence descriptor p_drop / seed): after eng.lr = ... (LR schedule, checkpoint.resume, --reset_lr) asking again captures
+        # a step with the new values instead of handing back the stale replay (ADVICE r5)
+        key = (block.data_ptr(), tuple(block.shape), id(allreduce) if allreduce is not None else None, self.reserve_cus, tuple(sorted(self.side_off))) + self._baked_scalars()
         hit = self._captures.get(key)
         if hit is not None:   # the same static buffer, the same exchange: the capture that exists (see _LIVE_GRAPHS)
             return hit
@@ -1271,11 +1282,15 @@ class DPCEngine:
         cur.wait_stream(side)
         tail, head, whole, result = self.flat_g[self.grad_split:], self.flat_g[:self.grad_split], self.flat_g, self.result
         me = weakref.ref(self)   # the cached closure must not keep its engine (tens of GB of buffers) alive through a cycle
+        baked = self._baked_scalars()
 
         def replay():
             eng = me()
             if eng is None:
                 raise RuntimeError("replay of a captured train step whose engine is gone")
+            if eng._baked_scalars() != baked:   # loud, not stale: the graph would go on stepping with the values of its capture
+                raise RuntimeError(f"lr / wd / dropout changed since this step was captured ({baked} -> {eng._baked_scalars()}): "
+                                   "call capture_train_step() again (it captures a new step for the new values)")
             graphs[0].replay()
             if two_bucket:
                 allreduce.start(tail)

@@ -107,3 +107,25 @@ def shard_of(global_batch: int, world: int, rank: int) -> slice:
     """contiguous dim-0 shard of the global batch owned by `rank` (drop_last semantics, main.py:313)"""
     per = global_batch // world
     return slice(rank * per, (rank + 1) * per)
+
+
+def gather_step_times(dist, seconds: float, steps: int, device, world: int):
+    """bench.py's clock: every rank timed the same K steps between barriers; returns (max over ranks in seconds, [ms per step of every
+    rank]).  The max is what `value` is computed from; the list shows stragglers as a spread."""
+    t = torch.tensor([seconds], device=device, dtype=torch.float64)
+    if dist is None:
+        return seconds, [1e3 * seconds / steps]
+    every = [torch.zeros_like(t) for _ in range(world)]
+    dist.all_gather(every, t)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return t.item(), [1e3 * e.item() / steps for e in every]
+
+
+def ranks_agree(dist, ok: bool, device) -> bool:
+    """every rank learns whether ALL ranks got here without an exception (one tiny all-reduce, same place on every rank): what one
+    rank could not do (a capture refused, out of memory), no rank goes on with -- their collectives would no longer pair up"""
+    if dist is None:
+        return bool(ok)
+    f = torch.tensor([1.0 if ok else 0.0], device=device)
+    dist.all_reduce(f, op=dist.ReduceOp.MIN)
+    return bool(f.item() > 0.5)

@@ -193,3 +193,62 @@ def test_bad_draws_are_rejected_on_the_host():
     for bad in ([[1, 8, 4, 0]], [[0, 9, 4, 0]], [[0, 8, 5, 0]], [[-1, 0, 0, 0]]):   # last frame 1 + 9 = 10 >= F; box leaves the frame
         with pytest.raises(ValueError):
             frames_to_input(lib, fr, torch.tensor(bad, dtype=torch.int32), None, 2, 2, 3, 16, block, None)
+
+
+# ---- the caller: python -m dpc_amd.main --frames (replaces dpc/dataset_3d.py:97-111 + the DataLoader of dpc/main.py:304-313)
+def _frames_entry_case(lib, dev_name, tmp_path, golden_dir, dtype, widths, B, size, steps):
+    """`main --frames` for one epoch of `steps` batches == the same batches fed by hand as f32 blocks: FrameSource's draws replayed
+    with the same seeds -> recipe_to_input(block=...) -- the block tests/golden/aug.npz pins bit for bit to the reference's own
+    transform classes -- -> engine.train_step(block).  Parameters and Adam moments after the epoch must be bit-identical."""
+    import random
+    from dpc_amd import main as dpc_main
+    from dpc_amd.data import FrameSource, recipe_to_input
+    from dpc_amd.engine import DPCEngine
+    from dpc_amd.model import DPC_RNN
+    g = np.load(os.path.join(golden_dir, "aug.npz"))
+    base = g["frames"]                                            # [14, 60, 80, 3] u8: the frames the reference's transform saw
+    rng = np.random.default_rng(3)
+    clips = np.stack([np.roll(base, k, axis=0) if k % 2 == 0 else base[:, ::-1][:, :, ::-1].copy() for k in range(B * steps)])
+    clips = (clips.astype(np.int16) + rng.integers(-3, 4, clips.shape)).clip(0, 255).astype(np.uint8)
+    path = os.path.join(str(tmp_path), "clips.npy")
+    np.save(path, clips)
+    N, SL, P, ds = 4, 3, 1, 1                                    # 12 of the 14 frames
+    pr = os.path.join(str(tmp_path), "probe"); os.makedirs(pr, exist_ok=True)
+    argv = ["--net", "resnet18", "--img_dim", str(size), "--batch_size", str(B), "--gpu", "0", "--print_freq", "1", "--dtype", dtype,
+            "--num_seq", str(N), "--seq_len", str(SL), "--pred_step", str(P), "--ds", str(ds), "--epochs", "1", "--dataset", "ucf101",
+            "--crop", "56", "--frames", path]
+    sim = lib if lib.kind != "hip" else None
+    dpc_main.main(argv, _simulator=sim, _widths=widths, _probe=pr)
+    got = torch.load(os.path.join(pr, "rank0.pt"))
+    assert got["step"] == steps
+    # by hand: same seeds (dpc_amd.main seeds torch 0, random / np.random with the rank), same draws, but through an f32 block
+    torch.manual_seed(0)
+    cdt = torch.bfloat16 if dtype == "bf16" else torch.float32
+    from dpc_amd.plan import LAYER_WIDTH
+    eng = DPCEngine("resnet18", size, N, SL, P, B, dev_name, cdt, widths or LAYER_WIDTH, lib=sim, seed=233)
+    init = DPC_RNN(size, N, SL, P, "resnet18", widths=widths or LAYER_WIDTH, seed=0)
+    eng.load_params({k: v.detach() for k, v in init.named_parameters()})
+    random.seed(0); np.random.seed(0)
+    src = FrameSource(path, "ucf101", N, SL, ds, size, B, crop=56)
+    assert len(src) == steps and src.span == N * SL
+    n = 0
+    for frames, starts, cl in src.epoch(torch.device(dev_name)):
+        block = torch.empty(B, N, 3, SL, size, size, device=dev_name)
+        recipe_to_input(eng.lib, frames, starts, cl, N, SL, src.ds, size, block, None)
+        assert torch.isfinite(block).all() and block.std() > 0.3
+        eng.train_step(block)
+        n += 1
+    assert n == steps
+    if dev_name != "cpu":
+        torch.cuda.synchronize()
+    assert torch.equal(got["flat_p"], eng.flat_p.cpu()) and torch.equal(got["flat_m"], eng.flat_m.cpu())
+
+
+def test_main_frames_entry_emu(tmp_path, golden_dir):
+    subprocess.run(["make", "-s", "-j8", "emu"], cwd=ROOT, check=True)
+    _frames_entry_case(L.load_emulator(), "cpu", tmp_path, golden_dir, "f32", (8, 16, 32, 32), 1, 64, 2)
+
+
+@pytest.mark.gpu
+def test_main_frames_entry_gpu(tmp_path, golden_dir):
+    _frames_entry_case(L.load_hip(), "cuda:0", tmp_path, golden_dir, "bf16", None, 2, 64, 2)

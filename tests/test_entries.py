@@ -83,6 +83,41 @@ def test_main_and_lc_main_on_the_simulator(emu, tmp_path, capsys):
     _check_lc(capsys.readouterr().out, f2, nb=1)
 
 
+def test_main_two_ranks(emu, tmp_path, capfd):
+    """`--gpu 0,1`: the rank processes of dpc_amd.main (mp.spawn, init_process_group, per-rank dropout seeds, the two-bucket gradient
+    exchange inside train_step, the averaged metrics, rank-0-only checkpointing) -- what replaces nn.DataParallel (dpc/main.py:65,
+    torch data_parallel.py:173-198).  On this tier the ranks run the simulator and exchange over gloo; on an 8-GPU node the same
+    lines run over RCCL."""
+    from dpc_amd import main as dpc_main
+    d, pr = str(tmp_path / "run"), str(tmp_path / "probe")
+    os.makedirs(pr)
+    common = ["--net", "resnet18", "--img_dim", "64", "--batch_size", "2", "--gpu", "0,1", "--synthetic", "2", "--print_freq", "1",
+              "--dtype", "f32", "--num_seq", "4", "--pred_step", "1"]
+    dpc_main.main(common + ["--epochs", "1", "--save_dir", d], _simulator=emu, _widths=WIDTHS, _probe=pr)
+    out = capfd.readouterr().out
+    ck1 = _check_run1(d, out, nb=2)
+    assert out.count("Training from ep 0 to ep 1 finished") == 1 and out.count("Epoch: [0][0/2]") == 1   # rank 0 alone reports
+    assert [f for f in sorted(os.listdir(d)) if f.startswith("epoch")] == ["epoch1.pth.tar"]                # ... and alone writes the file
+    r = [torch.load(os.path.join(pr, f"rank{i}.pt")) for i in range(2)]
+    assert [x["rank"] for x in r] == [0, 1] and all(x["world"] == 2 and x["per_gpu"] == 1 and x["step"] == 2 for x in r)
+    assert r[0]["seed"] == 233 and r[1]["seed"] == 234                      # independent dropout streams per replica (dpc/model_3d.py:18)
+    assert torch.equal(r[0]["flat_p"], r[1]["flat_p"]) and torch.equal(r[0]["flat_m"], r[1]["flat_m"])   # averaged gradients, same update
+    assert torch.isfinite(r[0]["flat_p"]).all() and r[0]["flat_m"].abs().sum() > 0
+    # the saved state_dict is rank 0's arena
+    sd = ck1["state_dict"]
+    assert torch.equal(sd["module.backbone.conv1.weight"].flatten(), r[0]["flat_p"][:sd["module.backbone.conv1.weight"].numel()])
+    # ... and it resumes on two ranks: strict load + optimizer state, one more epoch, both ranks still identical
+    dpc_main.main(common + ["--epochs", "2", "--save_dir", d, "--resume", os.path.join(d, "epoch1.pth.tar")],
+                  _simulator=emu, _widths=WIDTHS, _probe=pr)
+    out = capfd.readouterr().out
+    assert out.count(f"=> loaded resumed checkpoint '{os.path.join(d, 'epoch1.pth.tar')}' (epoch 1)") == 1
+    assert "Epoch: [1][0/2]" in out and "Training from ep 1 to ep 2 finished" in out
+    r2 = [torch.load(os.path.join(pr, f"rank{i}.pt")) for i in range(2)]
+    assert all(x["step"] == 4 for x in r2) and torch.equal(r2[0]["flat_p"], r2[1]["flat_p"]) and not torch.equal(r2[0]["flat_p"], r[0]["flat_p"])
+    ck2 = torch.load(os.path.join(d, "epoch2.pth.tar"), map_location="cpu", weights_only=False)
+    assert ck2["epoch"] == 2 and float(ck2["optimizer"]["state"][0]["step"]) == 4.0 and [f for f in sorted(os.listdir(d)) if f.startswith("epoch")] == ["epoch2.pth.tar"]
+
+
 def test_entry_errors_follow_the_reference():
     from dpc_amd import main as dpc_main
     a = dpc_main.build_parser().parse_args(["--model", "dpc", "--gpu", "0"])

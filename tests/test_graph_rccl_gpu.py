@@ -48,11 +48,23 @@ def test_graph_replay_equals_eager(dtype):
     x.copy_(torch.randn(x.shape, device=DEV, generator=torch.Generator(DEV).manual_seed(2)))
     r7 = replay().clone()
     assert not torch.equal(r7, rb)
+    # lr / wd are kernel arguments of the captured Adam launch: a new learning rate is a new capture, the old replay refuses
+    p7 = b.flat_p.clone()
+    b.lr = 0.5e-3
+    with pytest.raises(RuntimeError, match="capture_train_step"):
+        replay()
+    replay2 = b.capture_train_step(x, warmup=0)
+    assert replay2 is not replay and len(b._capture_graphs) == 2
+    replay2()
+    torch.cuda.synchronize()
+    assert not torch.equal(b.flat_p, p7)
+    b.lr = 1e-3
+    assert b.capture_train_step(x, warmup=0) is replay   # the first capture is still there for its own lr
     # dropped captures are parked until the process exits, never destroyed while it runs (engine._LIVE_GRAPHS says why)
     g0 = replay.graphs[0]
     b.release_captures()
     if os.environ.get("DPC_KEEP_GRAPHS", "1") != "0":
-        assert not b._captures and any(g is g0 for g in E_._LIVE_GRAPHS) and len(E_._LIVE_GRAPHS) == live + 2   # the graph + its events
+        assert not b._captures and any(g is g0 for g in E_._LIVE_GRAPHS) and len(E_._LIVE_GRAPHS) == live + 4   # two graphs + their events
     else:   # the A/B of scripts/gpu_r5_graph_destroy.sh: destroyed here, graphs first
         assert not b._captures and len(E_._LIVE_GRAPHS) == live and not replay.graphs
 

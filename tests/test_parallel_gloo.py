@@ -145,3 +145,32 @@ def test_rccl_defaults_for_data_parallel_runs():
     got = configure_rccl(2, env)
     assert env["NCCL_MAX_NCHANNELS"] == "16" == env["NCCL_MIN_NCHANNELS"] and got["DPC_RESERVE_CUS"] == 0
     assert default_reserve_cus(1, {}) == 0 and default_reserve_cus(4, {}) == DEFAULT_CHANNELS
+
+
+def _clock_main(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    from dpc_amd.parallel import gather_step_times, ranks_agree
+    from dpc_amd.main import average_over_ranks
+    dev = torch.device("cpu")
+    mx, per = gather_step_times(dist, 1.0 + rank, 10, dev, world)          # rank r "took" 1 + r seconds for 10 steps
+    ok_all = ranks_agree(dist, True, dev)
+    ok_one = ranks_agree(dist, rank != 1, dev)                              # rank 1 "failed its capture": nobody goes on
+    vals = average_over_ranks(dist, torch.tensor([1.0 + rank, 10.0 * rank, 0.0, 4.0]), world)
+    torch.save({"max": mx, "per": per, "ok_all": ok_all, "ok_one": ok_one, "vals": vals}, os.path.join(out_dir, f"clock{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bench_clock_and_agreement_two_ranks(tmp_path):
+    """the multi-rank lines of bench.py (per-rank times gathered, the MAX is the clock; side schedules only when every rank agrees) and
+    dpc_amd.main's averaged metrics, over gloo: their first execution with world > 1 must not be the driver's 8-GPU run"""
+    world, port = 2, 29900 + os.getpid() % 90
+    mp.spawn(_clock_main, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    r = [torch.load(tmp_path / f"clock{i}.pt") for i in range(world)]
+    for x in r:
+        assert x["max"] == 2.0 and x["per"] == [100.0, 200.0]
+        assert x["ok_all"] is True and x["ok_one"] is False
+        assert torch.equal(x["vals"], torch.tensor([1.5, 5.0, 0.0, 4.0]))
+    from dpc_amd.parallel import gather_step_times, ranks_agree
+    assert gather_step_times(None, 3.0, 6, torch.device("cpu"), 1) == (3.0, [500.0]) and ranks_agree(None, False, None) is False
