@@ -194,16 +194,24 @@ def golden_eval_p5():
 
 # ---------------------------------------------------------------- bf16 anchor
 def golden_anchor16():
-    """fp32 reference run at r18 / 128^2 / B=16 -- a batch at which the engine's throughput (bf16) mode selects
+    golden_anchor("resnet18", 128, 16, "anchor_r18_128_b16.npz")
+
+
+def golden_anchor34():
+    """the 224^2 family (BASELINE configs[3], [4]: resnet34, 56^2 / 28^2 / 14x14x3 / 7x7x2 planes) -- round 6"""
+    golden_anchor("resnet34", 224, 4, "anchor_r34_224_b4.npz", sub=512)
+
+
+def golden_anchor(net, size, B, fname, sub=1024):
+    """fp32 reference run at a batch at which the engine's throughput (bf16) mode selects
     every specialised kernel -- so the bf16 path is anchored to the reference instead of to itself."""
     out = {}
-    net, size, B = "resnet18", 128, 16
     x = O.make_input_pcg(B, 8, 5, size)
     m, _ = build_ref(net, size)
     m.train()
     m.agg.dropout_layer.p = 0.0
     score, mask = m(x)
-    R = B * 3 * 16
+    R = B * 3 * (-(-size // 32)) ** 2
     flat = score.view(R, -1)
     tgt = (mask.contiguous() == 1).view(flat.shape).to(int).argmax(dim=1)
     loss = nn.CrossEntropyLoss()(flat, tgt)
@@ -219,7 +227,7 @@ def golden_anchor16():
     out["grad_norm"] = np.array([p.grad.norm().item() for _, p in m.named_parameters()])
     for k, p in m.named_parameters():
         g = p.grad.flatten()
-        stride = max(1, g.numel() // 1024)
+        stride = max(1, g.numel() // sub)
         out["grad_sub::" + k] = g[::stride].numpy().copy()
         out["grad_substride::" + k] = np.array(stride)
     # ---- how far bf16 storage alone moves these outputs: the SAME reference model with every Conv3d / BatchNorm3d /
@@ -251,7 +259,7 @@ def golden_anchor16():
     out["noise_grad_norm"] = np.array([abs(p2.grad.norm().item() / ref_g[k].grad.norm().item() - 1.0) for k, p2 in m2.named_parameters()])
     print("bf16-rounding noise of the reference: score", float(out["noise_score_l2"]), "grad rel-L2 max", float(out["noise_grad_l2"].max()),
           "grad-norm max", float(out["noise_grad_norm"].max()))
-    save("anchor_r18_128_b16.npz", **out)
+    save(fname, **out)
 
 
 # ---------------------------------------------------------------- checkpoint layout
@@ -392,7 +400,7 @@ def golden_ops():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["mask", "ops", "eval", "eval_p5", "train", "anchor", "ckpt", "lc"]
+    which = sys.argv[1:] or ["mask", "ops", "eval", "eval_p5", "train", "anchor", "anchor34", "ckpt", "lc"]
     if "mask" in which:
         golden_mask()
     if "ops" in which:
@@ -409,3 +417,5 @@ if __name__ == "__main__":
         golden_lc()
     if "anchor" in which:
         golden_anchor16()
+    if "anchor34" in which:
+        golden_anchor34()

@@ -1,7 +1,7 @@
 """GPU tier: the bf16 (throughput) mode's backward, block by block, against an oracle that rounds where the engine rounds.
 
-The end-to-end bf16 gradients can only be held to the rounding noise of 17 stacked layers (30-46 % rel-L2 in layer1 / stem,
-tests/golden/anchor_r18_128_b16.npz) -- a dropped tap in one weight gradient (+33 %) would pass.  Here every BasicBlock type is
+The end-to-end bf16 gradients can only be held to the rounding noise of 17 / 33 stacked layers (30-46 % rel-L2 in layer1 / stem,
+tests/golden/anchor_r18_128_b16.npz, anchor_r34_224_b4.npz) -- a dropped tap in one weight gradient (+33 %) would pass.  Here every BasicBlock type is
 differentiated in isolation: the engine's own saved block input (bf16) and a random incoming gradient go through
 ``_Block.backward`` -- the specialised kernels the benchmark runs: role-specialised patch kernel with fused epilogues, plane and
 loader/compute implicit GEMMs, staged-patch / transpose-read weight gradients, parity-class strided input-gradients -- and
@@ -27,22 +27,44 @@ def nchw(t):  # engine activation [N,T,H,W,C] -> [N,C,T,H,W]
     return t.permute(0, 4, 1, 2, 3).contiguous()
 
 
-@pytest.fixture(scope="module")
-def eng():
-    # B = 16: the batch at which every specialised bf16 kernel of cfg2 is selected (tests/test_plan.py pins the plan)
-    e = DPCEngine("resnet18", 128, 8, 5, 3, 16, DEV, torch.bfloat16)
-    e.load_params(O.init_params_reference_style("resnet18", seed=0))
-    x = O.make_input_pcg(16, 8, 5, 128).to(DEV)
+def _filled(net, size, B):
+    e = DPCEngine(net, size, 8, 5, 3, B, DEV, torch.bfloat16)
+    e.load_params(O.init_params_reference_style(net, seed=0))
+    x = O.make_input_pcg(B, 8, 5, size).to(DEV)
     e.forward(x, train=False)   # fills every block's saved tensors (x_in, raw, act1, masks, statistics)
     torch.cuda.synchronize()
     return e
 
 
+@pytest.fixture(scope="module")
+def eng():
+    # B = 16: the batch at which every specialised bf16 kernel of cfg2 is selected (tests/test_plan.py pins the plan)
+    return _filled("resnet18", 128, 16)
+
+
+@pytest.fixture(scope="module")
+def eng34():
+    # the 224^2 family of BASELINE configs[3] / [4] (backbone/resnet_2d3d.py:278-284: resnet34 = [3, 4, 6, 3] blocks): 56^2 and 28^2
+    # planes (wgrad_patch<64> / <32>), 14 x 14 x 3 and 7 x 7 x 2 volumes (padded-grid wgrad2, igemm_ws tiles that straddle clips)
+    return _filled("resnet34", 224, 4)
+
+
 @pytest.mark.parametrize("bi", [0, 1, 2, 3, 4, 5, 6, 7])
 def test_block_backward_vs_rounding_oracle(eng, bi):
+    _block_case(eng, bi)
+
+
+# one block of every kind r34 / 224^2 has: layer1.0 / .1 (fold_prev) / .2, layer2.0 (strided + downsample) / .1 / .3, layer3.0 / .1 / .5,
+# layer4.0 / .1 / .2 (no final ReLU)
+@pytest.mark.parametrize("bi", [0, 1, 2, 3, 4, 6, 7, 8, 12, 13, 14, 15])
+def test_block_backward_vs_rounding_oracle_r34_224(eng34, bi):
+    _block_case(eng34, bi)
+
+
+def _block_case(eng, bi):
     blk = eng.blocks[bi]
-    li, bj = bi // 2, bi % 2
-    pre = f"backbone.layer{li + 1}.{bj}."
+    pre = "backbone." + blk.site
+    li, bj = int(blk.site[5]) - 1, int(blk.site.split(".")[1])
     g = torch.Generator().manual_seed(100 + bi)
     # an incoming gradient that is CORRELATED with the activations, as a loss gradient is (plus noise).  With a purely random one
     # the weight gradients are sums of uncorrelated products -- tiny against their own bf16 rounding noise (6 % on layer1.0.conv1
@@ -90,15 +112,10 @@ def test_fused_reduction_of_the_previous_block_is_what_the_standalone_pass_compu
     dout = (torch.randn(tuple(blk.out.shape), generator=g) * 0.05).to(torch.bfloat16).to(DEV)
     dx = blk.backward(dout.clone(), need_dx=True)
     u = prev.c2
-    if u._coef_ready:   # round 4: the block finalises the carried sums itself, before it forks its weight gradient (bn_prepare)
-        assert u.reduced_rows == 0
-        dgam, dbet = eng.G[u.bnname + ".weight"].clone(), eng.G[u.bnname + ".bias"].clone()
-        u._coef_ready = False
-    else:               # DPC_EARLY_FINALIZE=0: the partial rows wait in eng.stats for the previous block's backward
-        rows = u.reduced_rows
-        assert rows > 0
-        dgam, dbet, coef = (torch.empty(n, device=DEV) for n in (u.Co, u.Co, 2 * u.Co))
-        eng.call("dpc_bn_bwd_finalize", eng.stats, rows, u.Co, float(u.rows), dgam, dbet, coef)
+    # the block finalises the carried sums itself, before it forks its weight gradient (bn_prepare)
+    assert u._coef_ready and u.reduced_rows == 0
+    dgam, dbet = eng.G[u.bnname + ".weight"].clone(), eng.G[u.bnname + ".bias"].clone()
+    u._coef_ready = False
     pr = C.c_int32(0)
     part = torch.empty_like(eng.stats)
     eng.call("dpc_bn_bwd_reduce", dx, None, u.mask, u.raw, L.BF16, u.rows, u.Co, u.mean, u.invstd, 1, part, C.byref(pr))

@@ -207,14 +207,15 @@ ANCHOR_NOISE_FACTOR = 2.0  # the hooks round at module boundaries; the engine al
 ANCHOR_GRADNORM = 0.15
 
 
-def test_bf16_anchored_to_reference(golden_dir):
+@pytest.mark.parametrize("net,size,B,fixture", [("resnet18", 128, 16, "anchor_r18_128_b16.npz"), ("resnet34", 224, 4, "anchor_r34_224_b4.npz")])
+def test_bf16_anchored_to_reference(golden_dir, net, size, B, fixture):
     """Throughput (bf16) mode at r18 / 128^2 / B=16 -- every specialised bf16 kernel (loader/compute implicit GEMM,
-    role-specialised patch kernel, staged-patch weight gradients) is selected at this batch -- against the fp32
-    outputs of the REFERENCE itself on the same input (tests/golden/anchor_r18_128_b16.npz, dropout p=0)."""
-    g = gold(golden_dir, "anchor_r18_128_b16.npz")
-    B = 16
-    eng = engine("resnet18", 128, B, torch.bfloat16)
-    x = O.make_input_pcg(B, 8, 5, 128).to(DEV)
+    role-specialised patch kernel, staged-patch weight gradients) is selected at this batch -- and at r34 / 224^2 / B=4 (the family of
+    BASELINE configs[3] / [4]: 56^2 ... 7x7x2 planes, 33 stacked conv layers; round 6) against the fp32 outputs of the REFERENCE
+    itself on the same input (tests/golden/anchor_*.npz from make_golden.golden_anchor, dropout p=0)."""
+    g = gold(golden_dir, fixture)
+    eng = engine(net, size, B, torch.bfloat16)
+    x = O.make_input_pcg(B, 8, 5, size).to(DEV)
     ones = torch.ones(eng.n_steps, eng.M, eng.D, device=DEV)
     score = eng.forward(x, train=True, dropout_masks=ones).cpu().flatten()
     res = eng.loss_topk(True).cpu()
@@ -240,8 +241,12 @@ def test_bf16_anchored_to_reference(golden_dir):
     assert e_score < ANCHOR_NOISE_FACTOR * float(g["noise_score_l2"])
     assert abs(res[0].item() - e[0]) < max(0.1, 10 * float(g["noise_loss"]))
     assert res[1:].tolist() == pytest.approx(list(e[1:]), abs=8.0 / eng.R)  # a handful of near-tie rows may reorder
+    noise_norm = {str(n): float(v) for n, v in zip(g["param_names"], g["noise_grad_norm"])}
     for n, e_norm, e_l2, noise in rows:
-        assert e_norm < ANCHOR_GRADNORM, (n, e_norm)
+        # (r34 / 224^2 / B = 4: 33 stacked layers under batch statistics of 32 x 5 frames carry the reference's OWN bf16 noise to
+        # 11 % on the score, 13 % on gradient norms, 27-81 % rel-L2 on gradients -- the end-to-end anchor is as sharp as that noise;
+        # what holds the 224^2 kernels to 2 % is tests/test_block_grads_gpu.py, block by block)
+        assert e_norm < max(ANCHOR_GRADNORM, ANCHOR_NOISE_FACTOR * noise_norm[n]), (n, e_norm)
         assert e_l2 < ANCHOR_NOISE_FACTOR * noise + 0.02, (n, e_l2, noise)
 
 
