@@ -174,7 +174,7 @@ template <class T> __device__ __forceinline__ unsigned sign_bits(const u32x4& v)
 
 template <class T, bool FIXED, bool NT, int U = 1>
 __global__ void bn_apply_kernel(const T* x, T* y, long long units, int C, const float* scale, const float* shift,
-                                const T* res, const float* rscale, const float* rshift, int relu, uint8_t* mask) {
+                                const T* res, const float* rscale, const float* rshift, int relu, uint8_t* mask, int rev) {
     constexpr int E = Elt<T>::PER16;
     float sc[E], sh[E], rs[E], rb[E];
     if (FIXED) {
@@ -187,8 +187,11 @@ __global__ void bn_apply_kernel(const T* x, T* y, long long units, int C, const 
     }
     // one contiguous span per workgroup (a multiple of 256 units, so a thread keeps its channel group): streams
     // 4 KB per step from one DRAM region instead of striding the whole tensor (+8 % bandwidth measured)
+    // rev (round 6): the spans are handed out from the END of the tensor.  The convolution that produced x wrote it front to back, so
+    // its tail is what the Infinity Cache (256 MB) / L2 still hold when this kernel starts; and y, written back to front, leaves its
+    // HEAD in the cache for the convolution that reads it front to back next (bn_bwd_apply_kernel has walked its spans this way since round 3).
     const long long span = (units + (long long)gridDim.x * 256 - 1) / ((long long)gridDim.x * 256) * 256;
-    const long long sb = (long long)blockIdx.x * span;
+    const long long sb = (long long)(rev ? gridDim.x - 1 - blockIdx.x : blockIdx.x) * span;
     const long long se = sb + span < units ? sb + span : units;
     long long i = sb + threadIdx.x;
     // Round 4: U units per thread in flight.  The rolled loop has ONE 16-byte load (two with a residual) outstanding per thread --
@@ -265,11 +268,13 @@ extern "C" int dpc_bn_apply(const void* x, void* y, int32_t dtype, int64_t rows,
     if (C % E) return DPC_ERR_UNSUPPORTED;
     const long long units = rows * C / E;
     const bool fixed = (256 * E) % C == 0;
+    static const int rev_on = getenv("DPC_BN_APPLY_REV") ? atoi(getenv("DPC_BN_APPLY_REV")) : 0;
+    const int rev = rev_on && bn_streaming(units) ? 1 : 0;   // small tensors fit the caches whole: the order does not matter
     if (dtype == DPC_F32) {
         if (fixed) {
-            if (bn_streaming(units)) { DPC_LAUNCH((bn_apply_kernel<float, true, true>), dim3(grid_for(units)), dim3(256), stream, (const float*)x, (float*)y, units, C, scale, shift, (const float*)res, rscale, rshift, relu, mask); } else { DPC_LAUNCH((bn_apply_kernel<float, true, false>), dim3(grid_for(units)), dim3(256), stream, (const float*)x, (float*)y, units, C, scale, shift, (const float*)res, rscale, rshift, relu, mask); }
+            if (bn_streaming(units)) { DPC_LAUNCH((bn_apply_kernel<float, true, true>), dim3(grid_for(units)), dim3(256), stream, (const float*)x, (float*)y, units, C, scale, shift, (const float*)res, rscale, rshift, relu, mask, rev); } else { DPC_LAUNCH((bn_apply_kernel<float, true, false>), dim3(grid_for(units)), dim3(256), stream, (const float*)x, (float*)y, units, C, scale, shift, (const float*)res, rscale, rshift, relu, mask, rev); }
         } else {
-            if (bn_streaming(units)) { DPC_LAUNCH((bn_apply_kernel<float, false, true>), dim3(grid_for(units)), dim3(256), stream, (const float*)x, (float*)y, units, C, scale, shift, (const float*)res, rscale, rshift, relu, mask); } else { DPC_LAUNCH((bn_apply_kernel<float, false, false>), dim3(grid_for(units)), dim3(256), stream, (const float*)x, (float*)y, units, C, scale, shift, (const float*)res, rscale, rshift, relu, mask); }
+            if (bn_streaming(units)) { DPC_LAUNCH((bn_apply_kernel<float, false, true>), dim3(grid_for(units)), dim3(256), stream, (const float*)x, (float*)y, units, C, scale, shift, (const float*)res, rscale, rshift, relu, mask, rev); } else { DPC_LAUNCH((bn_apply_kernel<float, false, false>), dim3(grid_for(units)), dim3(256), stream, (const float*)x, (float*)y, units, C, scale, shift, (const float*)res, rscale, rshift, relu, mask, rev); }
         }
     } else if (dtype == DPC_BF16) {
         if (fixed) {
@@ -277,12 +282,12 @@ extern "C" int dpc_bn_apply(const void* x, void* y, int32_t dtype, int64_t rows,
             const bool nt = bn_streaming(units);
             const int un = nt ? bn_unroll() : bn_small_unroll();
             const unsigned grid = grid_for((units + un - 1) / un, 256, nt ? (un > 1 ? bn_unroll_grid() : 8192) : bn_small_grid(512));   // small tensors: workgroup dispatch (~5 ns each) is what 8 192 short workgroups cost
-#define DPC_BN_GO(NTV, UV) DPC_LAUNCH((bn_apply_kernel<bf16_t, true, NTV, UV>), dim3(grid), dim3(256), stream, (const bf16_t*)x, (bf16_t*)y, units, C, scale, shift, (const bf16_t*)res, rscale, rshift, relu, mask)
+#define DPC_BN_GO(NTV, UV) DPC_LAUNCH((bn_apply_kernel<bf16_t, true, NTV, UV>), dim3(grid), dim3(256), stream, (const bf16_t*)x, (bf16_t*)y, units, C, scale, shift, (const bf16_t*)res, rscale, rshift, relu, mask, rev)
             if (nt) { if (un == 4) DPC_BN_GO(true, 4); else if (un == 2) DPC_BN_GO(true, 2); else DPC_BN_GO(true, 1); }
             else { if (un == 4) DPC_BN_GO(false, 4); else if (un == 2) DPC_BN_GO(false, 2); else DPC_BN_GO(false, 1); }
 #undef DPC_BN_GO
         } else {
-            if (bn_streaming(units)) { DPC_LAUNCH((bn_apply_kernel<bf16_t, false, true>), dim3(grid_for(units)), dim3(256), stream, (const bf16_t*)x, (bf16_t*)y, units, C, scale, shift, (const bf16_t*)res, rscale, rshift, relu, mask); } else { DPC_LAUNCH((bn_apply_kernel<bf16_t, false, false>), dim3(grid_for(units)), dim3(256), stream, (const bf16_t*)x, (bf16_t*)y, units, C, scale, shift, (const bf16_t*)res, rscale, rshift, relu, mask); }
+            if (bn_streaming(units)) { DPC_LAUNCH((bn_apply_kernel<bf16_t, false, true>), dim3(grid_for(units)), dim3(256), stream, (const bf16_t*)x, (bf16_t*)y, units, C, scale, shift, (const bf16_t*)res, rscale, rshift, relu, mask, rev); } else { DPC_LAUNCH((bn_apply_kernel<bf16_t, false, false>), dim3(grid_for(units)), dim3(256), stream, (const bf16_t*)x, (bf16_t*)y, units, C, scale, shift, (const bf16_t*)res, rscale, rshift, relu, mask, rev); }
         }
     } else {
         return DPC_ERR_ARG;

@@ -492,9 +492,17 @@ __global__ __launch_bounds__(512, 2) void conv_halo_ws_kernel(HaloParams p) {
             u32x4 add[NQ], raw[NQ];
             unsigned ab[NQ], bb[NQ];
         };
-        Pre cur;
+        // Two buffers, tile t's operands in pre[t & 1], and the tile loop unrolled by two so that each is a fixed set of registers.
+        // (Rounds 1-5 kept "cur" and "nxt" and copied nxt into cur at the end of every iteration: a copy of registers whose loads are
+        // in flight, so hipcc put s_waitcnt vmcnt(0) in front of it -- right behind the LDS-DMA of patch j+2, which is there to stay
+        // in flight for two intervals.  Every tile of the residual / fused-reduction variants drained its whole memory pipeline:
+        // their memory side ran 3.3 us per tile against 1.45 for the plain kernel, profiles/r06_halo_epi_probe.txt.)
+        Pre pre0, pre1;
         DPC_UNROLL
-        for (int q = 0; q < NQ; ++q) { cur.add[q] = u32x4{0u, 0u, 0u, 0u}; cur.raw[q] = u32x4{0u, 0u, 0u, 0u}; cur.ab[q] = ~0u; cur.bb[q] = ~0u; }
+        for (int q = 0; q < NQ; ++q) {
+            pre0.add[q] = u32x4{0u, 0u, 0u, 0u}; pre0.raw[q] = u32x4{0u, 0u, 0u, 0u}; pre0.ab[q] = ~0u; pre0.bb[q] = ~0u;
+            pre1.add[q] = u32x4{0u, 0u, 0u, 0u}; pre1.raw[q] = u32x4{0u, 0u, 0u, 0u}; pre1.ab[q] = ~0u; pre1.bb[q] = ~0u;
+        }
         const bool bnred = EPI && p.epi.bn_raw != nullptr;
         float mu[EPO], is[EPO];
         DPC_UNROLL
@@ -516,17 +524,18 @@ __global__ __launch_bounds__(512, 2) void conv_halo_ws_kernel(HaloParams p) {
         auto prefetch = [&](int j, Pre& d) {
             int rows[NQ];
             tile_rows(j, rows);
+            // branch-free: rows outside the image read unit 0 of the tensors (their values are never used) -- a load behind a
+            // divergent branch makes hipcc lose count of the operations in flight and wait vmcnt(0) at the first use
             DPC_UNROLL
             for (int q = 0; q < NQ; ++q) {
-                const bool ok = rows[q] >= 0;
-                const long long eo = (long long)rows[q] * p.ldo + col0;
+                const long long eo = rows[q] >= 0 ? (long long)rows[q] * p.ldo + col0 : 0ll;
                 if (HAS_ADD) {
-                    d.add[q] = *(const u32x4*)(ok ? (const char*)p.addend + eo * 2 : zero);
-                    if (EPI && p.epi.addend_mask) d.ab[q] = ok ? (unsigned)p.epi.addend_mask[eo >> 3] : 0u;
+                    d.add[q] = *(const u32x4*)((const char*)p.addend + eo * 2);
+                    if (EPI && p.epi.addend_mask) d.ab[q] = (unsigned)p.epi.addend_mask[eo >> 3];
                 }
                 if (bnred) {
-                    d.raw[q] = *(const u32x4*)(ok ? (const char*)p.epi.bn_raw + eo * 2 : zero);
-                    if (p.epi.bn_mask) d.bb[q] = ok ? (unsigned)p.epi.bn_mask[eo >> 3] : 0u;
+                    d.raw[q] = *(const u32x4*)((const char*)p.epi.bn_raw + eo * 2);
+                    if (p.epi.bn_mask) d.bb[q] = (unsigned)p.epi.bn_mask[eo >> 3];
                 }
             }
         };
@@ -551,14 +560,29 @@ __global__ __launch_bounds__(512, 2) void conv_halo_ws_kernel(HaloParams p) {
         DPC_UNROLL
         for (int a = 1; a < NPB - 1; ++a)
             if (ntiles > a) issue(a);
-        if (PRE) prefetch(0, cur);
-        for (int j = 0; j <= ntiles; ++j) {
+        if (PRE) prefetch(0, pre0);
+        // one interval: patch j is awaited and published, the operands of tile j are requested into `fill`, tile j-1 leaves with the
+        // operands in `use`, patch j+NPB-1 is issued.  STEADY (1 <= j <= ntiles - NPB): every one of those happens, unconditionally --
+        // hipcc's wait-count pass then KNOWS what is in flight (a load or its use behind a condition leaves it guessing, and its
+        // guess is vmcnt(0): the patch DMA drained once per tile again).  The first interval and the last NPB run the general form.
+        auto touch = [&](const Pre& d) {   // the loads into `d` are waited for HERE, on every path (then their registers are free to be re-used)
+#ifndef DPC_SIMT_EMU
+            DPC_UNROLL
+            for (int q = 0; q < NQ; ++q) asm volatile("" ::"v"(d.add[q]), "v"(d.raw[q]), "v"(d.ab[q]), "v"(d.bb[q]));
+#else
+            (void)d;
+#endif
+        };
+        auto interval = [&](auto steady_c, int j, Pre& fill, const Pre& use) {
+            constexpr bool STEADY = decltype(steady_c)::value;
             // patch j must have landed.  Newer than its pieces are: this wave's stores of older tiles and the LIT pieces of each
             // of the patches j+1 .. j+NPB-2.  Loads (LDS-DMA included) complete in order among themselves, so "at most that many
             // outstanding" implies every piece of patch j is done whatever the stores do.  (The addend / raw / mask loads of the
             // residual and fused-reduction variants are requested between two patches: counting them as absent only makes the
             // wait stricter.)
-            if (j < ntiles) {
+            if constexpr (STEADY) {
+                if (NPB - 2 >= 2) wait_vmcnt<2 * LIT>(); else wait_vmcnt<LIT>();
+            } else if (j < ntiles) {
                 const int newer = ntiles - 1 - j < NPB - 2 ? ntiles - 1 - j : NPB - 2;
                 if (newer >= 2) wait_vmcnt<2 * LIT>(); else if (newer == 1) wait_vmcnt<LIT>(); else wait_vmcnt<0>();
             }
@@ -603,16 +627,22 @@ __global__ __launch_bounds__(512, 2) void conv_halo_ws_kernel(HaloParams p) {
                 }
             }
 #endif
-            if (PRE) {
-                Pre nxt = cur;
-                if (j < ntiles && j >= 1) prefetch(j, nxt);
-                if (j >= 1 && !HP_DBG(8)) epilogue(j - 1, cur);
-                cur = nxt;
-            } else if (j >= 1 && !HP_DBG(8)) {
-                epilogue(j - 1, cur);
-            }
-            if (j + NPB - 1 < ntiles) issue(j + NPB - 1);  // into the buffer of patch j-1, released at B2(j-1)
+            if (PRE && (STEADY || (j < ntiles && j >= 1))) prefetch(j, fill);
+            if (PRE) touch(use);
+            if ((STEADY || j >= 1) && !HP_DBG(8)) epilogue(j - 1, use);
+            if (STEADY || j + NPB - 1 < ntiles) issue(j + NPB - 1);  // into the buffer of patch j-1, released at B2(j-1)
             barrier_lds_only();  // B2(j)
+        };
+        const std::true_type steady = {};
+        const std::false_type general = {};
+        interval(general, 0, pre0, pre1);
+        int j = 1;
+        for (; j + 1 + NPB - 1 < ntiles; j += 2) {   // j odd: tile j's operands in pre1, tile j-1's in pre0
+            interval(steady, j, pre1, pre0);
+            interval(steady, j + 1, pre0, pre1);
+        }
+        for (; j <= ntiles; ++j) {
+            if (j & 1) interval(general, j, pre1, pre0); else interval(general, j, pre0, pre1);
         }
         // every patch has been consumed (last B2 passed): the first patch buffer becomes the reduction scratch
         float* red = (float*)lds;  // [2][256][EPO]

@@ -327,10 +327,15 @@ extern "C" int dpc_transpose2d_bf16x2(const void* in0, const void* in1, int32_t 
 // thread = one (n,t,hb,wb) cell; reads are float2 along W (coalesced NCDHW rows),
 // the write is one contiguous 16-channel cell.
 template <class TO>
-__global__ void pack_input_s2d_kernel(const float* in, TO* out, int BN, int T, int H, int W) {
+__global__ void pack_input_s2d_kernel(const float* in, TO* out, int BN, int T, int H, int W, int rev) {
     const int Hb = H / 2, Wb = W / 2;
     const long long cells = (long long)BN * T * Hb * Wb;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < cells; i += (long long)gridDim.x * blockDim.x) {
+    // rev (round 6): sweeps from the end of the tensor to its start, so that the HEAD of the operand is what the Infinity Cache holds
+    // when the stem convolution starts reading it front to back
+    const long long stride = (long long)gridDim.x * blockDim.x, first = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long nsweep = first < cells ? (cells - 1 - first) / stride + 1 : 0;
+    for (long long k = 0; k < nsweep; ++k) {
+        const long long i = first + (rev ? nsweep - 1 - k : k) * stride;
         const unsigned ci = (unsigned)i;  // cells < 2^31: 32-bit index math
         const unsigned q1 = ci / (unsigned)Wb;
         const int wb = (int)(ci - q1 * (unsigned)Wb);
@@ -364,10 +369,11 @@ extern "C" int dpc_pack_input_s2d(const float* block, void* out, int32_t dtype_o
     if (!block || !out || BN <= 0 || T <= 0 || H <= 0 || W <= 0) return DPC_ERR_ARG;
     if ((H & 1) || (W & 1)) return DPC_ERR_UNSUPPORTED;
     const long long cells = (long long)BN * T * (H / 2) * (W / 2);
+    static const int rev = getenv("DPC_PACK_REV") ? atoi(getenv("DPC_PACK_REV")) : 0;
     if (dtype_out == DPC_F32) {
-        DPC_LAUNCH((pack_input_s2d_kernel<float>), dim3(grid_for(cells, 256, 16384)), dim3(256), stream, block, (float*)out, BN, T, H, W);
+        DPC_LAUNCH((pack_input_s2d_kernel<float>), dim3(grid_for(cells, 256, 16384)), dim3(256), stream, block, (float*)out, BN, T, H, W, rev);
     } else if (dtype_out == DPC_BF16) {
-        DPC_LAUNCH((pack_input_s2d_kernel<bf16_t>), dim3(grid_for(cells, 256, 16384)), dim3(256), stream, block, (bf16_t*)out, BN, T, H, W);
+        DPC_LAUNCH((pack_input_s2d_kernel<bf16_t>), dim3(grid_for(cells, 256, 16384)), dim3(256), stream, block, (bf16_t*)out, BN, T, H, W, rev);
     } else {
         return DPC_ERR_ARG;
     }

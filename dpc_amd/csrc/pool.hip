@@ -15,7 +15,7 @@ static inline unsigned grid_for(long long n, int block = 256, int cap = 16384) {
 // scan order (torch max_pool semantics), or 9 when the maximum is 0 (ReLU kills the gradient).
 template <class T>
 __global__ void bn_relu_maxpool_fwd_kernel(const T* x, int NT, int H, int W, int C, int Ho, int Wo,
-                                           const float* scale, const float* shift, T* y, uint8_t* argmax) {
+                                           const float* scale, const float* shift, T* y, uint8_t* argmax, int rev) {
     constexpr int E = Elt<T>::PER16;
     const int upr = C / E;
     const long long units = (long long)NT * Ho * Wo * upr;
@@ -26,7 +26,12 @@ __global__ void bn_relu_maxpool_fwd_kernel(const T* x, int NT, int H, int W, int
     // -- 2 048 independent streams -- measured slower: 1 132 us against 878.)
     unsigned blk = blockIdx.x;
     if ((gridDim.x & 7u) == 0u) blk = (blk & 7u) * (gridDim.x >> 3) + (blk >> 3);
-    for (long long i = (long long)blk * blockDim.x + threadIdx.x; i < units; i += (long long)gridDim.x * blockDim.x) {
+    // rev (round 6): the sweeps of the grid run from the END of the tensor to its start -- the stem convolution wrote x front to back
+    // (its tail is what the Infinity Cache still holds) and layer1's first convolution reads y front to back next
+    const long long stride = (long long)gridDim.x * blockDim.x, first = (long long)blk * blockDim.x + threadIdx.x;
+    const long long nsweep = first < units ? (units - 1 - first) / stride + 1 : 0;
+    for (long long k = 0; k < nsweep; ++k) {
+        const long long i = first + (rev ? nsweep - 1 - k : k) * stride;
         const unsigned pidx = (unsigned)(i / upr);  // pooled position < 2^31: 32-bit index math from here on
         const int cu = (int)(i - (long long)pidx * upr);
         const unsigned q1 = pidx / (unsigned)Wo;
@@ -93,12 +98,13 @@ extern "C" int dpc_bn_relu_maxpool_fwd(const void* x, int32_t dtype, int32_t NT,
     if (!x || !y || !argmax || !scale || !shift || NT <= 0 || H <= 0 || W <= 0 || C <= 0) return DPC_ERR_ARG;
     const int E = dtype == DPC_BF16 ? 8 : 4;
     if (C % E) return DPC_ERR_UNSUPPORTED;
+    static const int rev = getenv("DPC_POOL_FWD_REV") ? atoi(getenv("DPC_POOL_FWD_REV")) : 0;
     const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
     const long long units = (long long)NT * Ho * Wo * (C / E);
     if (dtype == DPC_F32) {
-        DPC_LAUNCH((bn_relu_maxpool_fwd_kernel<float>), dim3(grid_for(units)), dim3(256), stream, (const float*)x, NT, H, W, C, Ho, Wo, scale, shift, (float*)y, argmax);
+        DPC_LAUNCH((bn_relu_maxpool_fwd_kernel<float>), dim3(grid_for(units)), dim3(256), stream, (const float*)x, NT, H, W, C, Ho, Wo, scale, shift, (float*)y, argmax, rev);
     } else if (dtype == DPC_BF16) {
-        DPC_LAUNCH((bn_relu_maxpool_fwd_kernel<bf16_t>), dim3(grid_for(units)), dim3(256), stream, (const bf16_t*)x, NT, H, W, C, Ho, Wo, scale, shift, (bf16_t*)y, argmax);
+        DPC_LAUNCH((bn_relu_maxpool_fwd_kernel<bf16_t>), dim3(grid_for(units)), dim3(256), stream, (const bf16_t*)x, NT, H, W, C, Ho, Wo, scale, shift, (bf16_t*)y, argmax, rev);
     } else {
         return DPC_ERR_ARG;
     }

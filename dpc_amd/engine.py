@@ -456,9 +456,10 @@ class _Block:
         fold_c1   conv2's input-gradient takes bn1's backward reduction;
         gate      conv1's input-gradient adds the block's incoming gradient gated by the output ReLU mask (no dz tensor);
         fold_prev ... and takes the backward reduction of the PREVIOUS block's bn2, whose output gradient it writes."""
-        self.fold_c1 = self.c2.supports(False, False, True)
+        red = bool(int(os.environ.get("DPC_FOLD_RED", "1")))   # probe: the reductions as their own launches, the gated addend stays fused
+        self.fold_c1 = red and self.c2.supports(False, False, True)
         self.gate = self.ds is None and self.c1.supports(True, self.final_relu, False)
-        self.fold_prev = bool(prev is not None and self.gate and self.c1.supports(True, self.final_relu, True))
+        self.fold_prev = bool(red and prev is not None and self.gate and self.c1.supports(True, self.final_relu, True))
         self.prev = prev
 
     def backward(self, dout: torch.Tensor, need_dx: bool = True) -> Optional[torch.Tensor]:
