@@ -24,6 +24,8 @@ from __future__ import annotations
 
 import math
 import os
+import threading
+import warnings
 from typing import Dict, List, Optional
 
 import torch
@@ -35,12 +37,23 @@ from .engine import DPCEngine, LAYER_PLAN, LAYER_WIDTH, param_shapes
 
 _DTYPE_NAMES = {"bf16": torch.bfloat16, "bfloat16": torch.bfloat16, "f32": torch.float32, "float32": torch.float32}
 
-# nn.DataParallel over several devices (dpc/main.py:65 with more than one id in --gpu): torch replicates the module per forward --
-# shallow copies whose parameters are broadcast non-leaf tensors (torch nn/parallel/replicate.py) -- and runs them in threads.  The
-# engine behind this module is ONE device's static schedule (buffers, arenas, captured graphs): a replica would rebuild a whole engine
-# every forward, on another device, and hand its gradients to nobody.  The multi-GPU route of this build is one process per GPU with
-# an RCCL all-reduce (dpc_amd/parallel.py), so a replica's forward stops here.  One visible device is fine: DataParallel then calls
-# the module itself (torch nn/parallel/data_parallel.py:187-195) and never replicates.
+# nn.DataParallel over several devices (dpc/main.py:65-66 with more than one id in --gpu): torch replicates the module per forward --
+# shallow copies whose parameters are broadcast non-leaf tensors (torch nn/parallel/replicate.py) -- and runs them in one thread per
+# device (data_parallel.py:173-198).  The engine behind this module is ONE device's static schedule (buffers, arenas), so a replica
+# does not own one: it looks up the engine of ITS device in a registry that hangs off the root module (built at the replica's first
+# forward there, kept across steps), copies the broadcast parameters into that engine's arena -- the 58 MB per device and step that
+# the reference's broadcast costs as well -- and returns a score whose backward hands the engine's gradients to the broadcast
+# copies, so torch's Broadcast.backward reduce-adds them onto the root's parameters on device 0 exactly as for the reference.
+# Negatives, BatchNorm statistics and dropout are per replica, as they are under the reference's DataParallel (dpc/main.py:180,
+# 211-213).  This is the reference's unmodified entry made to work, not the fast route: one process per GPU with an RCCL all-reduce
+# (`python -m dpc_amd.main --gpu 0,1,...`, dpc_amd/parallel.py) keeps parameters resident, overlaps the exchange and replays graphs.
+_REPLICA_NOTE = ("dpc_amd.DPC_RNN under nn.DataParallel over several devices: every forward re-broadcasts the parameters and copies them "
+                 "into a per-device engine (the reference's DataParallel semantics, kept for drop-in compatibility).  The fast multi-GPU "
+                 "route is one process per GPU with an RCCL gradient all-reduce: `python -m dpc_amd.main --gpu 0,1,...` (same flags as "
+                 "dpc/main.py) or torch.nn.parallel.DistributedDataParallel under torch.distributed.run")
+
+
+# the downstream classifier (dpc_amd/lc.py) keeps the single-device rule
 _REPLICA_ERROR = ("dpc_amd.DPC_RNN cannot run as an nn.DataParallel replica (DataParallel over more than one device replicates the "
                   "module every forward; the MI355X engine is a single-device static schedule).  Multi-GPU training is one process "
                   "per GPU with an RCCL gradient all-reduce: `python -m dpc_amd.main --gpu 0,1,...` (same flags as dpc/main.py), or "
@@ -129,6 +142,29 @@ class _DPCScore(torch.autograd.Function):
         return (None, None, None, None) + tuple(grads)
 
 
+class _DPCScoreReplica(torch.autograd.Function):
+    """the score of one nn.DataParallel replica: forward on the replica's device engine, backward hands that engine's gradients to the
+    broadcast parameter copies (views of its gradient arena: Broadcast.backward's reduce-add reads them before the next forward)"""
+
+    @staticmethod
+    def forward(ctx, eng, names, block, train, masks, *params):
+        eng.load_params({k: p.detach() for k, p in zip(names, params)})
+        eng._replica_generation = getattr(eng, "_replica_generation", 0) + 1
+        score = eng.forward(block, train=train, dropout_masks=masks)
+        ctx.eng, ctx.names, ctx.generation, ctx.used = eng, names, eng._replica_generation, False
+        return score
+
+    @staticmethod
+    def backward(ctx, dscore):
+        eng = ctx.eng
+        if ctx.generation != eng._replica_generation or ctx.used:
+            raise RuntimeError("dpc_amd.DPC_RNN (DataParallel replica): backward of a score whose saved activations are gone (a later "
+                               "forward on the same device, or a second backward)")
+        ctx.used = True
+        eng.backward(dscore_external=dscore)
+        return (None, None, None, None, None) + tuple(eng.G[k] for k in ctx.names)
+
+
 class DPC_RNN(nn.Module):
     """DPC with RNN (dpc/model_3d.py:14)"""
 
@@ -152,6 +188,10 @@ class DPC_RNN(nn.Module):
         self._fwd_generation = 0
         self._simulator = _simulator  # tests only: the host-side SIMT simulator handle (CPU tier); never set by the product
         self._score_bufs = None
+        # engines of nn.DataParallel replicas by (device, slot, batch, compute dtype); the dict and its lock are shared with every replica
+        # (a replica's __dict__ is a shallow copy of the root's: torch nn/modules/module.py _replicate_for_data_parallel)
+        self._replica_engines: Dict[tuple, DPCEngine] = {}
+        self._replica_lock = threading.Lock()
         if os.environ.get("DPC_COMPUTE_DTYPE"):   # select the throughput mode without touching the reference's constructor call
             want = os.environ["DPC_COMPUTE_DTYPE"].lower()
             if want not in _DTYPE_NAMES:
@@ -195,7 +235,7 @@ class DPC_RNN(nn.Module):
     def forward(self, block):
         # block: [B, N, C, SL, H, W] (dpc/model_3d.py:47-49)
         if getattr(self, "_is_replica", False):
-            raise RuntimeError(_REPLICA_ERROR)
+            return self._replica_forward(block)
         if block.device.type != "cuda" and self._simulator is None:
             raise L.DpcError("dpc_amd.DPC_RNN runs on MI355X only: move the module and the input to a cuda (HIP) device")
         self._ensure_engine(block)
@@ -206,6 +246,36 @@ class DPC_RNN(nn.Module):
         if self.mask is None:  # only compute mask once (model_3d.py:86-96); contiguous
             self.mask = self._engine.get_mask()
         return [score, self.mask]
+
+    def _replica_forward(self, block):
+        """forward of an nn.DataParallel replica (see _REPLICA_NOTE): per-device engine from the root's registry, parameters = the
+        broadcast copies torch hung on this replica, gradients back through them"""
+        if block.device.type != "cuda" and self._simulator is None:
+            raise L.DpcError("dpc_amd.DPC_RNN runs on MI355X only: move the module and the input to a cuda (HIP) device")
+        dev, B = block.device, block.shape[0]
+        slot = getattr(self, "_replica_slot", dev.index or 0)   # tests on the simulator tell two "devices" apart by slot
+        params = []
+        for k in self._param_names:   # the broadcast copies are plain attributes of the replicated holder modules (replicate.py)
+            obj = self
+            for part in k.split("."):
+                obj = getattr(obj, part)
+            params.append(obj)
+        key = (str(dev), slot, B, self.compute_dtype)
+        with self._replica_lock:
+            eng = self._replica_engines.get(key)
+            if eng is None:
+                if not self._replica_engines:
+                    warnings.warn(_REPLICA_NOTE, stacklevel=3)
+                eng = DPCEngine(self.network, self.sample_size, self.num_seq, self.seq_len, self.pred_step, B, dev, self.compute_dtype,
+                                self.widths, lib=self._simulator, seed=233 + slot)   # per-replica dropout stream (dpc/model_3d.py:18 seeds 233)
+                for old_key in [q for q in self._replica_engines if q[:2] == key[:2]]:   # another batch size / dtype on this device: one engine per device
+                    del self._replica_engines[old_key]
+                self._replica_engines[key] = eng
+        masks = self._forced_masks
+        if isinstance(masks, (list, tuple)):
+            masks = masks[slot]
+        score = _DPCScoreReplica.apply(eng, tuple(self._param_names), block.float(), self.training, masks, *params)
+        return [score, eng.get_mask()]
 
     def reset_mask(self):
         self.mask = None

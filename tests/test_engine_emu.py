@@ -248,8 +248,8 @@ def _small(emu, seed):
 
 def test_data_parallel_entry(emu):
     """dpc/main.py:65-66: `model = nn.DataParallel(model)`.  With one (or no) visible device DataParallel calls the wrapped module
-    itself (torch nn/parallel/data_parallel.py:187-195): the wrapped drop-in steps exactly like the bare one.  A REPLICA -- what
-    DataParallel builds per forward over several devices -- refuses loudly and names the supported multi-GPU entry."""
+    itself (torch nn/parallel/data_parallel.py:187-195): the wrapped drop-in steps exactly like the bare one.  (Several devices:
+    test_data_parallel_replicas below.)"""
     from dpc_amd.optim import Adam
     x = O.make_input_pcg(1, 4, 5, 64)
     crit = torch.nn.CrossEntropyLoss()
@@ -261,9 +261,75 @@ def test_data_parallel_entry(emu):
     assert la == lb
     for (ka, pa), (kb, pb) in zip(bare.named_parameters(), wrapped.module.named_parameters()):
         assert ka == kb and torch.equal(pa, pb), ka
-    replica = wrapped.module._replicate_for_data_parallel()
-    with pytest.raises(RuntimeError, match=r"python -m dpc_amd\.main --gpu"):
-        replica(x)
+
+
+def _cpu_replicas(root, n):
+    """what torch.nn.parallel.replicate builds per forward (replicate.py): shallow module copies (_replicate_for_data_parallel) wired
+    like the original, whose parameters are NON-LEAF copies set as plain attributes.  p.clone() stands in for Broadcast.apply: a
+    differentiable copy whose gradients add up on the root's leaf parameter, as Broadcast.backward's reduce-add does across devices."""
+    modules = list(root.modules())
+    idx = {m: i for i, m in enumerate(modules)}
+    out = []
+    for j in range(n):
+        copies = [m._replicate_for_data_parallel() for m in modules]
+        for i, m in enumerate(modules):
+            for key, child in m._modules.items():
+                setattr(copies[i], key, copies[idx[child]])
+            for key, prm in m._parameters.items():
+                setattr(copies[i], key, prm.clone())
+        copies[0]._replica_slot = j          # on the GPU the device index tells the replicas apart
+        out.append(copies[0])
+    return out
+
+
+def test_data_parallel_replicas(emu):
+    """dpc/main.py:65-66 with several ids in --gpu: DataParallel scatters the batch, replicates the module, runs the replicas and
+    gathers [score, mask] along dim 0 (data_parallel.py:187-198).  A replica of the drop-in finds the engine of ITS device in the
+    root's registry, loads the broadcast parameters, and its backward feeds the broadcast copies: the root's .grad is the gradient
+    of the reference's loss over the gathered rows = the mean of the per-shard reference gradients (per-GPU negatives and batch
+    statistics, dpc/main.py:180,211-213).  Two hand-made replicas on the simulator; the GPU form needs two devices."""
+    import warnings
+    root = _small(emu, 4)
+    xg = O.make_input_pcg(2, 4, 5, 64)
+    crit = torch.nn.CrossEntropyLoss()
+    opt = torch.optim.Adam(root.parameters(), lr=1e-3, weight_decay=1e-5)      # dpc/main.py:80-81 (root parameters stay ordinary leaves)
+    p0 = {k: v.detach().clone() for k, v in root.named_parameters()}
+    engines = []
+    for step in range(2):
+        reps = _cpu_replicas(root, 2)
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            outs = [r(xg[j:j + 1]) for j, r in enumerate(reps)]                 # parallel_apply
+        assert (len(w) == 1 and "dpc_amd.main --gpu" in str(w[0].message)) == (step == 0)   # the pointer to the fast route, once
+        score_, mask_ = torch.cat([o[0] for o in outs]), torch.cat([o[1] for o in outs])   # gather
+        B, NP, SQ, B2, NS, _ = mask_.size()                                   # dpc/main.py:209-217: B = 2 replicas x B2 = 1
+        assert (B, B2) == (2, 1)
+        target = (mask_ == 1).view(B * NP * SQ, B2 * NS * SQ).to(int).argmax(dim=1)
+        loss = crit(score_.view(B * NP * SQ, B2 * NS * SQ), target)
+        opt.zero_grad()
+        loss.backward()
+        if step == 0:
+            grads = {k: v.grad.clone() for k, v in root.named_parameters()}
+            loss0 = loss.item()
+        opt.step()
+        engines.append(sorted(id(e) for e in root._replica_engines.values()))
+    assert len(root._replica_engines) == 2 and engines[0] == engines[1]          # one engine per device, kept across steps
+    assert sorted(e.seed for e in root._replica_engines.values()) == [233, 234]  # per-replica dropout streams
+    assert root.engine is None                                                  # the root itself never ran
+    want_loss, want = 0.0, {k: torch.zeros_like(v) for k, v in p0.items()}
+    names = list(p0)
+    for j in range(2):   # the oracle on ONE shard (4 score rows: too few for train_step_reference's top-5)
+        leaves = {k: p0[k].clone().requires_grad_(True) for k in names}
+        sc = O.dpc_forward(leaves, xg[j:j + 1], "resnet18", 1, None)
+        l = torch.nn.functional.cross_entropy(sc.reshape(4, 4), torch.arange(4))
+        g = dict(zip(names, torch.autograd.grad(l, [leaves[k] for k in names])))
+        want_loss += 0.5 * l.item()
+        for k in want:
+            want[k] += 0.5 * g[k]
+    assert abs(loss0 - want_loss) < 1e-4
+    for k, g in want.items():
+        assert (grads[k] - g).abs().max().item() < 2e-3 * max(g.abs().max().item(), 1e-6), k
+    assert any(not torch.equal(p0[k], v.detach()) for k, v in root.named_parameters())   # torch's Adam stepped the root's leaves
 
 
 def test_engine_rebuild_keeps_the_optimizer_state(emu):

@@ -139,18 +139,12 @@ def test_module_drop_in(golden_dir):
 def test_data_parallel_entry_vs_reference(golden_dir):
     """The reference's literal entry, dpc/main.py:65-66: `model = nn.DataParallel(model); model = model.to(cuda)`, then its loop lines
     (:198-231) -- score, loss, gradient norms and the Adam step against the reference's own outputs (train.npz).  With one visible
-    device DataParallel calls the module itself (torch nn/parallel/data_parallel.py:187-195); over several devices it replicates,
-    and a replica refuses loudly (tests/test_engine_emu.py::test_data_parallel_entry holds the message on the CPU tier)."""
+    device DataParallel calls the module itself (torch nn/parallel/data_parallel.py:187-195); several devices:
+    test_data_parallel_two_devices below, tests/test_engine_emu.py::test_data_parallel_replicas on the CPU tier."""
     g = gold(golden_dir, "train.npz")
     model = DPC_RNN(sample_size=64, num_seq=8, seq_len=5, pred_step=3, network="resnet18")
     model.load_state_dict(O.make_params_pcg("resnet18"), strict=True)
-    if torch.cuda.device_count() > 1:
-        many = torch.nn.DataParallel(model).to(DEV)
-        with pytest.raises(RuntimeError, match=r"python -m dpc_amd\.main --gpu"):
-            many(O.make_input_pcg(2, 8, 5, 64).to(DEV))
-        model = torch.nn.DataParallel(model, device_ids=[0])
-    else:
-        model = torch.nn.DataParallel(model)                     # dpc/main.py:65
+    model = torch.nn.DataParallel(model, device_ids=[0]) if torch.cuda.device_count() > 1 else torch.nn.DataParallel(model)   # dpc/main.py:65
     model = model.to(DEV)                                         # :66
     criterion = torch.nn.CrossEntropyLoss()                       # :67
     params = model.parameters()                                   # :74
@@ -182,6 +176,37 @@ def test_data_parallel_entry_vs_reference(golden_dir):
         w = sd["module." + n].cpu()
         slack = 2e-3 * (2 + 2e-3 * w.numel())
         assert w.double().sum().item() == pytest.approx(float(g["adam_sum_p0"][i]), rel=1e-5, abs=slack), n
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two MI355X on the node")
+def test_data_parallel_two_devices():
+    """dpc/main.py:65-66 with `--gpu 0,1`: torch's own DataParallel over two devices -- scatter, replicate (parameter broadcast),
+    one thread per replica, gather of [score, mask] -- around the drop-in.  The gathered score is [B, P, SQ, B2, P, SQ] with per-GPU
+    negatives (dpc/main.py:211-213); loss and the root's gradients equal the mean of the per-shard reference steps."""
+    p = O.make_params_pcg("resnet18")
+    model = DPC_RNN(sample_size=64, num_seq=8, seq_len=5, pred_step=3, network="resnet18")
+    model.load_state_dict(p, strict=True)
+    model = torch.nn.DataParallel(model, device_ids=[0, 1]).to(DEV).eval()
+    x = O.make_input_pcg(4, 8, 5, 64)
+    with pytest.warns(UserWarning, match="dpc_amd.main --gpu"):
+        score_, mask_ = model(x.to(DEV))
+    B, NP, SQ, B2, NS, _ = mask_.size()
+    assert (B, B2) == (4, 2) and score_.shape == mask_.shape and score_.device == torch.device(DEV)
+    target = (mask_ == 1).view(B * NP * SQ, B2 * NS * SQ).to(int).argmax(dim=1)
+    loss = torch.nn.CrossEntropyLoss()(score_.view(B * NP * SQ, B2 * NS * SQ), target)
+    loss.backward()
+    want_loss, want = 0.0, None
+    for j in range(2):
+        l, _, gr, sc = O.train_step_reference(p, x[2 * j:2 * j + 2], "resnet18", 3, None)
+        assert (score_[2 * j:2 * j + 2].detach().cpu() - sc).abs().max().item() < TOL
+        want_loss += 0.5 * l.item()
+        want = {k: 0.5 * v for k, v in gr.items()} if want is None else {k: want[k] + 0.5 * v for k, v in gr.items()}
+    assert abs(loss.item() - want_loss) < TOL
+    named = dict(model.module.named_parameters())
+    for k, gref in want.items():
+        got = named[k].grad.cpu()
+        assert ((got - gref).norm() / gref.norm().clamp_min(1e-12)).item() < 2e-2, k
+    assert len(model.module._replica_engines) == 2 and model.module.engine is None
 
 
 def test_bf16_mode_tracks_fp32(golden_dir):
