@@ -60,11 +60,12 @@ def csrc_sha16():
     return h.hexdigest()[:16]
 
 
-def live_pmc_traffic(config="cfg2", timeout_s=150):
+def live_pmc_traffic(config="cfg2", timeout_s=90):
     """HBM bytes per launch of the conv family, measured IN THIS RUN: two rocprofv3 passes (FETCH_SIZE, then WRITE_SIZE -- separate
     --pmc runs with --kernel-trace only, as /opt/skills/guides/MI355X_MICROARCH.md prescribes) of a child `bench.py` that launches two
-    eager steps of the same workload, summarised with the guide's gfx950 correction (scripts/pmc_traffic.py).  Returns
-    (summary dict, None) or (None, reason).  Costs ~40 s; `--pmc file` reads the tracked profile instead, `--pmc off` skips it."""
+    eager steps of the same workload, summarised with the guide's gfx950 correction (scripts/pmc_traffic.py; both child steps run the same static schedule, so averaging over them
+    changes nothing).  Returns (summary dict, None) or (None, reason).  Costs ~40 s, at most 2 x 90 s when a pass hangs (it is killed, the line
+    then falls back to the tracked profile); `--pmc file` reads the tracked profile instead, `--pmc off` skips it."""
     import glob
     import shutil
     import subprocess
@@ -364,6 +365,9 @@ def main():
                          "collectives; opt-in: a side measurement must not be able to cost a scaling run its line)")
     ap.add_argument("--no-schedules", action="store_true", help="(accepted for compatibility: the side schedules are opt-in since round 5)")
     ap.add_argument("--no-graph", action="store_true", help="launch the step kernel by kernel instead of replaying a hipGraph")
+    ap.add_argument("--fresh-input", action="store_true", help="draw a new N(0,1) block on the device inside every timed step (torch's randn kernel, "
+                    "captured into the graph): +0.3 ms per step at cfg2.  Default: ONE resident synthetic block, re-used by every step "
+                    "(config.input says which)")
     ap.add_argument("--pmc", default="auto", choices=["auto", "live", "file", "off"],
                     help="roofline.traffic: live = two rocprofv3 --pmc passes of a child run (default at cfg2 / bf16 / one GPU: 'auto' tries it and "
                          "falls back to the tracked profiles/*_pmc_traffic.json, flagged); file = the tracked profile only; off = null")
@@ -415,12 +419,12 @@ def main():
     step_fn = None
     if use_graph:
         try:
-            step_fn = eng.capture_train_step(block, allreduce=allreduce)
+            step_fn = eng.capture_train_step(block, allreduce=allreduce, refill=(lambda: block.normal_()) if args.fresh_input else None)
         except Exception as e:  # report it, never hide it: the line says which launch mode was timed
             use_graph, graph_note = False, f" (hipGraph capture failed: {type(e).__name__}: {str(e)[:120]})"
             torch.cuda.synchronize()
     if step_fn is None:
-        step_fn = lambda: eng.train_step(block, allreduce=allreduce)  # noqa: E731
+        step_fn = (lambda: eng.train_step(block.normal_(), allreduce=allreduce)) if args.fresh_input else (lambda: eng.train_step(block, allreduce=allreduce))  # noqa: E731
 
     def sync():
         if dist is not None:
@@ -513,6 +517,9 @@ def main():
             "config": {"workload": f"{args.config}: {net} 2d3d, img_dim {img}, seq_len 5, num_seq 8, pred_step {P}, "
                                    f"batch {batch}/GPU, full train step (fwd+CE/top-k+bwd+all-reduce+Adam)",
                        "global_batch": batch * world, "parallelism": f"dp{world}", "init": "reference init, random",
+                       "input": ("a new N(0,1) block drawn on the device inside every timed step" if args.fresh_input else
+                                 "one resident N(0,1) block [B,8,3,5,H,W] f32 drawn on the device before the timed region and re-used by every step "
+                                 "(--fresh-input draws one per step inside the graph)"),
                        "launch": "hipGraph replay" if use_graph else "kernel by kernel" + graph_note,
                        "streams": 2 if getattr(eng, "_side", None) is not None else 1},   # weight gradients beside the next BatchNorm backward
             "final_loss": round(loss[0], 4),

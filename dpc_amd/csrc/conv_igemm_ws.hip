@@ -760,6 +760,228 @@ __global__ __launch_bounds__(512, 2) void igemm_wsp_kernel(WsParams p) {
     }
 }
 
+
+// =====================================================================================================================
+// Strided input-gradient over 16 x 16 gradient planes ("wsd", round 6): the input-gradient of layer2.0.conv1 of the 128 x 128
+// configurations -- Conv3d(64, 128, (1,3,3), stride (1,2,2), pad (0,1,1)), backbone/resnet_2d3d.py:24-32,241-244 -- which the
+// generic kernel ran in 520 us (0.37 PFLOP/s: parity-class tiles of 2..8 K chunks, each with its own decode, first-chunk round
+// trip and epilogue; HBM floor 160 us) and igemm_ws_kernel<., true> on its half-empty 128-column tile in 643.
+//
+// The transposed convolution as a DENSE-ish unit-stride one.  Output position (2a + py, 2b + px) of class (py, px) reads the
+// gradient positions (a + sy, b + sx) with sy <= py, sx <= px through tap ky = py ? (sy ? 0 : 2) : 1 (kx alike): over the 16 x 16
+// positions (a, b) of a gradient plane that is a 2 x 2 unit-stride convolution from 128 channels to 4 classes x 64 columns whose
+// weight matrix has 9 non-zero 128 x 64 blocks of 16.  igemm_wsp_kernel's machinery runs it: a tile IS one gradient plane staged
+// once as a zero-padded 18 x 18 patch per 64-channel group (the shifts are fragment-address constants), the weights stream
+// through the ring, rows of wd[ci][tap][co] picked per class and shift by the loaders (a class that does not see a shift gets
+// zero rows from the buffer resource), and the epilogue scatters a tile row's two 64-column halves to the two output positions
+// of its classes.  Classes are paired so that both kinds of column tile see at least three shifts (a patch must be issued three
+// chunk slots before its first use): A = {(1,1), (0,0)} over the four shifts, B = {(1,0), (0,1)} over three -- 14 chunks per plane
+// for 9 chunks' worth of products (64 % useful; the {(1,1),(1,0)} / {(0,1),(0,0)} pairing has 12 but a two-chunk group).  A
+// workgroup serves ONE kind (blockIdx < gm: A), its planes strided by the number of workgroups of its kind; the split between
+// the kinds follows their chunk counts (plus the epilogue both pay per plane).
+__global__ __launch_bounds__(512, 2) void igemm_wsd_kernel(WsParams p) {
+    typedef bf16_t TO;
+    constexpr int BM = 256, BN = 128;
+    constexpr int PWD = 18, NPP = PWD * PWD, NPIECE = (NPP + 7) / 8, PATCH = NPIECE * 1024;
+    constexpr int BST = BN * 128, NSB = 4;
+    constexpr int EPO = 8;
+    constexpr int MAXP = (NPIECE + 3) / 4;
+    static_assert(4 * WS_STG_WAVE <= PATCH, "epilogue staging fits a patch buffer");
+    static_assert(2 * PATCH + NSB * BST <= 160 * 1024, "patches + ring fit the CU's LDS");
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * PATCH + NSB * BST];
+    unsigned char* const bring = lds + 2 * PATCH;
+
+    const GatherGeom& g = p.g;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+#ifdef DPC_SIMT_EMU
+    const int wv = tid >> 6;
+#else
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+#endif
+    const bool kindB = (int)blockIdx.x >= p.gm;
+    const int m_prog = kindB ? (int)blockIdx.x - p.gm : (int)blockIdx.x;
+    const int gmk = kindB ? p.ntn : p.gm;          // workgroups of this kind (p.ntn carries kind B's count)
+    const int CPG = kindB ? 3 : 4;                 // chunks (= shifts) per channel group
+    const int G = g.Ci >> 6;
+    const int nkc = CPG * G;
+    const int my_tiles = m_prog < p.ntm ? (p.ntm - m_prog + gmk - 1) / gmk : 0;
+    const int total = my_tiles * nkc;
+    // classes of the two 64-column halves: kind A (1,1) | (0,0), kind B (1,0) | (0,1)
+    const int py0 = 1, px0 = kindB ? 0 : 1, py1 = 0, px1 = kindB ? 1 : 0;
+    // shift of chunk q of a group: A (0,0) (0,1) (1,0) (1,1); B (0,0) (1,0) (0,1)
+    auto shift_of = [&](int q, int& sy, int& sx) {
+        if (kindB) { sy = q == 1; sx = q == 2; } else { sy = q >> 1; sx = q & 1; }
+    };
+
+    if (wv >= 4) {
+        // ------------------------------------------------------------------ loader waves
+        const int lw = wv - 4;
+        const int rl = lane >> 3;
+        const BufRsrc rs_a = make_buf_rsrc(p.src, p.src_bytes);
+        const BufRsrc rs_b = make_buf_rsrc(p.wgt, p.wgt_bytes);
+        const int ub = (lane & 7) ^ lds_swz1(8 * lw + rl);
+        // weight-tile rows 8 (lw + 4 i) + rl: i = 0, 1 are the first class half, i = 2, 3 the second; row inside the half = output column ci
+        unsigned wrow[4];
+        DPC_UNROLL
+        for (int i = 0; i < 4; ++i) {
+            const int n = 8 * (lw + 4 * (i & 1)) + rl;
+            wrow[i] = (unsigned)(n * p.ldw + ub * 8) * 2u;
+        }
+        unsigned poff[MAXP];
+        DPC_UNROLL
+        for (int i = 0; i < MAXP; ++i) {
+            const int pp = 8 * (lw + 4 * i) + rl;
+            const int pr = pp / PWD, pc = pp - pr * PWD;
+            const bool ok = pp < NPP && pr >= 1 && pr <= 16 && pc >= 1 && pc <= 16;
+            const int up = (lane & 7) ^ ((pc >> 1) & 7);
+            poff[i] = ok ? (unsigned)((((pr - 1) * 16 + (pc - 1)) * g.src_ld + up * 8) * 2) : DPC_BUF_OOB;
+        }
+        const int n_mine = (NPIECE - lw + 3) / 4;
+        int issued = 0;
+        auto issue_patch = [&](int gg, int i0, int i1) {
+            const int tl = gg / G, grp = gg - tl * G;
+            const int mt = m_prog + tl * gmk;
+            const unsigned soff = (unsigned)((mt * BM * g.src_ld + grp * 64) * 2);
+            unsigned char* dst = lds + (gg & 1) * PATCH;
+            DPC_UNROLL
+            for (int i = 0; i < MAXP; ++i)
+                if (i >= i0 && i < i1 && i < n_mine) {
+                    glds16_buf(rs_a, poff[i], soff, dst + (lw + 4 * i) * 1024, lane);
+                    ++issued;
+                }
+        };
+        auto issue_b = [&](int gc) {
+            const int gg = gc / CPG, q = gc - gg * CPG;
+            const int grp = gg % G;
+            int sy, sx;
+            shift_of(q, sy, sx);
+            unsigned char* st = bring + (gc % NSB) * BST;
+            DPC_UNROLL
+            for (int i = 0; i < 4; ++i) {
+                const int py = i < 2 ? py0 : py1, px = i < 2 ? px0 : px1;
+                const bool valid = sy <= py && sx <= px;
+                const int ky = py ? (sy ? 0 : 2) : 1, kx = px ? (sx ? 0 : 2) : 1;
+                const unsigned kd = (unsigned)((ky * 3 + kx) * g.Ci + grp * 64);
+                glds16_buf(rs_b, valid ? wrow[i] : DPC_BUF_OOB, kd * 2u, st + (lw + 4 * i) * 1024, lane);
+            }
+            issued += 4;
+        };
+        // slots as in igemm_wsp_kernel: what is issued between two chunk barriers, patch pieces first, the weights of chunk c+3 last;
+        // "at most (slot c-2) + (slot c-1) operations outstanding" = the weights of chunk c, and every patch piece issued before them,
+        // have landed.  A group has only CPG = 4 / 3 chunks, and its patch must be complete at its first chunk's barrier, i.e. issued
+        // in slots <= first - 3: all of the NEXT group's pieces go out in the first CPG - 2 slots of this group.
+        const int pslots = CPG - 2, ppc = (MAXP + pslots - 1) / pslots;
+        if (total > 0) {
+            issue_patch(0, 0, MAXP);
+            issue_b(0);
+        }
+        issued = 0;
+        if (total > 1) issue_b(1);
+        int o2 = issued;
+        issued = 0;
+        if (total > 2) issue_b(2);
+        int o1 = issued;
+        for (int gc = 0; gc < total; ++gc) {
+            wait_vmcnt_upto(o1 + o2);
+            ws_barrier();  // chunk gc (and, at a group's first chunk, its patch) is published; every reader is done with chunk gc-1
+            const int gg = gc / CPG, q = gc - gg * CPG;
+            issued = 0;
+            if (q < pslots && (gg + 1) * CPG < total) issue_patch(gg + 1, ppc * q, ppc * q + ppc);
+            if (gc + 3 < total) issue_b(gc + 3);
+            o2 = o1;
+            o1 = issued;
+            if (q == CPG - 1 && (gg + 1) % G == 0) ws_barrier();  // matches the compute waves' "tile fully read" barrier
+        }
+        return;
+    }
+
+    // ---------------------------------------------------------------------- compute waves
+    const int l31 = lane & 31, lhi = lane >> 5;
+    // A fragments as in igemm_wsp_kernel: tile row r = gradient position (r >> 4, r & 15); shift (sy, sx) reads patch position
+    // (r >> 4 + 1 + sy) * 18 + (r & 15) + 1 + sx; slot swizzle by (patch column >> 1) & 7
+    int va[2];
+    {
+        const int pos0 = ((wv * 64 + l31) >> 4) * PWD + (l31 & 15);
+        DPC_UNROLL
+        for (int sx = 0; sx < 2; ++sx) {
+            const int dw = 1 + sx;
+            const int p7 = (((l31 & 15) + dw) >> 1) & 7;
+            va[sx] = (pos0 + dw) * 128 + ((lhi ^ p7) << 4);
+        }
+    }
+    const ldsa_t lds0 = ldsa(lds);
+    const int vb = lds_unit_off(l31, lhi);
+    const int cu = lane & 15, er = lane >> 4;
+    const int hpy = (cu >> 3) ? py1 : py0, hpx = (cu >> 3) ? px1 : px0;   // class of this lane's output unit
+    const int ccol = (cu & 7) * EPO;
+
+    int gc = 0;
+#ifndef DPC_SIMT_EMU
+    __builtin_amdgcn_s_setprio(3);
+#endif
+    for (int t = 0; t < my_tiles; ++t) {
+        const int mt = m_prog + t * gmk;
+        f32x16 acc[2][4];
+        DPC_UNROLL
+        for (int i = 0; i < 2; ++i)
+            DPC_UNROLL
+            for (int j = 0; j < 4; ++j)
+                DPC_UNROLL
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        {
+            FragSet f0, f1;
+            ws_barrier();  // first chunk of the tile (and its patch) published
+            int grp = 0, q = 0;
+            ldsa_t a_pat = lds0 + ((t * G) & 1) * PATCH;
+            ldsa_t pa = a_pat + PWD * 128 + va[0];   // shift (0, 0): patch row + 1
+            ldsa_t pb = lds0 + 2 * PATCH + (gc % NSB) * BST + vb;
+            frag_read_p2<4608>(f0, pa, pb);
+            for (int c = 0; c < nkc; ++c) {
+                step_il<true, 4608>(acc, f0, f1, pa ^ 32, pb ^ 32);
+                step_il<true, 4608>(acc, f1, f0, pa ^ 64, pb ^ 64);
+                step_il<true, 4608>(acc, f0, f1, pa ^ 96, pb ^ 96);
+                frag_wait<0>(f1);   // this wave's last reads of the chunk have landed
+                ws_barrier();  // next chunk published -- or, after the tile's last chunk, "tile fully read"
+                ++gc;
+                if (++q == CPG) { q = 0; ++grp; }
+                int sy, sx;
+                shift_of(q, sy, sx);
+                a_pat = lds0 + ((t * G + grp) & 1) * PATCH;
+                pa = a_pat + (1 + sy) * (PWD * 128) + (sx ? va[1] : va[0]);
+                pb = lds0 + 2 * PATCH + (gc % NSB) * BST + vb;
+                // after the tile's last chunk these reads fetch nothing useful (the next tile re-reads after ITS first barrier):
+                // unconditional, so that the MFMAs stay out of a branch
+                step_il<true, 4608>(acc, f1, f0, pa, pb);
+            }
+            WS_RETIRE_TAIL_READS(f0);
+        }
+
+        // ---- epilogue: two passes of 32 rows through this wave's 8 KB of the last group's patch buffer; a row's two 64-column
+        // halves go to the output positions of their classes
+        unsigned char* mine = lds + ((t * G + G - 1) & 1) * PATCH + wv * WS_STG_WAVE;
+        DPC_UNROLL
+        for (int i = 0; i < 2; ++i) {
+            stage_block(mine, acc[i], l31, lhi);
+            wave_lds_fence();
+            u32x4 ov[8];
+            DPC_UNROLL
+            for (int it = 0; it < 8; ++it) {
+                const int row_l = er + 4 * it;
+                ov[it] = *(const u32x4*)(mine + row_l * WS_STG_ROW + cu * EPO * 2);
+            }
+            wave_lds_fence();
+            DPC_UNROLL
+            for (int it = 0; it < 8; ++it) {
+                const int r = wv * 64 + i * 32 + er + 4 * it;
+                const int a = r >> 4, b = r & 15;
+                const long long orow = ((long long)mt * g.RH + 2 * a + hpy) * g.RW + 2 * b + hpx;
+                if (mt < p.ntm) *(u32x4*)((char*)p.out + (orow * p.ldo + ccol) * 2) = ov[it];
+            }
+        }
+    }
+}
+
 static int env_int(const char* name, int dflt) {
     const char* e = getenv(name);
     return e ? atoi(e) : dflt;
@@ -832,6 +1054,37 @@ static bool ws_plan(const dpc_conv_desc* d, WsParams* p) {
     return true;
 }
 
+// igemm_wsd_kernel: bf16 input-gradient of a 1 x 3 x 3 convolution with stride (1, 2, 2), pad (0, 1, 1) from 128 to 64 channels over
+// 16 x 16 gradient planes (32 x 32 output planes).  p->gm / p->ntn = workgroups of kind A / B, p->ntm = planes.
+static bool wsd_plan(const dpc_conv_desc* d, WsParams* p) {
+    static const int on = env_int("DPC_IGEMM_WSD", 1);
+    if (!on || !ws_enabled()) return false;
+    if (d->dtype_in != DPC_BF16 || d->dtype_out != DPC_BF16 || d->mode != 1) return false;
+    if (d->KT != 1 || d->KH != 3 || d->KW != 3 || d->st != 1 || d->sh != 2 || d->sw != 2 || d->pt != 0 || d->ph != 1 || d->pw != 1) return false;
+    if (d->RT != d->ST || d->SH != 16 || d->SW != 16 || d->RH != 32 || d->RW != 32) return false;
+    if (d->Ci != 128 || d->src_ld != 128 || d->Co != 64 || d->ldo % 8 || d->ldo < 64 || d->ldw % 8 || d->ldw < 9 * 128) return false;
+    GatherGeom& g = p->g;
+    if (make_gather_geom(d, &g)) return false;
+    const long long planes = (long long)d->N * d->RT;
+    if (planes * 256 * 128 * 2 >= (1ll << 30) || planes * 1024 * (long long)d->ldo * 2 >= (1ll << 40)) return false;   // 32-bit source offsets
+    static const int min_planes = env_int("DPC_WSD_MINPLANES", 512);
+    if (planes < min_planes) return false;   // too few planes to feed both kinds of workgroup: the generic kernel balances better
+    p->parity = 0; p->plane = 0; p->tgroup = 0; p->hw = 1; p->nclip = 0; p->tpt = 1; p->cpkt = 1; p->d_hw = make_fastdiv(1);
+    p->Ncol = d->Co; p->ldw = d->ldw; p->ldo = d->ldo;
+    p->src_bytes = (unsigned)(planes * 256 * 128 * 2);
+    p->wgt_bytes = (unsigned)(((long long)(d->Co - 1) * d->ldw + 9 * 128) * 2);
+    p->ntm = (int)planes;
+    // kind A walks 4 shifts x 2 groups = 8 chunks per plane, kind B 6, and both pay one epilogue (~2 chunks' worth): 10 : 8
+    static const int a_share = env_int("DPC_WSD_A_PERMILLE", 556);
+    const int wgs = dpc_persistent_grid(ws_max_programs());
+    int gma = (int)((long long)wgs * a_share / 1000);
+    if (gma < 1) gma = 1;
+    if (gma > wgs - 1) gma = wgs - 1;
+    p->gm = gma;
+    p->ntn = wgs - gma;
+    return wgs >= 2;
+}
+
 int dpc_conv_ws_rows(const dpc_conv_desc* d) {
     WsParams p;
     if (!d || !ws_plan(d, &p)) return 0;
@@ -842,6 +1095,12 @@ int dpc_conv_ws_rows(const dpc_conv_desc* d) {
 int dpc_conv_ws_try(const dpc_conv_desc* d, const void* src, const void* wgt, void* out, const void* addend, float* stats,
                     const EpiExtra& epi, hipStream_t stream) {
     WsParams p;
+    if (!addend && !stats && !epi_any(epi) && wsd_plan(d, &p)) {
+        if (((uintptr_t)out % 16) || ((uintptr_t)src % 16) || ((uintptr_t)wgt % 16)) return 1;
+        p.src = src; p.wgt = wgt; p.out = out; p.addend = nullptr; p.stats = nullptr; p.dbg = 0;
+        DPC_LAUNCH(igemm_wsd_kernel, dim3((unsigned)(p.gm + p.ntn)), dim3(512), stream, p);
+        return dpc_launch_status();
+    }
     if (!ws_plan(d, &p)) return 1;
     if (epi_any(epi)) return 1;  // the fused backward pieces of dpc_conv_igemm_ex are not built into these kernels (yet)
     if (addend && stats) return 1;  // not a combination of this path: the generic kernel serves it

@@ -474,7 +474,15 @@ __device__ __forceinline__ void wait_vmcnt_upto(int n) {
         case 9: wait_vmcnt<9>(); break;
         case 10: wait_vmcnt<10>(); break;
         case 11: wait_vmcnt<11>(); break;
-        default: wait_vmcnt<12>(); break;  // n >= 12: waiting for fewer outstanding operations is always safe
+        case 12: wait_vmcnt<12>(); break;
+        case 13: wait_vmcnt<13>(); break;
+        case 14: wait_vmcnt<14>(); break;
+        case 15: wait_vmcnt<15>(); break;
+        case 16: case 17: wait_vmcnt<16>(); break;   // waiting for fewer outstanding operations is always safe
+        case 18: case 19: wait_vmcnt<18>(); break;
+        case 20: case 21: wait_vmcnt<20>(); break;
+        case 22: case 23: wait_vmcnt<22>(); break;
+        default: if (n >= 24) wait_vmcnt<24>(); else wait_vmcnt<0>(); break;   // (n < 0 cannot happen: drain)
     }
 }
 

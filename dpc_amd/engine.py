@@ -203,6 +203,8 @@ def executed_fraction(name, args, kernel: str) -> float:
     algorithmic count."""
     if name not in ("dpc_conv_igemm", "dpc_conv_igemm_ex") or not kernel.startswith("igemm_ws_kernel"):
         return 1.0
+    if os.environ.get("DPC_IGEMM_WS_TGROUP", "1") == "0":   # the A/B switch of the temporal grouping: every tap runs
+        return 1.0
     d = args[0]._obj
     unit = d.st == 1 and d.sh == 1 and d.sw == 1
     if not (d.KT > 1 and unit and d.RT == d.ST and d.RT > 1):
@@ -1219,7 +1221,7 @@ class DPCEngine:
         gd = getattr(self, "gru_desc", None)
         return (float(self.lr), float(self.wd), float(gd.p_drop) if gd is not None else 0.0, int(gd.seed) if gd is not None else 0)
 
-    def capture_train_step(self, block: torch.Tensor, allreduce=None, warmup: int = 2):
+    def capture_train_step(self, block: torch.Tensor, allreduce=None, warmup: int = 2, refill=None):
         """Captures the whole train step on `block` (a static device buffer: refill it in place between replays) into
         hipGraphs and returns ``replay() -> device f32[4]``.  One graph without data parallelism; with the two-bucket
         gradient exchange the capture is cut where the backward hands the gradient tail to RCCL, so the replay is
@@ -1231,7 +1233,10 @@ class DPCEngine:
         # every host scalar the capture bakes into kernel arguments is part of the key (dpc_adam_dev takes lr / wd by value, the
         # recurrence descriptor p_drop / seed): after eng.lr = ... (LR schedule, checkpoint.resume, --reset_lr) asking again captures
         # a step with the new values instead of handing back the stale replay
-        key = (block.data_ptr(), tuple(block.shape), id(allreduce) if allreduce is not None else None, self.reserve_cus, tuple(sorted(self.side_off))) + self._baked_scalars()
+        # refill: optional callable captured in FRONT of the step (e.g. ``lambda: block.normal_()``: a fresh synthetic batch per replay
+        # from torch's graph-safe default generator -- SURVEY section 8d "generated ON DEVICE"); part of the key by identity
+        key = (block.data_ptr(), tuple(block.shape), id(allreduce) if allreduce is not None else None, self.reserve_cus, tuple(sorted(self.side_off)),
+               id(refill) if refill is not None else None) + self._baked_scalars()
         hit = self._captures.get(key)
         if hit is not None:   # the same static buffer, the same exchange: the capture that exists (see _LIVE_GRAPHS)
             return hit
@@ -1268,6 +1273,8 @@ class DPCEngine:
             with torch.cuda.stream(side):
                 begin()
                 self.packed_for_step = -1
+                if refill is not None:
+                    refill()
                 self.forward(block, train=True, materialise=False)
                 self.loss_topk(with_grad=True)
                 self.backward(on_tail_ready=cut if two_bucket else None)
@@ -1308,6 +1315,7 @@ class DPCEngine:
         replay.graphs = graphs
         replay.events = events   # destroyed after the graphs, not before
         replay.block = block   # the static input buffer stays alive (and its address un-reused) as long as the capture does
+        replay.refill = refill
         self._captures[key] = replay
         self._capture_graphs.append(_Capture(graphs, events))
         return replay

@@ -295,10 +295,19 @@ class LC(nn.Module):
         first = self.backbone.conv1.weight
         if self._engine is not None and self._engine_key == key and first.data_ptr() == self._engine.PRM["backbone.conv1.weight"].data_ptr():
             return
+        named = dict(self.named_parameters())
+        bad = [k for k, v in named.items() if v.dtype != torch.float32]
+        if bad:   # .half() / .double() cast the Parameters themselves; the arena holds f32 master weights (as dpc_amd.DPC_RNN)
+            raise TypeError(f"dpc_amd.LC keeps float32 master parameters; {bad[0]} is {named[bad[0]].dtype}.  Select the kernels' operand "
+                            "type with model.bfloat16() / model.float(); .half() and .double() are not supported")
         eng = LCEngine(self.network, self.sample_size, self.num_seq, self.seq_len, block.shape[0], block.device, self.compute_dtype,
                        self.widths, self._simulator, dropout=self.dropout, num_class=self.num_class)
         eng.load_params({k: v.detach() for k, v in self.state_dict().items()})
-        named = dict(self.named_parameters())
+        if self._engine is not None:
+            # a rebuild (another batch size, model.bfloat16() after training started, a device move) continues the SAME optimisation:
+            # Adam moments, step counter, bias corrections, dropout draw counter, lr / wd (DPC_RNN._ensure_engine does the same)
+            eng.adopt_optimizer_state(self._engine)
+            eng.train_mode = self._engine.train_mode
         for k, t in eng.PRM.items():
             named[k].data = t  # re-point the Parameter at its slice of the flat arena
         for k, t in eng.BUF.items():
@@ -313,11 +322,43 @@ class LC(nn.Module):
     def engine(self) -> Optional[LCEngine]:
         return self._engine
 
+    # ---- compute dtype through the calls a user of the reference would make (as dpc_amd.DPC_RNN): parameters stay f32
+    def bfloat16(self):
+        self.compute_dtype = torch.bfloat16
+        return self
+
+    def float(self):
+        self.compute_dtype = torch.float32
+        return self
+
+    def half(self):
+        raise TypeError("dpc_amd.LC: fp16 is not a mode of this build (bf16 operands with f32 accumulation and f32 master weights are: model.bfloat16())")
+
+    def double(self):
+        raise TypeError("dpc_amd.LC: parameters are float32 master weights; there is no f64 mode")
+
+    def to(self, *args, **kwargs):
+        """device moves as nn.Module.to; an explicit floating dtype selects the compute dtype instead of casting the master parameters"""
+        dtype = kwargs.get("dtype")
+        rest = [a for a in args if not isinstance(a, torch.dtype)]
+        for a in args:
+            if isinstance(a, torch.dtype):
+                dtype = a
+        if dtype is not None:
+            if dtype not in (torch.float32, torch.bfloat16):
+                raise TypeError(f"dpc_amd.LC.to({dtype}): compute dtypes are torch.float32 and torch.bfloat16")
+            self.compute_dtype = dtype
+        kw = {k: v for k, v in kwargs.items() if k != "dtype"}
+        return super().to(*rest, **kw) if (rest or kw) else self
+
     def __deepcopy__(self, memo):
         """a fresh module with the same constructor arguments, cloned parameter / buffer values and no engine (as DPC_RNN.__deepcopy__)"""
         new = type(self)(self.sample_size, self.num_seq, self.seq_len, self.network, self.dropout, self.num_class, self.compute_dtype,
                          self.widths, _simulator=self._simulator)
         new.load_state_dict({k: v.detach().clone() for k, v in self.state_dict().items()})
+        mine = dict(self.named_parameters())
+        for k, q in new.named_parameters():   # --train_what ft / last freeze parameters: the copy keeps that (ADVICE r5)
+            q.requires_grad_(mine[k].requires_grad)
         new.train(self.training)
         memo[id(self)] = new
         return new

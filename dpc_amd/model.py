@@ -301,14 +301,19 @@ class DPC_RNN(nn.Module):
     def to(self, *args, **kwargs):
         """device moves as nn.Module.to; a floating dtype selects the compute dtype like .bfloat16() / .float() instead of casting
         the f32 master parameters (model.to(torch.bfloat16) == model.bfloat16())"""
-        device, dtype, non_blocking, fmt = torch._C._nn._parse_to(*args, **kwargs)
+        dtype = kwargs.get("dtype")          # only an EXPLICIT dtype argument is a compute-dtype selection; everything else
+        rest = [a for a in args if not isinstance(a, torch.dtype)]   # (device, tensor, memory_format, non_blocking) goes to nn.Module.to
+        for a in args:
+            if isinstance(a, torch.dtype):
+                dtype = a
         if dtype is not None:
             if dtype not in (torch.float32, torch.bfloat16):
                 raise TypeError(f"dpc_amd.DPC_RNN.to({dtype}): compute dtypes are torch.float32 and torch.bfloat16")
             self.compute_dtype = dtype
-        if device is not None:
-            return super().to(device, non_blocking=non_blocking)
-        return self
+        kw = {k: v for k, v in kwargs.items() if k != "dtype"}
+        if rest and isinstance(rest[0], torch.Tensor):   # model.to(tensor): its device only, never its dtype
+            rest[0] = rest[0].device
+        return super().to(*rest, **kw) if (rest or kw) else self
 
     # ---- copies.  The engine holds device buffers, ctypes descriptors and captured graphs: none of that is copied or pickled.
     def __deepcopy__(self, memo):
@@ -316,6 +321,7 @@ class DPC_RNN(nn.Module):
         it builds its own at its first forward (copy.deepcopy(model): EMA / averaged copies, torch.optim.swa_utils.AveragedModel)"""
         new = type(self)(self.sample_size, self.num_seq, self.seq_len, self.pred_step, self.network, compute_dtype=self.compute_dtype,
                          widths=self.widths, _simulator=self._simulator)
+        new.compute_dtype = self.compute_dtype   # the constructor lets DPC_COMPUTE_DTYPE override its argument; a copy keeps what the original RUNS in
         mine = dict(self.named_parameters())
         with torch.no_grad():
             for k, q in new.named_parameters():

@@ -49,7 +49,9 @@ def test_conv_fwd(k, dtype, shape):
     (40, 128, 256, 3, 28, 28, (3, 3, 3), (2, 2, 2), (1, 1, 1), "igemm_ws_kernel<false,true>"),   # layer3.0.conv1 of the 224-pixel family
     (8, 128, 128, 2, 32, 32, (1, 3, 3), (1, 2, 2), (0, 1, 1), "igemm_ws_kernel<false,true>"),    # 2D stride, two channel groups
     (24, 128, 256, 3, 15, 17, (3, 3, 3), (2, 2, 2), (1, 1, 1), "igemm_ws_kernel<false,true>"),    # odd extents: unequal classes, class after class
-    (64, 64, 128, 1, 32, 32, (1, 3, 3), (1, 2, 2), (0, 1, 1), "igemm_kernel<T,TO,BN,3>"),        # layer2.0.conv1 (64 output columns): generic kernel, interleaved classes
+    (64, 64, 128, 1, 32, 32, (1, 3, 3), (1, 2, 2), (0, 1, 1), "igemm_kernel<T,TO,BN,3>"),        # layer2.0.conv1 (64 output columns), few planes: generic kernel, interleaved classes
+    (600, 64, 128, 1, 32, 32, (1, 3, 3), (1, 2, 2), (0, 1, 1), "igemm_wsd_kernel"),              # layer2.0.conv1 at 128^2 (round 6): 2 x 2 shift convolution over 16 x 16 gradient planes
+    (131, 64, 128, 4, 32, 32, (1, 3, 3), (1, 2, 2), (0, 1, 1), "igemm_wsd_kernel"),              # 524 planes: kinds A / B walk 3-4 / 4-5 planes, ragged ends
     (40, 64, 128, 1, 56, 56, (1, 3, 3), (1, 2, 2), (0, 1, 1), "igemm_kernel<T,TO,BN,3>"),        # the same layer of the 224-pixel family (classes rotate over the rounds)
 ])
 def test_conv_dgrad_strided(k, dtype, shape):

@@ -62,7 +62,9 @@ def test_throughput_mode_uses_the_specialised_kernels(tabs, cfg):
             assert kern == want or kern in want, (unit, op, kern)
         elif op.startswith("dgrad"):
             add = "true" if op == "dgrad+addend" else "false"
-            if strided and ("downsample" in unit or unit.startswith("layer2.")):   # in-place 1x1s; layer2.0.conv1 has 64 output columns
+            if strided and unit == "layer2.0.conv1" and img == 128:   # 64 output columns over 16 x 16 gradient planes: the shift-convolution kernel (round 6)
+                assert kern == "igemm_wsd_kernel", (unit, op, kern)
+            elif strided and ("downsample" in unit or unit.startswith("layer2.")):   # in-place 1x1s; layer2.0.conv1 (28 x 28 planes at 224 px) has 64 output columns
                 assert kern.startswith("igemm_kernel<T,TO,BN,3>[T=bf16"), (unit, op, kern)  # in-place 1x1: parity classes of the generic kernel, never the dense gather
             elif strided:
                 assert kern == "igemm_ws_kernel<false,true>", (unit, op, kern)               # parity classes on the loader / compute kernel

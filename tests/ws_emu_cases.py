@@ -49,6 +49,10 @@ def main():
     kc.case_conv_dgrad(k, BF16, 1, 136, 64, 1, 64, 144, (1, 3, 3), (1, 2, 2), (0, 1, 1), expect=PAR, with_add=False)   # 9 tiles per class: interleaved class order; ragged column tile
     kc.case_conv_dgrad(k, BF16, 2, 128, 64, 3, 7, 9, (3, 3, 3), (2, 2, 2), (1, 1, 1), expect=PAR, with_add=False)      # odd extents: unequal classes, class after class
     kc.case_conv_dgrad(k, BF16, 2, 64, 128, 1, 16, 24, (1, 3, 3), (1, 2, 2), (0, 1, 1), expect=PAR, with_add=False)     # 64 output columns on the 128-column tile
+    # strided input-gradient over 16 x 16 gradient planes as a 2 x 2 unit-stride convolution onto 4 classes x 64 columns
+    # (igemm_wsd_kernel: layer2.0.conv1 of the 128 x 128 configurations); one workgroup of each kind walks 4 / 5 planes
+    kc.case_conv_dgrad(k, BF16, 2, 64, 128, 2, 32, 32, (1, 3, 3), (1, 2, 2), (0, 1, 1), expect="igemm_wsd_kernel", with_add=False)
+    kc.case_conv_dgrad(k, BF16, 5, 64, 128, 1, 32, 32, (1, 3, 3), (1, 2, 2), (0, 1, 1), seed=11, expect="igemm_wsd_kernel", with_add=False)
     # the generic kernel's class order with several rounds per program (DPC_IGEMM_GM_CAP = 32 programs, 72 tiles): the class of a
     # block rotates with the round
     kc.case_conv_dgrad(k, BF16, 1, 32, 64, 1, 64, 144, (1, 3, 3), (1, 2, 2), (0, 1, 1), expect="igemm_kernel<T,TO,BN,3>", with_add=False)
