@@ -119,7 +119,7 @@ def score_block(eng, sc, steps, peak):
         "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
         "us_per_step": round(1e3 * sc["ms"] / steps, 1), "launches_per_step": sc["launches"] // steps,
         "flops_per_step": round(sc["flops"] / steps / 1e9, 2), "flops_unit": "GFLOP (algorithmic: 3 x 2 R^2 D)",
-        "score_bytes_f32": R * R * 4,
+        "score_bytes": R * R * (2 if "bf16 logits" in eng.score_mode else 4), "logits": "bf16" if "bf16 logits" in eng.score_mode else "f32",
         "includes": ("the softmax statistics / loss and the recomputation of dS inside the backward (no [R][R] tensor is "
                      "written)" if eng.score_mode == "fused" else "the three GEMMs with the reductions of their split-K slabs (CE/top-k and dS are a separate kernel)"),
     }

@@ -118,6 +118,7 @@ _SIGS = {
     "dpc_pool_bn_bwd_apply": [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp],
     "dpc_mask_gen": [_vp, _i32, _i32, _i32, _vp],
     "dpc_ce_topk": [_vp, _i32, _i32, _i32, _vp, _vp, _vp, _i32, _i32, _vp],
+    "dpc_ce_topk_bf16": [_vp, _i32, _i32, _i32, _vp, _vp, _vp, _i32, _vp],
     "dpc_step_advance": [_vp, _vp, _f64, _f64, _vp],
     "dpc_adam_dev": [_vp, _vp, _vp, _vp, _i64, _f32, _f64, _f64, _f32, _f32, _vp, _f32, _vp],
     "dpc_counter_advance": [_vp, _vp],

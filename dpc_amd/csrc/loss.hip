@@ -176,6 +176,85 @@ __global__ __launch_bounds__(256) void ce_row_vec_kernel(const float* score, int
     }
 }
 
+
+// bf16 LOGITS (round 6): the train step never returns its score (engine.train_step), so the materialised score of that path is
+// written and read in the compute dtype -- 75 MB instead of 151 MB at R = 6 144 on each side.  Same one-read row kernel: a thread
+// holds NV 16-byte units of 8 logits; loss, rank and d(loss)/d(score) are those of the ROUNDED logits (the target logit included,
+// so "strictly greater than the target" is decided among values of one precision).
+template <int NV>
+__global__ __launch_bounds__(256) void ce_row_vec16_kernel(const bf16_t* score, int rows, int cols, int ld, float* row_ws, bf16_t* dscore, int ld_d) {
+    __shared__ float sh[8];
+    const int row = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const bf16_t* s = score + (long long)row * ld;
+    const float tgt = bf16_to_f32(s[row]);
+    const int nq = cols >> 3;
+    float v[NV][8];
+    float mx = -3.0e38f;
+    DPC_UNROLL
+    for (int i = 0; i < NV; ++i) {
+        const int q = tid + 256 * i;
+        if (q < nq) {
+            const u32x4 t = ((const u32x4*)s)[q];
+            DPC_UNROLL
+            for (int e = 0; e < 8; ++e) { v[i][e] = unit_get<bf16_t>(t, e); mx = v[i][e] > mx ? v[i][e] : mx; }
+        } else {
+            DPC_UNROLL
+            for (int e = 0; e < 8; ++e) v[i][e] = -3.0e38f;
+        }
+    }
+    mx = wave_max(mx);
+    if (lane == 0) sh[wv] = mx;
+    __syncthreads();
+    mx = sh[0];
+    DPC_UNROLL
+    for (int w = 1; w < 4; ++w) mx = sh[w] > mx ? sh[w] : mx;
+    float se = 0.f, rk = 0.f;
+    const float nm = -mx * 1.4426950408889634f;
+    DPC_UNROLL
+    for (int i = 0; i < NV; ++i) {
+        const bool ok = tid + 256 * i < nq;
+        DPC_UNROLL
+        for (int e = 0; e < 8; ++e) {
+            const float x = v[i][e];
+            rk += (ok && x > tgt) ? 1.f : 0.f;
+            const float ex = fast_exp2(fmaf(x, 1.4426950408889634f, nm));
+            v[i][e] = ok ? ex : 0.f;
+            se += v[i][e];
+        }
+    }
+    se = wave_sum(se);
+    rk = wave_sum(rk);
+    __syncthreads();
+    if (lane == 0) { sh[wv] = se; sh[4 + wv] = rk; }
+    __syncthreads();
+    se = sh[0] + sh[1] + sh[2] + sh[3];
+    rk = sh[4] + sh[5] + sh[6] + sh[7];
+    if (tid == 0) {
+        row_ws[2 * row + 0] = logf(se) + mx - tgt;
+        row_ws[2 * row + 1] = rk;
+    }
+    if (dscore) {
+        const float inv = 1.f / se, invr = 1.f / (float)rows;
+        bf16_t* d = dscore + (long long)row * ld_d;
+        DPC_UNROLL
+        for (int i = 0; i < NV; ++i) {
+            const int q = tid + 256 * i;
+            if (q < nq) {
+                float g[8];
+                DPC_UNROLL
+                for (int e = 0; e < 8; ++e) {
+                    float t = v[i][e] * inv;
+                    if (8 * q + e == row) t -= 1.f;
+                    g[e] = t * invr;
+                }
+                *(u32x4*)(d + 8 * q) = unit_pack<bf16_t>(g);
+            }
+        }
+        for (int j = cols + tid; j < ld_d; j += 256) d[j] = Elt<bf16_t>::from_f32(0.f);
+    }
+}
+
 __global__ __launch_bounds__(256) void ce_finalize_kernel(const float* row_ws, int rows, float* result) {
     __shared__ float sh[4][4];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -222,6 +301,23 @@ extern "C" int dpc_ce_topk(const float* score, int32_t rows, int32_t cols, int32
         }
     } else {
         return DPC_ERR_ARG;
+    }
+    DPC_LAUNCH(ce_finalize_kernel, dim3(1), dim3(256), stream, row_ws, rows, result);
+    return dpc_launch_status();
+}
+
+// dpc_ce_topk on bf16 logits with a bf16 gradient (the train step's materialised score in the compute dtype): rows of 16-byte units,
+// cols a multiple of 8, at most 16 384 columns -- anything else is DPC_ERR_UNSUPPORTED (the caller keeps f32 logits then).
+extern "C" int dpc_ce_topk_bf16(const void* score, int32_t rows, int32_t cols, int32_t ld, float* row_ws, float* result,
+                                void* dscore, int32_t ld_d, dpc_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!score || !row_ws || !result || rows <= 0 || cols < rows || ld < cols) return DPC_ERR_ARG;
+    if (dscore && ld_d < cols) return DPC_ERR_ARG;
+    if (cols % 8 || ld % 8 || ((uintptr_t)score % 16) || cols > 16384 || (dscore && (ld_d % 8 || ((uintptr_t)dscore % 16)))) return DPC_ERR_UNSUPPORTED;
+    if (cols <= 2048 * 4) {
+        DPC_LAUNCH((ce_row_vec16_kernel<4>), dim3(rows), dim3(256), stream, (const bf16_t*)score, rows, cols, ld, row_ws, (bf16_t*)dscore, ld_d);
+    } else {
+        DPC_LAUNCH((ce_row_vec16_kernel<8>), dim3(rows), dim3(256), stream, (const bf16_t*)score, rows, cols, ld, row_ws, (bf16_t*)dscore, ld_d);
     }
     DPC_LAUNCH(ce_finalize_kernel, dim3(1), dim3(256), stream, row_ws, rows, result);
     return dpc_launch_status();

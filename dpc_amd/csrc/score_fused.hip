@@ -438,7 +438,9 @@ __device__ __forceinline__ void dma_rows8(unsigned char* tile, const bf16_t* src
     }
 }
 
-template <int KS>
+// OUT16 (round 6): the same tile leaves as bf16 -- the logits of a train step that never returns its score (75 MB instead of 151 MB
+// at R = 6 144): a staged row is 64 columns x 2 bytes = one 128-byte line, eight rows per store instruction, four instructions per tile.
+template <int KS, bool OUT16 = false>
 __global__ __launch_bounds__(512, 2) void score_gemm2_kernel(GemmKP p) {
     DPC_DYN_SMEM(smem);
     const int lane = threadIdx.x & 63;
@@ -461,12 +463,14 @@ __global__ __launch_bounds__(512, 2) void score_gemm2_kernel(GemmKP p) {
     if (jt1 > p.ntiles) jt1 = p.ntiles;
     if (jt0 < jt1) dma_rows8(smem, p.b, p.ldb, jt0 * BN, p.N, p.D, wave, lane);
     const int l31 = lane & 31, lhi = lane >> 5;
-    const int su = lane & 15, sr = lane >> 4;   // store phase: 16-byte unit of the 256-byte row, row inside a group of four
-    // store instructions this wave issues per tile: a group of four rows whose first row is outside the matrix is skipped as a
-    // whole (exec = 0), so the count the wait below leaves in flight is per wave (8 except in the last row block)
+    constexpr int UPRW = OUT16 ? 8 : 16, RPI = 64 / UPRW, NIT = 32 / RPI;   // 16-byte units per staged row, rows per store instruction, instructions per tile
+    constexpr int ROWB = OUT16 ? BN * 2 + 16 : SG2_ROWB;
+    const int su = lane & (UPRW - 1), sr = lane / UPRW;   // store phase: 16-byte unit of the row, row inside a group of RPI
+    // store instructions this wave issues per tile: a group of rows whose first row is outside the matrix is skipped as a
+    // whole (exec = 0), so the count the wait below leaves in flight is per wave (NIT except in the last row block)
     int nst = 0;
     DPC_UNROLL
-    for (int it = 0; it < 8; ++it) nst += (r0 + 4 * it < p.M) ? 1 : 0;
+    for (int it = 0; it < NIT; ++it) nst += (r0 + RPI * it < p.M) ? 1 : 0;
     for (int jt = jt0; jt < jt1; ++jt) {
         const int buf = (jt - jt0) & 1;
         // the pieces of tile jt are older than the nst stores of tile jt - 1: let at most those stay in flight (if the compiler issues
@@ -480,19 +484,27 @@ __global__ __launch_bounds__(512, 2) void score_gemm2_kernel(GemmKP p) {
         for (int t = 0; t < 2; ++t)
             DPC_UNROLL
             for (int k = 0; k < 4; ++k) {
-                const f32x4 v = {s[t][4 * k], s[t][4 * k + 1], s[t][4 * k + 2], s[t][4 * k + 3]};
-                *(f32x4*)(stg + l31 * SG2_ROWB + (t * 32 + 8 * k + 4 * lhi) * 4) = v;
+                if constexpr (OUT16) {
+                    const u32x2 v = {bf16x2_pack(s[t][4 * k], s[t][4 * k + 1]), bf16x2_pack(s[t][4 * k + 2], s[t][4 * k + 3])};
+                    *(u32x2*)(stg + l31 * ROWB + (t * 32 + 8 * k + 4 * lhi) * 2) = v;
+                } else {
+                    const f32x4 v = {s[t][4 * k], s[t][4 * k + 1], s[t][4 * k + 2], s[t][4 * k + 3]};
+                    *(f32x4*)(stg + l31 * ROWB + (t * 32 + 8 * k + 4 * lhi) * 4) = v;
+                }
             }
         wave_lds_fence();
-        f32x4 ov[8];
+        f32x4 ov[NIT];
         DPC_UNROLL
-        for (int it = 0; it < 8; ++it) ov[it] = *(const f32x4*)(stg + (4 * it + sr) * SG2_ROWB + su * 16);
+        for (int it = 0; it < NIT; ++it) ov[it] = *(const f32x4*)(stg + (RPI * it + sr) * ROWB + su * 16);
         wave_lds_fence();  // the next tile's staging writes must not pass these reads
-        const int c = jt * BN + su * 4;
+        const int c = jt * BN + su * (OUT16 ? 8 : 4);
         DPC_UNROLL
-        for (int it = 0; it < 8; ++it) {
-            const int row = r0 + 4 * it + sr;
-            if (row < p.M && c < p.N) __builtin_nontemporal_store(ov[it], (f32x4*)(p.out + (long long)row * p.ldo + c));   // N % 4 == 0 (vec)
+        for (int it = 0; it < NIT; ++it) {
+            const int row = r0 + RPI * it + sr;
+            if (row < p.M && c < p.N) {   // N % 4 == 0 (vec); OUT16: N % 8 == 0
+                if constexpr (OUT16) __builtin_nontemporal_store(ov[it], (f32x4*)((bf16_t*)p.out + (long long)row * p.ldo + c));
+                else __builtin_nontemporal_store(ov[it], (f32x4*)(p.out + (long long)row * p.ldo + c));
+            }
         }
         vm_note_stores(nst);   // simulator bookkeeping for wait_vmcnt_upto(nst) above; nothing on the device
     }
@@ -527,7 +539,9 @@ void plan_splits(int R, int target_wgs, int* ntiles, int* tps, int* nsplit) {
 // dpc_conv_igemm hands plain NT GEMMs with bf16 operands, f32 output and K = 256 (or 32: the width-reduced test networks) to
 // score_gemm_kernel when the output is large; returns 1 when the shape is not served (the generic kernel runs it)
 int dpc_score_gemm_try(const dpc_conv_desc* d, const void* src, const void* wgt, void* out, hipStream_t stream) {
-    if (d->dtype_in != DPC_BF16 || d->dtype_out != DPC_F32 || d->mode != 0) return 1;
+    if (d->dtype_in != DPC_BF16 || (d->dtype_out != DPC_F32 && d->dtype_out != DPC_BF16) || d->mode != 0) return 1;
+    const bool out16 = d->dtype_out == DPC_BF16;   // bf16 logits: the staged 8-wave form only, whole 128-byte lines (N, ldo multiples of 64)
+    if (out16 && (d->Co % 64 || d->ldo % 64 || ((uintptr_t)out % 16))) return 1;
     if (d->KT * d->KH * d->KW != 1 || d->RT * d->RH * d->RW != 1 || d->ST * d->SH * d->SW != 1) return 1;
     if (d->st != 1 || d->sh != 1 || d->sw != 1 || d->pt || d->ph || d->pw) return 1;
     if (d->Ci != 256 && d->Ci != 32) return 1;
@@ -544,7 +558,7 @@ int dpc_score_gemm_try(const dpc_conv_desc* d, const void* src, const void* wgt,
     // = 5.8 TB/s of score writes -- and loses its fixed cost on ten tiles per workgroup (R = 6 144: 44.8 against 42.1 us); rows that
     // are not cache-line multiples (R = 6 468) make a non-temporal store a partial-line write: 85 against 45 us.  Hence: large
     // outputs with 128-byte-aligned rows only (profiles/r04_head_kernels.txt).
-    if (v2 && p.vec && p.N % 4 == 0 && (v2 > 1 || ((long long)p.M * p.N >= (1ll << 26) && p.ldo % 32 == 0))) {
+    if (out16 || (v2 && p.vec && p.N % 4 == 0 && (v2 > 1 || ((long long)p.M * p.N >= (1ll << 26) && p.ldo % 32 == 0)))) {
         const int nrb2 = (p.M + 255) / 256;
         int sp2 = dpc_persistent_grid(256) / nrb2;   // one workgroup per CU (132 KB of LDS) and ONE wave of workgroups: rounding up put
                                                       // 264 of them on 256 CUs at R = 6 144 -- 50.8 us against 42 for the 4-wave form
@@ -554,7 +568,15 @@ int dpc_score_gemm_try(const dpc_conv_desc* d, const void* src, const void* wgt,
         p.nsplit = (p.ntiles + p.tiles_per_split - 1) / p.tiles_per_split;
         const dim3 grid2(nrb2, p.nsplit);
         const size_t lds2 = 2 * (size_t)((p.D * 2 + 127) / 128) * BN * 128 + 8 * (size_t)SG2_WAVE;
-        if (p.D == 256) {
+        if (out16) {
+            if (p.D == 256) {
+                if (int e = allow_lds(score_gemm2_kernel<16, true>, lds2)) return e;
+                DPC_LAUNCH_DYN((score_gemm2_kernel<16, true>), grid2, dim3(512), lds2, stream, p);
+            } else {
+                if (int e = allow_lds(score_gemm2_kernel<2, true>, lds2)) return e;
+                DPC_LAUNCH_DYN((score_gemm2_kernel<2, true>), grid2, dim3(512), lds2, stream, p);
+            }
+        } else if (p.D == 256) {
             if (int e = allow_lds(score_gemm2_kernel<16>, lds2)) return e;
             DPC_LAUNCH_DYN((score_gemm2_kernel<16>), grid2, dim3(512), lds2, stream, p);
         } else {

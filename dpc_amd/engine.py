@@ -713,6 +713,14 @@ class DPCEngine:
             self.lib.call("dpc_score_ws_floats", R, D, C.byref(nf), C.byref(nb))
             self.score_ws = self.empty((max(nf.value, nb.value),), f32)
             self.score_diag, self.score_lse2 = self.empty((R,), f32), self.empty((R,), f32)
+        # bf16 LOGITS for the step that does not return its score (train_step / capture_train_step / validate: forward(materialise=False)):
+        # the score GEMM writes, and the loss kernel reads, [R][R] in the compute dtype -- 75 MB instead of 151 MB each way at cfg2,
+        # 492 instead of 983 MB at cfg5.  forward(materialise=True) -- the module boundary, everything that looks at the score -- keeps
+        # f32.  Needs whole 128-byte rows (R a multiple of 64: cfg2 6 144, cfg5 15 680; cfg4's 6 468 keeps f32); DPC_SCORE_BF16=0: off.
+        self.score16 = None
+        if dt == torch.bfloat16 and R % 64 == 0 and R <= 16384 and D in (256, 32) and not self.score_fusable and int(os.environ.get("DPC_SCORE_BF16", "1")):
+            self.score16 = self.empty((R, R), dt)
+        self._score16_live = False
         self.d_pred = self.empty((B, P, SQ, D), f32)
         self.d_finf = self.empty((B, P, SQ, D), f32)
         self.d_featrelu = self.empty((self.n_agg, M, D), f32)
@@ -1092,6 +1100,12 @@ class DPCEngine:
                           self.score_ws)
             self.score_mode = "fused"
             return None
+        self._score16_live = bool(self.score16 is not None and not materialise)
+        if self._score16_live:   # nobody reads the score but the loss: logits in the compute dtype
+            self.score_mode = "materialised (bf16 logits)"
+            with self.tag("score"):
+                self.gemm(self.pred, self.feat_inf, self.score16, R, R, D, out_f32=False)
+            return None
         self.score_mode = "materialised"
         with self.tag("score"):
             self.gemm(self.pred, self.feat_inf, self.score, R, R, D)
@@ -1117,6 +1131,9 @@ class DPCEngine:
         R = self.R
         if self._score_fused:  # per-row (loss term, rank) pairs are already there; d/dscore is recomputed inside the backward
             self.call("dpc_ce_finalize", self.row_ws, R, self.result)
+            return self.result
+        if self._score16_live:
+            self.call("dpc_ce_topk_bf16", self.score16, R, R, R, self.row_ws, self.result, self.dscore if with_grad else None, self.ld_d)
             return self.result
         self.call("dpc_ce_topk", self.score, R, R, R, self.row_ws, self.result, self.dscore if with_grad else None,
                   L.dtype_code(self.cdtype), self.ld_d)

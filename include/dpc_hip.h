@@ -263,6 +263,10 @@ int dpc_colsum(const void* x, int32_t dtype, int32_t ld, int32_t M, int32_t D, f
 int dpc_mask_gen(int8_t* mask, int32_t B, int32_t P, int32_t SQ, dpc_stream_t stream);
 int dpc_ce_topk(const float* score, int32_t rows, int32_t cols, int32_t ld, float* row_ws, float* result,
                 void* dscore, int32_t dtype_d, int32_t ld_d, dpc_stream_t stream);
+/* the same on bf16 logits with a bf16 gradient: the materialised score of a train step that does not return it (dpc/main.py:198-218
+ * reads `score_` only through the loss).  cols % 8 == 0, ld % 8 == 0, 16-byte aligned rows, cols <= 16384; else DPC_ERR_UNSUPPORTED. */
+int dpc_ce_topk_bf16(const void* score_bf16, int32_t rows, int32_t cols, int32_t ld, float* row_ws, float* result,
+                     void* dscore_bf16, int32_t ld_d, dpc_stream_t stream);
 
 /* ---- fused score + loss (throughput mode, bf16 operands): the [R][R] score and its gradient never touch HBM --------
  * score_fwd: S = pred @ finf^T (dpc/model_3d.py:83) tile by tile; per row the running max / sum-exp / #{s > s_target}

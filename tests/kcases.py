@@ -1018,3 +1018,45 @@ def case_stem_wgrad_fused(k: K, BN, T, H, W, Co=64, seed=8):
     gyr = gy.double().view(BN, T, Ho, Wo, Co).permute(0, 4, 1, 2, 3)
     gw = torch.autograd.grad(pz, wq, gyr)[0]
     assert relerr(dw_b, gw) < 0.15  # sanity: bf16 raw / dz and argmax near-ties at a tiny batch (observed 0.09, identical for (a))
+
+
+# ------------------------------------------------------------------ bf16 logits of the train step (round 6)
+def case_ce_topk_bf16(k: K, rows, cols, seed=10):
+    """dpc_ce_topk_bf16: loss, top-1/3/5 and d(loss)/d(score) of bf16-ROUNDED logits (the expectation is computed on the rounded
+    values: what the kernel is given); exact ties at the target's value rank behind it"""
+    g = torch.Generator().manual_seed(seed)
+    s = torch.randn(rows, cols, generator=g) * 3
+    idx = torch.arange(0, rows, 3)
+    s[idx, idx] += 6.0
+    sq = s.to(torch.bfloat16)
+    sd = sq.double().requires_grad_()
+    tgt = torch.arange(rows)
+    loss = F.cross_entropy(sd, tgt)
+    loss.backward()
+    rank = (sq.float() > sq.float().diagonal().view(-1, 1)[:, :1].expand(rows, cols)).sum(1)
+    accs = [(rank < kk).float().mean().item() for kk in (1, 3, 5)]
+    ld_d = (cols + 7) // 8 * 8
+    ws, res = k.empty(rows, 2), k.empty(4)
+    ds = k.empty(rows, ld_d, dtype=torch.bfloat16)
+    k.call("dpc_ce_topk_bf16", k.t(sq, torch.bfloat16), rows, cols, cols, ws, res, ds, ld_d)
+    k.sync()
+    r = res.cpu()
+    assert abs(r[0].item() - loss.item()) < 2e-5 * max(1.0, abs(loss.item()))
+    assert [round(v, 6) for v in r[1:].tolist()] == [round(v, 6) for v in accs]
+    assert relerr(ds[:, :cols], sd.grad) < tol(torch.bfloat16)
+
+
+def case_gemm_nt_bf16out(k: K, M, N, Kd, seed=3, expect="score_gemm2_kernel<KS,OUT16>"):
+    """the materialised score in the compute dtype: A @ B^T rounded once to bf16 (whole 128-byte rows: N a multiple of 64)"""
+    g = torch.Generator().manual_seed(seed)
+    dtype = torch.bfloat16
+    A = q(torch.randn(M, Kd, generator=g), dtype)
+    B = q(torch.randn(N, Kd, generator=g), dtype)
+    d = conv_desc(dtype, dtype, 0, M, (1, 1, 1), (1, 1, 1), Kd, Kd, N, Kd, N, (1, 1, 1), (1, 1, 1), (0, 0, 0))
+    out = k.empty(M, N, dtype=dtype)
+    k.call("dpc_conv_igemm", C.byref(d), k.t(A, dtype), k.t(B, dtype), out, None, None)
+    check_kernel(k, expect)
+    k.sync()
+    want = (A.double() @ B.double().t())
+    assert relerr(out, want) < 2.0 ** -8          # one rounding of an f32 accumulator
+    assert torch.equal(out.cpu(), want.float().to(dtype)) or (out.cpu().float() - want.float()).abs().max().item() <= 2.0 ** -7 * want.abs().max().item()

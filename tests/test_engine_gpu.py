@@ -387,6 +387,39 @@ def test_full_batch_properties(dtype):
     assert res[0].item() < res0[0].item()
 
 
+@pytest.mark.parametrize("net,size,B,P", [("resnet18", 128, 128, 3), ("resnet34", 224, 64, 5)])
+def test_bf16_logits_step_tracks_f32_logits(net, size, B, P):
+    """round 6: the step that does not return its score (train_step, validate) writes and reads the materialised score in the compute
+    dtype.  At cfg2 and cfg5 size, against the f32-logit form of the SAME forward (same operands, same dropout draw): loss within 1e-3,
+    top-k within 3 rows, every parameter gradient within the rounding of a bf16 d/dscore."""
+    eng = DPCEngine(net, size, 8, 5, P, B, DEV, torch.bfloat16)
+    assert eng.score16 is not None and eng.R % 64 == 0
+    eng.load_params(O.init_params_reference_style(net, seed=0))
+    x = torch.randn(B, 8, 3, 5, size, size, device=DEV, generator=torch.Generator(DEV).manual_seed(1))
+    R = eng.R
+    for train in (True, False):
+        assert eng.forward(x, train=train, materialise=True, new_draw=train) is not None and eng.score_mode == "materialised"
+        r32 = eng.loss_topk(train).clone().cpu()
+        if train:
+            eng.backward()
+            torch.cuda.synchronize()
+            g32 = eng.flat_g.clone()
+        assert eng.forward(x, train=train, materialise=False, new_draw=False) is None and eng.score_mode == "materialised (bf16 logits)"
+        r16 = eng.loss_topk(train).clone().cpu()
+        assert (eng.score16.float() - eng.score).abs().max().item() <= 2.0 ** -8 * eng.score.abs().max().item() * 1.001   # one rounding of the same accumulators
+        assert abs(r16[0].item() - r32[0].item()) < 1e-3 * max(1.0, abs(r32[0].item())), (r16, r32)
+        assert r16[1:].tolist() == pytest.approx(r32[1:].tolist(), abs=3.0 / R)
+        if train:
+            eng.backward()
+            torch.cuda.synchronize()
+            assert ((eng.flat_g - g32).norm() / g32.norm()).item() < 3e-2
+    r0 = eng.train_step(x).cpu()
+    assert eng.score_mode == "materialised (bf16 logits)"
+    for _ in range(3):
+        r = eng.train_step(x).cpu()
+    assert torch.isfinite(r).all() and r[0].item() < r0[0].item()
+
+
 def test_stem_fused_step_is_bit_identical():
     """The opt-in fused stem weight gradient (csrc/conv_wgrad_stem.hip, no dz tensor) gives the same step, bit for bit."""
     x = torch.randn(4, 8, 3, 5, 128, 128, device=DEV, generator=torch.Generator(DEV).manual_seed(5))

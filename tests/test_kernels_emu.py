@@ -141,6 +141,13 @@ def test_score_gemm(k, mn, kern, monkeypatch):
     kc.case_gemm_nt(k, BF16, mn[0], mn[1], 32, expect=kern)
 
 
+def test_score_gemm_bf16_logits(k):
+    """the same product written in the compute dtype (the train step's logits, round 6): 8-wave form, 128-byte staged rows; ragged
+    last row block, several column tiles per split"""
+    kc.case_gemm_nt_bf16out(k, 1100, 1088, 32, expect="score_gemm2_kernel<2,true>")
+    kc.case_gemm_nt_bf16out(k, 520, 2048, 32, seed=9, expect="score_gemm2_kernel<2,true>")
+
+
 @pytest.mark.parametrize("dtype", [F32, BF16])
 def test_stem_s2d(k, dtype):
     kc.case_stem(k, dtype, 2, 2, 16, 20)
@@ -209,6 +216,12 @@ def test_ce_topk(k, dtype_d):
     kc.case_ce_topk(k, 300, 300, dtype_d)
     kc.case_ce_topk(k, 37, 37, dtype_d)      # odd width: the three-sweep kernel
     kc.case_ce_topk(k, 1100, 1100, dtype_d)  # register-resident rows, NV = 8, more than one float4 per thread
+
+
+def test_ce_topk_bf16_logits(k):
+    kc.case_ce_topk_bf16(k, 24, 24)
+    kc.case_ce_topk_bf16(k, 304, 304)      # ragged: 38 units over 256 threads
+    kc.case_ce_topk_bf16(k, 2304, 2304)    # more than one unit per thread
 
 
 def test_adam(k):

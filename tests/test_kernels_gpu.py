@@ -139,6 +139,12 @@ def test_gemm_nt(k, dtype, mnk):
     kc.case_gemm_nt(k, dtype, *mnk, expect=("score_gemm2_kernel<16>" if v2 else "score_gemm_kernel<16>") if big else ("igemm_kernel" if dtype == BF16 else None))
 
 
+def test_score_gemm_bf16_logits(k):
+    """the train step's logits in the compute dtype (round 6): cfg2 and cfg5 size, and a ragged row count"""
+    for mnk in ((6144, 6144, 256), (15680, 15680, 256), (1100, 1088, 256)):
+        kc.case_gemm_nt_bf16out(k, *mnk, expect="score_gemm2_kernel<16,true>")
+
+
 def test_score_gemm_8wave_form_on_ragged_shapes(k, monkeypatch):
     """score_gemm2_kernel forced onto shapes it does not serve by default: ragged last row block (waves without any row), rows that
     are not cache-line multiples, R = 6 144"""
@@ -229,6 +235,11 @@ def test_ce_topk(k, dtype_d):
     kc.case_ce_topk(k, 1764, 1764, dtype_d)
     kc.case_ce_topk(k, 6144, 6144, dtype_d)
     kc.case_ce_topk(k, 15680, 15680, dtype_d)  # cfg5: 983 MB of logits
+
+
+def test_ce_topk_bf16_logits(k):
+    for r in (24, 1768, 6144, 15680):
+        kc.case_ce_topk_bf16(k, r, r)
 
 
 def test_adam(k):
