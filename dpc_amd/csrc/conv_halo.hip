@@ -636,6 +636,11 @@ __global__ __launch_bounds__(512, 2) void conv_halo_ws_kernel(HaloParams p) {
         const std::true_type steady = {};
         const std::false_type general = {};
         interval(general, 0, pre0, pre1);
+        // tile 0's operands are waited for HERE, outside the loop (hipcc: vmcnt(0), once): on the loop's entry edge nothing of pre0 is
+        // pending then, and on its back edge pre0's loads are followed by a patch DMA and the next tile's requests -- without this
+        // the merge of the two edges made the first wait INSIDE the loop a vmcnt(0) again (scripts/asm_drain_lint.py found it in the
+        // reduction-only variant: the patch DMA drained every second tile)
+        if (PRE) touch(pre0);
         int j = 1;
         for (; j + 1 + NPB - 1 < ntiles; j += 2) {   // j odd: tile j's operands in pre1, tile j-1's in pre0
             interval(steady, j, pre1, pre0);

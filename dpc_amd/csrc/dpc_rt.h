@@ -441,6 +441,8 @@ __device__ __forceinline__ void lds_wait_tie_n(int n, u32x4& a, u32x4& b) {  // 
     else lds_wait_tie<0>(a, b);
 }
 
+
+
 // wait until at most N of this wave's vector-memory operations (LDS-DMA pieces included) are outstanding
 template <int N> __device__ __forceinline__ void wait_vmcnt() {
 #ifndef DPC_SIMT_EMU

@@ -31,3 +31,52 @@ def test_lint_sees_the_round3_hazard():
     kinds = {h[1] for h in hits}
     kernels = {h[2] for h in hits}
     assert "WAW" in kinds and any("igemm_ws_kernel" in k for k in kernels) and any("igemm_wsp_kernel" in k for k in kernels), hits[:5]
+
+
+def test_no_compiler_wait_drains_an_lds_dma_ring():
+    """round 6: hipcc must not put `s_waitcnt vmcnt(0)` into an innermost loop that issues LDS-DMA meant to stay in flight -- the
+    residual / fused-reduction variants of conv_halo_ws_kernel carried one for five rounds (a register copy of in-flight loads at the
+    end of every helper interval: 3.3 us per tile instead of 1.45; profiles/r06_halo_epi_probe.txt).  scripts/asm_drain_lint.py reads
+    `hipcc -S` of every ring kernel.  Positive control: a minimal loop of the shape rounds 1-5 had (operands requested one iteration
+    ahead, one of them behind a lane condition, copied over the loop edge behind the DMA piece) must be reported."""
+    import asm_drain_lint as dl
+    import subprocess
+    import tempfile
+    hits = dl.build_and_lint(ROOT)
+    assert not hits, "\n".join(f"{h[0]}: {h[1]}: vmcnt(0) at line {h[3]} in the DMA loop at line {h[2]}" for h in hits[:10])
+    ctl = r'''
+#include "dpc_rt.h"
+__global__ void ctl_kernel(const u32x4* src, const uint8_t* m, const void* dma_src, u32x4* out, int n, int lim) {
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[4096];
+    const BufRsrc rs = make_buf_rsrc(dma_src, 1u << 20);
+    const bool ok0 = (int)threadIdx.x < lim;
+    u32x4 cur = src[threadIdx.x], acc = {0u, 0u, 0u, 0u};
+    unsigned cb = ok0 ? (unsigned)m[threadIdx.x] : 0u;
+    for (int j = 1; j < n; ++j) {
+        wait_vmcnt<1>();
+        barrier_lds_only();
+        u32x4 nxt = cur;
+        unsigned nb = cb;
+        if (j + 1 < n) {
+            const bool ok = (int)(threadIdx.x + j) < lim;
+            nxt = *(const u32x4*)(ok ? (const char*)(src + j * 64 + threadIdx.x) : (const char*)dpc_zero16);
+            nb = ok ? (unsigned)m[j * 64 + threadIdx.x] : 0u;      // a load behind a divergent branch
+        }
+        acc[0] += (cur[0] ^ cur[3]) + cb;
+        acc[1] += ((const uint32_t*)lds)[threadIdx.x];
+        out[j * 64 + threadIdx.x] = acc;
+        glds16_buf(rs, (unsigned)(threadIdx.x * 16 + j * 1024), 0u, lds + (j & 3) * 1024, threadIdx.x & 63);
+        barrier_lds_only();
+        cur = nxt;                                   // copied over the loop edge
+        cb = nb;
+    }
+    out[threadIdx.x] = acc;
+}
+'''
+    with tempfile.TemporaryDirectory() as tmp:
+        src, asm = os.path.join(tmp, "ctl.hip"), os.path.join(tmp, "ctl.s")
+        open(src, "w").write(ctl)
+        subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", f"-I{os.path.join(ROOT, 'include')}",
+                        f"-I{os.path.join(ROOT, 'dpc_amd', 'csrc')}", "-S", "--cuda-device-only", src, "-o", asm], check=True, capture_output=True,
+                       stdin=subprocess.DEVNULL, timeout=600)
+        assert dl.lint_file(asm), "the lint did not see the drain of the control kernel"
