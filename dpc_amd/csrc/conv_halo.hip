@@ -318,6 +318,9 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(HaloParams p) {
 #ifndef HALO_WS_D
 #define HALO_WS_D 3
 #endif
+#ifndef HALO_WS_NPB
+#define HALO_WS_NPB 3
+#endif
 // UPP = 8: 3x3 taps over 128-byte positions (one tap = one K chunk).  UPP = 2: the space-to-depth stem, 4x4 taps over
 // 32-byte positions (one K chunk = the four kw taps of a kernel row = four neighbouring positions).
 // BM = output positions per tile: 128, or 256 for the stem (its MFMA phase is only 16 steps, so the fixed cost of a
@@ -336,7 +339,7 @@ __global__ __launch_bounds__(512, 2) void conv_halo_ws_kernel(HaloParams p) {
     constexpr int LIT = UPP == 8 ? 8 : (BM == 128 ? 3 : 5);       // DMA pieces per helper wave and patch: LIT x 256 lanes x 16 B >= positions x (UPP+1) slots
     constexpr int PATCH = LIT * 256 * 16;
     constexpr int STG = BM * BN * 2;
-    constexpr int NPB = 3;                        // patch ring: two tiles of lookahead (a fourth buffer = all 160 KB of LDS was measured: no change)
+    constexpr int NPB = HALO_WS_NPB;              // patch ring: two tiles of lookahead (a fourth buffer = all 160 KB of LDS was measured: no change)
     static_assert(NPB * PATCH + 2 * STG <= 160 * 1024 && 2 * (NPB * PATCH + 2 * STG) > 160 * 1024, "one workgroup per CU");
     // (round 3 claimed all 160 KB here as a precaution; the failure it guarded against was a register hazard of igemm_ws_kernel,
     // conv_igemm_ws.hip WS_RETIRE_TAIL_READS -- this kernel's asm reads are all consumed, scripts/asm_hazard_lint.py)
