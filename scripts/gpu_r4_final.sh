@@ -1,4 +1,6 @@
 #!/bin/bash
+# HISTORICAL (round 4): sets DPC_SCORE_GEMM_COUNTED / DPC_EARLY_FINALIZE, switches that were removed in round 5 -- those A/B arms now run
+# identical code.  Kept for the record of what round 4 measured; the current recipes are scripts/gpu_r6_*.sh.
 # round 4 closing session: GPU tier, head timings and one bench line on the final build, PMC traffic re-measured on the final kernel sources
 R=$GRAFT_REPO_ROOT; cd $R; mkdir -p gpurun_out
 timeout 1700 python -X faulthandler -m pytest tests -m gpu -q -p no:cacheprovider > gpurun_out/g_test_full.log 2>&1; echo "rc=$?" >> gpurun_out/g_test_full.log

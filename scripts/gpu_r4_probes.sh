@@ -1,4 +1,6 @@
 #!/bin/bash
+# HISTORICAL (round 4): sets DPC_SCORE_GEMM_COUNTED / DPC_EARLY_FINALIZE, switches that were removed in round 5 -- those A/B arms now run
+# identical code.  Kept for the record of what round 4 measured; the current recipes are scripts/gpu_r6_*.sh.
 # round 4: the probes behind DESIGN section 9.2 / 9.4 / section 5 (sessions D and E of the round): head kernel timings, the forward
 # two-stream probe, the finalize-before-fork A/B, bf16x6 against the reference goldens and its step rate beside exact f32
 R=$GRAFT_REPO_ROOT; cd $R; mkdir -p gpurun_out
