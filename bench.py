@@ -392,6 +392,13 @@ def main():
     if under_launcher:
         from dpc_amd.parallel import configure_rccl
         rccl_knobs = configure_rccl(world)  # before the first HIP call: channel count of the gradient all-reduce, CU carve-out (parallel.py)
+    # DPC_BENCH_REHEARSAL=1: every rank on cuda:0 with gloo carrying the collectives -- the multi-rank control flow of this file (the
+    # three-graph replay with a live exchange between the graphs, barriers, the clock's all_gather, the side schedules and their
+    # rank agreement) executed on a ONE-GPU box (scripts/gpu_r6_tworank.sh).  RCCL refuses two ranks on one device; the line such a
+    # run prints says "rehearsal" in `scaling` and is not a measurement.
+    rehearsal = os.environ.get("DPC_BENCH_REHEARSAL") == "1" and world > 1
+    if rehearsal:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if under_launcher:
@@ -399,7 +406,10 @@ def main():
         dist = dist_
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if rehearsal:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from dpc_amd.engine import DPCEngine, KernelTimer, HBM_FAMILY
     from dpc_amd.model import DPC_RNN
@@ -513,7 +523,7 @@ def main():
         out = {
             "metric": "clips/sec (train step, B x8x3x5xHxW)", "value": round(clips / dt, 2), "unit": "clips/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "higher_is_better": True, "scaling": "rehearsal (ranks share cuda:0, gloo): not a measurement" if rehearsal else "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": f"{args.config}: {net} 2d3d, img_dim {img}, seq_len 5, num_seq 8, pred_step {P}, "
                                    f"batch {batch}/GPU, full train step (fwd+CE/top-k+bwd+all-reduce+Adam)",
                        "global_batch": batch * world, "parallelism": f"dp{world}", "init": "reference init, random",

@@ -1,5 +1,5 @@
 """Assembles DESIGN.md from its parts (docs/design_parts/*.md) and fills the measured-numbers placeholders of section 8 / 9 / 11 from a
-bench.py JSON line:  python scripts/make_design.py <bench_line.json> [graph_destroy_summary.txt]"""
+bench.py JSON line:  python scripts/make_design.py profiles/r06_bench_cfg2.json docs/design_parts/graph_destroy.txt"""
 import json
 import os
 import sys
