@@ -15,44 +15,74 @@ static inline unsigned grid_for(long long n, int block = 256, int cap = 8192) {
 }
 
 // ------------------------------------------------------------------ forward finalize
-// one workgroup = 32 channels x 32 row lanes: the partial rows are summed in parallel (f64), then a
-// 32-way LDS tree; a serial per-channel loop over ~1-2k rows was latency-bound (0.4 ms per call).
-__device__ __forceinline__ void partial_rows_sum(const float* partials, int rows, int C, int c, int rl, double& s1, double& s2,
-                                                 double (*red)[32][32]) {
-    s1 = 0.0; s2 = 0.0;
-    if (c < C) {
-        // four rows per trip, loaded before any is added: the loop is a chain of L2 round trips otherwise (1024 partial rows of
-        // the backward reduction: 10.8 us per call, 20 calls per step).  The summation order stays fixed: ((r, r+32), (r+64, r+96)).
-        int r = rl;
-        for (; r + 96 < rows; r += 128) {
-            const float a0 = partials[((long long)r * 2 + 0) * C + c], b0 = partials[((long long)r * 2 + 1) * C + c];
-            const float a1 = partials[((long long)(r + 32) * 2 + 0) * C + c], b1 = partials[((long long)(r + 32) * 2 + 1) * C + c];
-            const float a2 = partials[((long long)(r + 64) * 2 + 0) * C + c], b2 = partials[((long long)(r + 64) * 2 + 1) * C + c];
-            const float a3 = partials[((long long)(r + 96) * 2 + 0) * C + c], b3 = partials[((long long)(r + 96) * 2 + 1) * C + c];
-            s1 += ((double)a0 + (double)a1) + ((double)a2 + (double)a3);
-            s2 += ((double)b0 + (double)b1) + ((double)b2 + (double)b3);
+// One workgroup = 32 channels, 256 threads = four waves, one per SIMD: thread (q = tid & 7, rl = tid >> 3) sums channels 4q..4q+3 of
+// rows rl, rl + 32, ... with 16-byte loads (f64), the eight row lanes of a wave meet through lane shuffles, the four waves through
+// 2 KB of LDS.  Small on purpose (rounds 1-5: 1 024 threads, 16 KB): these kernels run on the main stream while a weight gradient
+// of the side stream holds every CU -- two wgrad_patch workgroups leave 112 VGPRs per SIMD lane and 66 KB of LDS, room for a
+// 60-register wave per SIMD but not for four -- and the big workgroup waited for a whole CU to drain: 230 us on the critical path
+// of layer2.0 in every step (profiles/r06_r18_128_graph_timeline.txt: bn_bwd_finalize at 17.235 ms; 0.44 ms per step in these
+// kernels against 0.11 ms of work).  A serial per-channel loop over ~1-2k rows was latency-bound (0.4 ms per call, round 1).
+// After the call threads 0..31 hold the sums of channel blockIdx.x * 32 + tid.  The summation order is fixed (deterministic).
+constexpr int FIN_THREADS = 256;
+__device__ __forceinline__ void partial_rows_sum(const float* partials, int rows, int C, double& s1, double& s2, double (*red)[4][32]) {
+    const int tid = threadIdx.x, q = tid & 7, rl = tid >> 3;
+    const int c0 = blockIdx.x * 32 + 4 * q;
+    double a[4] = {0.0, 0.0, 0.0, 0.0}, b[4] = {0.0, 0.0, 0.0, 0.0};
+    if ((C & 3) == 0 && ((uintptr_t)partials & 15) == 0) {
+        if (c0 < C) {
+            // four rows per trip, loaded before any is added: the loop is a chain of L2 round trips otherwise
+            int r = rl;
+            for (; r + 96 < rows; r += 128) {
+                f32x4 x[4], y[4];
+                DPC_UNROLL
+                for (int k = 0; k < 4; ++k) {
+                    x[k] = *(const f32x4*)(partials + ((long long)(r + 32 * k) * 2 + 0) * C + c0);
+                    y[k] = *(const f32x4*)(partials + ((long long)(r + 32 * k) * 2 + 1) * C + c0);
+                }
+                DPC_UNROLL
+                for (int e = 0; e < 4; ++e) {
+                    a[e] += ((double)x[0][e] + (double)x[1][e]) + ((double)x[2][e] + (double)x[3][e]);
+                    b[e] += ((double)y[0][e] + (double)y[1][e]) + ((double)y[2][e] + (double)y[3][e]);
+                }
+            }
+            for (; r < rows; r += 32) {
+                const f32x4 x = *(const f32x4*)(partials + ((long long)r * 2 + 0) * C + c0);
+                const f32x4 y = *(const f32x4*)(partials + ((long long)r * 2 + 1) * C + c0);
+                DPC_UNROLL
+                for (int e = 0; e < 4; ++e) { a[e] += (double)x[e]; b[e] += (double)y[e]; }
+            }
         }
-        for (; r < rows; r += 32) {
-            s1 += (double)partials[((long long)r * 2 + 0) * C + c];
-            s2 += (double)partials[((long long)r * 2 + 1) * C + c];
-        }
+    } else {   // channel counts that are no multiple of four (or an unaligned table): the same walk, element by element
+        for (int r = rl; r < rows; r += 32)
+            DPC_UNROLL
+            for (int e = 0; e < 4; ++e)
+                if (c0 + e < C) {
+                    a[e] += (double)partials[((long long)r * 2 + 0) * C + c0 + e];
+                    b[e] += (double)partials[((long long)r * 2 + 1) * C + c0 + e];
+                }
     }
-    red[0][rl][c & 31] = s1;
-    red[1][rl][c & 31] = s2;
+    // lanes q, q + 8, ..., q + 56 of a wave hold the same channels
+    DPC_UNROLL
+    for (int m = 8; m < 64; m <<= 1)
+        DPC_UNROLL
+        for (int e = 0; e < 4; ++e) { a[e] += __shfl_xor(a[e], m); b[e] += __shfl_xor(b[e], m); }
+    const int wave = tid >> 6;
+    if ((tid & 63) < 8)
+        DPC_UNROLL
+        for (int e = 0; e < 4; ++e) { red[0][wave][4 * q + e] = a[e]; red[1][wave][4 * q + e] = b[e]; }
     __syncthreads();
-    if (rl == 0) {
-        s1 = 0.0; s2 = 0.0;
-        for (int k = 0; k < 32; ++k) { s1 += red[0][k][c & 31]; s2 += red[1][k][c & 31]; }
-    }
+    s1 = 0.0; s2 = 0.0;
+    if (tid < 32)
+        for (int w = 0; w < 4; ++w) { s1 += red[0][w][tid]; s2 += red[1][w][tid]; }
 }
 
-__global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* partials, int rows, int C, double count, const float* gamma,
+__global__ __launch_bounds__(FIN_THREADS) void bn_finalize_kernel(const float* partials, int rows, int C, double count, const float* gamma,
                                    const float* beta, float eps, float* mean, float* invstd, float* scale, float* shift) {
-    __shared__ double red[2][32][32];
-    const int c = blockIdx.x * 32 + (threadIdx.x & 31), rl = threadIdx.x >> 5;
+    __shared__ double red[2][4][32];
+    const int c = blockIdx.x * 32 + (int)threadIdx.x;
     double s1, s2;
-    partial_rows_sum(partials, rows, C, c, rl, s1, s2, red);
-    if (rl != 0 || c >= C) return;
+    partial_rows_sum(partials, rows, C, s1, s2, red);
+    if (threadIdx.x >= 32 || c >= C) return;
     const double m = s1 / count;
     double var = s2 / count - m * m;
     if (var < 0.0) var = 0.0;
@@ -69,22 +99,22 @@ extern "C" int dpc_bn_finalize(const float* partials, int32_t rows, int32_t C, d
                                dpc_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (!partials || rows <= 0 || C <= 0 || count <= 0 || !gamma || !beta || !mean || !invstd || !scale || !shift) return DPC_ERR_ARG;
-    DPC_LAUNCH(bn_finalize_kernel, dim3((C + 31) / 32), dim3(1024), stream, partials, rows, C, count, gamma, beta, eps, mean, invstd, scale, shift);
+    DPC_LAUNCH(bn_finalize_kernel, dim3((C + 31) / 32), dim3(FIN_THREADS), stream, partials, rows, C, count, gamma, beta, eps, mean, invstd, scale, shift);
     return dpc_launch_status();
 }
 
 // ---- BatchNorm3d with track_running_stats=True (the LC classifier's backbone, eval/model_3d_lc.py:27-29) --------------------
 // train: batch statistics as above + running_mean/var <- (1-m) running + m batch (variance unbiased, torch semantics);
 // eval: coefficients from the running buffers (dpc_bn_eval_coeffs), no batch statistics at all.
-__global__ __launch_bounds__(1024) void bn_finalize_running_kernel(const float* partials, int rows, int C, double count, const float* gamma,
+__global__ __launch_bounds__(FIN_THREADS) void bn_finalize_running_kernel(const float* partials, int rows, int C, double count, const float* gamma,
                                    const float* beta, float eps, float* mean, float* invstd, float* scale, float* shift,
                                    float* rmean, float* rvar, long long* nbt, float momentum) {
-    __shared__ double red[2][32][32];
-    const int c = blockIdx.x * 32 + (threadIdx.x & 31), rl = threadIdx.x >> 5;
+    __shared__ double red[2][4][32];
+    const int c = blockIdx.x * 32 + (int)threadIdx.x;
     double s1, s2;
-    partial_rows_sum(partials, rows, C, c, rl, s1, s2, red);
+    partial_rows_sum(partials, rows, C, s1, s2, red);
     if (blockIdx.x == 0 && threadIdx.x == 0 && nbt) nbt[0] += 1;
-    if (rl != 0 || c >= C) return;
+    if (threadIdx.x >= 32 || c >= C) return;
     const double m = s1 / count;
     double var = s2 / count - m * m;
     if (var < 0.0) var = 0.0;
@@ -105,7 +135,7 @@ extern "C" int dpc_bn_finalize_running(const float* partials, int32_t rows, int3
     hipStream_t stream = (hipStream_t)stream_;
     if (!partials || rows <= 0 || C <= 0 || count <= 0 || !gamma || !beta || !mean || !invstd || !scale || !shift || !running_mean || !running_var)
         return DPC_ERR_ARG;
-    DPC_LAUNCH(bn_finalize_running_kernel, dim3((C + 31) / 32), dim3(1024), stream, partials, rows, C, count, gamma, beta, eps, mean, invstd, scale,
+    DPC_LAUNCH(bn_finalize_running_kernel, dim3((C + 31) / 32), dim3(FIN_THREADS), stream, partials, rows, C, count, gamma, beta, eps, mean, invstd, scale,
                shift, running_mean, running_var, (long long*)num_batches_tracked, momentum);
     return dpc_launch_status();
 }
@@ -419,12 +449,12 @@ extern "C" int dpc_bn_bwd_reduce(const void* dy, const void* y, const uint8_t* m
     return dpc_launch_status();
 }
 
-__global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* partials, int prow, int C, double count, float* dgamma, float* dbeta, float* coef) {
-    __shared__ double red[2][32][32];
-    const int c = blockIdx.x * 32 + (threadIdx.x & 31), rl = threadIdx.x >> 5;
+__global__ __launch_bounds__(FIN_THREADS) void bn_bwd_finalize_kernel(const float* partials, int prow, int C, double count, float* dgamma, float* dbeta, float* coef) {
+    __shared__ double red[2][4][32];
+    const int c = blockIdx.x * 32 + (int)threadIdx.x;
     double s1, s2;
-    partial_rows_sum(partials, prow, C, c, rl, s1, s2, red);
-    if (rl != 0 || c >= C) return;
+    partial_rows_sum(partials, prow, C, s1, s2, red);
+    if (threadIdx.x >= 32 || c >= C) return;
     dbeta[c] = (float)s1;
     dgamma[c] = (float)s2;
     coef[c] = (float)(s1 / count);
@@ -435,7 +465,7 @@ extern "C" int dpc_bn_bwd_finalize(const float* partials, int32_t prow, int32_t 
                                    float* dbeta, float* coef, dpc_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (!partials || prow <= 0 || C <= 0 || count <= 0 || !dgamma || !dbeta || !coef) return DPC_ERR_ARG;
-    DPC_LAUNCH(bn_bwd_finalize_kernel, dim3((C + 31) / 32), dim3(1024), stream, partials, prow, C, count, dgamma, dbeta, coef);
+    DPC_LAUNCH(bn_bwd_finalize_kernel, dim3((C + 31) / 32), dim3(FIN_THREADS), stream, partials, prow, C, count, dgamma, dbeta, coef);
     return dpc_launch_status();
 }
 

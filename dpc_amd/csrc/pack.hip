@@ -128,7 +128,7 @@ __global__ __launch_bounds__(256) void reduce_unpack_kernel(const float* part, i
 }
 
 // Same reduction with 16-byte loads: a thread owns FOUR consecutive outputs (d2 % 4 == 0, so they share i0, i1), a workgroup
-// 128 outputs x 8 split lanes; each split lane walks its slabs two at a time.  The 4-byte form reads 128 bytes per 32 lanes and
+// 128 outputs x 8 split lanes; each split lane walks its slabs eight at a time.  The 4-byte form reads 128 bytes per 32 lanes and
 // slab: 34 us for the 75 MB of layer1's 512 slabs (2.2 TB/s).  Summation order is fixed by (lane, slab index): deterministic.
 __global__ __launch_bounds__(256) void reduce_unpack4_kernel(const float* part, int nsplit, float* out, int d0, int d1, int d2, long long s0,
                                       long long s1, long long s2, int accumulate) {
@@ -136,20 +136,37 @@ __global__ __launch_bounds__(256) void reduce_unpack4_kernel(const float* part, 
     const long long n = (long long)d0 * d1 * d2;
     const int ol = threadIdx.x & 31, sl = threadIdx.x >> 5;
     const long long i = ((long long)blockIdx.x * 32 + ol) * 4;
-    float a[4] = {0.f, 0.f, 0.f, 0.f}, b[4] = {0.f, 0.f, 0.f, 0.f};
+    // EIGHT slabs per split lane and trip, loaded before any is added: with two (rounds 3-5) the walk was a chain of HBM round trips --
+    // 62 us for the 512 slabs x 32 KB of layer2.0's downsample gradient (64 workgroups), on the side stream's critical path there
+    float acc[8][4];
+    DPC_UNROLL
+    for (int j = 0; j < 8; ++j)
+        DPC_UNROLL
+        for (int e = 0; e < 4; ++e) acc[j][e] = 0.f;
     if (i < n) {
         int k = sl;
-        for (; k + 8 < nsplit; k += 16) {
-            const u32x4 v0 = *(const u32x4*)(part + (long long)k * n + i);
-            const u32x4 v1 = *(const u32x4*)(part + (long long)(k + 8) * n + i);
+        for (; k + 56 < nsplit; k += 64) {
+            u32x4 v[8];
             DPC_UNROLL
-            for (int e = 0; e < 4; ++e) { a[e] += unit_get<float>(v0, e); b[e] += unit_get<float>(v1, e); }
-        }
-        if (k < nsplit) {
-            const u32x4 v0 = *(const u32x4*)(part + (long long)k * n + i);
+            for (int j = 0; j < 8; ++j) v[j] = *(const u32x4*)(part + (long long)(k + 8 * j) * n + i);
             DPC_UNROLL
-            for (int e = 0; e < 4; ++e) a[e] += unit_get<float>(v0, e);
+            for (int j = 0; j < 8; ++j)
+                DPC_UNROLL
+                for (int e = 0; e < 4; ++e) acc[j][e] += unit_get<float>(v[j], e);
         }
+        DPC_UNROLL
+        for (int j = 0; j < 8; ++j)
+            if (k + 8 * j < nsplit) {
+                const u32x4 v0 = *(const u32x4*)(part + (long long)(k + 8 * j) * n + i);
+                DPC_UNROLL
+                for (int e = 0; e < 4; ++e) acc[j][e] += unit_get<float>(v0, e);
+            }
+    }
+    float a[4], b[4];
+    DPC_UNROLL
+    for (int e = 0; e < 4; ++e) {
+        a[e] = (acc[0][e] + acc[1][e]) + (acc[2][e] + acc[3][e]);
+        b[e] = (acc[4][e] + acc[5][e]) + (acc[6][e] + acc[7][e]);
     }
     DPC_UNROLL
     for (int e = 0; e < 4; ++e) red[sl][ol][e] = a[e] + b[e];
@@ -419,20 +436,37 @@ __global__ __launch_bounds__(256) void unpack_stem_wgrad_kernel(const float* par
     const int n = Co * 256;
     const int ol = threadIdx.x & 31, sl = threadIdx.x >> 5;
     const int i = (blockIdx.x * 32 + ol) * 4;
-    float a[4] = {0.f, 0.f, 0.f, 0.f}, b[4] = {0.f, 0.f, 0.f, 0.f};
+    // EIGHT slabs per split lane and trip, loaded before any is added: with two (rounds 3-5) the walk was a chain of HBM round trips --
+    // 62 us for the 512 slabs x 32 KB of layer2.0's downsample gradient (64 workgroups), on the side stream's critical path there
+    float acc[8][4];
+    DPC_UNROLL
+    for (int j = 0; j < 8; ++j)
+        DPC_UNROLL
+        for (int e = 0; e < 4; ++e) acc[j][e] = 0.f;
     if (i < n) {
         int k = sl;
-        for (; k + 8 < nsplit; k += 16) {
-            const u32x4 v0 = *(const u32x4*)(part + (long long)k * n + i);
-            const u32x4 v1 = *(const u32x4*)(part + (long long)(k + 8) * n + i);
+        for (; k + 56 < nsplit; k += 64) {
+            u32x4 v[8];
             DPC_UNROLL
-            for (int e = 0; e < 4; ++e) { a[e] += unit_get<float>(v0, e); b[e] += unit_get<float>(v1, e); }
-        }
-        if (k < nsplit) {
-            const u32x4 v0 = *(const u32x4*)(part + (long long)k * n + i);
+            for (int j = 0; j < 8; ++j) v[j] = *(const u32x4*)(part + (long long)(k + 8 * j) * n + i);
             DPC_UNROLL
-            for (int e = 0; e < 4; ++e) a[e] += unit_get<float>(v0, e);
+            for (int j = 0; j < 8; ++j)
+                DPC_UNROLL
+                for (int e = 0; e < 4; ++e) acc[j][e] += unit_get<float>(v[j], e);
         }
+        DPC_UNROLL
+        for (int j = 0; j < 8; ++j)
+            if (k + 8 * j < nsplit) {
+                const u32x4 v0 = *(const u32x4*)(part + (long long)(k + 8 * j) * n + i);
+                DPC_UNROLL
+                for (int e = 0; e < 4; ++e) acc[j][e] += unit_get<float>(v0, e);
+            }
+    }
+    float a[4], b[4];
+    DPC_UNROLL
+    for (int e = 0; e < 4; ++e) {
+        a[e] = (acc[0][e] + acc[1][e]) + (acc[2][e] + acc[3][e]);
+        b[e] = (acc[4][e] + acc[5][e]) + (acc[6][e] + acc[7][e]);
     }
     DPC_UNROLL
     for (int e = 0; e < 4; ++e) red[sl][ol][e] = a[e] + b[e];

@@ -456,6 +456,34 @@ def case_bn_fwd_bwd(k: K, dtype, rows, Cc, relu, res_mode, seed=5):
         assert relerr(dz, dz_ref) < tol(dtype)
 
 
+def case_bn_finalize(k: K, rows, Cc, misalign=0, seed=11):
+    """dpc_bn_finalize / dpc_bn_bwd_finalize on a table of `rows` partial rows: f64 column sums (the unrolled four-row trips, the row tail,
+    channel counts that are no multiple of four, a table that is not 16-byte aligned)"""
+    g = torch.Generator().manual_seed(seed)
+    parts = torch.randn(rows, 2, Cc, generator=g)
+    parts[:, 1] = parts[:, 1].abs() * 3 + parts[:, 0] ** 2          # sum of squares >= (sum)^2 / n per row
+    count = float(rows * 7)
+    gamma, beta = torch.rand(Cc, generator=g) + 0.5, torch.randn(Cc, generator=g)
+    buf = k.zeros(rows * 2 * Cc + 4)
+    pk = buf[misalign:misalign + rows * 2 * Cc].view(rows, 2, Cc)
+    pk.copy_(parts)
+    s1, s2 = parts[:, 0].double().sum(0), parts[:, 1].double().sum(0)
+    m = s1 / count
+    var = (s2 / count - m * m).clamp_min(0)
+    inv = 1.0 / torch.sqrt(var + 1e-5)
+    dm, di, dsc, dsh = (k.empty(Cc) for _ in range(4))
+    k.call("dpc_bn_finalize", pk, rows, Cc, count, k.t(gamma), k.t(beta), 1e-5, dm, di, dsc, dsh)
+    dgam, dbet, coef = k.empty(Cc), k.empty(Cc), k.empty(2, Cc)
+    k.call("dpc_bn_bwd_finalize", pk, rows, Cc, count, dgam, dbet, coef)
+    k.sync()
+    f = lambda t: t.float().cpu()  # noqa: E731
+    assert torch.allclose(f(dm), m.float(), rtol=1e-6, atol=1e-7) and torch.allclose(f(di), inv.float(), rtol=1e-6)
+    sc = gamma * inv.float()
+    assert torch.allclose(f(dsc), sc, rtol=1e-6) and torch.allclose(f(dsh), beta - m.float() * sc, rtol=1e-5, atol=1e-6)
+    assert torch.allclose(f(dbet), s1.float(), rtol=1e-6, atol=1e-6) and torch.allclose(f(dgam), s2.float(), rtol=1e-6)
+    assert torch.allclose(f(coef[0]), (s1 / count).float(), rtol=1e-6, atol=1e-7) and torch.allclose(f(coef[1]), (s2 / count).float(), rtol=1e-6)
+
+
 def case_stem_pool(k: K, dtype, NT, H, W, Cc, seed=6):
     """relu(bn(x)) -> MaxPool3d((1,3,3),(1,2,2),(0,1,1)) and its backward (resnet_2d3d.py:212-214)"""
     g = torch.Generator().manual_seed(seed)

@@ -162,6 +162,12 @@ def test_bn(k, dtype, relu, res_mode, C):
     kc.case_bn_fwd_bwd(k, dtype, 333, C, relu, res_mode)
 
 
+@pytest.mark.parametrize("rows,C,misalign", [(1, 64, 0), (3, 5, 0), (37, 70, 0), (131, 64, 0), (300, 128, 0), (1030, 64, 0), (256, 512, 0), (129, 64, 1)])
+def test_bn_finalize(k, rows, C, misalign):
+    """the compact finalize kernels (256 threads: they must start beside a side-stream weight gradient that holds every CU) against f64 sums"""
+    kc.case_bn_finalize(k, rows, C, misalign)
+
+
 @pytest.mark.parametrize("unroll", ["4", "2", "1"])
 @pytest.mark.parametrize("relu,res_mode,C", [(True, 0, 64), (True, 1, 128), (False, 2, 256)])
 def test_bn_streaming_forms(k, monkeypatch, unroll, relu, res_mode, C):
@@ -201,6 +207,8 @@ def test_reduce_unpack_forms(k):
     kc.case_reduce_unpack(k, 3, 300, 4, 256, False, True, expect="reduce_unpack4_kernel")      # + accumulate
     kc.case_reduce_unpack(k, 8, 2049, 1, 128, True, False, expect="reduce_unpack4_kernel")     # permuted strides
     kc.case_reduce_unpack(k, 19, 64, 9, 64, True, True, expect="reduce_unpack4_kernel")        # many slabs: the split-lane form
+    kc.case_reduce_unpack(k, 150, 8, 1, 64, False, False, expect="reduce_unpack4_kernel")      # two eight-slab trips per split lane + a ragged tail
+    kc.case_reduce_unpack(k, 64, 8, 1, 32, False, True, expect="reduce_unpack4_kernel")        # exactly one trip, empty tail
     kc.case_reduce_unpack(k, 4, 64, 9, 64, True, False, expect="reduce_unpack_t_kernel")       # conv layout, few slabs
     kc.case_reduce_unpack(k, 3, 33, 5, 7, False, True, expect="reduce_unpack_kernel")          # unaligned: element form
 

@@ -180,6 +180,12 @@ def test_stem_s2d(k, dtype):
     kc.case_stem(k, dtype, 1, 2, 32, 224, expect=(ws, ws and "wgrad_stem_kernel"))   # two 64-column segments per row
 
 
+@pytest.mark.parametrize("rows,C,misalign", [(1, 64, 0), (3, 5, 0), (37, 70, 0), (131, 64, 0), (300, 128, 0), (1030, 64, 0), (256, 512, 0), (129, 64, 1)])
+def test_bn_finalize(k, rows, C, misalign):
+    """the compact finalize kernels (256 threads: they must start beside a side-stream weight gradient that holds every CU) against f64 sums"""
+    kc.case_bn_finalize(k, rows, C, misalign)
+
+
 @pytest.mark.parametrize("dtype", [F32, BF16])
 @pytest.mark.parametrize("relu,res_mode,C", [(True, 0, 64), (True, 1, 128), (False, 2, 256), (True, 2, 256), (True, 1, 16)])
 def test_bn(k, dtype, relu, res_mode, C):
@@ -220,6 +226,7 @@ def test_reduce_unpack_forms(k):
     kc.case_reduce_unpack(k, 2, 15680, 1, 256, False, True, expect="reduce_unpack4_kernel")    # cfg5, accumulate
     kc.case_reduce_unpack(k, 8, 2049, 1, 128, True, False, expect="reduce_unpack4_kernel")     # permuted strides
     kc.case_reduce_unpack(k, 300, 64, 9, 64, True, True, expect="reduce_unpack4_kernel")       # many slabs: the split-lane form
+    kc.case_reduce_unpack(k, 512, 128, 1, 64, False, False, expect="reduce_unpack4_kernel")    # layer2.0 downsample gradient at cfg2: 512 slabs x 32 KB
     kc.case_reduce_unpack(k, 4, 256, 27, 256, True, False, expect="reduce_unpack_t_kernel")    # conv layout, few slabs
     kc.case_reduce_unpack(k, 3, 33, 5, 7, False, True, expect="reduce_unpack_kernel")          # unaligned: element form
 
