@@ -85,6 +85,7 @@ def _block_case(eng, bi):
     dx = blk.backward(dout.to(DEV).clone(), need_dx=True)
     if blk.prev is not None:
         blk.prev.c2.reduced_rows = 0   # the fused reduction of the previous block's bn2 is not consumed here
+        blk.prev.c2._coef_ready = False   # ... nor the coefficients the block prepared for it (plan_backward: fold_prev / reduce_first_prev)
     torch.cuda.synchronize()
     errs = {"dx": rel(nchw(dx), x.grad)}
     for k, v in p.items():
