@@ -402,6 +402,15 @@ __global__ __launch_bounds__(512, 2) void conv_halo_ws_kernel(HaloParams p) {
             frag_a[i] = (r * p.HWd + c) * CBP + lhi * 16;
         }
         const int rowpitch = p.HWd * CBP;
+#ifndef DPC_SIMT_EMU
+        // The weights are waited for HERE: their loads go through generic pointers (the zero page for channels beyond Co), flat loads
+        // count on vmcnt AND lgkmcnt, and with the first use inside the tile loop hipcc put "s_waitcnt vmcnt(0) lgkmcnt(0)" in front of
+        // every tile's first MFMA -- behind the eight hand-issued fragment reads of which that MFMA needs two.
+        DPC_UNROLL
+        for (int tap = 0; tap < NTAPS; ++tap)
+            DPC_UNROLL
+            for (int kk = 0; kk < 4; ++kk) asm volatile("" : "+v"(fbr[tap][kk]));
+#endif
         for (int j = 0; j < ntiles; ++j) {
             f32x16 acc[MI];
             DPC_UNROLL
@@ -447,7 +456,7 @@ __global__ __launch_bounds__(512, 2) void conv_halo_ws_kernel(HaloParams p) {
                     const int row_l = wm * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
                     tile[row_l * BN + wn * 32 + l31] = f32_to_bf16(acc[i][r]);
                 }
-            barrier_lds_only();  // B2(j)
+            barrier_lds_only_tracked();  // B2(j): hipcc knows the staging stores have retired (no wait of its own behind the next tile's first fragment reads)
         }
         barrier_lds_only();
         barrier_lds_only();

@@ -312,6 +312,19 @@ __device__ __forceinline__ void barrier_lds_only() {
 #endif
 }
 
+// The same barrier with the wait as a compiler-visible instruction.  For a wave whose last LDS operations before the barrier are
+// compiler-generated stores (a staging tile written from accumulator registers): behind the asm form hipcc still counts those stores
+// as outstanding and puts its own s_waitcnt lgkmcnt(0) in front of the first instruction that overwrites their source registers --
+// the first MFMA of the next tile, i.e. behind the hand-issued fragment reads that were meant to stay in flight under it.
+__device__ __forceinline__ void barrier_lds_only_tracked() {
+#ifdef DPC_SIMT_EMU
+    simt::sync_block();
+#else
+    __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0), vmcnt / expcnt untouched
+    asm volatile("s_barrier" ::: "memory");
+#endif
+}
+
 // LDS transpose read (gfx950 ds_read_b64_tr_b16): see tests/simt_emu/simt_emu.h for the lane map.
 // Lane l of a 16-lane group passes the address of row (l>>2), columns 4*(l&3).. of a 4 x 16 block of
 // 16-bit elements and receives column (l&15) of that block (4 elements, row order).

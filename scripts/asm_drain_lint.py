@@ -77,6 +77,60 @@ def lint_file(path):
     return hits
 
 
+def lint_file_reads(path, skip=("conv_halo_kernel", "score_fwd_kernel", "score_bwd_kernel")):
+    """Second class (late round 6): a compiler-inserted ``lgkmcnt(0)`` in an innermost loop whose LDS fragment reads are hand-issued
+    (inline asm) and retired with hand-counted ``lgkmcnt(N)`` -- it waits for ALL of them where the next MFMA needs the oldest two.
+    conv_halo_ws_kernel had one in front of every tile's first MFMA: its register-resident weights were loaded through generic
+    pointers (flat loads count on vmcnt AND lgkmcnt) and first used inside the tile loop.  A wait directly in front of a barrier is
+    what the code asks for and is not reported; `skip`: kernels that are not pipelined across iterations (one-barrier-per-chunk
+    generic forms).  -> list of (kernel, first line of the loop, line of the wait, number of hand-issued reads in the loop)"""
+    lines = open(path).read().split("\n")
+    hits = []
+    kern, start, bounds = None, 0, []
+    for i, l in enumerate(lines):
+        m = re.match(r"^(_Z\w+):", l)
+        if m:
+            if kern:
+                bounds.append((kern, start, i))
+            kern, start = m.group(1), i
+    if kern:
+        bounds.append((kern, start, len(lines)))
+    for kern, a, b in bounds:
+        if any(k in kern for k in skip):
+            continue
+        i = a
+        while i < b:
+            m = re.match(r"^(\.LBB\d+_\d+):.*Inner Loop Header", lines[i])
+            if not m:
+                i += 1
+                continue
+            label = m.group(1)
+            end = None
+            for j in range(i + 1, b):
+                if re.search(r"s_cbranch\w*\s+" + re.escape(label) + r"\b|s_branch\s+" + re.escape(label) + r"\b", lines[j]):
+                    end = j
+            if end is None:
+                i += 1
+                continue
+            body = lines[i:end + 1]
+            inasm, reads, waits = False, 0, []
+            for off, x in enumerate(body):
+                if "ASMSTART" in x:
+                    inasm = True
+                elif "ASMEND" in x:
+                    inasm = False
+                elif inasm and re.search(r"\bds_read", x):
+                    reads += 1
+                elif not inasm and re.search(r"s_waitcnt.*lgkmcnt\(0\)", x):
+                    nxt = [y for y in body[off + 1:off + 5] if y.strip() and "ASMSTART" not in y and "ASMEND" not in y and not y.strip().startswith(";")]
+                    if not (nxt and "s_barrier" in nxt[0]):
+                        waits.append(off)
+            if reads:
+                hits += [(kern, i + 1, i + off + 1, reads) for off in waits]
+            i = end + 1
+    return hits
+
+
 def build_and_lint(root, srcs=None, defines=()):
     srcs = srcs or RING_SOURCES
     out = []
@@ -87,6 +141,7 @@ def build_and_lint(root, srcs=None, defines=()):
                    "--cuda-device-only"] + [f"-D{d}" for d in defines] + [os.path.join(root, "dpc_amd", "csrc", s), "-o", asm]
             subprocess.run(cmd, check=True, capture_output=True, stdin=subprocess.DEVNULL, timeout=900)
             out += [(s,) + h for h in lint_file(asm)]
+            out += [(s, h[0], h[1], h[2], -h[3]) for h in lint_file_reads(asm)]   # (negative count: the fragment-read class)
     names = demangle(sorted({h[1] for h in out}))
     return [(h[0], names.get(h[1], h[1]), h[2], h[3], h[4]) for h in out]
 
@@ -99,7 +154,11 @@ if __name__ == "__main__":
         hits = []
         for f in sys.argv[1:]:
             hits += [(f,) + h for h in lint_file(f)]
+            hits += [(f, h[0], h[1], h[2], -h[3]) for h in lint_file_reads(f)]
     for h in hits:
+        if h[4] < 0:
+            print(f"{h[0]}: {h[1][:100]}: compiler-inserted lgkmcnt(0) at line {h[3]} in the loop at line {h[2]} ({-h[4]} hand-issued LDS reads)")
+            continue
         print(f"{h[0]}: {h[1][:100]}: compiler-inserted vmcnt(0) at line {h[3]} in the DMA loop at line {h[2]} ({h[4]} LDS-DMA instructions)")
     print(f"{len(hits)} drain(s)")
     sys.exit(1 if hits else 0)

@@ -80,3 +80,44 @@ __global__ void ctl_kernel(const u32x4* src, const uint8_t* m, const void* dma_s
                         f"-I{os.path.join(ROOT, 'dpc_amd', 'csrc')}", "-S", "--cuda-device-only", src, "-o", asm], check=True, capture_output=True,
                        stdin=subprocess.DEVNULL, timeout=600)
         assert dl.lint_file(asm), "the lint did not see the drain of the control kernel"
+        # second class (late round 6): operands that live in registers, loaded through GENERIC pointers (flat loads count on vmcnt and
+        # lgkmcnt) and first used inside a loop whose LDS reads are hand-issued: hipcc waits lgkmcnt(0) behind the reads.  Waiting for
+        # the operands in front of the loop (an empty asm that consumes them, conv_halo.hip) removes it.
+        ctl2 = r'''
+#include "dpc_rt.h"
+template <bool FIX>
+__global__ void ctl2_kernel(const void* wgt, int Co, float* out, int n) {
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[8192];
+    const int lane = threadIdx.x & 63;
+    const char* wp = lane < Co ? (const char*)wgt + lane * 64 : nullptr;
+    u32x4 b[4];
+    for (int k = 0; k < 4; ++k) b[k] = *(const u32x4*)(wp ? wp + k * 16 : (const char*)dpc_zero16);
+    if (FIX)
+        for (int k = 0; k < 4; ++k) asm volatile("" : "+v"(b[k]));
+    f32x16 acc;
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    for (int j = 0; j < n; ++j) {
+        barrier_lds_only();
+        u32x4 a[4];
+        for (int k = 0; k < 4; ++k) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(a[k]) : "v"((uint32_t)(lane * 16 + (j & 1) * 4096)), "n"(0) : "memory");
+        for (int k = 0; k < 4; ++k) {
+            if (k == 0) asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(a[0]));
+            if (k == 1) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(a[1]));
+            if (k == 2) asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(a[2]));
+            if (k == 3) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a[3]));
+            acc = mfma_32x32x16_bf16(a[k], b[k], acc);
+        }
+    }
+    for (int r = 0; r < 16; ++r) out[threadIdx.x * 16 + r] = acc[r];
+}
+template __global__ void ctl2_kernel<false>(const void*, int, float*, int);
+template __global__ void ctl2_kernel<true>(const void*, int, float*, int);
+'''
+        src2, asm2 = os.path.join(tmp, "ctl2.hip"), os.path.join(tmp, "ctl2.s")
+        open(src2, "w").write(ctl2)
+        subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", f"-I{os.path.join(ROOT, 'include')}",
+                        f"-I{os.path.join(ROOT, 'dpc_amd', 'csrc')}", "-S", "--cuda-device-only", src2, "-o", asm2], check=True, capture_output=True,
+                       stdin=subprocess.DEVNULL, timeout=600)
+        got = dl.lint_file_reads(asm2)
+        assert any("Lb0E" in h[0] for h in got), "the lint did not see the fragment-read drain of the control kernel"
+        assert not any("Lb1E" in h[0] for h in got), got
