@@ -358,7 +358,10 @@ __global__ __launch_bounds__(512, 2) void igemm_ws_kernel(WsParams p) {
                 const int row = PAR ? par_row(ck, wv * 64 + i * 32 + er + 4 * it) : tile_row(mt, wv * 64 + i * 32 + er + 4 * it);
                 const bool ok = row < g.M && col0 < p.Ncol;
                 const char* a = (const char*)p.addend + ((long long)row * p.ldo + col0) * 2;
-                dst[it] = *(const u32x4*)(ok ? a : zero);
+                // rows outside the tensor read its unit 0 (never used: their outputs are not stored).  Not the zero page: a select between
+                // a kernel-argument pointer and a device constant is a GENERIC pointer, its flat loads count on lgkmcnt as well and hipcc
+                // waits lgkmcnt(0) for them -- behind the hand-issued fragment reads of the chunk (scripts/asm_drain_lint.py)
+                dst[it] = *(const u32x4*)(ok ? a : (const char*)p.addend);
             }
         };
         int stage_last = 0;
@@ -641,7 +644,10 @@ __global__ __launch_bounds__(512, 2) void igemm_wsp_kernel(WsParams p) {
                 const int row = mt * BM + wv * 64 + i * 32 + er + 4 * it;
                 const bool ok = row < g.M && col0 < p.Ncol;
                 const char* a = (const char*)p.addend + ((long long)row * p.ldo + col0) * 2;
-                dst[it] = *(const u32x4*)(ok ? a : zero);
+                // rows outside the tensor read its unit 0 (never used: their outputs are not stored).  Not the zero page: a select between
+                // a kernel-argument pointer and a device constant is a GENERIC pointer, its flat loads count on lgkmcnt as well and hipcc
+                // waits lgkmcnt(0) for them -- behind the hand-issued fragment reads of the chunk (scripts/asm_drain_lint.py)
+                dst[it] = *(const u32x4*)(ok ? a : (const char*)p.addend);
             }
         };
         // Chunk loop: (channel group, kh) outer, kw unrolled (its address table is then a compile-time choice).  Four steps per

@@ -32,6 +32,21 @@ def demangle(names):
         return {n: n for n in names}
 
 
+def inner_loop_label(lines, i):
+    """the label of line i if it heads an INNERMOST loop.  hipcc annotates `.LBBx_y: ; =>This Inner Loop Header` on the label line for a
+    top-level loop, and on a comment-only continuation line (`;   Parent Loop ...` / `; =>  This Inner Loop Header: Depth=2`) for a
+    nested one -- the K loops of the persistent kernels are nested in their tile loops (the first version of this lint missed them)"""
+    m = re.match(r"^(\.LBB\d+_\d+):(.*)", lines[i])
+    if not m:
+        return None
+    note = m.group(2)
+    j = i + 1
+    while j < len(lines) and re.match(r"^\s*;", lines[j]) and "ASMSTART" not in lines[j] and "ASMEND" not in lines[j]:
+        note += lines[j]
+        j += 1
+    return m.group(1) if "Inner Loop Header" in note else None
+
+
 def lint_file(path):
     """-> list of (kernel, first line of the loop, line of the wait, number of DMA instructions in the loop)"""
     lines = open(path).read().split("\n")
@@ -50,11 +65,10 @@ def lint_file(path):
         # innermost loops as hipcc annotates them: a block label with "Inner Loop Header" up to the backward branch to it
         i = a
         while i < b:
-            m = re.match(r"^(\.LBB\d+_\d+):.*Inner Loop Header", lines[i])
-            if not m:
+            label = inner_loop_label(lines, i)
+            if not label:
                 i += 1
                 continue
-            label = m.group(1)
             end = None
             for j in range(i + 1, b):
                 if re.search(r"s_cbranch\w*\s+" + re.escape(label) + r"\b|s_branch\s+" + re.escape(label) + r"\b", lines[j]):
@@ -100,11 +114,10 @@ def lint_file_reads(path, skip=("conv_halo_kernel", "score_fwd_kernel", "score_b
             continue
         i = a
         while i < b:
-            m = re.match(r"^(\.LBB\d+_\d+):.*Inner Loop Header", lines[i])
-            if not m:
+            label = inner_loop_label(lines, i)
+            if not label:
                 i += 1
                 continue
-            label = m.group(1)
             end = None
             for j in range(i + 1, b):
                 if re.search(r"s_cbranch\w*\s+" + re.escape(label) + r"\b|s_branch\s+" + re.escape(label) + r"\b", lines[j]):
