@@ -187,6 +187,33 @@ __global__ __launch_bounds__(256) void reduce_unpack4_kernel(const float* part, 
     }
 }
 
+// Few slabs (<= 8: the score's backward products, 5 slabs of 6 MB at cfg2; the small weight gradients of layer3 / layer4): one thread
+// owns four consecutive outputs and reads ALL its slabs before adding any -- no split lanes (with nsplit = 5 three of the eight idle),
+// no LDS hop.  Sums left to right, which is what the split-lane form computes for nsplit <= 8 (lane k holds slab k alone, the tree
+// adds lanes 0..7 in order): bit-identical results.
+template <int NS>
+__global__ __launch_bounds__(256) void reduce_unpack_few_kernel(const float* part, float* out, int d0, int d1, int d2, long long s0, long long s1,
+                                                                long long s2, int accumulate) {
+    const long long n = (long long)d0 * d1 * d2;
+    const long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i >= n) return;
+    u32x4 v[NS];
+    DPC_UNROLL
+    for (int k = 0; k < NS; ++k) v[k] = *(const u32x4*)(part + (long long)k * n + i);
+    const int i2 = (int)(i % d2);
+    const long long q = i / d2;
+    const int i1 = (int)(q % d1);
+    const int i0 = (int)(q / d1);
+    float* o = out + i0 * s0 + i1 * s1 + i2 * s2;
+    DPC_UNROLL
+    for (int e = 0; e < 4; ++e) {
+        float t = 0.f;
+        DPC_UNROLL
+        for (int k = 0; k < NS; ++k) t += unit_get<float>(v[k], e);
+        o[e * s2] = accumulate ? (o[e * s2] + t) : t;
+    }
+}
+
 // The conv weight-gradient case: slabs [co][tap][ci] -> parameter layout [co][ci][tap] (s0 = d1*d2, s1 = 1, s2 = d1).  The
 // generic kernel above writes it with 4-byte stores `taps` floats apart and reads 128 bytes per wave and slab (34 us for a
 // 256 x 256 x 27 gradient, 25 launches per step); here a workgroup owns (co, 64 input channels): the slab sums are read as
@@ -236,7 +263,14 @@ extern "C" int dpc_reduce_unpack(const float* part, int32_t nsplit, float* out, 
         return dpc_launch_status();
     }
     const long long n = (long long)d0 * d1 * d2;
-    if (d2 % 4 == 0 && ((uintptr_t)part % 16) == 0) {   // n % 4 == 0 follows: every slab starts 16-byte aligned
+    if (d2 % 4 == 0 && ((uintptr_t)part % 16) == 0 && nsplit <= 8) {   // n % 4 == 0 follows: every slab starts 16-byte aligned
+        const dim3 grid((unsigned)((n / 4 + 255) / 256)), block(256);
+#define DPC_RUF(NS) case NS: DPC_LAUNCH((reduce_unpack_few_kernel<NS>), grid, block, stream, part, out, d0, d1, d2, (long long)s0, (long long)s1, (long long)s2, accumulate); break
+        switch (nsplit) { DPC_RUF(1); DPC_RUF(2); DPC_RUF(3); DPC_RUF(4); DPC_RUF(5); DPC_RUF(6); DPC_RUF(7); DPC_RUF(8); }
+#undef DPC_RUF
+        return dpc_launch_status();
+    }
+    if (d2 % 4 == 0 && ((uintptr_t)part % 16) == 0) {
         DPC_LAUNCH(reduce_unpack4_kernel, dim3((unsigned)((n / 4 + 31) / 32)), dim3(256), stream, part, nsplit, out, d0, d1, d2, (long long)s0, (long long)s1,
                    (long long)s2, accumulate);
         return dpc_launch_status();

@@ -203,9 +203,9 @@ def test_tpool_split(k, dtype):
 
 def test_reduce_unpack_forms(k):
     """every kernel behind dpc_reduce_unpack"""
-    kc.case_reduce_unpack(k, 5, 1100, 1, 256, False, False, expect="reduce_unpack4_kernel")    # few slabs, many sums (score backward)
-    kc.case_reduce_unpack(k, 3, 300, 4, 256, False, True, expect="reduce_unpack4_kernel")      # + accumulate
-    kc.case_reduce_unpack(k, 8, 2049, 1, 128, True, False, expect="reduce_unpack4_kernel")     # permuted strides
+    kc.case_reduce_unpack(k, 5, 1100, 1, 256, False, False, expect="reduce_unpack_few_kernel")    # few slabs, many sums (score backward)
+    kc.case_reduce_unpack(k, 3, 300, 4, 256, False, True, expect="reduce_unpack_few_kernel")      # + accumulate
+    kc.case_reduce_unpack(k, 8, 2049, 1, 128, True, False, expect="reduce_unpack_few_kernel")     # permuted strides
     kc.case_reduce_unpack(k, 19, 64, 9, 64, True, True, expect="reduce_unpack4_kernel")        # many slabs: the split-lane form
     kc.case_reduce_unpack(k, 150, 8, 1, 64, False, False, expect="reduce_unpack4_kernel")      # two eight-slab trips per split lane + a ragged tail
     kc.case_reduce_unpack(k, 64, 8, 1, 32, False, True, expect="reduce_unpack4_kernel")        # exactly one trip, empty tail

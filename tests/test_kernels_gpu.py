@@ -222,9 +222,9 @@ def test_tpool_split(k, dtype):
 
 def test_reduce_unpack_forms(k):
     """every kernel behind dpc_reduce_unpack"""
-    kc.case_reduce_unpack(k, 5, 6144, 1, 256, False, False, expect="reduce_unpack4_kernel")    # the score backward's reductions at cfg2
-    kc.case_reduce_unpack(k, 2, 15680, 1, 256, False, True, expect="reduce_unpack4_kernel")    # cfg5, accumulate
-    kc.case_reduce_unpack(k, 8, 2049, 1, 128, True, False, expect="reduce_unpack4_kernel")     # permuted strides
+    kc.case_reduce_unpack(k, 5, 6144, 1, 256, False, False, expect="reduce_unpack_few_kernel")    # the score backward's reductions at cfg2
+    kc.case_reduce_unpack(k, 2, 15680, 1, 256, False, True, expect="reduce_unpack_few_kernel")    # cfg5, accumulate
+    kc.case_reduce_unpack(k, 8, 2049, 1, 128, True, False, expect="reduce_unpack_few_kernel")     # permuted strides
     kc.case_reduce_unpack(k, 300, 64, 9, 64, True, True, expect="reduce_unpack4_kernel")       # many slabs: the split-lane form
     kc.case_reduce_unpack(k, 512, 128, 1, 64, False, False, expect="reduce_unpack4_kernel")    # layer2.0 downsample gradient at cfg2: 512 slabs x 32 KB
     kc.case_reduce_unpack(k, 4, 256, 27, 256, True, False, expect="reduce_unpack_t_kernel")    # conv layout, few slabs
